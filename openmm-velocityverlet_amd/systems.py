@@ -1,0 +1,235 @@
+"""Synthetic particle systems for the BASELINE.json configurations (C1..C5).
+
+The reference's example drivers build an OpenMM ``System`` from gro/psf/prm files
+(/root/reference/examples/run-bulk.py:56-75, run-edl.py:82-100).  Neither OpenMM nor
+those files exist on the benchmark machine, so this module generates systems with the
+same *integrator-relevant* structure procedurally: particle masses, charges, molecule
+membership, Drude (Drude, parent) pairs, constraint pairs (for DOF accounting only),
+Langevin / image / electrolyte particle sets.  Chemistry facts used: element masses,
+the CL&Pol convention that every heavy atom carries a Drude particle of mass 0.4 taken
+from its parent and placed at index parent+1 (examples/ommhelper/oplspsffile.py:1515),
+c2c1im+ = 8 heavy atoms + 11 H (27 particles), dca- = 5 heavy atoms (10 particles).
+
+Everything is deterministic: ``numpy.random.default_rng(20241008)``.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Tuple
+
+import numpy as np
+
+BOLTZ = (1.380649e-23 * 6.02214076e23) / 1000.0  # kJ/mol/K, as OpenMM's SimTKOpenMMRealType.h
+SEED = 20241008
+
+_M_N, _M_C, _M_H, _M_D = 14.007, 12.011, 1.008, 0.4
+# particle pattern of one c2c1im+ cation: heavy atom followed by its Drude; H are plain particles
+_CATION = "ND CD ND CD CD CD H CD H H H H H CD H H H H H".replace(" ", "")
+_ANION = "NDCDNDCDND"
+
+
+def _template(pattern: str, net_charge: float):
+    masses, is_drude, charges = [], [], []
+    heavy = {"N": _M_N, "C": _M_C}
+    for ch in pattern:
+        if ch == "D":
+            masses[-1] -= _M_D
+            masses.append(_M_D)
+            is_drude.append(True)
+            charges[-1] += 2.0
+            charges.append(-2.0)
+        elif ch == "H":
+            masses.append(_M_H)
+            is_drude.append(False)
+            charges.append(0.1)
+        else:
+            masses.append(heavy[ch])
+            is_drude.append(False)
+            charges.append(-0.05)
+    charges = np.array(charges)
+    charges[0] += net_charge - charges.sum()
+    return np.array(masses), np.array(is_drude), charges
+
+
+@dataclass
+class SystemSpec:
+    """What VVIntegrator::initialize and the kernels' initialize() read from an OpenMM System."""
+    name: str
+    masses: np.ndarray            # float64 [N]
+    charges: np.ndarray           # float64 [N]
+    positions: np.ndarray         # float64 [N,3] nm
+    velocities: np.ndarray        # float64 [N,3] nm/ps
+    box: np.ndarray               # float64 [3] nm (orthorhombic)
+    mol_id: np.ndarray            # int32 [N]  (ContextImpl::getMolecules())
+    drude_pairs: np.ndarray       # int32 [Np,2] (drude, parent)  (DrudeForce::getParticleParameters p, p1)
+    constraints: np.ndarray       # int32 [Nc,2]  DOF accounting only; the solvers are OpenMM's
+    has_cm_motion_remover: bool = True
+    particles_ld: List[int] = field(default_factory=list)
+    image_pairs: List[Tuple[int, int]] = field(default_factory=list)   # (image, parent)
+    particles_electrolyte: List[int] = field(default_factory=list)
+
+    @property
+    def num_atoms(self) -> int:
+        return int(self.masses.shape[0])
+
+    @property
+    def num_molecules(self) -> int:
+        return int(self.mol_id.max()) + 1 if self.num_atoms else 0
+
+
+def _maxwell_boltzmann(rng, masses, is_drude_of, parent_of, T, T_drude):
+    """Normal particles ~ MB(T); Drude pairs: centre of mass ~ MB(T, m1+m2), relative ~ MB(T_D, mu)."""
+    n = masses.shape[0]
+    v = np.zeros((n, 3))
+    massive = masses > 0
+    sig = np.zeros(n)
+    sig[massive] = np.sqrt(BOLTZ * T / masses[massive])
+    v[:] = rng.standard_normal((n, 3)) * sig[:, None]
+    d = np.nonzero(is_drude_of)[0]
+    if d.size:
+        p = parent_of[d]
+        m1, m2 = masses[d], masses[p]
+        mt = m1 + m2
+        mu = m1 * m2 / mt
+        vcm = rng.standard_normal((d.size, 3)) * np.sqrt(BOLTZ * T / mt)[:, None]
+        vrel = rng.standard_normal((d.size, 3)) * np.sqrt(BOLTZ * T_drude / mu)[:, None]   # v_d - v_p
+        v[d] = vcm + vrel * (m2 / mt)[:, None]
+        v[p] = vcm - vrel * (m1 / mt)[:, None]
+    return v
+
+
+def _assemble(name, mol_templates, counts_per_cell, cells, cell_box, T, T_drude, rng):
+    """Tile `cells` unit cells; each unit cell lists all molecules of kind 0, then kind 1, ... (as conf.gro does)."""
+    masses, charges, isd, molid = [], [], [], []
+    nmol = 0
+    mols_per_cell = sum(counts_per_cell)
+    cx, cy, cz = cells
+    centers = []
+    for ic in range(cx * cy * cz):
+        ox = np.array([ic // (cy * cz), (ic // cz) % cy, ic % cz], dtype=float) * cell_box
+        side = int(np.ceil(mols_per_cell ** (1.0 / 3.0)))
+        grid = np.stack(np.meshgrid(*[np.arange(side)] * 3, indexing="ij"), -1).reshape(-1, 3)[:mols_per_cell]
+        grid = rng.permutation(grid)
+        k = 0
+        for (m, q, d), cnt in zip(mol_templates, counts_per_cell):
+            for _ in range(cnt):
+                masses.append(m)
+                charges.append(q)
+                isd.append(d)
+                molid.append(np.full(m.shape[0], nmol, dtype=np.int32))
+                centers.append(ox + (grid[k] + 0.5) / side * cell_box)
+                nmol += 1
+                k += 1
+    sizes = [m.shape[0] for m in masses]
+    masses = np.concatenate(masses)
+    charges = np.concatenate(charges)
+    isd = np.concatenate(isd)
+    molid = np.concatenate(molid)
+    n = masses.shape[0]
+    pos = np.repeat(np.array(centers), sizes, axis=0) + rng.uniform(-0.15, 0.15, size=(n, 3))
+    parent_of = np.arange(n) - 1
+    d = np.nonzero(isd)[0]
+    pos[d] = pos[d - 1] + rng.normal(0.0, 0.003, size=(d.size, 3))   # Drude sits ~0.005 nm from its parent
+    vel = _maxwell_boltzmann(rng, masses, isd, parent_of, T, T_drude)
+    box = cell_box * np.array(cells, dtype=float)
+    pairs = np.stack([d, d - 1], axis=1).astype(np.int32) if d.size else np.zeros((0, 2), np.int32)
+    return SystemSpec(name=name, masses=masses, charges=charges, positions=pos, velocities=vel, box=box,
+                      mol_id=molid, drude_pairs=pairs, constraints=np.zeros((0, 2), np.int32))
+
+
+def drude_il(cells=(2, 2, 3), pairs_per_cell=250, T=333.0, T_drude=1.0, seed=SEED, name=None) -> SystemSpec:
+    """C3/C4: Im21-like Drude ionic liquid; default 2x2x3 cells x 250 ion pairs = 111 000 particles,
+    6 000 molecules, 39 000 Drude pairs, 33 000 plain (H) particles (SURVEY.md §8 header)."""
+    rng = np.random.default_rng(seed)
+    cat = _template(_CATION, +0.8)
+    ani = _template(_ANION, -0.8)
+    spec = _assemble(name or f"drude_il_{cells[0]}x{cells[1]}x{cells[2]}x{pairs_per_cell}",
+                     [(cat[0], cat[2], cat[1]), (ani[0], ani[2], ani[1])], [pairs_per_cell, pairs_per_cell],
+                     cells, np.array([3.1, 3.1, 6.1]) * (pairs_per_cell / 250.0) ** (1.0 / 3.0), T, T_drude, rng)
+    return spec
+
+
+def nondrude_il(num_pairs=83, T=333.0, seed=SEED) -> SystemSpec:
+    """C1: non-Drude cut -- Drude masses/charges merged back into their parents; 24 particles per ion pair."""
+    rng = np.random.default_rng(seed)
+
+    def merged(pattern, q):
+        m, d, c = _template(pattern, q)
+        keep = ~d
+        mm = m.copy()
+        cc = c.copy()
+        idx = np.nonzero(d)[0]
+        mm[idx - 1] += m[idx]
+        cc[idx - 1] += c[idx]
+        return mm[keep], cc[keep], np.zeros(int(keep.sum()), bool)
+    cat, ani = merged(_CATION, 0.8), merged(_ANION, -0.8)
+    spec = _assemble(f"nondrude_il_{num_pairs}", [cat, ani], [num_pairs, num_pairs], (1, 1, 1),
+                     np.array([3.1, 3.1, 6.1]) * (num_pairs / 250.0) ** (1.0 / 3.0), T, 1.0, rng)
+    return spec
+
+
+def spce_water(num_molecules=3333, T=300.0, seed=SEED) -> SystemSpec:
+    """C2: SPC/E-like water, 3 particles per molecule (O, H, H); rigid-water constraints are OpenMM's,
+    so the parity/bench run is unconstrained and the DOF are counted accordingly."""
+    rng = np.random.default_rng(seed)
+    m = np.array([15.9994, 1.008, 1.008])
+    q = np.array([-0.8476, 0.4238, 0.4238])
+    d = np.zeros(3, bool)
+    box = (num_molecules / 33.4) ** (1.0 / 3.0)
+    return _assemble(f"spce_{num_molecules}", [(m, q, d)], [num_molecules], (1, 1, 1), np.array([box] * 3), T, 1.0, rng)
+
+
+def edl_slab(num_ion_pairs=511, num_electrode=2496, T=333.0, T_drude=1.0, seed=SEED) -> SystemSpec:
+    """C5: Drude IL slab + Langevin electrode subset + massless image particles (examples/run-edl.py:82-100).
+    Default counts follow SURVEY.md §8d C5: 2 496 electrode atoms + 18 907 IL particles + 18 907 images.
+    Each image is in its parent's molecule (run-edl.py:95 bonds them; quirk Q11) and has mass 0."""
+    rng = np.random.default_rng(seed)
+    il = drude_il(cells=(1, 1, 1), pairs_per_cell=num_ion_pairs, T=T, T_drude=T_drude, seed=seed + 1)
+    lz = 16.0
+    n_il = il.num_atoms
+    # squeeze the IL into the lower half of the box (z in (0.5, lz/2 - 0.5)); mirror plane at lz/2
+    z = il.positions[:, 2]
+    il.positions[:, 2] = 0.5 + (z - z.min()) / max(z.max() - z.min(), 1e-9) * (lz / 2 - 1.0)
+    # electrode: alternating Mo / S atoms near z = 0.2, every atom its own molecule, Langevin-thermostatted
+    m_el = np.where(np.arange(num_electrode) % 3 == 0, 95.94, 32.06)
+    q_el = np.zeros(num_electrode)
+    p_el = np.stack([rng.uniform(0, il.box[0], num_electrode), rng.uniform(0, il.box[1], num_electrode),
+                     rng.uniform(0.1, 0.3, num_electrode)], axis=1)
+    v_el = rng.standard_normal((num_electrode, 3)) * np.sqrt(BOLTZ * T / m_el)[:, None]
+    # order as in edl_*/conf.gro: electrode, IL, images
+    o_il = num_electrode
+    o_img = num_electrode + n_il
+    masses = np.concatenate([m_el, il.masses, np.zeros(n_il)])
+    charges = np.concatenate([q_el, il.charges, -il.charges])
+    pos_img = il.positions.copy()
+    pos_img[:, 2] = lz - pos_img[:, 2]          # 2*mirror - z with mirror = lz/2
+    positions = np.concatenate([p_el, il.positions, pos_img])
+    velocities = np.concatenate([v_el, il.velocities, np.zeros((n_il, 3))])
+    nmol_il = il.num_molecules
+    mol_id = np.concatenate([np.arange(num_electrode, dtype=np.int32),
+                             il.mol_id + num_electrode, il.mol_id + num_electrode]).astype(np.int32)
+    spec = SystemSpec(name=f"edl_{num_ion_pairs}", masses=masses, charges=charges, positions=positions,
+                      velocities=velocities, box=np.array([il.box[0], il.box[1], lz]), mol_id=mol_id,
+                      drude_pairs=(il.drude_pairs + o_il).astype(np.int32), constraints=np.zeros((0, 2), np.int32),
+                      has_cm_motion_remover=False)
+    spec.particles_ld = list(range(num_electrode))
+    spec.image_pairs = [(o_img + i, o_il + i) for i in range(n_il)]
+    spec.particles_electrolyte = list(range(o_il, o_il + n_il))
+    assert nmol_il + num_electrode == spec.num_molecules
+    return spec
+
+
+def make_config(name: str, scale: float = 1.0) -> SystemSpec:
+    """BASELINE.json configs by id.  `scale` < 1 gives a reduced copy for fast parity tests."""
+    if name == "C1":
+        return nondrude_il(max(2, int(round(83 * scale))))
+    if name == "C2":
+        return spce_water(max(4, int(round(3333 * scale))))
+    if name in ("C3", "C4"):
+        if scale >= 1.0:
+            k = int(round(scale))
+            return drude_il(cells=(2, 2, 3 * k))
+        return drude_il(cells=(1, 1, 1), pairs_per_cell=max(2, int(round(3000 * scale))))
+    if name == "C5":
+        return edl_slab(max(2, int(round(511 * scale))), max(3, int(round(2496 * scale))))
+    raise ValueError(f"unknown config {name!r}")

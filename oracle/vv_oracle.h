@@ -1,0 +1,169 @@
+/*
+ * oracle/vv_oracle.h -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement (plain C11) of the per-step velocity-Verlet / Nose-Hoover /
+ * TGNH / Langevin / cos-acceleration / image-charge path of
+ * z-gong/openmm-velocityVerlet.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this; the product (libvvhip) never does.
+ *
+ * Pinning: every kernel-level function here is checked bit-for-bit against the
+ * reference's own kernel sources compiled in place by `make ref`
+ * (oracle/_ref/libvvref_*.so; see ref_prelude.h for how and under which stated
+ * assumptions), by tests/test_oracle_vs_ref.py in this container, and against the
+ * golden vectors those runs produced (tests/golden/*.npz) everywhere else.
+ * NOT pinned by reference code: vvo_propagate_nh_chain (the reference routine,
+ * openmmapi/src/VVIntegrator.cpp:340-376, needs OpenMM headers that are absent;
+ * it is pinned only by an independent pure-Python restatement and analytic
+ * identities) and vvo_tether_force (our own synthetic force provider).
+ *
+ * Build once per precision mode (oracle/Makefile):
+ *   VVO_SINGLE real=float  mixed=float
+ *   VVO_MIXED  real=float  mixed=double   (reference default, examples/run-bulk.py:78)
+ *   VVO_DOUBLE real=double mixed=double
+ */
+#ifndef VV_ORACLE_H
+#define VV_ORACLE_H
+
+#if defined(VVO_DOUBLE)
+typedef double vvo_real;  typedef double vvo_mixed;
+#elif defined(VVO_MIXED)
+typedef float  vvo_real;  typedef double vvo_mixed;
+#elif defined(VVO_SINGLE)
+typedef float  vvo_real;  typedef float  vvo_mixed;
+#else
+#error "define one of VVO_SINGLE / VVO_MIXED / VVO_DOUBLE"
+#endif
+
+typedef struct { vvo_real x, y, z, w; } vvo_real4;
+typedef struct { vvo_real x, y, z; } vvo_real3;
+typedef struct { vvo_mixed x, y, z, w; } vvo_mixed4;
+typedef struct { float x, y, z, w; } vvo_float4;
+typedef struct { int x, y; } vvo_int2;
+
+#define VVO_MAX_CHAINS 8
+#define VVO_NUM_TG_MAX 3
+
+/* One simulated system + integrator configuration.  All arrays are caller-owned. */
+typedef struct {
+    /* sizes */
+    int num_atoms, padded_num_atoms, num_molecules;
+    /* OpenMM-owned state (CudaVVKernels.cpp:144-147,179-184) */
+    vvo_mixed4* velm;          /* xyz = v, w = 1/m            [num_atoms]          */
+    vvo_real4*  posq;          /* xyz = x, w = charge         [num_atoms]          */
+    vvo_real4*  posq_corr;     /* mixed mode only, else NULL  [num_atoms]          */
+    long long*  force;         /* planar x|y|z, fixed point x 2^32 [3*padded]      */
+    vvo_mixed4* pos_delta;     /*                             [num_atoms]          */
+    /* plugin-owned state */
+    vvo_real3*  force_extra;   /* [num_atoms]  */
+    vvo_mixed4* old_delta;     /* [num_atoms]  */
+    vvo_mixed4* com_velm;      /* [num_molecules] */
+    vvo_mixed*  v_buffer;      /* [num_atoms] cos-acceleration bias buffer */
+    /* Drude pairs for the hard wall: x = Drude, y = parent (CudaVVKernels.cpp:68-73) */
+    int num_drude_pairs;  const vvo_int2* drude_pairs;
+    /* NH tables (CudaVVKernels.cpp:483-529) */
+    int num_particles_nh; const int* particles_nh;
+    int num_molecules_nh; const int* molecules_nh;
+    int num_normal_nh;    const int* normal_nh;
+    int num_pairs_nh;     const vvo_int2* pairs_nh;
+    const int* particle_mol_id;            /* [num_atoms]     */
+    const vvo_int2* particles_in_molecules;/* (count,start) [num_molecules] */
+    const int* particles_sorted_by_mol_id; /* [num_atoms]     */
+    int num_tg;                            /* 1..3 (CudaVVKernels.cpp:567-573) */
+    int use_com_tg;
+    /* NH chain state, double on the host in the reference (CudaVVKernels.h:206-207) */
+    int num_chains, loops_per_step;
+    double eta[VVO_NUM_TG_MAX][VVO_MAX_CHAINS];
+    double eta_dot[VVO_NUM_TG_MAX][VVO_MAX_CHAINS + 1];
+    double eta_dotdot[VVO_NUM_TG_MAX][VVO_MAX_CHAINS];
+    double eta_mass[VVO_NUM_TG_MAX][VVO_MAX_CHAINS];
+    double tg_nkbt[VVO_NUM_TG_MAX];
+    double ke2[VVO_NUM_TG_MAX];            /* out: last 2*KE per group   */
+    double vscale[VVO_NUM_TG_MAX];         /* out: last scale factors    */
+    /* Langevin subset (CudaVVKernels.cpp:775-804) */
+    int num_particles_ld;
+    int num_normal_ld;    const int* normal_ld;
+    int num_pairs_ld;     const vvo_int2* pairs_ld;
+    const vvo_float4* random; unsigned int random_size, random_index;
+    /* image charges / E-field */
+    int num_images;       const vvo_int2* image_pairs;   /* x = image, y = parent */
+    int num_electrolyte;  const int* particles_electrolyte;
+    /* integrator parameters (VVIntegrator.h) */
+    double dt, temperature, drude_temperature;
+    double friction, drude_friction, max_drude_distance;
+    double mirror, efield, cos_accel;
+    double box[3];
+    double inv_mass_total;
+    int use_middle;
+    /* synthetic force provider (ours; 0 = forces are whatever the caller left in `force`) */
+    int force_mode;                        /* 1 = tether */
+    const vvo_real4* site;                 /* tether anchor positions [num_atoms] */
+    double k_tether, k_drude;
+    /* classic-VV bookkeeping (VVIntegrator.cpp:286-292) */
+    int forces_valid;
+    int num_threads;                       /* OpenMP threads for the step drivers */
+} vvo_system;
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+int vvo_sizeof_real(void);
+int vvo_sizeof_mixed(void);
+int vvo_sizeof_system(void);
+
+/* ---- kernel-level restatements (one per reference __global__) ---- */
+void vvo_integrate_middle_vel(int n, int padded, vvo_mixed4* velm, const long long* force,
+                              const vvo_real3* force_extra, vvo_mixed dt);
+void vvo_integrate_middle_pos1(int n, const vvo_mixed4* velm, vvo_mixed4* pos_delta, vvo_mixed4* old_delta, vvo_mixed dt);
+void vvo_integrate_middle_pos2(int n, const vvo_mixed4* velm, vvo_mixed4* pos_delta, vvo_mixed4* old_delta, vvo_mixed dt);
+void vvo_integrate_middle_pos3(int n, vvo_real4* posq, vvo_real4* posq_corr, const vvo_mixed4* pos_delta,
+                               const vvo_mixed4* old_delta, vvo_mixed4* velm, vvo_mixed dt);
+void vvo_apply_hard_wall(int npairs, vvo_real4* posq, vvo_real4* posq_corr, vvo_mixed4* velm,
+                         const vvo_int2* drude_pairs, vvo_mixed dt, vvo_mixed max_drude_distance,
+                         vvo_mixed hardwall_scale_drude);
+void vvo_reset_extra_force(int n, vvo_real3* force_extra);
+void vvo_vv_integrate_velocities(int n, int padded, vvo_mixed4* velm, const long long* force,
+                                 const vvo_real3* force_extra, vvo_mixed4* pos_delta, vvo_mixed dt,
+                                 vvo_mixed fscale, int update_pos_delta);
+void vvo_vv_integrate_positions(int n, vvo_real4* posq, vvo_real4* posq_corr, const vvo_mixed4* pos_delta,
+                                vvo_mixed4* velm, vvo_mixed dt);
+void vvo_calc_com_velocities(int nmol_nh, const vvo_mixed4* velm, vvo_mixed4* com_velm,
+                             const vvo_int2* particles_in_molecules, const int* particles_sorted_by_mol_id,
+                             const int* molecules_nh);
+void vvo_normalize_velocities(int nnh, vvo_mixed4* velm, const vvo_mixed4* com_velm,
+                              const int* particle_mol_id, const int* particles_nh);
+void vvo_compute_kinetic_energies(int num_tg, int n_normal, int nmol_nh, int n_pairs, const vvo_mixed4* velm,
+                                  const vvo_mixed4* com_velm, const int* normal, const vvo_int2* pairs,
+                                  const int* molecules_nh, vvo_mixed* ke_out /*[num_tg]*/);
+void vvo_scale_velocity(int n_normal, int n_pairs, vvo_mixed4* velm, const vvo_mixed4* com_velm,
+                        const int* particle_mol_id, const int* normal, const vvo_int2* pairs,
+                        const vvo_mixed* vscale /*[3]*/);
+void vvo_add_cos_acceleration(int n, const vvo_real4* posq, const vvo_mixed4* velm, vvo_real3* force_extra,
+                              vvo_real acceleration, vvo_real inv_box_z);
+void vvo_calc_periodic_velocity_bias(int n, const vvo_real4* posq, const vvo_mixed4* velm, vvo_mixed* v_buffer,
+                                     vvo_real inv_box_z);
+void vvo_sum_v(int n, vvo_mixed* v_buffer, double inv_mass_total);
+void vvo_remove_periodic_velocity_bias(int n, const vvo_real4* posq, vvo_mixed4* velm, const vvo_mixed* v_buffer,
+                                       vvo_real inv_box_z);
+void vvo_restore_periodic_velocity_bias(int n, const vvo_real4* posq, vvo_mixed4* velm, const vvo_mixed* v_buffer,
+                                        vvo_real inv_box_z);
+void vvo_add_extra_force_drude_langevin(int n_normal, int n_pairs, const vvo_mixed4* velm, vvo_real3* force_extra,
+                                        const int* normal, const vvo_int2* pairs, vvo_mixed drag, vvo_mixed randf,
+                                        vvo_mixed drag_drude, vvo_mixed randf_drude, const vvo_float4* random,
+                                        unsigned int random_index);
+void vvo_add_extra_force_electric_field(int n_el, const vvo_real4* posq, vvo_real3* force_extra,
+                                        const int* particles_electrolyte, vvo_real efscale);
+void vvo_update_image_positions(int n_img, vvo_real4* posq, vvo_real4* posq_corr, const vvo_int2* image_pairs,
+                                vvo_mixed mirror);
+
+/* ---- host-side restatements ---- */
+void vvo_propagate_nh_chain(int num_chains, int loops_per_step, double step_size, double* eta, double* eta_dot,
+                            double* eta_dotdot, const double* eta_mass, double ke2, double ke2_target,
+                            double t_target, double* factor);
+void vvo_nh_scale_velocity(vvo_system* s);     /* CudaModifyDrudeNoseKernel::scaleVelocity */
+void vvo_tether_force(vvo_system* s);          /* ours: synthetic force provider           */
+void vvo_step(vvo_system* s, int steps);       /* VVIntegrator::step (middle or classic)   */
+double vvo_calc_viscosity(const vvo_system* s, double* vmax_out);
+#ifdef __cplusplus
+}
+#endif
+#endif

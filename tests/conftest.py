@@ -1,0 +1,21 @@
+"""pytest configuration: `gpu` marker, import paths, and building the oracle (checker) libraries."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the oracle is test infrastructure: build it here, never from product code
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "all"], check=True)
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return os.path.join(ROOT, "tests", "golden")
