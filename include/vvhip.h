@@ -1,0 +1,241 @@
+/*
+ * vvhip.h -- C ABI of libvvhip.so: the MI355X-native (HIP, gfx950) implementation of the per-step
+ * hot path of z-gong/openmm-velocityVerlet.
+ *
+ * Boundary.  In the reference the hot path sits behind seven OpenMM KernelImpl interfaces
+ * (openmmapi/include/openmm/VVKernels.h:48-270) that a platform plugin implements in C++
+ * (platforms/cuda/include/CudaVVKernels.h, platforms/cuda/src/CudaVVKernels.cpp).  This header is
+ * the same surface flattened to C: one entry point per KernelImpl virtual (split where the
+ * reference method calls OpenMM's constraint solvers in the middle), raw device pointers instead
+ * of CudaArray, plain scalars instead of VVIntegrator getters.  The OpenMM-facing C++ adapters that
+ * call it (HipVVKernelFactory, Hip*Kernel) live in platforms/hip/ and are described in
+ * INTEGRATION.md.  Citations below are reference file:line under /root/reference; "HOST" is
+ * platforms/cuda/src/CudaVVKernels.cpp, "API" is openmmapi/src/VVIntegrator.cpp.
+ *
+ * Conventions.  Every function returns VVHIP_OK (0) or a negative error code; the text of the last
+ * error of a plan is available from vvhip_last_error().  Errors that the reference raises as
+ * OpenMMException keep the reference's message text.  Nothing here falls back to a CPU path.
+ * All launches go to the hipStream_t given in vvhip_buffers.stream and never synchronise with the
+ * host unless the function's comment says so.  A plan is not re-entrant (as the reference: one
+ * integrator <-> one context, API:93-94).
+ */
+#ifndef VVHIP_H
+#define VVHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VVHIP_VERSION 1
+#define VVHIP_MAX_CHAINS 8
+#define VVHIP_NUM_TG 3            /* TG_ATOM, TG_COM, TG_DRUDE (HOST:49) */
+
+enum {
+    VVHIP_OK = 0,
+    VVHIP_ERR_INVALID = -1,       /* bad argument / API misuse */
+    VVHIP_ERR_TOPOLOGY = -2,      /* the reference's OpenMMException cases (API:149,155; HOST:519,537,787,801) */
+    VVHIP_ERR_UNSUPPORTED = -3,   /* valid for the reference, not implemented here (message says what) */
+    VVHIP_ERR_HIP = -4,           /* a HIP runtime call failed */
+    VVHIP_ERR_NO_DEVICE = -5      /* no usable GPU: the product has no CPU path */
+};
+
+/* OpenMM's CudaPrecision / HipPrecision property (examples/run-bulk.py:78) */
+enum { VVHIP_SINGLE = 0, VVHIP_MIXED = 1, VVHIP_DOUBLE = 2 };
+
+typedef struct vvhip_plan vvhip_plan;
+
+/* What the reference's initialize() methods read from OpenMM::System, DrudeForce and VVIntegrator
+ * (API:92-188, HOST:56-117, 462-667, 761-824, 878-902, 940-969, 998-1035). Host pointers, copied. */
+typedef struct {
+    int32_t num_atoms;
+    int32_t padded_num_atoms;          /* cu.getPaddedNumAtoms(): stride of the planar force buffer */
+    const double* masses;              /* System::getParticleMass            [num_atoms]            */
+    const int32_t* mol_id;             /* ContextImpl::getMolecules() as particle -> molecule id    */
+    int32_t num_molecules;
+    int32_t num_drude_pairs;
+    const int32_t* drude_pairs;        /* (drude, parent) = DrudeForce p, p1 (HOST:68-73)   [2*n]   */
+    int32_t num_constraints;
+    const int32_t* constraints;        /* System::getConstraintParameters, DOF accounting   [2*n]   */
+    int32_t has_cm_motion_remover;     /* HOST:550-558                                              */
+    int32_t num_particles_ld;
+    const int32_t* particles_ld;       /* VVIntegrator::addParticleLangevin                         */
+    int32_t num_image_pairs;
+    const int32_t* image_pairs;        /* (image, parent) = VVIntegrator::addImagePair      [2*n]   */
+    int32_t num_electrolyte;
+    const int32_t* particles_electrolyte; /* VVIntegrator::addParticleElectrolyte                   */
+    /* particle shard owned by this process: atoms [shard_begin, shard_end) of the system described
+     * above; must not cut a molecule or a Drude pair.  Device arrays passed to vvhip_bind are indexed
+     * from shard_begin.  0,0 = the whole system. */
+    int32_t shard_begin, shard_end;
+} vvhip_system_desc;
+
+/* VVIntegrator's parameters (openmmapi/include/openmm/VVIntegrator.h:70-431).  The reference reads
+ * them through getters at every kernel call; here they are re-read whenever vvhip_set_params is
+ * called.  Thermostat masses / DOF are fixed at plan creation, as in the reference (HOST:583-594). */
+typedef struct {
+    double temperature, frequency, drude_temperature, drude_frequency, step_size;
+    int32_t num_nh_chains, loops_per_step;
+    double max_drude_distance;
+    double friction, drude_friction;
+    double mirror_location;
+    double electric_field;             /* kJ/(nm e) per particle, as VVIntegrator::setElectricField  */
+    double cos_acceleration;
+    int32_t use_com_temp_group, use_middle_scheme;
+    int32_t auto_set_com_temp_group;   /* 1 = constructor default not overridden (API:67,106-121)    */
+    int32_t auto_set_friction;
+} vvhip_params;
+
+/* Device arrays owned by the caller (OpenMM's HipContext / HipIntegrationUtilities in the plugin). */
+typedef struct {
+    void* velm;            /* mixed4 [n]: xyz = velocity, w = 1/mass       cu.getVelm()            */
+    void* posq;            /* real4  [n]: xyz = position, w = charge       cu.getPosq()            */
+    void* posq_correction; /* real4  [n], mixed mode only, else NULL       cu.getPosqCorrection()  */
+    void* force;           /* int64  [3*padded]: planar x|y|z, x 2^32      cu.getForce()           */
+    void* pos_delta;       /* mixed4 [n], only for the split (constraint) entry points; may be NULL */
+    const void* random;    /* float4 [random_size] N(0,1)                  integration.getRandom() */
+    uint32_t random_size;
+    void* stream;          /* hipStream_t; NULL = the null stream                                  */
+} vvhip_buffers;
+
+/* Results of the host-side analysis (readable without a GPU). */
+typedef struct {
+    int32_t num_particles_nh, num_molecules_nh, num_normal_nh, num_pairs_nh;
+    int32_t num_normal_ld, num_pairs_ld, num_images, num_electrolyte;
+    int32_t num_temp_groups;                     /* HOST:567-573 */
+    int32_t use_com_temp_group;                  /* after the auto rule, API:106-121 */
+    double friction;                             /* after the auto rule */
+    double dof[VVHIP_NUM_TG], nkbt[VVHIP_NUM_TG];
+    double eta_mass[VVHIP_NUM_TG][VVHIP_MAX_CHAINS];
+    double inv_mass_total;                       /* HOST:1028-1031 */
+    int32_t num_waves, num_slots_used;           /* work-item layout: 64 slots per wave */
+    int32_t max_cluster;                         /* largest set of particles that must share a wave */
+} vvhip_plan_info;
+
+/* Nose-Hoover chain state + last reduction results (HOST: CudaVVKernels.h:206-215).  The reference
+ * keeps these on the host and loses them on restart; here they live on the device and can be saved. */
+typedef struct {
+    double eta[VVHIP_NUM_TG][VVHIP_MAX_CHAINS];
+    double eta_dot[VVHIP_NUM_TG][VVHIP_MAX_CHAINS + 1];
+    double eta_dotdot[VVHIP_NUM_TG][VVHIP_MAX_CHAINS];
+    double ke2[VVHIP_NUM_TG];                    /* last 2*KE per temperature group */
+    double vscale[VVHIP_NUM_TG];                 /* last velocity scale factors     */
+    double v_bias;                               /* last periodic velocity bias V (vMaxBuffer[0]) */
+} vvhip_nh_state;
+
+/* ---------------------------------------------------------------- life cycle */
+/* Host-only: partitions particles (NH / Langevin / image), checks the reference's conflict rules,
+ * counts DOF, sizes the thermostat chains and lays particles out in 64-lane waves so that every
+ * Drude pair and (with the COM temperature group) every molecule sits inside one wave.
+ * Replaces VVIntegrator::initialize's table building (API:123-155) and the initialize() methods of
+ * all seven Cuda*Kernel classes.  Does not touch the GPU. */
+int vvhip_plan_create(const vvhip_system_desc* system, const vvhip_params* params, int precision,
+                      vvhip_plan** plan_out, char* errbuf, size_t errbuf_len);
+void vvhip_plan_destroy(vvhip_plan* plan);
+const char* vvhip_last_error(const vvhip_plan* plan);
+int vvhip_plan_get_info(const vvhip_plan* plan, vvhip_plan_info* info);
+/* Copies the wave layout: slots[2*i] = particle index (shard-relative, -1 = idle lane),
+ * slots[2*i+1] = packed role word.  `capacity` in slots; returns the number of slots or <0. */
+int vvhip_plan_get_slots(const vvhip_plan* plan, int32_t* slots, int32_t capacity);
+
+/* Binds device arrays and allocates the plan's own device state (forceExtra, oldDelta, accumulators,
+ * chain state, layout tables) on the current device.  First call that needs a GPU. */
+int vvhip_bind(vvhip_plan* plan, const vvhip_buffers* buffers);
+int vvhip_set_params(vvhip_plan* plan, const vvhip_params* params);
+int vvhip_set_box(vvhip_plan* plan, const double box[3]);      /* cu.getPeriodicBoxSize() (HOST:1057,1129) */
+/* Blocking copies of the thermostat state (checkpoint / tests). */
+int vvhip_get_nh_state(vvhip_plan* plan, vvhip_nh_state* out);
+int vvhip_set_nh_state(vvhip_plan* plan, const vvhip_nh_state* in);
+
+/* ---------------------------------------------------------------- fused path
+ * One whole VVIntegrator step between two force evaluations, for systems without constraints /
+ * virtual sites (those solvers are OpenMM's).  Forces for the step must already be in `force`.
+ *
+ * Middle scheme (API:232-270 after calcForcesAndEnergy): 2 launches
+ *   pass A: extra forces (Langevin, E-field, cos) + full kick + molecular COM + per-group 2KE
+ *           (+ cos bias moments) -> fixed-point accumulators
+ *   pass B: NH chain (device) + velocity scaling + bias remove/restore + both half drifts +
+ *           hard wall + image mirror
+ * With cos acceleration a third launch sits between them (bias must be known before the KE).
+ * Classic scheme: vvhip_step_vv_first() = API:295-310, vvhip_step_vv_second() = API:316-336.
+ * `random_index` = integration.prepareRandomNumbers(...) for this step (HOST:863), ignored unless
+ * Langevin particles exist. */
+int vvhip_step_middle(vvhip_plan* plan, uint32_t random_index);
+int vvhip_step_vv_first(vvhip_plan* plan);
+int vvhip_step_vv_second(vvhip_plan* plan, uint32_t random_index);
+/* vvhip_step_middle cut at its global reductions, for hosts that shard particles over GPUs and run a
+ * collective in between.  A step has vvhip_step_middle_phases() phases (2, or 3 with cos acceleration:
+ * the bias must be known before the kinetic energies).  After every phase but the last, the host sums
+ * the accumulator range reported by vvhip_accumulators(phase) element-wise over ranks (ncclSum on
+ * int64; fixed point makes the result independent of rank order) on the plan's stream:
+ *     for (ph = 0; ph < P; ph++) { vvhip_step_middle_phase(plan, ph, ri); if (ph < P-1) all_reduce(acc(ph)); }
+ * That <= 32-byte all-reduce is the only cross-GPU exchange per thermostat application. */
+int vvhip_step_middle_phases(const vvhip_plan* plan);
+int vvhip_step_middle_phase(vvhip_plan* plan, int phase, uint32_t random_index);
+int vvhip_accumulators(vvhip_plan* plan, int phase, void** device_ptr, int32_t* count);
+
+/* ---------------------------------------------------------------- kernel-interface level
+ * One entry per KernelImpl virtual, for use inside OpenMM where constraint solvers run between them. */
+/* IntegrateMiddleStepKernel (VVKernels.h:50-86; HOST:119-235) */
+int vvhip_reset_extra_force(vvhip_plan* plan);                 /* resetExtraForce                      */
+int vvhip_middle_kick(vvhip_plan* plan);                       /* firstIntegrate, before applyVelocityConstraints (HOST:144-148) */
+int vvhip_middle_half_drift1(vvhip_plan* plan);                /* firstIntegrate, after  (HOST:154-158) */
+int vvhip_middle_half_drift2(vvhip_plan* plan);                /* secondIntegrate, before applyConstraints (HOST:169-173) */
+int vvhip_middle_finish(vvhip_plan* plan);                     /* secondIntegrate, after: Pos3 + hard wall (HOST:179-212) */
+/* IntegrateVVStepKernel (VVKernels.h:94-130; HOST:296-442) */
+int vvhip_vv_half_kick(vvhip_plan* plan, int update_pos_delta);/* HOST:341-348 / 417-424 */
+int vvhip_vv_positions(vvhip_plan* plan);                      /* HOST:355-372: positions + hard wall */
+/* ModifyDrudeNoseKernel (VVKernels.h:138-157; HOST:670-754): 2 launches, no host round trip */
+int vvhip_scale_velocity(vvhip_plan* plan);
+/* ModifyDrudeLangevinKernel (VVKernels.h:165-184; HOST:826-872) */
+int vvhip_apply_langevin_force(vvhip_plan* plan, uint32_t random_index);
+/* ModifyImageChargeKernel (VVKernels.h:192-211; HOST:904-934) */
+int vvhip_update_image_positions(vvhip_plan* plan);
+/* ModifyElectricFieldKernel (VVKernels.h:219-238; HOST:971-992) */
+int vvhip_apply_electric_force(vvhip_plan* plan);
+/* ModifyCosineAccelerateKernel (VVKernels.h:246-269; HOST:1037-1134) */
+int vvhip_apply_cosine_force(vvhip_plan* plan);
+int vvhip_calc_velocity_bias(vvhip_plan* plan);
+int vvhip_remove_velocity_bias(vvhip_plan* plan);
+int vvhip_restore_velocity_bias(vvhip_plan* plan);
+int vvhip_calc_viscosity(vvhip_plan* plan, double* v_max, double* inv_viscosity);   /* blocks; 8-byte copy */
+/* Device pointer of the plan-owned forceExtra array (real3[n]); getForceExtra() of the reference
+ * (CudaVVKernels.h:86-88). */
+int vvhip_force_extra(vvhip_plan* plan, void** device_ptr);
+
+/* ---------------------------------------------------------------- stand-alone host support
+ * NOT part of the reference path: lets a host without OpenMM (tests, bench.py) own device memory and
+ * produce forces.  vvhip_synth_tether_force writes F = -k_t (x - site) on every massive particle plus a
+ * Drude-parent spring -k_d (x_d - x_p), in OpenMM's fixed-point planar layout. */
+int vvhip_device_count(int* count);
+int vvhip_set_device(int device);
+int vvhip_malloc(void** ptr, size_t bytes);
+int vvhip_free(void* ptr);
+int vvhip_memcpy_h2d(void* dst, const void* src, size_t bytes);
+int vvhip_memcpy_d2h(void* dst, const void* src, size_t bytes);
+int vvhip_memset(void* dst, int value, size_t bytes);
+int vvhip_synchronize(vvhip_plan* plan);
+int vvhip_stream_create(void** stream);          /* hipStreamCreateWithFlags(non-blocking) */
+int vvhip_stream_destroy(void* stream);
+int vvhip_synth_tether_force(vvhip_plan* plan, const void* site /* real4[n] */, double k_tether, double k_drude);
+/* Captures `steps_per_graph` steps (optionally with the synthetic force kernel in front of each) into a
+ * hipGraph once and replays it; returns after enqueueing.  Middle scheme only. */
+int vvhip_run_graph(vvhip_plan* plan, int nsteps, int steps_per_graph, const void* site, double k_tether, double k_drude);
+/* HIP-event timing of the dominant kernels on the plan's stream, for bench.py's roofline block. */
+int vvhip_timing_enable(vvhip_plan* plan, int enable);
+int vvhip_timing_read(vvhip_plan* plan, double* ms_pass_a, double* ms_pass_b, double* ms_other, int32_t launches[3]);
+
+/* ---------------------------------------------------------------- test hooks
+ * Used by tests/ to drive single stages against the oracle; not needed by an integrating host.
+ * kernel: 0 = A (produce), 1 = B (consume), 2 = chain; flags are the stage bits of csrc/vv_kernels.hpp. */
+int vvhip_debug_launch(vvhip_plan* plan, int kernel, uint32_t flags, uint32_t random_index);
+int vvhip_debug_read_accumulators(vvhip_plan* plan, double out[4], int zero_after);  /* blocks */
+int vvhip_debug_set_scales(vvhip_plan* plan, const double scales[4]);                /* vscale[3], bias V; blocks */
+int vvhip_debug_old_delta(vvhip_plan* plan, void** device_ptr);                       /* plan-owned oldDelta (mixed4[n]) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VVHIP_H */

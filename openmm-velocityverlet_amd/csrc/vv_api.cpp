@@ -1,0 +1,632 @@
+// vv_api.cpp -- the C ABI of include/vvhip.h on top of vv_host (analysis) and vv_kernels (HIP).
+// "HOST" = platforms/cuda/src/CudaVVKernels.cpp, "API" = openmmapi/src/VVIntegrator.cpp of the reference.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "vv_host.hpp"
+#include "vv_kernels.hpp"
+
+namespace {
+constexpr double kAvogadro = 6.02214076e23;
+constexpr double kBoltz = (1.380649e-23 * kAvogadro) / 1000.0;
+enum TimerClass { T_A = 0, T_B = 1, T_OTHER = 2 };
+}  // namespace
+
+struct vvhip_plan {
+    vv::HostPlan hp;
+    std::string err;
+    bool bound = false;
+    vvhip_buffers buf{};
+    hipStream_t stream = nullptr;
+    double box[3] = {1, 1, 1};
+    double acc_scale[vv::NUM_ACC], acc_inv_scale[vv::NUM_ACC];
+    int block_threads = 256;
+    // plan-owned device state
+    int2* d_slots = nullptr;
+    int32_t* d_slot_image = nullptr;
+    int32_t* d_slot_rand = nullptr;
+    int2* d_image_pairs = nullptr;
+    void* d_fextra = nullptr;
+    void* d_old_delta = nullptr;
+    void* d_pos_delta = nullptr;   // used when the caller does not supply one
+    unsigned long long* d_acc = nullptr;
+    vv::NHDevState* d_nh = nullptr;
+    // HIP-event timing (eager launches only)
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events[3];
+    // captured graph for vvhip_run_graph
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_steps = 0;
+    const void* graph_site = nullptr;
+    double graph_kt = 0, graph_kd = 0;
+    bool capturing = false;
+};
+
+namespace {
+
+int fail(vvhip_plan* p, int code, const std::string& msg) {
+    if (p) p->err = msg;
+    return code;
+}
+int hip_fail(vvhip_plan* p, hipError_t e, const char* what) {
+    return fail(p, e == hipErrorNoDevice || e == hipErrorInvalidDevice ? VVHIP_ERR_NO_DEVICE : VVHIP_ERR_HIP,
+                std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(p, call)                                         \
+    do {                                                         \
+        hipError_t e_ = (call);                                  \
+        if (e_ != hipSuccess) return hip_fail(p, e_, #call);     \
+    } while (0)
+#define NEED_BOUND(p)                                                                  \
+    do {                                                                               \
+        if (!(p)) return VVHIP_ERR_INVALID;                                            \
+        if (!(p)->bound) return fail(p, VVHIP_ERR_INVALID, "vvhip_bind has not been called"); \
+    } while (0)
+
+size_t sizeof_real(int prec) { return prec == VVHIP_DOUBLE ? 8 : 4; }
+size_t sizeof_mixed(int prec) { return prec == VVHIP_SINGLE ? 4 : 8; }
+
+// 2^k fixed-point scale leaving `headroom` x `bound` below 2^62
+double pick_scale(double bound, double headroom) {
+    double top = std::ldexp(1.0, 62) / (std::max(bound, 1.0) * headroom);
+    int k = (int) std::floor(std::log2(top));
+    k = std::max(0, std::min(k, 40));
+    return std::ldexp(1.0, k);
+}
+
+void fill_scales(vvhip_plan* p) {
+    const vvhip_plan_info& in = p->hp.info;
+    for (int g = 0; g < 3; g++) {
+        p->acc_scale[g] = pick_scale(in.nkbt[g], 64.0);          // overflow only if a group is > 64x hotter than its target
+        p->acc_inv_scale[g] = 1.0 / p->acc_scale[g];
+    }
+    p->acc_scale[3] = pick_scale(40.0 / in.inv_mass_total, 4.0);  // |sum m vx 2cos| <= 2 M |v|max, |v|max ~ 20 nm/ps
+    p->acc_inv_scale[3] = 1.0 / p->acc_scale[3];
+}
+
+vv::KArgs make_args(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
+    const vvhip_params& q = p->hp.params;
+    vv::KArgs a{};
+    a.velm = p->buf.velm;
+    a.posq = p->buf.posq;
+    a.corr = p->hp.precision == VVHIP_MIXED ? p->buf.posq_correction : nullptr;
+    a.force = (const long long*) p->buf.force;
+    a.fextra = p->d_fextra;
+    a.pos_delta = p->buf.pos_delta ? p->buf.pos_delta : p->d_pos_delta;
+    a.old_delta = p->d_old_delta;
+    a.slots = p->d_slots;
+    a.slot_image = p->d_slot_image;
+    a.slot_rand = p->d_slot_rand;
+    a.random = (const float4*) p->buf.random;
+    a.acc = p->d_acc;
+    a.nh = p->d_nh;
+    a.padded = p->hp.padded_num_atoms;
+    a.nwaves = p->hp.info.num_waves;
+    a.flags = flags;
+    a.random_index = random_index;
+    a.dt = q.step_size;
+    a.fscale_vv = 0.5 * q.step_size / (double) 0x100000000;                                    // HOST:306
+    a.drag = q.friction;                                                                        // HOST:835-839
+    a.randf = std::sqrt(2.0 * kBoltz * q.temperature * q.friction / q.step_size);
+    a.drag_drude = q.drude_friction;
+    a.randf_drude = std::sqrt(2.0 * kBoltz * q.drude_temperature * q.drude_friction / q.step_size);
+    a.efscale = q.electric_field * kAvogadro;                                                   // HOST:978
+    a.cos_accel = q.cos_acceleration;
+    a.inv_box_z = 1.0 / p->box[2];
+    a.max_drude = q.max_drude_distance;
+    a.hw_scale = std::sqrt(kBoltz * q.drude_temperature);                                       // HOST:190
+    a.mirror = q.mirror_location;
+    a.inv_mass_total = p->hp.info.inv_mass_total;
+    for (int i = 0; i < vv::NUM_ACC; i++) { a.acc_scale[i] = p->acc_scale[i]; a.acc_inv_scale[i] = p->acc_inv_scale[i]; }
+    return a;
+}
+
+vv::NHConst make_chain(vvhip_plan* p, uint32_t flags) {
+    const vvhip_params& q = p->hp.params;
+    const vvhip_plan_info& in = p->hp.info;
+    vv::NHConst c{};
+    std::memcpy(c.eta_mass, in.eta_mass, sizeof(c.eta_mass));
+    for (int g = 0; g < 3; g++) {
+        c.nkbt[g] = in.nkbt[g];
+        c.temperature[g] = g == 2 ? q.drude_temperature : q.temperature;                        // HOST:728
+    }
+    c.step_size = q.step_size;
+    c.inv_mass_total = in.inv_mass_total;
+    for (int i = 0; i < vv::NUM_ACC; i++) c.acc_inv_scale[i] = p->acc_inv_scale[i];
+    c.num_chains = q.num_nh_chains;
+    c.loops_per_step = q.loops_per_step;
+    c.num_tg = in.num_temp_groups;
+    c.flags = flags;
+    return c;
+}
+
+struct ScopedTimer {
+    vvhip_plan* p;
+    int cls;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool on;
+    ScopedTimer(vvhip_plan* p_, int cls_) : p(p_), cls(cls_), on(p_->timing && !p_->capturing) {
+        if (on) {
+            (void) hipEventCreate(&e0);
+            (void) hipEventCreate(&e1);
+            (void) hipEventRecord(e0, p->stream);
+        }
+    }
+    ~ScopedTimer() {
+        if (on) {
+            (void) hipEventRecord(e1, p->stream);
+            p->events[cls].emplace_back(e0, e1);
+        }
+    }
+};
+
+int run_a(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
+    ScopedTimer t(p, T_A);
+    HIP_TRY(p, vv::launch_a(p->hp.precision, make_args(p, flags, random_index), p->block_threads, p->stream));
+    return VVHIP_OK;
+}
+int run_b(vvhip_plan* p, uint32_t flags) {
+    ScopedTimer t(p, T_B);
+    HIP_TRY(p, vv::launch_b(p->hp.precision, make_args(p, flags, 0), p->block_threads, p->stream));
+    return VVHIP_OK;
+}
+int run_chain(vvhip_plan* p, uint32_t flags) {
+    ScopedTimer t(p, T_OTHER);
+    HIP_TRY(p, vv::launch_chain(make_chain(p, flags), p->d_nh, p->d_acc, p->stream));
+    return VVHIP_OK;
+}
+
+uint32_t extra_flags(const vvhip_plan* p) {
+    uint32_t f = 0;
+    if (p->hp.has_ld) f |= vv::A_LD;
+    if (p->hp.has_ef) f |= vv::A_EF;
+    if (p->hp.params.cos_acceleration != 0) f |= vv::A_COS;
+    return f;
+}
+uint32_t tail_flags(const vvhip_plan* p) {      // what follows every position update (HOST:203-212, API:266-268)
+    uint32_t f = 0;
+    if (p->hp.params.max_drude_distance > 0 && p->hp.has_pairs) f |= vv::B_HARDWALL;
+    if (p->hp.has_images) f |= vv::B_IMAGE;
+    return f;
+}
+bool cos_on(const vvhip_plan* p) { return p->hp.params.cos_acceleration != 0; }
+
+#define TRY(x)                       \
+    do {                             \
+        int rc_ = (x);               \
+        if (rc_ != VVHIP_OK) return rc_; \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+// ------------------------------------------------------------------------------------------ life cycle
+int vvhip_plan_create(const vvhip_system_desc* system, const vvhip_params* params, int precision, vvhip_plan** plan_out,
+                      char* errbuf, size_t errbuf_len) {
+    auto report = [&](int code, const std::string& msg) {
+        if (errbuf && errbuf_len) std::snprintf(errbuf, errbuf_len, "%s", msg.c_str());
+        return code;
+    };
+    if (!system || !params || !plan_out) return report(VVHIP_ERR_INVALID, "null argument");
+    try {
+        vvhip_plan* p = new vvhip_plan();
+        p->hp = vv::analyze(*system, *params, precision);
+        fill_scales(p);
+        // small systems: one wave per block spreads the work over more CUs (256 CUs, 8 XCDs)
+        p->block_threads = p->hp.info.num_waves >= 2048 ? 256 : (p->hp.info.num_waves >= 512 ? 128 : 64);
+        *plan_out = p;
+        return VVHIP_OK;
+    } catch (const vv::Error& e) {
+        return report(e.code, e.what());
+    } catch (const std::exception& e) {
+        return report(VVHIP_ERR_INVALID, e.what());
+    }
+}
+
+void vvhip_plan_destroy(vvhip_plan* p) {
+    if (!p) return;
+    if (p->bound) {
+        (void) hipStreamSynchronize(p->stream);
+        for (void* ptr : {(void*) p->d_slots, (void*) p->d_slot_image, (void*) p->d_slot_rand, (void*) p->d_image_pairs,
+                          p->d_fextra, p->d_old_delta, p->d_pos_delta, (void*) p->d_acc, (void*) p->d_nh})
+            if (ptr) (void) hipFree(ptr);
+        if (p->graph_exec) (void) hipGraphExecDestroy(p->graph_exec);
+        for (auto& v : p->events)
+            for (auto& e : v) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
+    }
+    delete p;
+}
+
+const char* vvhip_last_error(const vvhip_plan* p) { return p ? p->err.c_str() : "null plan"; }
+
+int vvhip_plan_get_info(const vvhip_plan* p, vvhip_plan_info* info) {
+    if (!p || !info) return VVHIP_ERR_INVALID;
+    *info = p->hp.info;
+    return VVHIP_OK;
+}
+
+int vvhip_plan_get_slots(const vvhip_plan* p, int32_t* slots, int32_t capacity) {
+    if (!p) return VVHIP_ERR_INVALID;
+    const int32_t n = p->hp.info.num_waves * 64;
+    if (slots) {
+        if (capacity < n) return VVHIP_ERR_INVALID;
+        std::memcpy(slots, p->hp.slots.data(), (size_t) n * 2 * sizeof(int32_t));
+    }
+    return n;
+}
+
+int vvhip_bind(vvhip_plan* p, const vvhip_buffers* b) {
+    if (!p || !b) return VVHIP_ERR_INVALID;
+    if (!b->velm || !b->posq || !b->force) return fail(p, VVHIP_ERR_INVALID, "velm, posq and force must be device pointers");
+    if (p->hp.precision == VVHIP_MIXED && !b->posq_correction)
+        return fail(p, VVHIP_ERR_INVALID, "mixed precision needs posq_correction (the reference's image kernel dereferences it too: quirk Q5)");
+    if (p->hp.has_ld && (!b->random || b->random_size == 0))
+        return fail(p, VVHIP_ERR_INVALID, "Langevin particles present but no random buffer bound");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(p, VVHIP_ERR_NO_DEVICE, "no HIP device: libvvhip has no CPU path");
+    p->buf = *b;
+    p->stream = (hipStream_t) b->stream;
+    if (p->bound) return VVHIP_OK;      // re-binding only swaps the caller-owned pointers
+    const vv::HostPlan& hp = p->hp;
+    const size_t nloc = (size_t) (hp.shard_end - hp.shard_begin);
+    const size_t nslots = (size_t) hp.info.num_waves * 64;
+    const size_t rs = sizeof_real(hp.precision), ms = sizeof_mixed(hp.precision);
+    HIP_TRY(p, hipMalloc((void**) &p->d_slots, nslots * sizeof(int2)));
+    HIP_TRY(p, hipMemcpy(p->d_slots, hp.slots.data(), nslots * sizeof(int2), hipMemcpyHostToDevice));
+    if (!hp.slot_image.empty()) {
+        HIP_TRY(p, hipMalloc((void**) &p->d_slot_image, nslots * sizeof(int32_t)));
+        HIP_TRY(p, hipMemcpy(p->d_slot_image, hp.slot_image.data(), nslots * sizeof(int32_t), hipMemcpyHostToDevice));
+        if (!hp.image_pairs.empty()) {
+            HIP_TRY(p, hipMalloc((void**) &p->d_image_pairs, hp.image_pairs.size() * sizeof(int32_t)));
+            HIP_TRY(p, hipMemcpy(p->d_image_pairs, hp.image_pairs.data(), hp.image_pairs.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+    }
+    if (!hp.slot_rand.empty()) {
+        HIP_TRY(p, hipMalloc((void**) &p->d_slot_rand, nslots * sizeof(int32_t)));
+        HIP_TRY(p, hipMemcpy(p->d_slot_rand, hp.slot_rand.data(), nslots * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(p, hipMalloc(&p->d_fextra, nloc * 3 * rs));            // zero-initialised like HOST:79-89
+    HIP_TRY(p, hipMemset(p->d_fextra, 0, nloc * 3 * rs));
+    HIP_TRY(p, hipMalloc(&p->d_old_delta, nloc * 4 * ms));
+    HIP_TRY(p, hipMemset(p->d_old_delta, 0, nloc * 4 * ms));
+    HIP_TRY(p, hipMalloc(&p->d_pos_delta, nloc * 4 * ms));
+    HIP_TRY(p, hipMemset(p->d_pos_delta, 0, nloc * 4 * ms));
+    HIP_TRY(p, hipMalloc((void**) &p->d_acc, vv::NUM_ACC * sizeof(unsigned long long)));
+    HIP_TRY(p, hipMemset(p->d_acc, 0, vv::NUM_ACC * sizeof(unsigned long long)));
+    HIP_TRY(p, hipMalloc((void**) &p->d_nh, sizeof(vv::NHDevState)));
+    vv::NHDevState init{};
+    for (int g = 0; g < 3; g++) { init.s.vscale[g] = 1.0; init.scales[g] = 1.0; }
+    HIP_TRY(p, hipMemcpy(p->d_nh, &init, sizeof(init), hipMemcpyHostToDevice));
+    p->bound = true;
+    return VVHIP_OK;
+}
+
+int vvhip_set_params(vvhip_plan* p, const vvhip_params* q) {
+    if (!p || !q) return VVHIP_ERR_INVALID;
+    // topology-affecting choices are frozen at plan creation (the reference bakes them into its tables/JIT defines)
+    vvhip_params n = *q;
+    n.use_com_temp_group = p->hp.params.use_com_temp_group;
+    n.num_nh_chains = p->hp.params.num_nh_chains;
+    if (p->hp.params.auto_set_friction && q->auto_set_friction) n.friction = p->hp.params.friction;
+    if ((q->cos_acceleration != 0) && p->hp.has_ld)
+        return fail(p, VVHIP_ERR_TOPOLOGY, "Langevin thermostat and periodic perturbation shouldn't be used together");
+    p->hp.params = n;
+    if (p->graph_exec) { (void) hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
+    return VVHIP_OK;
+}
+
+int vvhip_set_box(vvhip_plan* p, const double box[3]) {
+    if (!p || !box) return VVHIP_ERR_INVALID;
+    for (int i = 0; i < 3; i++) p->box[i] = box[i];
+    if (p->graph_exec) { (void) hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
+    return VVHIP_OK;
+}
+
+int vvhip_get_nh_state(vvhip_plan* p, vvhip_nh_state* out) {
+    NEED_BOUND(p);
+    HIP_TRY(p, hipStreamSynchronize(p->stream));
+    HIP_TRY(p, hipMemcpy(out, &p->d_nh->s, sizeof(*out), hipMemcpyDeviceToHost));
+    return VVHIP_OK;
+}
+int vvhip_set_nh_state(vvhip_plan* p, const vvhip_nh_state* in) {
+    NEED_BOUND(p);
+    HIP_TRY(p, hipStreamSynchronize(p->stream));
+    HIP_TRY(p, hipMemcpy(&p->d_nh->s, in, sizeof(*in), hipMemcpyHostToDevice));
+    return VVHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------ fused path
+int vvhip_step_middle_phases(const vvhip_plan* p) {
+    if (!p) return VVHIP_ERR_INVALID;
+    if (!p->hp.has_nh) return 1;
+    return cos_on(p) ? 3 : 2;
+}
+
+int vvhip_step_middle_phase(vvhip_plan* p, int phase, uint32_t random_index) {
+    NEED_BOUND(p);
+    const uint32_t kick = vv::A_KICK_FULL | extra_flags(p);
+    const uint32_t drift = vv::B_DRIFT_MIDDLE | tail_flags(p);
+    if (!p->hp.has_nh) {                                   // API:251: no NH particles, nothing to reduce
+        if (phase != 0) return fail(p, VVHIP_ERR_INVALID, "phase out of range");
+        TRY(run_a(p, kick, random_index));
+        return run_b(p, drift);
+    }
+    if (!cos_on(p)) {
+        if (phase == 0) return run_a(p, kick | vv::A_KE, random_index);
+        if (phase == 1) { TRY(run_chain(p, vv::C_CHAIN)); return run_b(p, vv::B_SCALE | drift); }
+    } else {                                               // API:252-259: bias -> remove -> scale -> restore
+        if (phase == 0) return run_a(p, kick | vv::A_BIAS, random_index);
+        if (phase == 1) return run_a(p, vv::A_KE | vv::A_UNBIAS_ACC, 0);
+        if (phase == 2) { TRY(run_chain(p, vv::C_CHAIN | vv::C_BIAS)); return run_b(p, vv::B_SCALE | vv::B_UNBIAS | drift); }
+    }
+    return fail(p, VVHIP_ERR_INVALID, "phase out of range");
+}
+
+int vvhip_accumulators(vvhip_plan* p, int phase, void** device_ptr, int32_t* count) {
+    NEED_BOUND(p);
+    if (!device_ptr || !count) return VVHIP_ERR_INVALID;
+    if (cos_on(p) && phase == 0) { *device_ptr = p->d_acc + 3; *count = 1; }    // bias moment only
+    else { *device_ptr = p->d_acc; *count = 3; }                                 // the three 2KE sums
+    return VVHIP_OK;
+}
+
+int vvhip_step_middle(vvhip_plan* p, uint32_t random_index) {
+    NEED_BOUND(p);
+    if (!p->hp.params.use_middle_scheme) return fail(p, VVHIP_ERR_INVALID, "plan was created for the classic scheme");
+    const int n = vvhip_step_middle_phases(p);
+    for (int ph = 0; ph < n; ph++) TRY(vvhip_step_middle_phase(p, ph, random_index));
+    return VVHIP_OK;
+}
+
+// NH half-step used by the classic scheme (API:295-304, 327-336); `b_extra` is fused into the scaling kernel.
+static int nh_half(vvhip_plan* p, uint32_t a_first, uint32_t random_index, uint32_t b_extra) {
+    if (!p->hp.has_nh) {
+        if (a_first) TRY(run_a(p, a_first, random_index));
+        if (b_extra) TRY(run_b(p, b_extra));
+        return VVHIP_OK;
+    }
+    if (!cos_on(p)) {
+        TRY(run_a(p, a_first | vv::A_KE, random_index));
+        TRY(run_chain(p, vv::C_CHAIN));
+        return run_b(p, vv::B_SCALE | b_extra);
+    }
+    TRY(run_a(p, a_first | vv::A_BIAS, random_index));
+    TRY(run_a(p, vv::A_KE | vv::A_UNBIAS_ACC, 0));
+    TRY(run_chain(p, vv::C_CHAIN | vv::C_BIAS));
+    return run_b(p, vv::B_SCALE | vv::B_UNBIAS | b_extra);
+}
+
+int vvhip_step_vv_first(vvhip_plan* p) {                   // API:295-310 (forces for the old positions are in `force`)
+    NEED_BOUND(p);
+    return nh_half(p, 0, 0, vv::B_VV_KICK | tail_flags(p));
+}
+
+int vvhip_step_vv_second(vvhip_plan* p, uint32_t random_index) {   // API:316-336 (forces for the new positions)
+    NEED_BOUND(p);
+    uint32_t ex = extra_flags(p);
+    if (ex) ex |= vv::A_FE_STORE;                          // the first half of the NEXT step kicks with these (API:316-323)
+    return nh_half(p, vv::A_KICK_HALF | ex, random_index, 0);
+}
+
+// ------------------------------------------------------------------------------------------ kernel-interface level
+int vvhip_reset_extra_force(vvhip_plan* p) {               // K/middle.cu:227-231
+    NEED_BOUND(p);
+    ScopedTimer t(p, T_OTHER);
+    const size_t nloc = (size_t) (p->hp.shard_end - p->hp.shard_begin);
+    HIP_TRY(p, hipMemsetAsync(p->d_fextra, 0, nloc * 3 * sizeof_real(p->hp.precision), p->stream));
+    return VVHIP_OK;
+}
+int vvhip_middle_kick(vvhip_plan* p) { NEED_BOUND(p); return run_a(p, vv::A_FE_LOAD | vv::A_KICK_FULL, 0); }
+int vvhip_middle_half_drift1(vvhip_plan* p) { NEED_BOUND(p); return run_a(p, vv::A_POS1, 0); }
+int vvhip_middle_half_drift2(vvhip_plan* p) { NEED_BOUND(p); return run_b(p, vv::B_POS2); }
+int vvhip_middle_finish(vvhip_plan* p) {
+    NEED_BOUND(p);
+    uint32_t f = vv::B_POS3;
+    if (p->hp.params.max_drude_distance > 0 && p->hp.has_pairs) f |= vv::B_HARDWALL;
+    return run_b(p, f);
+}
+int vvhip_vv_half_kick(vvhip_plan* p, int update_pos_delta) {
+    NEED_BOUND(p);
+    return run_a(p, vv::A_FE_LOAD | vv::A_KICK_HALF | (update_pos_delta ? vv::A_POSDELTA_VV : 0), 0);
+}
+int vvhip_vv_positions(vvhip_plan* p) {
+    NEED_BOUND(p);
+    uint32_t f = vv::B_VV_POS;
+    if (p->hp.params.max_drude_distance > 0 && p->hp.has_pairs) f |= vv::B_HARDWALL;
+    return run_b(p, f);
+}
+int vvhip_scale_velocity(vvhip_plan* p) {                  // HOST:670-754 without the download/upload
+    NEED_BOUND(p);
+    if (!p->hp.has_nh) return VVHIP_OK;
+    TRY(run_a(p, vv::A_KE, 0));
+    TRY(run_chain(p, vv::C_CHAIN));
+    return run_b(p, vv::B_SCALE);
+}
+int vvhip_apply_langevin_force(vvhip_plan* p, uint32_t random_index) {
+    NEED_BOUND(p);
+    if (!p->hp.has_ld) return VVHIP_OK;
+    return run_a(p, vv::A_FE_LOAD | vv::A_LD | vv::A_FE_STORE, random_index);
+}
+int vvhip_apply_electric_force(vvhip_plan* p) {
+    NEED_BOUND(p);
+    if (!p->hp.has_ef) return VVHIP_OK;
+    return run_a(p, vv::A_FE_LOAD | vv::A_EF | vv::A_FE_STORE, 0);
+}
+int vvhip_apply_cosine_force(vvhip_plan* p) {
+    NEED_BOUND(p);
+    return run_a(p, vv::A_FE_LOAD | vv::A_COS | vv::A_FE_STORE, 0);
+}
+int vvhip_calc_velocity_bias(vvhip_plan* p) {              // HOST:1061-1082
+    NEED_BOUND(p);
+    TRY(run_a(p, vv::A_BIAS, 0));
+    return run_chain(p, vv::C_BIAS);
+}
+int vvhip_remove_velocity_bias(vvhip_plan* p) { NEED_BOUND(p); return run_b(p, vv::B_BIAS_REMOVE); }
+int vvhip_restore_velocity_bias(vvhip_plan* p) { NEED_BOUND(p); return run_b(p, vv::B_BIAS_RESTORE); }
+int vvhip_calc_viscosity(vvhip_plan* p, double* v_max, double* inv_vis) {   // HOST:1112-1134, 8-byte download instead of N values
+    NEED_BOUND(p);
+    double v = 0;
+    HIP_TRY(p, hipStreamSynchronize(p->stream));
+    HIP_TRY(p, hipMemcpy(&v, &p->d_nh->s.v_bias, sizeof(double), hipMemcpyDeviceToHost));
+    if (p->hp.precision == VVHIP_SINGLE) v = (double) (float) v;             // vMaxBuffer is `mixed`
+    const double vol = p->box[0] * p->box[1] * p->box[2];
+    if (v_max) *v_max = v;
+    if (inv_vis)
+        *inv_vis = v * vol * p->hp.info.inv_mass_total / p->hp.params.cos_acceleration * (2 * 3.1415926 / p->box[2]) *
+                   (2 * 3.1415926 / p->box[2]);
+    return VVHIP_OK;
+}
+int vvhip_update_image_positions(vvhip_plan* p) {          // HOST:904-934
+    NEED_BOUND(p);
+    if (!p->hp.has_images) return VVHIP_OK;
+    ScopedTimer t(p, T_OTHER);
+    HIP_TRY(p, vv::launch_image_pairs(p->hp.precision, p->buf.posq, p->buf.posq_correction, p->d_image_pairs,
+                                      (int) p->hp.image_pairs.size() / 2, p->hp.params.mirror_location, p->stream));
+    return VVHIP_OK;
+}
+int vvhip_force_extra(vvhip_plan* p, void** device_ptr) {
+    NEED_BOUND(p);
+    if (!device_ptr) return VVHIP_ERR_INVALID;
+    *device_ptr = p->d_fextra;
+    return VVHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------ stand-alone host support
+int vvhip_device_count(int* count) {
+    if (!count) return VVHIP_ERR_INVALID;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    *count = e == hipSuccess ? n : 0;
+    return VVHIP_OK;
+}
+int vvhip_set_device(int device) { return hipSetDevice(device) == hipSuccess ? VVHIP_OK : VVHIP_ERR_HIP; }
+int vvhip_malloc(void** ptr, size_t bytes) { return hipMalloc(ptr, bytes ? bytes : 16) == hipSuccess ? VVHIP_OK : VVHIP_ERR_HIP; }
+int vvhip_free(void* ptr) { return hipFree(ptr) == hipSuccess ? VVHIP_OK : VVHIP_ERR_HIP; }
+int vvhip_memcpy_h2d(void* dst, const void* src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess ? VVHIP_OK : VVHIP_ERR_HIP; }
+int vvhip_memcpy_d2h(void* dst, const void* src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? VVHIP_OK : VVHIP_ERR_HIP; }
+int vvhip_memset(void* dst, int value, size_t bytes) { return hipMemset(dst, value, bytes) == hipSuccess ? VVHIP_OK : VVHIP_ERR_HIP; }
+int vvhip_synchronize(vvhip_plan* p) {
+    NEED_BOUND(p);
+    HIP_TRY(p, hipStreamSynchronize(p->stream));
+    return VVHIP_OK;
+}
+
+int vvhip_stream_create(void** stream) {
+    if (!stream) return VVHIP_ERR_INVALID;
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return VVHIP_ERR_HIP;
+    *stream = (void*) s;
+    return VVHIP_OK;
+}
+int vvhip_stream_destroy(void* stream) { return hipStreamDestroy((hipStream_t) stream) == hipSuccess ? VVHIP_OK : VVHIP_ERR_HIP; }
+
+int vvhip_synth_tether_force(vvhip_plan* p, const void* site, double k_tether, double k_drude) {
+    NEED_BOUND(p);
+    if (!site) return VVHIP_ERR_INVALID;
+    ScopedTimer t(p, T_OTHER);
+    vv::TetherArgs ta{p->buf.posq, site, p->buf.velm, (long long*) p->buf.force, p->d_slots,
+                      p->hp.padded_num_atoms, p->hp.info.num_waves, k_tether, k_drude};
+    HIP_TRY(p, vv::launch_tether(p->hp.precision, ta, p->block_threads, p->stream));
+    return VVHIP_OK;
+}
+
+int vvhip_run_graph(vvhip_plan* p, int nsteps, int steps_per_graph, const void* site, double k_tether, double k_drude) {
+    NEED_BOUND(p);
+    if (nsteps < 0 || steps_per_graph < 1) return VVHIP_ERR_INVALID;
+    if (!p->hp.params.use_middle_scheme) return fail(p, VVHIP_ERR_UNSUPPORTED, "graph replay covers the middle scheme only");
+    if (p->hp.has_ld) return fail(p, VVHIP_ERR_UNSUPPORTED, "graph replay with Langevin particles needs a per-step random index");
+    hipStream_t s = p->stream;
+    if (!s) return fail(p, VVHIP_ERR_INVALID, "graph capture needs a non-null stream in vvhip_buffers.stream");
+    auto one_step = [&]() -> int {
+        if (site) TRY(vvhip_synth_tether_force(p, site, k_tether, k_drude));
+        return vvhip_step_middle(p, 0);
+    };
+    if (!p->graph_exec || p->graph_steps != steps_per_graph || p->graph_site != site || p->graph_kt != k_tether || p->graph_kd != k_drude) {
+        if (p->graph_exec) { (void) hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
+        hipGraph_t g = nullptr;
+        HIP_TRY(p, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        p->capturing = true;
+        int rc = VVHIP_OK;
+        for (int i = 0; i < steps_per_graph && rc == VVHIP_OK; i++) rc = one_step();
+        p->capturing = false;
+        hipError_t e = hipStreamEndCapture(s, &g);
+        if (rc != VVHIP_OK) { if (g) (void) hipGraphDestroy(g); return rc; }
+        if (e != hipSuccess) return hip_fail(p, e, "hipStreamEndCapture");
+        e = hipGraphInstantiate(&p->graph_exec, g, nullptr, nullptr, 0);
+        (void) hipGraphDestroy(g);
+        if (e != hipSuccess) return hip_fail(p, e, "hipGraphInstantiate");
+        p->graph_steps = steps_per_graph; p->graph_site = site; p->graph_kt = k_tether; p->graph_kd = k_drude;
+    }
+    int done = 0;
+    for (; done + steps_per_graph <= nsteps; done += steps_per_graph) HIP_TRY(p, hipGraphLaunch(p->graph_exec, s));
+    for (; done < nsteps; done++) TRY(one_step());
+    return VVHIP_OK;
+}
+
+int vvhip_timing_enable(vvhip_plan* p, int enable) {
+    if (!p) return VVHIP_ERR_INVALID;
+    p->timing = enable != 0;
+    return VVHIP_OK;
+}
+int vvhip_timing_read(vvhip_plan* p, double* ms_a, double* ms_b, double* ms_other, int32_t* launches) {
+    NEED_BOUND(p);
+    HIP_TRY(p, hipStreamSynchronize(p->stream));
+    double tot[3] = {0, 0, 0};
+    int32_t n[3] = {0, 0, 0};
+    for (int c = 0; c < 3; c++) {
+        for (auto& e : p->events[c]) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) { tot[c] += ms; n[c]++; }
+            (void) hipEventDestroy(e.first);
+            (void) hipEventDestroy(e.second);
+        }
+        p->events[c].clear();
+    }
+    if (ms_a) *ms_a = tot[0];
+    if (ms_b) *ms_b = tot[1];
+    if (ms_other) *ms_other = tot[2];
+    if (launches) { launches[0] = n[0]; launches[1] = n[1]; launches[2] = n[2]; }
+    return VVHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------ test hooks
+int vvhip_debug_launch(vvhip_plan* p, int kernel, uint32_t flags, uint32_t random_index) {
+    NEED_BOUND(p);
+    if (kernel == 0) return run_a(p, flags, random_index);
+    if (kernel == 1) return run_b(p, flags);
+    if (kernel == 2) return run_chain(p, flags);
+    return VVHIP_ERR_INVALID;
+}
+int vvhip_debug_read_accumulators(vvhip_plan* p, double out[4], int zero_after) {
+    NEED_BOUND(p);
+    long long raw[vv::NUM_ACC];
+    HIP_TRY(p, hipStreamSynchronize(p->stream));
+    HIP_TRY(p, hipMemcpy(raw, p->d_acc, sizeof(raw), hipMemcpyDeviceToHost));
+    for (int i = 0; i < vv::NUM_ACC; i++) out[i] = (double) raw[i] * p->acc_inv_scale[i];
+    if (zero_after) HIP_TRY(p, hipMemset(p->d_acc, 0, sizeof(raw)));
+    return VVHIP_OK;
+}
+int vvhip_debug_set_scales(vvhip_plan* p, const double scales[4]) {
+    NEED_BOUND(p);
+    HIP_TRY(p, hipStreamSynchronize(p->stream));
+    HIP_TRY(p, hipMemcpy(p->d_nh->scales, scales, 4 * sizeof(double), hipMemcpyHostToDevice));
+    return VVHIP_OK;
+}
+
+int vvhip_debug_old_delta(vvhip_plan* p, void** device_ptr) {
+    NEED_BOUND(p);
+    if (!device_ptr) return VVHIP_ERR_INVALID;
+    *device_ptr = p->d_old_delta;
+    return VVHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,333 @@
+// vv_host.cpp -- see vv_host.hpp.  "API" = openmmapi/src/VVIntegrator.cpp, "HOST" =
+// platforms/cuda/src/CudaVVKernels.cpp of the reference.
+#include "vv_host.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+namespace vv {
+
+namespace {
+// SimTKOpenMMRealType.h of OpenMM 8.1.2 (not vendored by the reference): BOLTZ = RGAS / KILO
+constexpr double kAvogadro = 6.02214076e23;
+constexpr double kBoltz = (1.380649e-23 * kAvogadro) / 1000.0;
+enum { TG_ATOM = 0, TG_COM = 1, TG_DRUDE = 2 };
+
+struct Cluster {            // particles that must share one wave
+    int32_t first;          // smallest particle index (ordering key)
+    std::vector<int32_t> members;
+    bool com_segment;       // members form one molecular COM segment
+};
+}  // namespace
+
+HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, int precision) {
+    if (precision != VVHIP_SINGLE && precision != VVHIP_MIXED && precision != VVHIP_DOUBLE)
+        throw Error(VVHIP_ERR_INVALID, "unknown precision mode");
+    const int n = sys.num_atoms;
+    if (n <= 0 || !sys.masses || !sys.mol_id || sys.num_molecules <= 0)
+        throw Error(VVHIP_ERR_INVALID, "system description is empty");
+    if (sys.padded_num_atoms < n)
+        throw Error(VVHIP_ERR_INVALID, "padded_num_atoms < num_atoms");
+    if (params_in.num_nh_chains < 1 || params_in.num_nh_chains > VVHIP_MAX_CHAINS)
+        throw Error(VVHIP_ERR_UNSUPPORTED, "numNHChains must be between 1 and " + std::to_string(VVHIP_MAX_CHAINS));
+    if (params_in.loops_per_step < 1)
+        throw Error(VVHIP_ERR_INVALID, "loopsPerStep must be >= 1");
+
+    HostPlan hp;
+    hp.precision = precision;
+    hp.params = params_in;
+    hp.num_atoms = n;
+    hp.padded_num_atoms = sys.padded_num_atoms;
+    vvhip_params& p = hp.params;
+    const int nmol = sys.num_molecules;
+    const int npairs_all = sys.num_drude_pairs;
+
+    // ---- API:106-121: thermostat defaults depend on whether the System has Drude particles
+    if (npairs_all == 0) {
+        if (p.auto_set_com_temp_group) p.use_com_temp_group = 0;
+        if (p.auto_set_friction) p.friction = 1.0;
+    } else {
+        if (p.auto_set_com_temp_group) p.use_com_temp_group = 1;
+        if (p.auto_set_friction) p.friction = 5.0;
+    }
+
+    // ---- API:123-135: molecule masses
+    for (int i = 0; i < n; i++)
+        if (sys.mol_id[i] < 0 || sys.mol_id[i] >= nmol)
+            throw Error(VVHIP_ERR_INVALID, "mol_id out of range");
+    std::vector<double> mol_mass(nmol, 0.0), mol_inv_mass(nmol);
+    for (int i = 0; i < n; i++) mol_mass[sys.mol_id[i]] += sys.masses[i];
+    for (int m = 0; m < nmol; m++) mol_inv_mass[m] = 1.0 / mol_mass[m];
+
+    // ---- API:138-151: NH / Langevin / image partition
+    std::vector<char> is_ld(n, 0), is_img(n, 0), is_el(n, 0);
+    auto check_index = [&](int i, const char* what) {
+        if (i < 0 || i >= n) throw Error(VVHIP_ERR_INVALID, std::string(what) + " index out of range");
+    };
+    for (int k = 0; k < sys.num_particles_ld; k++) { check_index(sys.particles_ld[k], "Langevin particle"); is_ld[sys.particles_ld[k]] = 1; }
+    std::vector<int32_t> image_of(n, -1);
+    for (int k = 0; k < sys.num_image_pairs; k++) {
+        int img = sys.image_pairs[2 * k], par = sys.image_pairs[2 * k + 1];
+        check_index(img, "image particle"); check_index(par, "image parent");
+        is_img[img] = 1;
+        if (image_of[par] >= 0)
+            throw Error(VVHIP_ERR_UNSUPPORTED, "a particle with more than one image particle is not supported");
+        image_of[par] = img;
+    }
+    for (int k = 0; k < sys.num_electrolyte; k++) { check_index(sys.particles_electrolyte[k], "electrolyte particle"); is_el[sys.particles_electrolyte[k]] = 1; }
+    std::vector<char> is_nh(n, 0), mol_is_nh(nmol, 0);
+    for (int i = 0; i < n; i++) {
+        if (!is_ld[i] && !is_img[i]) {
+            is_nh[i] = 1;
+            hp.particles_nh.push_back(i);
+            if (!mol_is_nh[sys.mol_id[i]]) { mol_is_nh[sys.mol_id[i]] = 1; hp.molecules_nh.push_back(sys.mol_id[i]); }
+        }
+    }
+    for (int i = 0; i < n; i++)
+        if (is_ld[i] && mol_is_nh[sys.mol_id[i]])
+            throw Error(VVHIP_ERR_TOPOLOGY, "NH and Langevin thermostat cannot be applied on the same molecule");
+    if (sys.num_particles_ld > 0 && p.cos_acceleration != 0)   // API:154-155
+        throw Error(VVHIP_ERR_TOPOLOGY, "Langevin thermostat and periodic perturbation shouldn't be used together");
+
+    // ---- HOST:496-529: DOF of the atomic group, NH pairs
+    double dof[3] = {0, 0, 0};
+    for (int i = 0; i < n; i++) {
+        const double mass = sys.masses[i];
+        if (is_nh[i] && mass != 0.0) {
+            dof[TG_ATOM] += 3;
+            if (p.use_com_temp_group) dof[TG_ATOM] -= 3 * mass * mol_inv_mass[sys.mol_id[i]];
+        }
+    }
+    std::vector<int32_t> partner(n, -1);
+    std::vector<char> is_drude(n, 0), in_pair(n, 0);
+    std::vector<char> nh_left(is_nh.begin(), is_nh.end()), ld_left(is_ld.begin(), is_ld.end());
+    for (int k = 0; k < npairs_all; k++) {
+        int d = sys.drude_pairs[2 * k], par = sys.drude_pairs[2 * k + 1];
+        check_index(d, "Drude particle"); check_index(par, "Drude parent");
+        if (in_pair[d] || in_pair[par] || d == par)
+            throw Error(VVHIP_ERR_UNSUPPORTED, "a particle that belongs to two Drude pairs is not supported");
+        in_pair[d] = in_pair[par] = 1;
+        is_drude[d] = 1;
+        partner[d] = par; partner[par] = d;
+        if (is_nh[d] != is_nh[par] || is_ld[d] != is_ld[par])   // HOST:518-519, 786-787
+            throw Error(VVHIP_ERR_TOPOLOGY, "Drude particle and its parent atom should be in the same thermostat");
+        if (is_nh[d]) {
+            nh_left[d] = nh_left[par] = 0;
+            hp.pairs_nh.push_back(d); hp.pairs_nh.push_back(par);
+            dof[TG_ATOM] -= 3;
+            dof[TG_DRUDE] += 3;
+        }
+        if (is_ld[d]) {                                          // HOST:788-792
+            ld_left[d] = ld_left[par] = 0;
+            hp.pairs_ld.push_back(d); hp.pairs_ld.push_back(par);
+        }
+    }
+    for (int i = 0; i < n; i++) {
+        if (nh_left[i]) hp.normal_nh.push_back(i);               // std::set order = ascending
+        if (ld_left[i]) hp.normal_ld.push_back(i);
+    }
+    // ---- HOST:531-541, 796-802: constraints
+    for (int k = 0; k < sys.num_constraints; k++) {
+        int a = sys.constraints[2 * k], b = sys.constraints[2 * k + 1];
+        check_index(a, "constraint"); check_index(b, "constraint");
+        if (is_nh[a] != is_nh[b] || is_ld[a] != is_ld[b])
+            throw Error(VVHIP_ERR_TOPOLOGY, "Constrained particle pair should be in the same thermostat");
+        if (is_nh[a]) dof[TG_ATOM] -= 1;
+    }
+    // ---- HOST:547-573
+    if (p.use_com_temp_group) dof[TG_COM] = 3.0 * (double) hp.molecules_nh.size();
+    if (sys.has_cm_motion_remover) {
+        if (p.use_com_temp_group) dof[TG_COM] -= 3;
+        else dof[TG_ATOM] -= 3;
+    }
+    for (double& d : dof) d = std::max(d, 0.0);
+    int num_tg = 3;
+    if (dof[TG_DRUDE] == 0) {
+        num_tg = 2;
+        if (dof[TG_COM] == 0) num_tg = 1;
+    }
+    // ---- HOST:577-594: chain masses
+    vvhip_plan_info& info = hp.info;
+    std::memset(&info, 0, sizeof(info));
+    const double real_kbt = kBoltz * p.temperature, drude_kbt = kBoltz * p.drude_temperature;
+    for (int i = 0; i < num_tg; i++) {
+        const double kbt = i == TG_DRUDE ? drude_kbt : real_kbt;
+        const double tg_mass = i == TG_DRUDE ? drude_kbt / std::pow(p.drude_frequency, 2) : real_kbt / std::pow(p.frequency, 2);
+        info.nkbt[i] = dof[i] * kbt;
+        info.eta_mass[i][0] = dof[i] * tg_mass;
+        for (int c = 1; c < p.num_nh_chains; c++) info.eta_mass[i][c] = tg_mass;
+    }
+    for (int i = 0; i < 3; i++) info.dof[i] = dof[i];
+    double mass_total = 0;                                      // HOST:1028-1031
+    for (int i = 0; i < n; i++) mass_total += sys.masses[i];
+    info.inv_mass_total = 1.0 / mass_total;
+    info.num_particles_nh = (int) hp.particles_nh.size();
+    info.num_molecules_nh = (int) hp.molecules_nh.size();
+    info.num_normal_nh = (int) hp.normal_nh.size();
+    info.num_pairs_nh = (int) hp.pairs_nh.size() / 2;
+    info.num_normal_ld = (int) hp.normal_ld.size();
+    info.num_pairs_ld = (int) hp.pairs_ld.size() / 2;
+    info.num_images = sys.num_image_pairs;
+    info.num_electrolyte = sys.num_electrolyte;
+    info.num_temp_groups = num_tg;
+    info.use_com_temp_group = p.use_com_temp_group;
+    info.friction = p.friction;
+    hp.has_nh = !hp.particles_nh.empty();
+    hp.has_ld = sys.num_particles_ld > 0;
+    hp.has_ef = sys.num_electrolyte > 0;
+    hp.has_images = sys.num_image_pairs > 0;
+    hp.has_pairs = npairs_all > 0;
+
+    // ---- shard
+    int sb = sys.shard_begin, se = sys.shard_end;
+    if (sb == 0 && se == 0) se = n;
+    if (sb < 0 || se > n || sb >= se) throw Error(VVHIP_ERR_INVALID, "bad particle shard range");
+    hp.shard_begin = sb; hp.shard_end = se;
+    auto in_shard = [&](int i) { return i >= sb && i < se; };
+
+    // ---- Langevin random offsets (K/drudeLangevin.cu:20,30,51-52): normal i -> i, pair i -> Nn + 2 i
+    std::vector<int32_t> rand_of(n, -1);
+    for (size_t i = 0; i < hp.normal_ld.size(); i++) rand_of[hp.normal_ld[i]] = (int32_t) i;
+    for (size_t i = 0; i < hp.pairs_ld.size() / 2; i++)
+        rand_of[hp.pairs_ld[2 * i]] = rand_of[hp.pairs_ld[2 * i + 1]] = (int32_t) (hp.normal_ld.size() + 2 * i);
+
+    // ---- which particles need a lane, and which must share a wave
+    auto needs_lane = [&](int i) {
+        if (sys.masses[i] != 0.0) return true;      // anything massive is integrated
+        if (in_pair[i]) return true;                // massless Drude parent (hard-wall branch K/middle.cu:151-173)
+        if (image_of[i] >= 0) return true;          // massless image parent: only the mirror copy
+        return false;
+    };
+    std::vector<Cluster> clusters;
+    std::vector<int32_t> cluster_of_mol(nmol, -1);
+    std::vector<char> done(n, 0);
+    for (int i = sb; i < se; i++) {
+        if (done[i] || !needs_lane(i)) continue;
+        const bool com = p.use_com_temp_group && is_nh[i];
+        if (com) {
+            int m = sys.mol_id[i];
+            if (cluster_of_mol[m] < 0) {
+                cluster_of_mol[m] = (int32_t) clusters.size();
+                clusters.push_back(Cluster{i, {}, true});
+            }
+            clusters[cluster_of_mol[m]].members.push_back(i);
+            done[i] = 1;
+        } else {
+            Cluster c{i, {i}, false};
+            done[i] = 1;
+            if (in_pair[i]) {
+                int q = partner[i];
+                if (!in_shard(q)) throw Error(VVHIP_ERR_INVALID, "particle shard cuts a Drude pair");
+                c.members.push_back(q);
+                done[q] = 1;
+                std::sort(c.members.begin(), c.members.end());
+                c.first = c.members[0];
+            }
+            clusters.push_back(c);
+        }
+    }
+    // a COM cluster must contain the whole molecule's thermostatted particles: check the shard did not cut it
+    if (p.use_com_temp_group)
+        for (int i = 0; i < n; i++)
+            if (is_nh[i] && needs_lane(i) && !in_shard(i) && cluster_of_mol[sys.mol_id[i]] >= 0)
+                throw Error(VVHIP_ERR_INVALID, "particle shard cuts a molecule");
+    std::stable_sort(clusters.begin(), clusters.end(), [](const Cluster& a, const Cluster& b) { return a.first < b.first; });
+    int max_cluster = 0;
+    for (auto& c : clusters) {
+        std::sort(c.members.begin(), c.members.end());
+        max_cluster = std::max(max_cluster, (int) c.members.size());
+    }
+    info.max_cluster = max_cluster;
+    if (max_cluster > 64)
+        throw Error(VVHIP_ERR_UNSUPPORTED,
+                    "a molecule with more than 64 thermostatted particles cannot use the COM temperature group "
+                    "in this backend yet (setUseCOMTempGroup(false) works)");
+
+    // ---- greedy wave packing in particle order
+    std::vector<int32_t>& slots = hp.slots;
+    int lane = 0, wave = -1;
+    auto new_wave = [&]() {
+        wave++;
+        lane = 0;
+        slots.resize((size_t) (wave + 1) * 128);
+        for (int l = 0; l < 64; l++) { slots[(size_t) wave * 128 + 2 * l] = -1; slots[(size_t) wave * 128 + 2 * l + 1] = 0; }
+    };
+    new_wave();
+    std::vector<int32_t> lane_of(n, -1), wave_of(n, -1);
+    int used = 0;
+    for (const Cluster& c : clusters) {
+        const int sz = (int) c.members.size();
+        if (lane + sz > 64) new_wave();
+        const int first_lane = lane, last_lane = lane + sz - 1;
+        for (int k = 0; k < sz; k++) { lane_of[c.members[k]] = lane + k; wave_of[c.members[k]] = wave; }
+        bool leader_set = false;
+        for (int k = 0; k < sz; k++, lane++) {
+            const int i = c.members[k];
+            uint32_t role;
+            const bool massive = sys.masses[i] != 0.0;
+            if (is_nh[i] && (massive || in_pair[i]))
+                role = in_pair[i] ? (is_drude[i] ? ROLE_NH_DRUDE : ROLE_NH_PARENT) : ROLE_NH_NORMAL;
+            else if (is_ld[i] && (massive || in_pair[i]))
+                role = in_pair[i] ? (is_drude[i] ? ROLE_LD_DRUDE : ROLE_LD_PARENT) : ROLE_LD_NORMAL;
+            else
+                role = massive ? ROLE_PLAIN : ROLE_NONE;
+            uint32_t meta = role;
+            const int pl = in_pair[i] ? lane_of[partner[i]] >= 0 ? lane_of[partner[i]] : lane : lane;
+            meta |= (uint32_t) pl << META_PARTNER_SHIFT;
+            const int sf = c.com_segment ? first_lane : lane, sl = c.com_segment ? last_lane : lane;
+            meta |= (uint32_t) sf << META_SEGFIRST_SHIFT;
+            meta |= (uint32_t) sl << META_SEGLAST_SHIFT;
+            if (is_el[i]) meta |= META_EFIELD;
+            if (image_of[i] >= 0) meta |= META_HAS_IMAGE;
+            if (c.com_segment && !leader_set) { meta |= META_COM_LEADER; leader_set = true; }
+            if (in_pair[i]) meta |= META_PAIR;
+            if (is_drude[i]) meta |= META_IS_DRUDE;
+            slots[(size_t) wave * 128 + 2 * lane] = i - sb;
+            slots[(size_t) wave * 128 + 2 * lane + 1] = (int32_t) meta;
+            used++;
+        }
+    }
+    // partner lanes were only known for the earlier member of each pair: fix them up
+    const int nwaves = wave + 1;
+    for (int w = 0; w < nwaves; w++)
+        for (int l = 0; l < 64; l++) {
+            int32_t a = slots[(size_t) w * 128 + 2 * l];
+            if (a < 0) continue;
+            const int i = a + sb;
+            if (in_pair[i]) {
+                if (wave_of[partner[i]] != w)
+                    throw Error(VVHIP_ERR_UNSUPPORTED, "a Drude particle and its parent are in different molecules");
+                uint32_t meta = (uint32_t) slots[(size_t) w * 128 + 2 * l + 1];
+                meta &= ~(0x3Fu << META_PARTNER_SHIFT);
+                meta |= (uint32_t) lane_of[partner[i]] << META_PARTNER_SHIFT;
+                slots[(size_t) w * 128 + 2 * l + 1] = (int32_t) meta;
+            }
+        }
+    info.num_waves = nwaves;
+    info.num_slots_used = used;
+
+    if (hp.has_images) {
+        hp.slot_image.assign((size_t) nwaves * 64, -1);
+        for (int k = 0; k < sys.num_image_pairs; k++) {
+            int img = sys.image_pairs[2 * k], par = sys.image_pairs[2 * k + 1];
+            if (!in_shard(par)) continue;
+            if (!in_shard(img)) throw Error(VVHIP_ERR_UNSUPPORTED, "image particle outside its parent's shard (image charges are single-GPU)");
+            hp.image_pairs.push_back(img - sb);
+            hp.image_pairs.push_back(par - sb);
+        }
+    }
+    if (hp.has_ld) hp.slot_rand.assign((size_t) nwaves * 64, -1);
+    if (hp.has_images || hp.has_ld)
+        for (int w = 0; w < nwaves; w++)
+            for (int l = 0; l < 64; l++) {
+                int32_t a = slots[(size_t) w * 128 + 2 * l];
+                if (a < 0) continue;
+                if (hp.has_images && image_of[a + sb] >= 0) hp.slot_image[(size_t) w * 64 + l] = image_of[a + sb] - sb;
+                if (hp.has_ld) hp.slot_rand[(size_t) w * 64 + l] = rand_of[a + sb];
+            }
+    return hp;
+}
+
+}  // namespace vv

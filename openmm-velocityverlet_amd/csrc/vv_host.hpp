@@ -1,0 +1,71 @@
+// vv_host.hpp -- host-side analysis shared by libvvhip (C ABI) and the openmmapi layer. No HIP here.
+//
+// Restates, for the HIP backend, what the reference spreads over VVIntegrator::initialize
+// (openmmapi/src/VVIntegrator.cpp:92-188) and the initialize() methods of the seven Cuda*Kernel
+// classes (platforms/cuda/src/CudaVVKernels.cpp:56-117, 462-667, 761-824, 878-902, 940-969,
+// 998-1035) -- "HOST" below -- and then lays the particles out for one-work-item-per-particle
+// kernels on 64-lane wavefronts.
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/vvhip.h"
+
+namespace vv {
+
+// Stands in for OpenMMException inside the core; carries the vvhip error code.
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+// ---- role word of one lane ("slot"): what this particle needs from the kernels -----------------
+enum Role : uint32_t {
+    ROLE_NONE = 0,       // no integration work (idle lane, or a massless particle kept only as image parent)
+    ROLE_PLAIN = 1,      // massive, neither NH nor Langevin (a massive image particle): kick + drift only
+    ROLE_NH_NORMAL = 2,  // NH thermostat, not in a Drude pair      (normalParticlesNH, HOST:529)
+    ROLE_NH_DRUDE = 3,   // NH, Drude particle of a pair (pair.x)   (pairParticlesNH,   HOST:523)
+    ROLE_NH_PARENT = 4,  // NH, parent atom of a pair (pair.y)
+    ROLE_LD_NORMAL = 5,  // Langevin subset                          (normalParticlesLD, HOST:804)
+    ROLE_LD_DRUDE = 6,   //                                          (pairParticlesLD,   HOST:791)
+    ROLE_LD_PARENT = 7,
+};
+constexpr uint32_t META_ROLE_MASK = 0xF;
+constexpr int META_PARTNER_SHIFT = 4;    // 6 bits: lane of the Drude partner (own lane if none)
+constexpr int META_SEGFIRST_SHIFT = 10;  // 6 bits: first lane of this lane's COM segment (molecule)
+constexpr int META_SEGLAST_SHIFT = 16;   // 6 bits: last lane of the segment
+constexpr uint32_t META_EFIELD = 1u << 22;     // particle is in particlesElectrolyte
+constexpr uint32_t META_HAS_IMAGE = 1u << 23;  // particle is the parent of an image particle
+constexpr uint32_t META_COM_LEADER = 1u << 24; // lane that adds its molecule's M*V^2 to TG_COM
+constexpr uint32_t META_PAIR = 1u << 25;       // member of a DrudeForce pair (hard wall applies)
+constexpr uint32_t META_IS_DRUDE = 1u << 26;   // the Drude (pair.x) of that pair
+
+inline uint32_t meta_role(uint32_t m) { return m & META_ROLE_MASK; }
+
+struct ResolvedParams : vvhip_params {};
+
+struct HostPlan {
+    int precision = VVHIP_MIXED;
+    vvhip_params params{};          // after the auto rules of API:106-121
+    vvhip_plan_info info{};
+    int32_t num_atoms = 0, padded_num_atoms = 0;
+    int32_t shard_begin = 0, shard_end = 0;
+    bool has_nh = false, has_ld = false, has_ef = false, has_images = false, has_pairs = false;
+    // work-item layout: 64 lanes per wave; slots[2*i] = shard-relative particle index or -1, slots[2*i+1] = meta
+    std::vector<int32_t> slots;
+    std::vector<int32_t> slot_image;   // [64*waves] shard-relative image particle of this lane's particle, or -1
+    std::vector<int32_t> slot_rand;    // [64*waves] offset into the Langevin slice of the random buffer, or -1
+    std::vector<int32_t> image_pairs;  // (image, parent) shard-relative, for the stand-alone image kernel
+    // reference-style tables, kept for inspection / tests (global particle indices)
+    std::vector<int32_t> particles_nh, molecules_nh, normal_nh, pairs_nh, normal_ld, pairs_ld;
+};
+
+// Throws vv::Error.  `sys` pointers are only read during the call.
+HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params, int precision);
+
+// CudaModifyDrudeNoseKernel::initialize's chain sizing for changed parameters is NOT redone on
+// set_params (the reference fixes etaMass / NkbT at initialize, HOST:583-594).
+
+}  // namespace vv

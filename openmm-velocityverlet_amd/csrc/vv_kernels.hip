@@ -1,0 +1,683 @@
+// vv_kernels.hip -- hand-written HIP kernels for gfx950 (MI355X, wave64).
+//
+// Work-item layout.  One work-item per particle; a 64-lane wave holds whole "clusters": every Drude
+// pair, and (with the COM temperature group) every molecule, sits inside ONE wave (vv_host.cpp).
+// Hence
+//   * the Drude partner's velocity/position comes from a cross-lane shuffle, not a second gather;
+//   * the molecular centre-of-mass velocity is a segmented wave scan, not the reference's serial
+//     per-molecule read-modify-write in global memory (K/drudeNoseHoover.cu:15-25);
+//   * per-group kinetic energies are reduced wave -> LDS -> one 64-bit fixed-point atomic per block,
+//     so the global sums do not depend on arrival order (bit-reproducible) and need no second
+//     "single block" pass (K/drudeNoseHoover.cu:121-151) nor a host round trip (HOST:709-746).
+// Global loads are 16/32-byte per lane and, for contiguous molecules, fully coalesced.
+//
+// Arithmetic.  Each expression keeps the operand types and association of the reference kernel it
+// replaces (cited per stage; K/ = platforms/cuda/src/kernels/) and the library is built with
+// -ffp-contract=off, so element-wise results equal the CPU oracle bit for bit; only the order of
+// the reductions differs.  No MFMA: there is no contraction on this path (HBM/latency bound).
+#include "vv_kernels.hpp"
+
+#include "vv_host.hpp"
+
+namespace vv {
+
+template <class T> struct Vec;
+template <> struct Vec<float> { using v4 = float4; using v3 = float3; };
+template <> struct Vec<double> { using v4 = double4; using v3 = double3; };
+
+// What OpenMM's context prepends to the reference kernels (assumption stated in oracle/ref_prelude.h):
+// single-precision sqrt/recip literals unless the `real` type is double.
+template <class real> struct Prec;
+template <> struct Prec<float> {
+    template <class T> static __device__ __forceinline__ float SQRT(T x) { return sqrtf((float) x); }
+    static __device__ __forceinline__ float RECIP(float x) { return 1.0f / x; }
+    static __device__ __forceinline__ double RECIP(double x) { return 1.0f / x; }
+};
+template <> struct Prec<double> {
+    static __device__ __forceinline__ double SQRT(double x) { return sqrt(x); }
+    static __device__ __forceinline__ double RECIP(double x) { return 1.0 / x; }
+};
+
+__device__ __forceinline__ float shfl(float x, int src) { return __shfl(x, src, 64); }
+__device__ __forceinline__ double shfl(double x, int src) { return __shfl(x, src, 64); }
+__device__ __forceinline__ float shfl_up(float x, int d) { return __shfl_up(x, d, 64); }
+__device__ __forceinline__ double shfl_up(double x, int d) { return __shfl_up(x, d, 64); }
+
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) x += __shfl_down(x, d, 64);
+    return x;   // valid in lane 0
+}
+
+// Segmented inclusive scan over contiguous lanes [first, last], then broadcast of the segment total.
+template <class T>
+__device__ __forceinline__ T segment_total(T x, int lane, int first, int last) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        T t = shfl_up(x, d);
+        if (lane - d >= first) x += t;
+    }
+    return shfl(x, last);
+}
+
+// Block partials -> fixed-point atomics.  vals[k] is the calling thread's contribution.
+template <int NV>
+__device__ __forceinline__ void block_accumulate(const double (&vals)[NV], const bool (&enabled)[NV],
+                                                 unsigned long long* acc, const double* scale) {
+    __shared__ double red[16][NV];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        double s = wave_sum(vals[k]);
+        if (lane == 0) red[w][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV && enabled[threadIdx.x]) {
+        double s = 0;
+        for (int i = 0; i < nw; i++) s += red[i][threadIdx.x];
+        const long long q = __double2ll_rn(s * scale[threadIdx.x]);
+        if (q != 0) atomicAdd(&acc[threadIdx.x], (unsigned long long) q);
+    }
+}
+
+template <class real>
+__device__ __forceinline__ double cos_kz(real z, real inv_box_z) {
+    return cos(2 * 3.1415926 * z * inv_box_z);   // literal pi and double cosine in every mode (quirk Q2)
+}
+
+// Molecular centre-of-mass velocity of this lane's segment (K/drudeNoseHoover.cu:5-31):
+// V = (sum m v) * RECIP(sum m), with comVelm.w = RECIP(sum m).
+template <class real, class mixed>
+__device__ __forceinline__ void com_velocity(bool contributes, mixed vx, mixed vy, mixed vz, mixed w, int lane,
+                                             unsigned meta, mixed& Vx, mixed& Vy, mixed& Vz, mixed& Vw) {
+    const int first = (meta >> META_SEGFIRST_SHIFT) & 63, last = (meta >> META_SEGLAST_SHIFT) & 63;
+    mixed mass = 0, mx = 0, my = 0, mz = 0;
+    if (contributes) {
+        mass = Prec<real>::RECIP(w);
+        mx = vx * mass; my = vy * mass; mz = vz * mass;
+    }
+    mx = segment_total(mx, lane, first, last);
+    my = segment_total(my, lane, first, last);
+    mz = segment_total(mz, lane, first, last);
+    mass = segment_total(mass, lane, first, last);
+    Vw = Prec<real>::RECIP(mass);
+    Vx = mx * Vw; Vy = my * Vw; Vz = mz * Vw;
+}
+
+// ================================================================================ kernel A
+template <class real, class mixed>
+__global__ void __launch_bounds__(256) vv_kernel_a(const KArgs a) {
+    using real4 = typename Vec<real>::v4;
+    using real3 = typename Vec<real>::v3;
+    using mixed4 = typename Vec<mixed>::v4;
+    using P = Prec<real>;
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t F = a.flags;
+    double k_atom = 0, k_com = 0, k_drude = 0, k_bias = 0;
+
+    if (wave < a.nwaves) {
+        const int2 slot = a.slots[(size_t) wave * 64 + lane];
+        const int atom = slot.x;
+        const unsigned meta = (unsigned) slot.y;
+        const unsigned role = meta & META_ROLE_MASK;
+        const int partner = (meta >> META_PARTNER_SHIFT) & 63;
+        const bool act = atom >= 0;
+        mixed4* velm = (mixed4*) a.velm;
+        mixed4 v = {0, 0, 0, 0};
+        if (act) v = velm[atom];
+        const bool massive = act && v.w != 0;
+        const mixed stepSize = (mixed) a.dt;
+
+        real4 pq = {0, 0, 0, 0};
+        const bool need_pos = (F & (A_COS | A_BIAS | A_UNBIAS_ACC)) || ((F & A_EF) && (meta & META_EFIELD));
+        if (act && need_pos) pq = ((const real4*) a.posq)[atom];
+
+        // ---------------- extra force (VVIntegrator.cpp:238-245), accumulated in `real` like forceExtra
+        real3 fe = {0, 0, 0};
+        if ((F & A_FE_LOAD) && act) fe = ((const real3*) a.fextra)[atom];
+        if (F & A_LD) {
+            const mixed pvx = shfl(v.x, partner), pvy = shfl(v.y, partner), pvz = shfl(v.z, partner), pvw = shfl(v.w, partner);
+            const mixed dragFactor = (mixed) a.drag, randFactor = (mixed) a.randf;
+            const mixed dragFactorDrude = (mixed) a.drag_drude, randFactorDrude = (mixed) a.randf_drude;
+            if (role == ROLE_LD_NORMAL && massive) {                        // K/drudeLangevin.cu:14-25
+                const mixed mass = P::RECIP(v.w);
+                const mixed sqrtMass = P::SQRT(mass);
+                const float4 rnd = a.random[a.random_index + a.slot_rand[(size_t) wave * 64 + lane]];
+                fe.x += (-dragFactor * mass * v.x + randFactor * sqrtMass * rnd.x);
+                fe.y += (-dragFactor * mass * v.y + randFactor * sqrtMass * rnd.y);
+                fe.z += (-dragFactor * mass * v.z + randFactor * sqrtMass * rnd.z);
+            } else if (role == ROLE_LD_DRUDE || role == ROLE_LD_PARENT) {   // K/drudeLangevin.cu:29-59
+                const bool isd = role == ROLE_LD_DRUDE;
+                const mixed v1x = isd ? v.x : pvx, v1y = isd ? v.y : pvy, v1z = isd ? v.z : pvz, v1w = isd ? v.w : pvw;
+                const mixed v2x = isd ? pvx : v.x, v2y = isd ? pvy : v.y, v2z = isd ? pvz : v.z, v2w = isd ? pvw : v.w;
+                const mixed mass1 = P::RECIP(v1w), mass2 = P::RECIP(v2w);
+                const mixed totMass = mass1 + mass2;
+                const mixed sqrtTotMass = P::SQRT(totMass);
+                const mixed redMass = P::RECIP((mass1 + mass2) * v1w * v2w);
+                const mixed sqrtRedMass = P::SQRT(redMass);
+                const mixed invTotMass = P::RECIP(totMass);
+                const mixed mass1fract = invTotMass * mass1, mass2fract = invTotMass * mass2;
+                const mixed cmx = v1x * mass1fract + v2x * mass2fract;
+                const mixed cmy = v1y * mass1fract + v2y * mass2fract;
+                const mixed cmz = v1z * mass1fract + v2z * mass2fract;
+                const mixed rx = v2x - v1x, ry = v2y - v1y, rz = v2z - v1z;
+                const unsigned ri = a.random_index + a.slot_rand[(size_t) wave * 64 + lane];
+                const float4 rand1 = a.random[ri], rand2 = a.random[ri + 1];
+                real3 cmForce, relForce;
+                cmForce.x = (-dragFactor * totMass * cmx + randFactor * sqrtTotMass * rand1.x);
+                cmForce.y = (-dragFactor * totMass * cmy + randFactor * sqrtTotMass * rand1.y);
+                cmForce.z = (-dragFactor * totMass * cmz + randFactor * sqrtTotMass * rand1.z);
+                relForce.x = (-dragFactorDrude * redMass * rx + randFactorDrude * sqrtRedMass * rand2.x);
+                relForce.y = (-dragFactorDrude * redMass * ry + randFactorDrude * sqrtRedMass * rand2.y);
+                relForce.z = (-dragFactorDrude * redMass * rz + randFactorDrude * sqrtRedMass * rand2.z);
+                if (isd) {      // scalar * real3 narrows the mass fraction to `real` (K/vectorOps.cu:427,451)
+                    const real m1f = (real) mass1fract;
+                    fe.x += m1f * cmForce.x - relForce.x; fe.y += m1f * cmForce.y - relForce.y; fe.z += m1f * cmForce.z - relForce.z;
+                } else {
+                    const real m2f = (real) mass2fract;
+                    fe.x += m2f * cmForce.x + relForce.x; fe.y += m2f * cmForce.y + relForce.y; fe.z += m2f * cmForce.z + relForce.z;
+                }
+            }
+        }
+        if ((F & A_EF) && act && (meta & META_EFIELD))                      // K/electricField.cu:8-10
+            fe.z += (real) a.efscale * pq.w;
+        if ((F & A_COS) && massive)                                         // K/cosineAccelerate.cu:9
+            fe.x += (real) a.cos_accel * cos_kz<real>(pq.z, (real) a.inv_box_z) * P::RECIP(v.w);
+        if ((F & A_FE_STORE) && act) ((real3*) a.fextra)[atom] = fe;
+
+        // ---------------- kick
+        if (F & (A_KICK_FULL | A_KICK_HALF)) {
+            if (massive) {
+                const long long fx = a.force[atom], fy = a.force[atom + a.padded], fz = a.force[atom + 2 * a.padded];
+                if (F & A_KICK_FULL) {                                      // K/middle.cu:11-21
+                    const mixed fscale = stepSize / (mixed) 0x100000000;
+                    v.x += stepSize * v.w * fe.x + fscale * v.w * fx;
+                    v.y += stepSize * v.w * fe.y + fscale * v.w * fy;
+                    v.z += stepSize * v.w * fe.z + fscale * v.w * fz;
+                } else {                                                    // K/velocityVerlet.cu:20-22 (0.5 is a double literal)
+                    const mixed fscale = (mixed) a.fscale_vv;
+                    v.x += 0.5 * stepSize * v.w * fe.x + fscale * v.w * fx;
+                    v.y += 0.5 * stepSize * v.w * fe.y + fscale * v.w * fy;
+                    v.z += 0.5 * stepSize * v.w * fe.z + fscale * v.w * fz;
+                }
+                velm[atom] = v;
+                if (F & A_POSDELTA_VV) {                                    // K/velocityVerlet.cu:24-26
+                    mixed4 d = {stepSize * v.x, stepSize * v.y, stepSize * v.z, 0};
+                    ((mixed4*) a.pos_delta)[atom] = d;
+                }
+            }
+        }
+        if ((F & A_POS1) && massive) {                                      // K/middle.cu:33-40
+            const mixed halfdt = 0.5f * stepSize;
+            mixed4 d = {halfdt * v.x, halfdt * v.y, halfdt * v.z, 0};
+            ((mixed4*) a.pos_delta)[atom] = d;
+            ((mixed4*) a.old_delta)[atom] = d;
+        }
+
+        // ---------------- periodic bias moment (K/cosineAccelerate.cu:24-27; massless -> 0)
+        if ((F & A_BIAS) && massive) {
+            const mixed t = P::RECIP(v.w) * v.x * 2 * cos_kz<real>(pq.z, (real) a.inv_box_z);
+            k_bias = (double) t;
+        }
+
+        // ---------------- kinetic energies of the thermostat groups
+        if (F & A_KE) {
+            const bool nh = role == ROLE_NH_NORMAL || role == ROLE_NH_DRUDE || role == ROLE_NH_PARENT;
+            mixed ux = v.x, uy = v.y, uz = v.z;
+            if (F & A_UNBIAS_ACC) {                                         // K/cosineAccelerate.cu:53-58, 69-71
+                // same expression as the chain kernel writes to scales[3], so kernel B removes exactly this V
+                const mixed V = (mixed) ((double) (long long) a.acc[3] * a.acc_inv_scale[3] * a.inv_mass_total);
+                if (act) ux -= V * cos_kz<real>(pq.z, (real) a.inv_box_z);
+            }
+            mixed Vx = 0, Vy = 0, Vz = 0, Vw = 0;
+            const bool use_com = ((meta >> META_SEGFIRST_SHIFT) & 63) != ((meta >> META_SEGLAST_SHIFT) & 63) ||
+                                 (meta & META_COM_LEADER);
+            // the COM stage is wave-uniform on purpose: lanes outside a COM segment scan a 1-lane segment
+            com_velocity<real, mixed>(nh && massive && use_com, ux, uy, uz, v.w, lane, meta, Vx, Vy, Vz, Vw);
+            if (!use_com) { Vx = 0; Vy = 0; Vz = 0; Vw = 0; }
+            if (nh) { ux -= Vx; uy -= Vy; uz -= Vz; }                       // K/drudeNoseHoover.cu:45-47
+            const mixed px = shfl(ux, partner), py = shfl(uy, partner), pz = shfl(uz, partner), pw = shfl(v.w, partner);
+            if (role == ROLE_NH_NORMAL && massive) {                        // K/drudeNoseHoover.cu:76-83
+                k_atom = (double) ((ux * ux + uy * uy + uz * uz) / v.w);
+            } else if (role == ROLE_NH_DRUDE) {                             // K/drudeNoseHoover.cu:97-114, pair.x = Drude
+                const mixed mass1 = P::RECIP(v.w), mass2 = P::RECIP(pw);
+                const mixed invTotalMass = P::RECIP(mass1 + mass2);
+                const mixed invReducedMass = (mass1 + mass2) * v.w * pw;
+                const mixed mass1fract = invTotalMass * mass1, mass2fract = invTotalMass * mass2;
+                const mixed cx = ux * mass1fract + px * mass2fract;
+                const mixed cy = uy * mass1fract + py * mass2fract;
+                const mixed cz = uz * mass1fract + pz * mass2fract;
+                const mixed rx = ux - px, ry = uy - py, rz = uz - pz;
+                k_atom = (double) ((cx * cx + cy * cy + cz * cz) * (mass1 + mass2));
+                k_drude = (double) ((rx * rx + ry * ry + rz * rz) / invReducedMass);
+            }
+            if ((meta & META_COM_LEADER) && use_com && Vw != 0)             // K/drudeNoseHoover.cu:85-94
+                k_com = (double) ((Vx * Vx + Vy * Vy + Vz * Vz) / Vw);
+        }
+    }
+    if (F & (A_KE | A_BIAS)) {
+        const double vals[NUM_ACC] = {k_atom, k_com, k_drude, k_bias};
+        const bool en[NUM_ACC] = {(F & A_KE) != 0, (F & A_KE) != 0, (F & A_KE) != 0, (F & A_BIAS) != 0};
+        block_accumulate<NUM_ACC>(vals, en, a.acc, a.acc_scale);
+    }
+}
+
+// ================================================================================ chain kernel
+// VVIntegrator::propagateNHChain (openmmapi/src/VVIntegrator.cpp:340-376) for every temperature group,
+// on the device in double, so the reference's blocking download / upload pair (HOST:709-746) disappears.
+// One wave: lane g < num_tg advances group g; lane 3 turns the bias moment into V.  It is the only
+// reader of the accumulators, so it also re-zeroes them for the next application.
+__global__ void __launch_bounds__(64) vv_kernel_chain(const NHConst c, NHDevState* st, unsigned long long* acc) {
+    __shared__ double eta[VVHIP_NUM_TG][VVHIP_MAX_CHAINS], eta_dot[VVHIP_NUM_TG][VVHIP_MAX_CHAINS + 1],
+        eta_dotdot[VVHIP_NUM_TG][VVHIP_MAX_CHAINS];
+    const int g = threadIdx.x;
+    const int numNHChains = c.num_chains;
+    double sum = 0;
+    if (g < NUM_ACC) sum = (double) (long long) acc[g] * c.acc_inv_scale[g];
+    __syncthreads();
+    if ((c.flags & C_CHAIN) && g < VVHIP_NUM_TG) {
+        double factor = 1.0;
+        if (g < c.num_tg) {
+            const double ke2 = sum, ke2_target = c.nkbt[g], t_target = c.temperature[g];
+            st->s.ke2[g] = ke2;
+            if (c.eta_mass[g][0] > 0) {                                      // HOST:729
+                for (int i = 0; i < numNHChains; i++) {
+                    eta[g][i] = st->s.eta[g][i]; eta_dot[g][i] = st->s.eta_dot[g][i]; eta_dotdot[g][i] = st->s.eta_dotdot[g][i];
+                }
+                eta_dot[g][numNHChains] = st->s.eta_dot[g][numNHChains];
+                const double* eta_mass = c.eta_mass[g];
+                double expfac = 1.0;
+                const double dt2 = c.step_size / c.loops_per_step / 2;
+                const double dt4 = dt2 / 2;
+                const double dt8 = dt4 / 2;
+                const double kT = ((1.380649e-23 * 6.02214076e23) / 1000.0) * t_target;
+                eta_dotdot[g][0] = (ke2 - ke2_target) / eta_mass[0];
+                for (int iloop = 0; iloop < c.loops_per_step; iloop++) {
+                    for (int ich = numNHChains - 1; ich >= 0; ich--) {
+                        expfac = exp(-dt8 * eta_dot[g][ich + 1]);
+                        eta_dot[g][ich] *= expfac;
+                        eta_dot[g][ich] += eta_dotdot[g][ich] * dt4;
+                        eta_dot[g][ich] *= expfac;
+                    }
+                    factor *= exp(-dt2 * eta_dot[g][0]);
+                    for (int ich = 0; ich < numNHChains; ich++) eta[g][ich] += dt2 * eta_dot[g][ich];
+                    eta_dotdot[g][0] = (ke2 * factor * factor - ke2_target) / eta_mass[0];
+                    eta_dot[g][0] *= expfac;                                 // stale expfac on purpose (quirk Q10)
+                    eta_dot[g][0] += eta_dotdot[g][0] * dt4;
+                    eta_dot[g][0] *= expfac;
+                    for (int ich = 1; ich < numNHChains; ich++) {
+                        expfac = exp(-dt8 * eta_dot[g][ich + 1]);
+                        eta_dot[g][ich] *= expfac;
+                        eta_dotdot[g][ich] = (eta_mass[ich - 1] * eta_dot[g][ich - 1] * eta_dot[g][ich - 1] - kT) / eta_mass[ich];
+                        eta_dot[g][ich] += eta_dotdot[g][ich] * dt4;
+                        eta_dot[g][ich] *= expfac;
+                    }
+                }
+                for (int i = 0; i < numNHChains; i++) {
+                    st->s.eta[g][i] = eta[g][i]; st->s.eta_dot[g][i] = eta_dot[g][i]; st->s.eta_dotdot[g][i] = eta_dotdot[g][i];
+                }
+            }
+        }
+        st->s.vscale[g] = factor;
+        st->scales[g] = factor;
+        acc[g] = 0;
+    }
+    if ((c.flags & C_BIAS) && g == 3) {                                      // K/cosineAccelerate.cu:57-59
+        st->s.v_bias = sum * c.inv_mass_total;
+        st->scales[3] = sum * c.inv_mass_total;
+        acc[3] = 0;
+    }
+}
+
+// ================================================================================ kernel B
+template <class real, class mixed>
+struct PosIO {
+    using real4 = typename Vec<real>::v4;
+    static constexpr bool kMixed = sizeof(real) != sizeof(mixed);
+    // K/middle.cu:81-96: positions are posq (+ posqCorrection in mixed mode)
+    static __device__ __forceinline__ void load(const void* posq, const void* corr, int i, mixed& x, mixed& y, mixed& z, mixed& w, real& zraw) {
+        const real4 p1 = ((const real4*) posq)[i];
+        zraw = p1.z;
+        if (kMixed) {
+            const real4 p2 = ((const real4*) corr)[i];
+            x = p1.x + (mixed) p2.x; y = p1.y + (mixed) p2.y; z = p1.z + (mixed) p2.z; w = p1.w;
+        } else {
+            x = p1.x; y = p1.y; z = p1.z; w = p1.w;
+        }
+    }
+    static __device__ __forceinline__ void store(void* posq, void* corr, int i, mixed x, mixed y, mixed z, mixed w) {
+        real4 p = {(real) x, (real) y, (real) z, (real) w};
+        ((real4*) posq)[i] = p;
+        if (kMixed) {
+            real4 c = {(real) (x - (real) x), (real) (y - (real) y), (real) (z - (real) z), 0};
+            ((real4*) corr)[i] = c;
+        }
+    }
+};
+
+template <class real, class mixed>
+__global__ void __launch_bounds__(256) vv_kernel_b(const KArgs a) {
+    using real4 = typename Vec<real>::v4;
+    using real3 = typename Vec<real>::v3;
+    using mixed4 = typename Vec<mixed>::v4;
+    using P = Prec<real>;
+    using IO = PosIO<real, mixed>;
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t F = a.flags;
+    if (wave >= a.nwaves) return;
+
+    const int2 slot = a.slots[(size_t) wave * 64 + lane];
+    const int atom = slot.x;
+    const unsigned meta = (unsigned) slot.y;
+    const unsigned role = meta & META_ROLE_MASK;
+    const int partner = (meta >> META_PARTNER_SHIFT) & 63;
+    const bool act = atom >= 0;
+    mixed4* velm = (mixed4*) a.velm;
+    mixed4 v = {0, 0, 0, 0};
+    if (act) v = velm[atom];
+    const bool massive = act && v.w != 0;
+    const mixed stepSize = (mixed) a.dt;
+    const bool touches_pos = F & (B_DRIFT_MIDDLE | B_POS3 | B_VV_POS | B_HARDWALL | B_IMAGE | B_UNBIAS | B_BIAS_REMOVE | B_BIAS_RESTORE);
+    mixed x = 0, y = 0, z = 0, q = 0;
+    real zraw = 0;
+    if (act && touches_pos) IO::load(a.posq, a.corr, atom, x, y, z, q, zraw);
+    const mixed4 v_old = v;          // velocity after the kick, before the thermostat (Pos1 uses it)
+    bool vel_dirty = false, pos_dirty = false;
+
+    // ---------------- bias removal (K/cosineAccelerate.cu:63-73); cos uses posq.z (real), all particles
+    double cz = 0;
+    mixed Vb = 0;
+    if (F & (B_UNBIAS | B_BIAS_REMOVE | B_BIAS_RESTORE)) {
+        Vb = (mixed) a.nh->scales[3];
+        cz = cos_kz<real>(zraw, (real) a.inv_box_z);
+        if ((F & (B_UNBIAS | B_BIAS_REMOVE)) && act) { v.x -= Vb * cz; vel_dirty = true; }
+    }
+
+    // ---------------- NH velocity scaling (K/drudeNoseHoover.cu:157-209)
+    if (F & B_SCALE) {
+        const mixed vscaleAtom = (mixed) a.nh->scales[0], vscaleCOM = (mixed) a.nh->scales[1], vscaleDrude = (mixed) a.nh->scales[2];
+        const bool nh = role == ROLE_NH_NORMAL || role == ROLE_NH_DRUDE || role == ROLE_NH_PARENT;
+        const bool use_com = ((meta >> META_SEGFIRST_SHIFT) & 63) != ((meta >> META_SEGLAST_SHIFT) & 63) || (meta & META_COM_LEADER);
+        mixed Vx = 0, Vy = 0, Vz = 0, Vw = 0;
+        com_velocity<real, mixed>(nh && massive && use_com, v.x, v.y, v.z, v.w, lane, meta, Vx, Vy, Vz, Vw);
+        if (!use_com) { Vx = 0; Vy = 0; Vz = 0; }
+        mixed ux = v.x, uy = v.y, uz = v.z;
+        if (nh) { ux -= Vx; uy -= Vy; uz -= Vz; }
+        const mixed px = shfl(ux, partner), py = shfl(uy, partner), pz = shfl(uz, partner), pw = shfl(v.w, partner);
+        if (role == ROLE_NH_NORMAL) {
+            if (massive) {
+                v.x = vscaleAtom * ux + vscaleCOM * Vx;
+                v.y = vscaleAtom * uy + vscaleCOM * Vy;
+                v.z = vscaleAtom * uz + vscaleCOM * Vz;
+                vel_dirty = true;
+            }
+        } else if (role == ROLE_NH_DRUDE || role == ROLE_NH_PARENT) {
+            const bool isd = role == ROLE_NH_DRUDE;      // velAtom1 = Drude (pair.x), velAtom2 = parent
+            const mixed a1x = isd ? ux : px, a1y = isd ? uy : py, a1z = isd ? uz : pz, a1w = isd ? v.w : pw;
+            const mixed a2x = isd ? px : ux, a2y = isd ? py : uy, a2z = isd ? pz : uz, a2w = isd ? pw : v.w;
+            const mixed mass1 = P::RECIP(a1w), mass2 = P::RECIP(a2w);
+            const mixed invTotalMass = P::RECIP(mass1 + mass2);
+            const mixed mass1fract = invTotalMass * mass1, mass2fract = invTotalMass * mass2;
+            mixed cmx = a1x * mass1fract + a2x * mass2fract;
+            mixed cmy = a1y * mass1fract + a2y * mass2fract;
+            mixed cmz = a1z * mass1fract + a2z * mass2fract;
+            mixed rx = a2x - a1x, ry = a2y - a1y, rz = a2z - a1z;
+            cmx = vscaleAtom * cmx; cmy = vscaleAtom * cmy; cmz = vscaleAtom * cmz;
+            rx = vscaleDrude * rx; ry = vscaleDrude * ry; rz = vscaleDrude * rz;
+            if (isd) {
+                v.x = cmx - rx * mass2fract + vscaleCOM * Vx;
+                v.y = cmy - ry * mass2fract + vscaleCOM * Vy;
+                v.z = cmz - rz * mass2fract + vscaleCOM * Vz;
+            } else {
+                v.x = cmx + rx * mass1fract + vscaleCOM * Vx;
+                v.y = cmy + ry * mass1fract + vscaleCOM * Vy;
+                v.z = cmz + rz * mass1fract + vscaleCOM * Vz;
+            }
+            vel_dirty = true;
+        }
+    }
+    if ((F & (B_UNBIAS | B_BIAS_RESTORE)) && act) { v.x += Vb * cz; vel_dirty = true; }   // K/cosineAccelerate.cu:76-85
+
+    // ---------------- classic VV first half: kick from the stored extra force, then posDelta (K/velocityVerlet.cu:6-29)
+    mixed dx = 0, dy = 0, dz = 0;
+    if ((F & B_VV_KICK) && massive) {
+        const real3 fe = ((const real3*) a.fextra)[atom];
+        const long long fx = a.force[atom], fy = a.force[atom + a.padded], fz = a.force[atom + 2 * a.padded];
+        const mixed fscale = (mixed) a.fscale_vv;
+        v.x += 0.5 * stepSize * v.w * fe.x + fscale * v.w * fx;
+        v.y += 0.5 * stepSize * v.w * fe.y + fscale * v.w * fy;
+        v.z += 0.5 * stepSize * v.w * fe.z + fscale * v.w * fz;
+        dx = stepSize * v.x; dy = stepSize * v.y; dz = stepSize * v.z;
+        vel_dirty = true;
+    }
+    // ---------------- position updates
+    if ((F & B_POS2) && massive) {                                          // K/middle.cu:51-58
+        const mixed halfdt = 0.5f * stepSize;
+        mixed4 d = {halfdt * v.x, halfdt * v.y, halfdt * v.z, 0};
+        mixed4 pd = ((mixed4*) a.pos_delta)[atom], od = ((mixed4*) a.old_delta)[atom];
+        pd.x += d.x; pd.y += d.y; pd.z += d.z; pd.w += d.w;
+        od.x += d.x; od.y += d.y; od.z += d.z; od.w += d.w;
+        ((mixed4*) a.pos_delta)[atom] = pd;
+        ((mixed4*) a.old_delta)[atom] = od;
+    }
+    if ((F & B_DRIFT_MIDDLE) && massive) {
+        // Pos1 (K/middle.cu:36-38) with the pre-thermostat velocity, Pos2 (:54-56) with the scaled one,
+        // no constraint solver in between => posDelta == oldDelta and Pos3's velocity correction
+        // (K/middle.cu:77-79) adds (d - d)/dt == 0 exactly.
+        const mixed halfdt = 0.5f * stepSize;
+        mixed ddx = halfdt * v_old.x, ddy = halfdt * v_old.y, ddz = halfdt * v_old.z;
+        ddx += halfdt * v.x; ddy += halfdt * v.y; ddz += halfdt * v.z;
+        const mixed invDt = 1 / stepSize;
+        v.x += (ddx - ddx) * invDt; v.y += (ddy - ddy) * invDt; v.z += (ddz - ddz) * invDt;
+        x += ddx; y += ddy; z += ddz;
+        pos_dirty = true; vel_dirty = true;
+    }
+    if ((F & B_POS3) && massive) {                                          // K/middle.cu:70-96
+        const mixed invDt = 1 / stepSize;
+        const mixed4 d = ((const mixed4*) a.pos_delta)[atom], od = ((const mixed4*) a.old_delta)[atom];
+        v.x += (d.x - od.x) * invDt; v.y += (d.y - od.y) * invDt; v.z += (d.z - od.z) * invDt;
+        x += d.x; y += d.y; z += d.z;
+        pos_dirty = true; vel_dirty = true;
+    }
+    if ((F & (B_VV_POS | B_VV_KICK)) && massive) {                          // K/velocityVerlet.cu:41-66
+        if (!(F & B_VV_KICK)) {
+            const mixed4 d = ((const mixed4*) a.pos_delta)[atom];
+            dx = d.x; dy = d.y; dz = d.z;
+        }
+        const mixed invStepSize = 1.0 / stepSize;
+        x += dx; y += dy; z += dz;
+        v.x = (mixed) (invStepSize * dx); v.y = (mixed) (invStepSize * dy); v.z = (mixed) (invStepSize * dz);
+        pos_dirty = true; vel_dirty = true;
+    }
+
+    // ---------------- hard wall on Drude pairs (K/middle.cu:106-221); pair.x = Drude = "1", parent = "2"
+    if (F & B_HARDWALL) {
+        const mixed ox = shfl(x, partner), oy = shfl(y, partner), oz = shfl(z, partner);
+        const mixed ovx = shfl(v.x, partner), ovy = shfl(v.y, partner), ovz = shfl(v.z, partner), ovw = shfl(v.w, partner);
+        if (act && (meta & META_PAIR)) {
+            const bool isd = (meta & META_IS_DRUDE) != 0;
+            const mixed maxDrudeDistance = (mixed) a.max_drude, hardwallscaleDrude = (mixed) a.hw_scale;
+            mixed p1x = isd ? x : ox, p1y = isd ? y : oy, p1z = isd ? z : oz;
+            mixed p2x = isd ? ox : x, p2y = isd ? oy : y, p2z = isd ? oz : z;
+            mixed vel1x = isd ? v.x : ovx, vel1y = isd ? v.y : ovy, vel1z = isd ? v.z : ovz, vel1w = isd ? v.w : ovw;
+            mixed vel2x = isd ? ovx : v.x, vel2y = isd ? ovy : v.y, vel2z = isd ? ovz : v.z, vel2w = isd ? ovw : v.w;
+            const mixed deltax = p1x - p2x, deltay = p1y - p2y, deltaz = p1z - p2z;
+            const mixed r = P::SQRT(deltax * deltax + deltay * deltay + deltaz * deltaz);
+            const mixed rInv = P::RECIP(r);
+            if (rInv * maxDrudeDistance < 1) {
+                const mixed bx = deltax * rInv, by = deltay * rInv, bz = deltaz * rInv;
+                const mixed mass1 = P::RECIP(vel1w), mass2 = P::RECIP(vel2w);
+                const mixed deltaR = r - maxDrudeDistance;
+                mixed deltaT = stepSize;
+                mixed dotvr1 = vel1x * bx + vel1y * by + vel1z * bz;
+                const mixed vb1x = bx * dotvr1, vb1y = by * dotvr1, vb1z = bz * dotvr1;
+                const mixed vp1x = vel1x - vb1x, vp1y = vel1y - vb1y, vp1z = vel1z - vb1z;
+                if (vel2w == 0) {                                           // massless parent (K/middle.cu:151-173)
+                    if (dotvr1 != 0) deltaT = deltaR / fabs((double) dotvr1);
+                    if (deltaT > stepSize) deltaT = stepSize;
+                    dotvr1 = -dotvr1 * hardwallscaleDrude / (fabs((double) dotvr1) * P::SQRT(mass1));
+                    const mixed dr = -deltaR + deltaT * dotvr1;
+                    p1x += bx * dr; p1y += by * dr; p1z += bz * dr;
+                    vel1x = vp1x + bx * dotvr1; vel1y = vp1y + by * dotvr1; vel1z = vp1z + bz * dotvr1;
+                    if (isd) { x = p1x; y = p1y; z = p1z; v.x = vel1x; v.y = vel1y; v.z = vel1z; pos_dirty = true; vel_dirty = true; }
+                } else {                                                    // both move (K/middle.cu:174-218)
+                    const mixed invTotalMass = P::RECIP(mass1 + mass2);
+                    mixed dotvr2 = vel2x * bx + vel2y * by + vel2z * bz;
+                    const mixed vb2x = bx * dotvr2, vb2y = by * dotvr2, vb2z = bz * dotvr2;
+                    const mixed vp2x = vel2x - vb2x, vp2y = vel2y - vb2y, vp2z = vel2z - vb2z;
+                    const mixed vbCMass = (mass1 * dotvr1 + mass2 * dotvr2) * invTotalMass;
+                    dotvr1 -= vbCMass;
+                    dotvr2 -= vbCMass;
+                    if (dotvr1 != dotvr2) deltaT = deltaR / fabs((double) (dotvr1 - dotvr2));
+                    if (deltaT > stepSize) deltaT = stepSize;
+                    const mixed vBond = hardwallscaleDrude / P::SQRT(mass1);
+                    dotvr1 = -dotvr1 * vBond * mass2 * invTotalMass / fabs((double) dotvr1);
+                    dotvr2 = -dotvr2 * vBond * mass1 * invTotalMass / fabs((double) dotvr2);
+                    const mixed dr1 = -deltaR * mass2 * invTotalMass + deltaT * dotvr1;
+                    const mixed dr2 = deltaR * mass1 * invTotalMass + deltaT * dotvr2;
+                    dotvr1 += vbCMass;
+                    dotvr2 += vbCMass;
+                    if (isd) {
+                        x = p1x + bx * dr1; y = p1y + by * dr1; z = p1z + bz * dr1;
+                        v.x = vp1x + bx * dotvr1; v.y = vp1y + by * dotvr1; v.z = vp1z + bz * dotvr1;
+                    } else {
+                        x = p2x + bx * dr2; y = p2y + by * dr2; z = p2z + bz * dr2;
+                        v.x = vp2x + bx * dotvr2; v.y = vp2y + by * dotvr2; v.z = vp2z + bz * dotvr2;
+                    }
+                    pos_dirty = true; vel_dirty = true;
+                }
+            }
+        }
+    }
+
+    // ---------------- write back
+    if (act && vel_dirty) velm[atom] = v;
+    if (act && pos_dirty) IO::store(a.posq, a.corr, atom, x, y, z, q);
+    if ((F & B_VV_KICK) && massive) {
+        mixed4 d = {dx, dy, dz, 0};
+        if (a.pos_delta) ((mixed4*) a.pos_delta)[atom] = d;
+    }
+
+    // ---------------- image charges (K/imageCharge.cu:10-26): x, y are bit copies, z is mirrored
+    if ((F & B_IMAGE) && act && (meta & META_HAS_IMAGE)) {
+        const int img = a.slot_image[(size_t) wave * 64 + lane];
+        real4* posq = (real4*) a.posq;
+        const real4 pp = posq[atom];       // re-read what was just stored: the copy must be of the stored bits
+        real4 pi = posq[img];
+        pi.x = pp.x; pi.y = pp.y;
+        if (IO::kMixed) {
+            real4* corr = (real4*) a.corr;
+            const real4 cp = corr[atom];
+            real4 ci = corr[img];
+            ci.x = cp.x; ci.y = cp.y;
+            mixed zz = (mixed) pp.z + (mixed) cp.z;
+            zz = (mixed) a.mirror * 2 - zz;
+            pi.z = (real) zz;
+            ci.z = (real) (zz - (real) zz);
+            corr[img] = ci;
+        } else {
+            pi.z = 2 * (mixed) a.mirror - pp.z;
+        }
+        posq[img] = pi;
+    }
+}
+
+// ================================================================================ stand-alone image kernel
+// vvhip_update_image_positions when called on its own (ModifyImageChargeKernel::updateImagePositions).
+template <class real, class mixed>
+__global__ void __launch_bounds__(256) vv_kernel_images(void* posq_, void* corr_, const int2* pairs, int npairs, double mirror) {
+    using real4 = typename Vec<real>::v4;
+    constexpr bool kMixed = sizeof(real) != sizeof(mixed);
+    real4* posq = (real4*) posq_;
+    real4* corr = (real4*) corr_;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npairs; i += blockDim.x * gridDim.x) {
+        const int2 pr = pairs[i];
+        const real4 pp = posq[pr.y];
+        real4 pi = posq[pr.x];
+        pi.x = pp.x; pi.y = pp.y;
+        if (kMixed) {
+            const real4 cp = corr[pr.y];
+            real4 ci = corr[pr.x];
+            ci.x = cp.x; ci.y = cp.y;
+            mixed z = (mixed) pp.z + (mixed) cp.z;
+            z = (mixed) mirror * 2 - z;
+            pi.z = (real) z;
+            ci.z = (real) (z - (real) z);
+            corr[pr.x] = ci;
+        } else {
+            pi.z = 2 * (mixed) mirror - pp.z;
+        }
+        posq[pr.x] = pi;
+    }
+}
+
+// ================================================================================ synthetic force provider (bench/test support)
+// Mirrors oracle vvo_tether_force bit for bit: tether on massive particles, Drude-parent spring, both
+// converted to fixed point by truncation and then added as integers.
+template <class real, class mixed>
+__global__ void __launch_bounds__(256) vv_kernel_tether(const TetherArgs t) {
+    using real4 = typename Vec<real>::v4;
+    using mixed4 = typename Vec<mixed>::v4;
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wave >= t.nwaves) return;
+    const int2 slot = t.slots[(size_t) wave * 64 + lane];
+    const int atom = slot.x;
+    const unsigned meta = (unsigned) slot.y;
+    const int partner = (meta >> META_PARTNER_SHIFT) & 63;
+    const bool act = atom >= 0;
+    real4 p = {0, 0, 0, 0}, s = {0, 0, 0, 0};
+    mixed w = 0;
+    if (act) { p = ((const real4*) t.posq)[atom]; s = ((const real4*) t.site)[atom]; w = ((const mixed4*) t.velm)[atom].w; }
+    const real kt = (real) t.k_tether, kd = (real) t.k_drude, scale = (real) 4294967296.0;
+    real fx = 0, fy = 0, fz = 0;
+    if (w != 0) { fx = -kt * (p.x - s.x); fy = -kt * (p.y - s.y); fz = -kt * (p.z - s.z); }
+    long long ix = (long long) (fx * scale), iy = (long long) (fy * scale), iz = (long long) (fz * scale);
+    const real ox = shfl(p.x, partner), oy = shfl(p.y, partner), oz = shfl(p.z, partner);
+    if (act && (meta & META_PAIR)) {
+        const bool isd = (meta & META_IS_DRUDE) != 0;
+        const real dxx = isd ? p.x - ox : ox - p.x, dyy = isd ? p.y - oy : oy - p.y, dzz = isd ? p.z - oz : oz - p.z;
+        const long long sx = (long long) (-kd * dxx * scale), sy = (long long) (-kd * dyy * scale), sz = (long long) (-kd * dzz * scale);
+        if (isd) { ix += sx; iy += sy; iz += sz; } else { ix -= sx; iy -= sy; iz -= sz; }
+    }
+    if (act) { t.force[atom] = ix; t.force[atom + t.padded] = iy; t.force[atom + 2 * t.padded] = iz; }
+}
+
+// ================================================================================ launchers
+static inline dim3 grid_for(int nwaves, int block_threads) {
+    const int wpb = block_threads / 64;
+    return dim3((unsigned) ((nwaves + wpb - 1) / wpb));
+}
+#define VV_DISPATCH(KERNEL, ...)                                                                       \
+    switch (precision) {                                                                               \
+        case VVHIP_SINGLE: hipLaunchKernelGGL((KERNEL<float, float>), __VA_ARGS__); break;             \
+        case VVHIP_MIXED: hipLaunchKernelGGL((KERNEL<float, double>), __VA_ARGS__); break;             \
+        default: hipLaunchKernelGGL((KERNEL<double, double>), __VA_ARGS__); break;                     \
+    }
+
+hipError_t launch_a(int precision, const KArgs& a, int block_threads, hipStream_t s) {
+    VV_DISPATCH(vv_kernel_a, grid_for(a.nwaves, block_threads), dim3(block_threads), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_b(int precision, const KArgs& a, int block_threads, hipStream_t s) {
+    VV_DISPATCH(vv_kernel_b, grid_for(a.nwaves, block_threads), dim3(block_threads), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_chain(const NHConst& c, NHDevState* st, unsigned long long* acc, hipStream_t s) {
+    hipLaunchKernelGGL(vv_kernel_chain, dim3(1), dim3(64), 0, s, c, st, acc);
+    return hipGetLastError();
+}
+hipError_t launch_tether(int precision, const TetherArgs& t, int block_threads, hipStream_t s) {
+    VV_DISPATCH(vv_kernel_tether, grid_for(t.nwaves, block_threads), dim3(block_threads), 0, s, t);
+    return hipGetLastError();
+}
+hipError_t launch_image_pairs(int precision, void* posq, void* corr, const int2* pairs, int npairs, double mirror, hipStream_t s) {
+    if (npairs <= 0) return hipSuccess;
+    const int blocks = (npairs + 255) / 256;
+    VV_DISPATCH(vv_kernel_images, dim3(blocks), dim3(256), 0, s, posq, corr, pairs, npairs, mirror);
+    return hipGetLastError();
+}
+
+}  // namespace vv

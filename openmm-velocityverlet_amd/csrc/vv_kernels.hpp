@@ -1,0 +1,114 @@
+// vv_kernels.hpp -- argument blocks and launch entry points of the HIP kernels (gfx950).
+// Device code lives in vv_kernels.hip; the C ABI (vv_api.cpp) only sees this header.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/vvhip.h"
+
+namespace vv {
+
+// ---- stage flags of kernel A ("produce": ends in reductions) -----------------------------------
+enum : uint32_t {
+    A_FE_LOAD = 1u << 0,     // start the extra force from the forceExtra array (else 0)
+    A_FE_STORE = 1u << 1,    // write the extra force back to the array
+    A_LD = 1u << 2,          // + Langevin drag/noise              (K/drudeLangevin.cu:2-60)
+    A_EF = 1u << 3,          // + electric field force             (K/electricField.cu:2-12)
+    A_COS = 1u << 4,         // + cosine acceleration force        (K/cosineAccelerate.cu:2-14)
+    A_KICK_FULL = 1u << 5,   // v += dt*invM*Fe + dt/2^32*invM*F   (K/middle.cu:6-23)
+    A_KICK_HALF = 1u << 6,   // v += 0.5*dt*invM*Fe + fscale*invM*F (K/velocityVerlet.cu:6-29)
+    A_POSDELTA_VV = 1u << 7, // posDelta = dt*v                    (K/velocityVerlet.cu:24-26)
+    A_POS1 = 1u << 8,        // posDelta = oldDelta = dt/2*v       (K/middle.cu:29-42)
+    A_BIAS = 1u << 9,        // accumulate sum m*vx*2cos(kz)       (K/cosineAccelerate.cu:16-61)
+    A_KE = 1u << 10,         // molecular COM + per-group sum m v^2 (K/drudeNoseHoover.cu:5-151)
+    A_UNBIAS_ACC = 1u << 11, // before the KE, subtract V*cos(kz) with V taken from accumulator 3
+};
+// ---- stage flags of kernel B ("consume": starts from the scale factors) -------------------------
+enum : uint32_t {
+    B_SCALE = 1u << 0,        // v = s_atom*(v-V) + s_com*V, Drude pairs split (K/drudeNoseHoover.cu:157-209)
+    B_UNBIAS = 1u << 1,       // remove the periodic bias before / restore after the scaling (fused)
+    B_BIAS_REMOVE = 1u << 2,  // only vx -= V cos(kz)                (K/cosineAccelerate.cu:63-73)
+    B_BIAS_RESTORE = 1u << 3, // only vx += V cos(kz)                (K/cosineAccelerate.cu:76-85)
+    B_DRIFT_MIDDLE = 1u << 4, // fused Pos1+Pos2+Pos3 without constraints: x += dt/2*v_old + dt/2*v_new
+    B_POS2 = 1u << 5,         // posDelta += dt/2*v; oldDelta += dt/2*v (K/middle.cu:47-60)
+    B_POS3 = 1u << 6,         // v += (posDelta-oldDelta)/dt; x += posDelta (K/middle.cu:66-100)
+    B_VV_KICK = 1u << 7,      // half kick from the forceExtra array + posDelta = dt*v (fused classic first half)
+    B_VV_POS = 1u << 8,       // x += posDelta; v = posDelta/dt        (K/velocityVerlet.cu:35-68)
+    B_HARDWALL = 1u << 9,     // (K/middle.cu:106-221)
+    B_IMAGE = 1u << 10,       // mirror copy to the image particle     (K/imageCharge.cu:2-28)
+};
+// ---- chain kernel --------------------------------------------------------------------------------
+enum : uint32_t { C_CHAIN = 1u << 0, C_BIAS = 1u << 1 };
+
+constexpr int NUM_ACC = 4;   // fixed-point accumulators: 2KE atom, 2KE com, 2KE drude, bias moment
+
+// Device-resident thermostat state (reference keeps it on the host: CudaVVKernels.h:206-215)
+struct NHDevState {
+    vvhip_nh_state s;
+    double scales[4];        // what kernel B consumes: vscale[3] and the periodic bias V
+};
+
+// Constants of the chain (HOST:577-594 fixed at init; temperatures read live as API:728 does)
+struct NHConst {
+    double eta_mass[VVHIP_NUM_TG][VVHIP_MAX_CHAINS];
+    double nkbt[VVHIP_NUM_TG];
+    double temperature[VVHIP_NUM_TG];
+    double step_size;
+    double inv_mass_total;
+    double acc_inv_scale[NUM_ACC];
+    int32_t num_chains, loops_per_step, num_tg;
+    uint32_t flags;
+};
+
+// One argument block for kernels A and B (passed by value); pointer types are erased so that the
+// same struct serves the three precision modes.
+struct KArgs {
+    void* velm;
+    void* posq;
+    void* corr;
+    const long long* force;
+    void* fextra;
+    void* pos_delta;
+    void* old_delta;
+    const int2* slots;
+    const int32_t* slot_image;
+    const int32_t* slot_rand;
+    const float4* random;
+    unsigned long long* acc;
+    const NHDevState* nh;
+    int32_t padded;
+    int32_t nwaves;
+    uint32_t flags;
+    uint32_t random_index;
+    double dt;                 // step size
+    double fscale_vv;          // 0.5*dt/2^32 computed in double on the host (HOST:306)
+    double drag, randf, drag_drude, randf_drude;   // HOST:835-839
+    double efscale;            // E * AVOGADRO (HOST:978)
+    double cos_accel;
+    double inv_box_z;
+    double max_drude, hw_scale;                    // HOST:189-190
+    double mirror;
+    double inv_mass_total;
+    double acc_scale[NUM_ACC], acc_inv_scale[NUM_ACC];
+};
+
+struct TetherArgs {
+    const void* posq;
+    const void* site;
+    const void* velm;
+    long long* force;
+    const int2* slots;
+    int32_t padded, nwaves;
+    double k_tether, k_drude;
+};
+
+// launchers (precision = VVHIP_SINGLE / MIXED / DOUBLE); return hipError_t of the launch
+hipError_t launch_a(int precision, const KArgs& a, int block_threads, hipStream_t s);
+hipError_t launch_b(int precision, const KArgs& a, int block_threads, hipStream_t s);
+hipError_t launch_chain(const NHConst& c, NHDevState* st, unsigned long long* acc, hipStream_t s);
+hipError_t launch_tether(int precision, const TetherArgs& t, int block_threads, hipStream_t s);
+hipError_t launch_image_pairs(int precision, void* posq, void* corr, const int2* pairs, int npairs, double mirror,
+                              hipStream_t s);
+
+}  // namespace vv

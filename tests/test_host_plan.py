@@ -1,0 +1,129 @@
+"""Host logic of the product (vvhip_plan_create: no GPU needed) against the numpy restatement of the
+reference's initialize() methods, the wave-layout invariants the kernels rely on, and the C-ABI export list."""
+import importlib
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pkg = importlib.import_module("openmm-velocityverlet_amd")
+H, I, systems = pkg.vvhip, pkg.integrator, pkg.systems
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _integrator(p: O.Params):
+    it = I.VVIntegrator(p.temperature, p.frequency, p.drude_temperature, p.drude_frequency, p.step_size, p.num_chains, p.loops_per_step)
+    it.setMaxDrudeDistance(p.max_drude_distance)
+    it._cosAcceleration = p.cos_acceleration
+    return it
+
+
+@pytest.mark.parametrize("cfg,scale", [("C1", 1.0), ("C2", 0.1), ("C3", 0.02), ("C3", 1.0), ("C5", 0.05)])
+def test_analysis_matches_reference_init(cfg, scale):
+    spec = systems.make_config(cfg, scale)
+    p = O.Params(temperature=333.0, drude_temperature=1.0, max_drude_distance=0.02)
+    t = O.build_tables(spec, p)
+    info, slots = I.plan_layout(spec, _integrator(p))
+    assert info.num_particles_nh == len(t["particles_nh"]) and info.num_molecules_nh == len(t["molecules_nh"])
+    assert info.num_normal_nh == len(t["normal_nh"]) and info.num_pairs_nh == len(t["pairs_nh"])
+    assert info.num_normal_ld == len(t["normal_ld"]) and info.num_pairs_ld == len(t["pairs_ld"])
+    assert info.num_temp_groups == t["num_tg"] and bool(info.use_com_temp_group) == t["params"].use_com_temp_group
+    assert info.friction == t["params"].friction
+    assert list(info.dof) == list(t["dof"])                       # same summation order => bit-equal
+    assert list(info.nkbt) == list(t["nkbt"])
+    assert np.array_equal(np.array([list(r) for r in info.eta_mass]), t["eta_mass"])
+    assert info.inv_mass_total == pytest.approx(t["inv_mass_total"], rel=1e-15)
+
+    # ---- wave layout invariants
+    atoms, meta = slots[:, 0], slots[:, 1].astype(np.uint32)
+    used = atoms >= 0
+    massive = spec.masses != 0
+    assert np.array_equal(np.sort(atoms[used]), np.nonzero(massive | np.isin(np.arange(spec.num_atoms), [par for _, par in spec.image_pairs]))[0])
+    lane = np.arange(slots.shape[0]) % 64
+    wave = np.arange(slots.shape[0]) // 64
+    slot_of = -np.ones(spec.num_atoms, dtype=np.int64)
+    slot_of[atoms[used]] = np.nonzero(used)[0]
+    role = meta & 0xF
+    partner = (meta >> 4) & 63
+    for d, par in spec.drude_pairs:
+        sd, sp = slot_of[d], slot_of[par]
+        assert wave[sd] == wave[sp], "a Drude pair must share a wave"
+        assert partner[sd] == lane[sp] and partner[sp] == lane[sd]
+        assert role[sd] in (3, 6) and role[sp] in (4, 7)
+    if info.use_com_temp_group:
+        first, last = (meta >> 10) & 63, (meta >> 16) & 63
+        nh = set(t["particles_nh"].tolist())
+        for m in np.unique(spec.mol_id):
+            members = [i for i in np.nonzero(spec.mol_id == m)[0] if massive[i] and i in nh]
+            if not members:
+                continue
+            s = slot_of[members]
+            assert len(set(wave[s])) == 1, "a molecule must share a wave"
+            assert (first[s] == lane[s].min()).all() and (last[s] == lane[s].max()).all()
+            assert ((meta[s] >> 24) & 1).sum() == 1, "exactly one COM leader per molecule"
+            if m > 40:
+                break
+
+
+def test_reference_error_cases_keep_their_messages():
+    spec = systems.make_config("C5", 0.02)
+    it = I.VVIntegrator(333, 10, 1, 40, 0.001)
+    it.setCosAcceleration(0.02)
+    with pytest.raises(H.VVHipError, match="Langevin thermostat and periodic perturbation shouldn't be used together") as e:
+        I.plan_layout(spec, it)
+    assert e.value.code == H.ERR_TOPOLOGY
+    it = I.VVIntegrator(333, 10, 1, 40, 0.001)
+    it.addParticleLangevin(spec.image_pairs[0][1])
+    with pytest.raises(H.VVHipError, match="NH and Langevin thermostat cannot be applied on the same molecule"):
+        I.plan_layout(spec, it)
+    spec = systems.make_config("C3", 0.01)
+    it = I.VVIntegrator(333, 10, 1, 40, 0.001)
+    it.addParticleLangevin(int(spec.drude_pairs[0][0]))
+    with pytest.raises(H.VVHipError):
+        I.plan_layout(spec, it)
+    spec.constraints = np.array([[0, spec.num_atoms - 1]], np.int32)
+    it = I.VVIntegrator(333, 10, 1, 40, 0.001)
+    for i in np.nonzero(spec.mol_id == spec.mol_id[0])[0]:
+        it.addParticleLangevin(int(i))
+    with pytest.raises(H.VVHipError, match="Constrained particle pair should be in the same thermostat"):
+        I.plan_layout(spec, it)
+
+
+def test_shards_are_molecule_aligned_and_cover_everything():
+    spec = systems.make_config("C3", 0.02)
+    it = I.VVIntegrator(333, 10, 1, 40, 0.001)
+    dist = importlib.import_module("openmm-velocityverlet_amd.distributed")
+    bounds = dist.shard_bounds(spec, 4)
+    assert bounds[0][0] == 0 and bounds[-1][1] == spec.num_atoms
+    total = 0
+    for b, e in bounds:
+        info, slots = I.plan_layout(spec, it, shard=(b, e))
+        a = slots[:, 0]
+        assert a[a >= 0].min() == 0 and a.max() == e - b - 1
+        total += info.num_slots_used
+        full, _ = I.plan_layout(spec, it)
+        assert list(info.dof) == list(full.dof)          # thermostat constants are global, not per shard
+    assert total == spec.num_atoms
+    with pytest.raises(H.VVHipError, match="cuts a"):
+        I.plan_layout(spec, it, shard=(0, bounds[0][1] - 1))
+
+
+def test_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "vvhip.h")).read()
+    declared = set(re.findall(r"\b(vvhip_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) > 45
+    import ctypes
+    lib = ctypes.CDLL(H.LIB_PATH)
+    missing = [n for n in sorted(declared) if not hasattr(lib, n)]
+    assert not missing, f"declared in include/vvhip.h but not exported: {missing}"
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    if H.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(H.VVHipError) as e:
+        I.Context(systems.make_config("C1"), I.VVIntegrator(300, 10, 1, 40, 0.001))
+    assert e.value.code == H.ERR_NO_DEVICE
