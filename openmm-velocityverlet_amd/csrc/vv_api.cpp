@@ -81,9 +81,13 @@ double pick_scale(double bound, double headroom) {
 }
 
 void fill_scales(vvhip_plan* p) {
+    // One common power-of-two scale for the three 2KE sums, sized on the TOTAL thermostat target with 1024x
+    // headroom: a cold group (Drude, 1 K) may transiently be orders of magnitude hotter than its own target
+    // without getting anywhere near overflow, and resolution stays ~1e-13 of even the smallest group.
     const vvhip_plan_info& in = p->hp.info;
+    const double total = in.nkbt[0] + in.nkbt[1] + in.nkbt[2];
     for (int g = 0; g < 3; g++) {
-        p->acc_scale[g] = pick_scale(in.nkbt[g], 64.0);          // overflow only if a group is > 64x hotter than its target
+        p->acc_scale[g] = pick_scale(total, 1024.0);
         p->acc_inv_scale[g] = 1.0 / p->acc_scale[g];
     }
     p->acc_scale[3] = pick_scale(40.0 / in.inv_mass_total, 4.0);  // |sum m vx 2cos| <= 2 M |v|max, |v|max ~ 20 nm/ps

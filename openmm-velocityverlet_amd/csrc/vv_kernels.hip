@@ -379,7 +379,7 @@ __global__ void __launch_bounds__(256) vv_kernel_b(const KArgs a) {
     if (act) v = velm[atom];
     const bool massive = act && v.w != 0;
     const mixed stepSize = (mixed) a.dt;
-    const bool touches_pos = F & (B_DRIFT_MIDDLE | B_POS3 | B_VV_POS | B_HARDWALL | B_IMAGE | B_UNBIAS | B_BIAS_REMOVE | B_BIAS_RESTORE);
+    const bool touches_pos = F & (B_DRIFT_MIDDLE | B_POS3 | B_VV_POS | B_VV_KICK | B_HARDWALL | B_IMAGE | B_UNBIAS | B_BIAS_REMOVE | B_BIAS_RESTORE);
     mixed x = 0, y = 0, z = 0, q = 0;
     real zraw = 0;
     if (act && touches_pos) IO::load(a.posq, a.corr, atom, x, y, z, q, zraw);

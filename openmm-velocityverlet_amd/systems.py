@@ -129,7 +129,7 @@ def _assemble(name, mol_templates, counts_per_cell, cells, cell_box, T, T_drude,
     pos = np.repeat(np.array(centers), sizes, axis=0) + rng.uniform(-0.15, 0.15, size=(n, 3))
     parent_of = np.arange(n) - 1
     d = np.nonzero(isd)[0]
-    pos[d] = pos[d - 1] + rng.normal(0.0, 0.003, size=(d.size, 3))   # Drude sits ~0.005 nm from its parent
+    pos[d] = pos[d - 1] + rng.normal(0.0, 2e-4, size=(d.size, 3))    # ~ sqrt(kT_D / k_D) at T_D = 1 K, k_D = 209 200
     vel = _maxwell_boltzmann(rng, masses, isd, parent_of, T, T_drude)
     box = cell_box * np.array(cells, dtype=float)
     pairs = np.stack([d, d - 1], axis=1).astype(np.int32) if d.size else np.zeros((0, 2), np.int32)
