@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- MD steps/s (ns/day) of the integrator hot path on the 100k-atom Drude ionic-liquid box.
+
+  python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one VVIntegrator step of the whole box: synthetic force provider (plays OpenMM's calcForcesAndEnergy,
+IN the timed region) + the fused middle-scheme integrator path (TGNH thermostat, Drude hard wall).  State is
+resident in HBM before the timed region starts.  Rank 0 prints ONE JSON line; see DESIGN.md "Measurement".
+"""
+import argparse
+import importlib
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic bytes per particle per launch, mixed precision (228 B/atom/step = A + B)
+ALGO_BYTES = {"mixed": {"A": 32 + 24 + 32 + 6, "B": 32 + 32 + 32 + 32 + 6},
+              "single": {"A": 16 + 24 + 16 + 6, "B": 16 + 16 + 16 + 16 + 6},
+              "double": {"A": 32 + 24 + 32 + 6, "B": 32 + 32 + 32 + 32 + 6}}
+HBM_PEAK_GBS = 8000.0      # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured float4 copy)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20000)
+    ap.add_argument("--warmup", type=int, default=2000)
+    ap.add_argument("--config", default="C3", choices=["C2", "C3", "C4", "C3x8", "C3x80"])
+    ap.add_argument("--precision", default="mixed", choices=["single", "mixed", "double"])
+    ap.add_argument("--forces", default="tether", choices=["tether", "static"])
+    ap.add_argument("--steps-per-graph", type=int, default=100)
+    ap.add_argument("--eager", action="store_true", help="no hipGraph replay (host-launched every step)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path is HIP only (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    pkg = importlib.import_module("openmm-velocityverlet_amd")
+    I, S, D = pkg.integrator, pkg.systems, pkg.distributed
+
+    # ---- workload (BASELINE.json configs[2] / [3]; C3xK = the same cell tiled K times along z)
+    cfg = args.config
+    if cfg.startswith("C3x"):
+        spec = S.make_config("C3", float(cfg[3:]))
+    else:
+        spec = S.make_config(cfg)
+    dt = 0.002 if cfg == "C2" else 0.001
+    it = I.VVIntegrator(300.0 if cfg == "C2" else 333.0, 10.0, 1.0, 40.0, dt)
+    if cfg != "C2":
+        it.setMaxDrudeDistance(0.02)
+    if cfg == "C4":
+        it.setCosAcceleration(0.02)
+    bounds = D.shard_bounds(spec, world)
+    stream = torch.cuda.current_stream().cuda_stream if world > 1 else None
+    ctx = I.Context(spec, it, precision=args.precision, force_provider=args.forces, shard=bounds[rank],
+                    device=local_rank, stream=stream)
+    stepper = D.ShardedStepper(ctx) if world > 1 else None
+    use_graph = world == 1 and not args.eager
+
+    def run(n):
+        if stepper is not None:
+            stepper.step(n)
+        elif use_graph:
+            ctx.run_graph(n, args.steps_per_graph)
+        else:
+            it.step(n)
+
+    def fence():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    run(args.warmup)
+    fence()
+    t0 = time.perf_counter()
+    run(args.steps)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    steps_per_s = args.steps / elapsed
+
+    x = ctx.getPositions()
+    if not np.isfinite(x).all():
+        raise SystemExit("non-finite positions after the timed run")
+
+    out = None
+    if rank == 0:
+        n = spec.num_atoms
+        out = {
+            "metric": "MD steps/sec, 100k-atom Drude IL box (integrator hot path)", "value": round(steps_per_s, 1),
+            "unit": "steps/s", "ns_per_day": round(steps_per_s * dt * 1e3 * 0.0864, 1), "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 6),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": {"mixed": "f64 velocities, f32+f32 positions (OpenMM 'mixed')", "single": "f32", "double": "f64"}[args.precision],
+            "data": "synthetic",
+            "config": {"workload": f"{cfg}: {spec.name}, {n} particles, {spec.num_molecules} molecules, "
+                                   f"{len(spec.drude_pairs)} Drude pairs; TGNH thermostat ({ctx.info.num_temp_groups} groups), middle scheme, "
+                                   f"hard wall 0.02 nm, dt {dt * 1e3:g} fs" + (", cos acceleration 0.02 nm/ps^2" if cfg == "C4" else ""),
+                       "force_provider": f"{args.forces} (synthetic, inside the timed region)" if args.forces == "tether" else "static buffer",
+                       "launch": "hipGraph replay, %d steps/graph" % args.steps_per_graph if use_graph else "host-launched per step",
+                       "parallelism": "1 GPU" if world == 1 else f"particle shards on molecule boundaries x{world}, int64 all-reduce per thermostat application",
+                       "atom_steps_per_s": round(steps_per_s * n, 1)},
+        }
+
+    # ---- roofline of the dominant kernel, measured live with HIP events on the plan's stream (N = 1 only)
+    if world == 1 and rank == 0:
+        # two HIP events around 300 back-to-back launches of each stage kernel with the fused step's stage bits
+        # (per-launch events in an eager stream starve the GPU and read ~2x high; the rocprofv3 averages under
+        # profiles/ are the cross-check).  Runs after the headline measurement: it scrambles the physical state.
+        ms_a = ctx.time_kernel(0, 300)
+        ms_b = ctx.time_kernel(1, 300)
+        dom = "B" if ms_b >= ms_a else "A"
+        ms = ms_b if dom == "B" else ms_a
+        bytes_per_launch = ALGO_BYTES[args.precision][dom] * spec.num_atoms
+        achieved = bytes_per_launch / (ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc):
+            try:
+                rec = json.load(open(pmc))
+                if rec.get("config") == cfg and rec.get("precision") == args.precision:
+                    traffic = rec.get(f"hbm_bytes_per_launch_{dom}")
+            except Exception:
+                traffic = None
+        out["roofline"] = {"bound": "hbm", "kernel": f"vv_kernel_{dom.lower()}", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                           "algorithmic_bytes_per_launch": bytes_per_launch,
+                           "avg_launch_us": {"A": round(ms_a * 1e3, 3), "B": round(ms_b * 1e3, 3)},
+                           "note": "working set is Infinity-Cache resident at this size; see DESIGN.md"}
+
+    # ---- CPU baseline: the oracle (our C restatement of the reference path, OpenMP) on this host's cores, bounded sample
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        from oracle import oracle as O
+        ncpu = os.cpu_count() or 1
+        p = O.Params(temperature=it.getTemperature(), drude_temperature=1.0, step_size=dt, max_drude_distance=it.getMaxDrudeDistance(),
+                     cos_acceleration=it.getCosAcceleration())
+        # pick the OpenMP thread count that is actually fastest on this host (a 256-thread team on 111k-particle loops is
+        # slower than 16): short calibration, then one bounded sample at the winner
+        best = None
+        for threads in sorted({1, 4, 8, 16, 32, 64, min(ncpu, 128)}):
+            if threads > ncpu:
+                continue
+            osys = O.OracleSystem(spec, p, args.precision, force_mode=1 if args.forces == "tether" else 0, num_threads=threads)
+            osys.step(2)
+            t0 = time.perf_counter()
+            osys.step(5)
+            per = (time.perf_counter() - t0) / 5
+            if best is None or per < best[1]:
+                best = (threads, per)
+        cores, per = best
+        osys = O.OracleSystem(spec, p, args.precision, force_mode=1 if args.forces == "tether" else 0, num_threads=cores)
+        osys.step(3)
+        nsteps = max(10, min(20000, int(args.cpu_seconds / max(per, 1e-6))))
+        t0 = time.perf_counter()
+        osys.step(nsteps)
+        cpu_elapsed = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(nsteps / cpu_elapsed, 2), "unit": "steps/s", "cores": cores, "kind": "port",
+                               "sample": f"{nsteps} steps of the same {cfg} workload ({cpu_elapsed:.1f} s), oracle/vv_oracle.c with OpenMP, "
+                                         f"fastest of 1..{min(ncpu, 128)} threads on a {ncpu}-CPU host"}
+    if rank == 0:
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

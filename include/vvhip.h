@@ -171,7 +171,8 @@ int vvhip_step_vv_second(vvhip_plan* plan, uint32_t random_index);
  * the accumulator range reported by vvhip_accumulators(phase) element-wise over ranks (ncclSum on
  * int64; fixed point makes the result independent of rank order) on the plan's stream:
  *     for (ph = 0; ph < P; ph++) { vvhip_step_middle_phase(plan, ph, ri); if (ph < P-1) all_reduce(acc(ph)); }
- * That <= 32-byte all-reduce is the only cross-GPU exchange per thermostat application. */
+ * That all-reduce (64 int64 slots per reduced quantity, <= 1.5 KB, latency-bound) is the only cross-GPU
+ * exchange per thermostat application. */
 int vvhip_step_middle_phases(const vvhip_plan* plan);
 int vvhip_step_middle_phase(vvhip_plan* plan, int phase, uint32_t random_index);
 int vvhip_accumulators(vvhip_plan* plan, int phase, void** device_ptr, int32_t* count);
@@ -224,6 +225,9 @@ int vvhip_synth_tether_force(vvhip_plan* plan, const void* site /* real4[n] */, 
  * hipGraph once and replays it; returns after enqueueing.  Middle scheme only. */
 int vvhip_run_graph(vvhip_plan* plan, int nsteps, int steps_per_graph, const void* site, double k_tether, double k_drude);
 /* HIP-event timing of the dominant kernels on the plan's stream, for bench.py's roofline block. */
+/* Average duration of `reps` back-to-back launches of one stage kernel (0 = A, 1 = B) with the given stage bits,
+ * bracketed by two HIP events on the plan's stream.  Destroys the physical state (timing only). */
+int vvhip_time_kernel(vvhip_plan* plan, int kernel, uint32_t flags, int reps, double* ms_per_launch);
 int vvhip_timing_enable(vvhip_plan* plan, int enable);
 int vvhip_timing_read(vvhip_plan* plan, double* ms_pass_a, double* ms_pass_b, double* ms_other, int32_t launches[3]);
 

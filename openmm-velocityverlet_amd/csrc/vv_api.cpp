@@ -35,14 +35,15 @@ struct vvhip_plan {
     void* d_fextra = nullptr;
     void* d_old_delta = nullptr;
     void* d_pos_delta = nullptr;   // used when the caller does not supply one
-    unsigned long long* d_acc = nullptr;
-    vv::NHDevState* d_nh = nullptr;
+    unsigned long long* d_acc = nullptr;   // [2 parities][NUM_ACC][ACC_SLOTS]
+    vv::NHDevState* d_nh = nullptr;         // [2 parities]
+    int parity = 0;                         // which copy the next reduction/consumer pair uses
     // HIP-event timing (eager launches only)
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events[3];
     // captured graph for vvhip_run_graph
     hipGraphExec_t graph_exec = nullptr;
-    int graph_steps = 0;
+    int graph_steps = 0, graph_parity = 0;
     const void* graph_site = nullptr;
     double graph_kt = 0, graph_kd = 0;
     bool capturing = false;
@@ -94,6 +95,9 @@ void fill_scales(vvhip_plan* p) {
     p->acc_inv_scale[3] = 1.0 / p->acc_scale[3];
 }
 
+vv::NHConst make_chain(vvhip_plan* p, uint32_t flags);
+constexpr int kAccN = vv::NUM_ACC * vv::ACC_SLOTS;
+
 vv::KArgs make_args(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
     const vvhip_params& q = p->hp.params;
     vv::KArgs a{};
@@ -108,8 +112,11 @@ vv::KArgs make_args(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
     a.slot_image = p->d_slot_image;
     a.slot_rand = p->d_slot_rand;
     a.random = (const float4*) p->buf.random;
-    a.acc = p->d_acc;
-    a.nh = p->d_nh;
+    a.acc = p->d_acc + p->parity * kAccN;
+    a.acc_next = p->d_acc + (p->parity ^ 1) * kAccN;
+    a.nh = p->d_nh + p->parity;
+    a.nh_next = p->d_nh + (p->parity ^ 1);
+    a.chain = make_chain(p, 0);
     a.padded = p->hp.padded_num_atoms;
     a.nwaves = p->hp.info.num_waves;
     a.flags = flags;
@@ -136,6 +143,8 @@ vv::NHConst make_chain(vvhip_plan* p, uint32_t flags) {
     const vvhip_plan_info& in = p->hp.info;
     vv::NHConst c{};
     std::memcpy(c.eta_mass, in.eta_mass, sizeof(c.eta_mass));
+    for (int g = 0; g < 3; g++)
+        for (int i = 0; i < VVHIP_MAX_CHAINS; i++) c.inv_eta_mass[g][i] = in.eta_mass[g][i] > 0 ? 1.0 / in.eta_mass[g][i] : 0.0;
     for (int g = 0; g < 3; g++) {
         c.nkbt[g] = in.nkbt[g];
         c.temperature[g] = g == 2 ? q.drude_temperature : q.temperature;                        // HOST:728
@@ -178,12 +187,20 @@ int run_a(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
 int run_b(vvhip_plan* p, uint32_t flags) {
     ScopedTimer t(p, T_B);
     HIP_TRY(p, vv::launch_b(p->hp.precision, make_args(p, flags, 0), p->block_threads, p->stream));
+    if (flags & vv::B_CHAIN) p->parity ^= 1;     // the advanced thermostat state now lives in the other copy
     return VVHIP_OK;
 }
 int run_chain(vvhip_plan* p, uint32_t flags) {
     ScopedTimer t(p, T_OTHER);
-    HIP_TRY(p, vv::launch_chain(make_chain(p, flags), p->d_nh, p->d_acc, p->stream));
+    HIP_TRY(p, vv::launch_chain(make_chain(p, flags), p->d_nh + p->parity, p->d_acc + p->parity * kAccN, p->stream));
     return VVHIP_OK;
+}
+
+// Scaling kernel with the chain in its head (chain length <= 4), or the stand-alone chain launch in front of it.
+int run_chain_and_b(vvhip_plan* p, uint32_t bflags, bool with_bias) {
+    if (p->hp.params.num_nh_chains <= 4) return run_b(p, vv::B_CHAIN | bflags);
+    int rc = run_chain(p, vv::C_CHAIN | (with_bias ? vv::C_BIAS : 0));
+    return rc != VVHIP_OK ? rc : run_b(p, bflags);
 }
 
 uint32_t extra_flags(const vvhip_plan* p) {
@@ -304,12 +321,13 @@ int vvhip_bind(vvhip_plan* p, const vvhip_buffers* b) {
     HIP_TRY(p, hipMemset(p->d_old_delta, 0, nloc * 4 * ms));
     HIP_TRY(p, hipMalloc(&p->d_pos_delta, nloc * 4 * ms));
     HIP_TRY(p, hipMemset(p->d_pos_delta, 0, nloc * 4 * ms));
-    HIP_TRY(p, hipMalloc((void**) &p->d_acc, vv::NUM_ACC * sizeof(unsigned long long)));
-    HIP_TRY(p, hipMemset(p->d_acc, 0, vv::NUM_ACC * sizeof(unsigned long long)));
-    HIP_TRY(p, hipMalloc((void**) &p->d_nh, sizeof(vv::NHDevState)));
-    vv::NHDevState init{};
-    for (int g = 0; g < 3; g++) { init.s.vscale[g] = 1.0; init.scales[g] = 1.0; }
-    HIP_TRY(p, hipMemcpy(p->d_nh, &init, sizeof(init), hipMemcpyHostToDevice));
+    HIP_TRY(p, hipMalloc((void**) &p->d_acc, 2 * kAccN * sizeof(unsigned long long)));
+    HIP_TRY(p, hipMemset(p->d_acc, 0, 2 * kAccN * sizeof(unsigned long long)));
+    HIP_TRY(p, hipMalloc((void**) &p->d_nh, 2 * sizeof(vv::NHDevState)));
+    vv::NHDevState init[2] = {};
+    for (int c = 0; c < 2; c++)
+        for (int g = 0; g < 3; g++) { init[c].s.vscale[g] = 1.0; init[c].scales[g] = 1.0; }
+    HIP_TRY(p, hipMemcpy(p->d_nh, init, sizeof(init), hipMemcpyHostToDevice));
     p->bound = true;
     return VVHIP_OK;
 }
@@ -338,13 +356,13 @@ int vvhip_set_box(vvhip_plan* p, const double box[3]) {
 int vvhip_get_nh_state(vvhip_plan* p, vvhip_nh_state* out) {
     NEED_BOUND(p);
     HIP_TRY(p, hipStreamSynchronize(p->stream));
-    HIP_TRY(p, hipMemcpy(out, &p->d_nh->s, sizeof(*out), hipMemcpyDeviceToHost));
+    HIP_TRY(p, hipMemcpy(out, &p->d_nh[p->parity].s, sizeof(*out), hipMemcpyDeviceToHost));
     return VVHIP_OK;
 }
 int vvhip_set_nh_state(vvhip_plan* p, const vvhip_nh_state* in) {
     NEED_BOUND(p);
     HIP_TRY(p, hipStreamSynchronize(p->stream));
-    HIP_TRY(p, hipMemcpy(&p->d_nh->s, in, sizeof(*in), hipMemcpyHostToDevice));
+    HIP_TRY(p, hipMemcpy(&p->d_nh[p->parity].s, in, sizeof(*in), hipMemcpyHostToDevice));
     return VVHIP_OK;
 }
 
@@ -366,11 +384,11 @@ int vvhip_step_middle_phase(vvhip_plan* p, int phase, uint32_t random_index) {
     }
     if (!cos_on(p)) {
         if (phase == 0) return run_a(p, kick | vv::A_KE, random_index);
-        if (phase == 1) { TRY(run_chain(p, vv::C_CHAIN)); return run_b(p, vv::B_SCALE | drift); }
+        if (phase == 1) return run_chain_and_b(p, vv::B_SCALE | drift, false);
     } else {                                               // API:252-259: bias -> remove -> scale -> restore
         if (phase == 0) return run_a(p, kick | vv::A_BIAS, random_index);
         if (phase == 1) return run_a(p, vv::A_KE | vv::A_UNBIAS_ACC, 0);
-        if (phase == 2) { TRY(run_chain(p, vv::C_CHAIN | vv::C_BIAS)); return run_b(p, vv::B_SCALE | vv::B_UNBIAS | drift); }
+        if (phase == 2) return run_chain_and_b(p, vv::B_SCALE | vv::B_UNBIAS | drift, true);
     }
     return fail(p, VVHIP_ERR_INVALID, "phase out of range");
 }
@@ -378,8 +396,9 @@ int vvhip_step_middle_phase(vvhip_plan* p, int phase, uint32_t random_index) {
 int vvhip_accumulators(vvhip_plan* p, int phase, void** device_ptr, int32_t* count) {
     NEED_BOUND(p);
     if (!device_ptr || !count) return VVHIP_ERR_INVALID;
-    if (cos_on(p) && phase == 0) { *device_ptr = p->d_acc + 3; *count = 1; }    // bias moment only
-    else { *device_ptr = p->d_acc; *count = 3; }                                 // the three 2KE sums
+    unsigned long long* cur = p->d_acc + p->parity * kAccN;
+    if (cos_on(p) && phase == 0) { *device_ptr = cur + 3 * vv::ACC_SLOTS; *count = vv::ACC_SLOTS; }   // bias moment slots only
+    else { *device_ptr = cur; *count = 3 * vv::ACC_SLOTS; }                                          // the three 2KE sums
     return VVHIP_OK;
 }
 
@@ -400,13 +419,11 @@ static int nh_half(vvhip_plan* p, uint32_t a_first, uint32_t random_index, uint3
     }
     if (!cos_on(p)) {
         TRY(run_a(p, a_first | vv::A_KE, random_index));
-        TRY(run_chain(p, vv::C_CHAIN));
-        return run_b(p, vv::B_SCALE | b_extra);
+        return run_chain_and_b(p, vv::B_SCALE | b_extra, false);
     }
     TRY(run_a(p, a_first | vv::A_BIAS, random_index));
     TRY(run_a(p, vv::A_KE | vv::A_UNBIAS_ACC, 0));
-    TRY(run_chain(p, vv::C_CHAIN | vv::C_BIAS));
-    return run_b(p, vv::B_SCALE | vv::B_UNBIAS | b_extra);
+    return run_chain_and_b(p, vv::B_SCALE | vv::B_UNBIAS | b_extra, true);
 }
 
 int vvhip_step_vv_first(vvhip_plan* p) {                   // API:295-310 (forces for the old positions are in `force`)
@@ -452,8 +469,7 @@ int vvhip_scale_velocity(vvhip_plan* p) {                  // HOST:670-754 witho
     NEED_BOUND(p);
     if (!p->hp.has_nh) return VVHIP_OK;
     TRY(run_a(p, vv::A_KE, 0));
-    TRY(run_chain(p, vv::C_CHAIN));
-    return run_b(p, vv::B_SCALE);
+    return run_chain_and_b(p, vv::B_SCALE, false);
 }
 int vvhip_apply_langevin_force(vvhip_plan* p, uint32_t random_index) {
     NEED_BOUND(p);
@@ -480,7 +496,7 @@ int vvhip_calc_viscosity(vvhip_plan* p, double* v_max, double* inv_vis) {   // H
     NEED_BOUND(p);
     double v = 0;
     HIP_TRY(p, hipStreamSynchronize(p->stream));
-    HIP_TRY(p, hipMemcpy(&v, &p->d_nh->s.v_bias, sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(p, hipMemcpy(&v, &p->d_nh[p->parity].s.v_bias, sizeof(double), hipMemcpyDeviceToHost));
     if (p->hp.precision == VVHIP_SINGLE) v = (double) (float) v;             // vMaxBuffer is `mixed`
     const double vol = p->box[0] * p->box[1] * p->box[2];
     if (v_max) *v_max = v;
@@ -546,6 +562,7 @@ int vvhip_synth_tether_force(vvhip_plan* p, const void* site, double k_tether, d
 int vvhip_run_graph(vvhip_plan* p, int nsteps, int steps_per_graph, const void* site, double k_tether, double k_drude) {
     NEED_BOUND(p);
     if (nsteps < 0 || steps_per_graph < 1) return VVHIP_ERR_INVALID;
+    if (steps_per_graph % 2) steps_per_graph += 1;   // the thermostat double-buffers by step parity: a graph must hold an even number of steps
     if (!p->hp.params.use_middle_scheme) return fail(p, VVHIP_ERR_UNSUPPORTED, "graph replay covers the middle scheme only");
     if (p->hp.has_ld) return fail(p, VVHIP_ERR_UNSUPPORTED, "graph replay with Langevin particles needs a per-step random index");
     hipStream_t s = p->stream;
@@ -554,11 +571,12 @@ int vvhip_run_graph(vvhip_plan* p, int nsteps, int steps_per_graph, const void* 
         if (site) TRY(vvhip_synth_tether_force(p, site, k_tether, k_drude));
         return vvhip_step_middle(p, 0);
     };
-    if (!p->graph_exec || p->graph_steps != steps_per_graph || p->graph_site != site || p->graph_kt != k_tether || p->graph_kd != k_drude) {
+    if (!p->graph_exec || p->graph_parity != p->parity || p->graph_steps != steps_per_graph || p->graph_site != site || p->graph_kt != k_tether || p->graph_kd != k_drude) {
         if (p->graph_exec) { (void) hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
         hipGraph_t g = nullptr;
         HIP_TRY(p, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
         p->capturing = true;
+        p->graph_parity = p->parity;
         int rc = VVHIP_OK;
         for (int i = 0; i < steps_per_graph && rc == VVHIP_OK; i++) rc = one_step();
         p->capturing = false;
@@ -573,6 +591,36 @@ int vvhip_run_graph(vvhip_plan* p, int nsteps, int steps_per_graph, const void* 
     int done = 0;
     for (; done + steps_per_graph <= nsteps; done += steps_per_graph) HIP_TRY(p, hipGraphLaunch(p->graph_exec, s));
     for (; done < nsteps; done++) TRY(one_step());
+    return VVHIP_OK;
+}
+
+int vvhip_time_kernel(vvhip_plan* p, int kernel, uint32_t flags, int reps, double* ms_per_launch) {
+    NEED_BOUND(p);
+    if (reps < 1 || !ms_per_launch) return VVHIP_ERR_INVALID;
+    if (flags == 0xFFFFFFFFu) {     // the stage bits vvhip_step_middle uses for this plan
+        if (kernel == 0) flags = vv::A_KICK_FULL | extra_flags(p) | (p->hp.has_nh ? (cos_on(p) ? vv::A_BIAS : vv::A_KE) : 0);
+        else flags = vv::B_DRIFT_MIDDLE | tail_flags(p) | (p->hp.has_nh ? ((p->hp.params.num_nh_chains <= 4 ? vv::B_CHAIN : 0) | vv::B_SCALE | (cos_on(p) ? vv::B_UNBIAS : 0)) : 0);
+    }
+    hipEvent_t e0, e1;
+    HIP_TRY(p, hipEventCreate(&e0));
+    HIP_TRY(p, hipEventCreate(&e1));
+    const int parity = p->parity;
+    const bool was_timing = p->timing;
+    p->timing = false;
+    int rc = VVHIP_OK;
+    for (int i = 0; i < 3 && rc == VVHIP_OK; i++) { p->parity = parity; rc = kernel == 0 ? run_a(p, flags, 0) : run_b(p, flags); }
+    HIP_TRY(p, hipEventRecord(e0, p->stream));
+    for (int i = 0; i < reps && rc == VVHIP_OK; i++) { p->parity = parity; rc = kernel == 0 ? run_a(p, flags, 0) : run_b(p, flags); }
+    HIP_TRY(p, hipEventRecord(e1, p->stream));
+    p->parity = parity;
+    p->timing = was_timing;
+    if (rc != VVHIP_OK) return rc;
+    HIP_TRY(p, hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(p, hipEventElapsedTime(&ms, e0, e1));
+    (void) hipEventDestroy(e0);
+    (void) hipEventDestroy(e1);
+    *ms_per_launch = (double) ms / reps;
     return VVHIP_OK;
 }
 
@@ -612,17 +660,21 @@ int vvhip_debug_launch(vvhip_plan* p, int kernel, uint32_t flags, uint32_t rando
 }
 int vvhip_debug_read_accumulators(vvhip_plan* p, double out[4], int zero_after) {
     NEED_BOUND(p);
-    long long raw[vv::NUM_ACC];
+    static long long raw[vv::NUM_ACC * vv::ACC_SLOTS];
     HIP_TRY(p, hipStreamSynchronize(p->stream));
-    HIP_TRY(p, hipMemcpy(raw, p->d_acc, sizeof(raw), hipMemcpyDeviceToHost));
-    for (int i = 0; i < vv::NUM_ACC; i++) out[i] = (double) raw[i] * p->acc_inv_scale[i];
-    if (zero_after) HIP_TRY(p, hipMemset(p->d_acc, 0, sizeof(raw)));
+    HIP_TRY(p, hipMemcpy(raw, p->d_acc + p->parity * kAccN, sizeof(raw), hipMemcpyDeviceToHost));
+    for (int i = 0; i < vv::NUM_ACC; i++) {
+        long long s = 0;
+        for (int j = 0; j < vv::ACC_SLOTS; j++) s += raw[i * vv::ACC_SLOTS + j];
+        out[i] = (double) s * p->acc_inv_scale[i];
+    }
+    if (zero_after) HIP_TRY(p, hipMemset(p->d_acc + p->parity * kAccN, 0, sizeof(raw)));
     return VVHIP_OK;
 }
 int vvhip_debug_set_scales(vvhip_plan* p, const double scales[4]) {
     NEED_BOUND(p);
     HIP_TRY(p, hipStreamSynchronize(p->stream));
-    HIP_TRY(p, hipMemcpy(p->d_nh->scales, scales, 4 * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(p, hipMemcpy(p->d_nh[p->parity].scales, scales, 4 * sizeof(double), hipMemcpyHostToDevice));
     return VVHIP_OK;
 }
 

@@ -284,6 +284,7 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
             if (c.com_segment && !leader_set) { meta |= META_COM_LEADER; leader_set = true; }
             if (in_pair[i]) meta |= META_PAIR;
             if (is_drude[i]) meta |= META_IS_DRUDE;
+            if (massive) meta |= META_MASSIVE;
             slots[(size_t) wave * 128 + 2 * lane] = i - sb;
             slots[(size_t) wave * 128 + 2 * lane + 1] = (int32_t) meta;
             used++;

@@ -41,6 +41,7 @@ constexpr uint32_t META_HAS_IMAGE = 1u << 23;  // particle is the parent of an i
 constexpr uint32_t META_COM_LEADER = 1u << 24; // lane that adds its molecule's M*V^2 to TG_COM
 constexpr uint32_t META_PAIR = 1u << 25;       // member of a DrudeForce pair (hard wall applies)
 constexpr uint32_t META_IS_DRUDE = 1u << 26;   // the Drude (pair.x) of that pair
+constexpr uint32_t META_MASSIVE = 1u << 27;    // mass != 0 (velm.w != 0)
 
 inline uint32_t meta_role(uint32_t m) { return m & META_ROLE_MASK; }
 

@@ -76,8 +76,18 @@ __device__ __forceinline__ void block_accumulate(const double (&vals)[NV], const
         double s = 0;
         for (int i = 0; i < nw; i++) s += red[i][threadIdx.x];
         const long long q = __double2ll_rn(s * scale[threadIdx.x]);
-        if (q != 0) atomicAdd(&acc[threadIdx.x], (unsigned long long) q);
+        if (q != 0) atomicAdd(&acc[threadIdx.x * ACC_SLOTS + (blockIdx.x & (ACC_SLOTS - 1))], (unsigned long long) q);
     }
+}
+
+// Sum of the ACC_SLOTS slots of quantity k (exact integer sum), computed cooperatively by one wave.
+__device__ __forceinline__ long long acc_total(const unsigned long long* acc, int k, int lane) {
+    long long s = 0;
+#pragma unroll
+    for (int j = 0; j < ACC_SLOTS / 64; j++) s += (long long) acc[k * ACC_SLOTS + lane + 64 * j];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
+    return __shfl(s, 0, 64);
 }
 
 template <class real>
@@ -105,7 +115,7 @@ __device__ __forceinline__ void com_velocity(bool contributes, mixed vx, mixed v
 }
 
 // ================================================================================ kernel A
-template <class real, class mixed>
+template <class real, class mixed, uint32_t SF>   // SF != 0: the stage bits are a compile-time constant (hot paths)
 __global__ void __launch_bounds__(256) vv_kernel_a(const KArgs a) {
     using real4 = typename Vec<real>::v4;
     using real3 = typename Vec<real>::v3;
@@ -113,7 +123,7 @@ __global__ void __launch_bounds__(256) vv_kernel_a(const KArgs a) {
     using P = Prec<real>;
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint32_t F = a.flags;
+    const uint32_t F = SF ? SF : a.flags;
     double k_atom = 0, k_com = 0, k_drude = 0, k_bias = 0;
 
     if (wave < a.nwaves) {
@@ -227,7 +237,7 @@ __global__ void __launch_bounds__(256) vv_kernel_a(const KArgs a) {
             mixed ux = v.x, uy = v.y, uz = v.z;
             if (F & A_UNBIAS_ACC) {                                         // K/cosineAccelerate.cu:53-58, 69-71
                 // same expression as the chain kernel writes to scales[3], so kernel B removes exactly this V
-                const mixed V = (mixed) ((double) (long long) a.acc[3] * a.acc_inv_scale[3] * a.inv_mass_total);
+                const mixed V = (mixed) ((double) acc_total(a.acc, 3, lane) * a.acc_inv_scale[3] * a.inv_mass_total);
                 if (act) ux -= V * cos_kz<real>(pq.z, (real) a.inv_box_z);
             }
             mixed Vx = 0, Vy = 0, Vz = 0, Vw = 0;
@@ -263,70 +273,194 @@ __global__ void __launch_bounds__(256) vv_kernel_a(const KArgs a) {
     }
 }
 
-// ================================================================================ chain kernel
-// VVIntegrator::propagateNHChain (openmmapi/src/VVIntegrator.cpp:340-376) for every temperature group,
-// on the device in double, so the reference's blocking download / upload pair (HOST:709-746) disappears.
-// One wave: lane g < num_tg advances group g; lane 3 turns the bias moment into V.  It is the only
-// reader of the accumulators, so it also re-zeroes them for the next application.
-__global__ void __launch_bounds__(64) vv_kernel_chain(const NHConst c, NHDevState* st, unsigned long long* acc) {
-    __shared__ double eta[VVHIP_NUM_TG][VVHIP_MAX_CHAINS], eta_dot[VVHIP_NUM_TG][VVHIP_MAX_CHAINS + 1],
-        eta_dotdot[VVHIP_NUM_TG][VVHIP_MAX_CHAINS];
-    const int g = threadIdx.x;
-    const int numNHChains = c.num_chains;
-    double sum = 0;
-    if (g < NUM_ACC) sum = (double) (long long) acc[g] * c.acc_inv_scale[g];
-    __syncthreads();
-    if ((c.flags & C_CHAIN) && g < VVHIP_NUM_TG) {
-        double factor = 1.0;
-        if (g < c.num_tg) {
-            const double ke2 = sum, ke2_target = c.nkbt[g], t_target = c.temperature[g];
-            st->s.ke2[g] = ke2;
-            if (c.eta_mass[g][0] > 0) {                                      // HOST:729
-                for (int i = 0; i < numNHChains; i++) {
-                    eta[g][i] = st->s.eta[g][i]; eta_dot[g][i] = st->s.eta_dot[g][i]; eta_dotdot[g][i] = st->s.eta_dotdot[g][i];
-                }
-                eta_dot[g][numNHChains] = st->s.eta_dot[g][numNHChains];
-                const double* eta_mass = c.eta_mass[g];
-                double expfac = 1.0;
-                const double dt2 = c.step_size / c.loops_per_step / 2;
-                const double dt4 = dt2 / 2;
-                const double dt8 = dt4 / 2;
-                const double kT = ((1.380649e-23 * 6.02214076e23) / 1000.0) * t_target;
-                eta_dotdot[g][0] = (ke2 - ke2_target) / eta_mass[0];
-                for (int iloop = 0; iloop < c.loops_per_step; iloop++) {
-                    for (int ich = numNHChains - 1; ich >= 0; ich--) {
-                        expfac = exp(-dt8 * eta_dot[g][ich + 1]);
-                        eta_dot[g][ich] *= expfac;
-                        eta_dot[g][ich] += eta_dotdot[g][ich] * dt4;
-                        eta_dot[g][ich] *= expfac;
-                    }
-                    factor *= exp(-dt2 * eta_dot[g][0]);
-                    for (int ich = 0; ich < numNHChains; ich++) eta[g][ich] += dt2 * eta_dot[g][ich];
-                    eta_dotdot[g][0] = (ke2 * factor * factor - ke2_target) / eta_mass[0];
-                    eta_dot[g][0] *= expfac;                                 // stale expfac on purpose (quirk Q10)
-                    eta_dot[g][0] += eta_dotdot[g][0] * dt4;
-                    eta_dot[g][0] *= expfac;
-                    for (int ich = 1; ich < numNHChains; ich++) {
-                        expfac = exp(-dt8 * eta_dot[g][ich + 1]);
-                        eta_dot[g][ich] *= expfac;
-                        eta_dotdot[g][ich] = (eta_mass[ich - 1] * eta_dot[g][ich - 1] * eta_dot[g][ich - 1] - kT) / eta_mass[ich];
-                        eta_dot[g][ich] += eta_dotdot[g][ich] * dt4;
-                        eta_dot[g][ich] *= expfac;
-                    }
-                }
-                for (int i = 0; i < numNHChains; i++) {
-                    st->s.eta[g][i] = eta[g][i]; st->s.eta_dot[g][i] = eta_dot[g][i]; st->s.eta_dotdot[g][i] = eta_dotdot[g][i];
-                }
+// ================================================================================ NH chain
+// VVIntegrator::propagateNHChain (openmmapi/src/VVIntegrator.cpp:340-376) on the device in double, so the
+// reference's blocking download / upload pair (HOST:709-746) disappears.  Lane g advances temperature group g.
+// exp(x) for the chain.  Its arguments are -dt/8*eta_dot and -dt/2*eta_dot: |x| << 1 in any sane run.  For
+// |x| <= 2^-4 a degree-11 Taylor polynomial (Horner, 11 dependent FMAs) is exact to < 1 ulp (truncation
+// x^12/12! < 1e-23 relative); anything larger goes to the library exp.
+__device__ __forceinline__ double chain_exp(double x) {
+    double p = 1.0 / 39916800.0;
+    p = fma(p, x, 1.0 / 3628800.0);
+    p = fma(p, x, 1.0 / 362880.0);
+    p = fma(p, x, 1.0 / 40320.0);
+    p = fma(p, x, 1.0 / 5040.0);
+    p = fma(p, x, 1.0 / 720.0);
+    p = fma(p, x, 1.0 / 120.0);
+    p = fma(p, x, 1.0 / 24.0);
+    p = fma(p, x, 1.0 / 6.0);
+    p = fma(p, x, 0.5);
+    p = fma(p, x, 1.0);
+    p = fma(p, x, 1.0);
+    if (__builtin_expect(__any(fabs(x) > 0.0625), 0)) p = fabs(x) > 0.0625 ? exp(x) : p;   // wave-uniform, practically never taken
+    return p;
+}
+
+// One temperature group, chain length NC known at compile time so the chain lives in registers.
+// Differences from the host routine, both below 1 ulp per operation: chain_exp for exp, and multiplication by
+// the reciprocal thermostat mass instead of a division.
+template <int NC>
+__device__ __forceinline__ double propagate_regs(const NHConst& c, int g, double ke2, const NHDevState* in, NHDevState* out) {
+    double eta[NC], eta_dot[NC + 1], eta_dotdot[NC], eta_mass[NC], inv_mass[NC];
+#pragma unroll
+    for (int i = 0; i < NC; i++) {
+        eta[i] = in->s.eta[g][i]; eta_dot[i] = in->s.eta_dot[g][i]; eta_dotdot[i] = in->s.eta_dotdot[g][i];
+        eta_mass[i] = c.eta_mass[g][i]; inv_mass[i] = c.inv_eta_mass[g][i];
+    }
+    eta_dot[NC] = in->s.eta_dot[g][NC];
+    double factor = 1.0;
+    if (g < c.num_tg && eta_mass[0] > 0) {                                       // HOST:729
+        const double ke2_target = c.nkbt[g];
+        double expfac = 1.0;
+        const double dt2 = c.step_size / c.loops_per_step / 2;
+        const double dt4 = dt2 / 2;
+        const double dt8 = dt4 / 2;
+        const double kT = ((1.380649e-23 * 6.02214076e23) / 1000.0) * c.temperature[g];
+        eta_dotdot[0] = (ke2 - ke2_target) * inv_mass[0];
+        for (int iloop = 0; iloop < c.loops_per_step; iloop++) {
+#pragma unroll
+            for (int ich = NC - 1; ich >= 0; ich--) {
+                expfac = chain_exp(-dt8 * eta_dot[ich + 1]);
+                eta_dot[ich] *= expfac;
+                eta_dot[ich] += eta_dotdot[ich] * dt4;
+                eta_dot[ich] *= expfac;
+            }
+            factor *= chain_exp(-dt2 * eta_dot[0]);
+#pragma unroll
+            for (int ich = 0; ich < NC; ich++) eta[ich] += dt2 * eta_dot[ich];
+            eta_dotdot[0] = (ke2 * factor * factor - ke2_target) * inv_mass[0];
+            eta_dot[0] *= expfac;                                                // stale expfac on purpose (quirk Q10)
+            eta_dot[0] += eta_dotdot[0] * dt4;
+            eta_dot[0] *= expfac;
+#pragma unroll
+            for (int ich = 1; ich < NC; ich++) {
+                expfac = chain_exp(-dt8 * eta_dot[ich + 1]);
+                eta_dot[ich] *= expfac;
+                eta_dotdot[ich] = (eta_mass[ich - 1] * eta_dot[ich - 1] * eta_dot[ich - 1] - kT) * inv_mass[ich];
+                eta_dot[ich] += eta_dotdot[ich] * dt4;
+                eta_dot[ich] *= expfac;
             }
         }
-        st->s.vscale[g] = factor;
-        st->scales[g] = factor;
-        acc[g] = 0;
     }
-    if ((c.flags & C_BIAS) && g == 3) {                                      // K/cosineAccelerate.cu:57-59
+    if (out) {
+#pragma unroll
+        for (int i = 0; i < NC; i++) { out->s.eta[g][i] = eta[i]; out->s.eta_dot[g][i] = eta_dot[i]; out->s.eta_dotdot[g][i] = eta_dotdot[i]; }
+        out->s.eta_dot[g][NC] = eta_dot[NC];
+        out->s.ke2[g] = g < c.num_tg ? ke2 : in->s.ke2[g];
+        out->s.vscale[g] = factor;
+        out->scales[g] = factor;
+    }
+    return factor;
+}
+
+// The same update on state that the caller has already loaded (kernel B issues those loads at its very top so their
+// latency overlaps the particle loads and the accumulator fold).  NC <= 4.
+struct ChainRegs { double eta[4], eta_dot[5], eta_dotdot[4]; };
+struct ChainLaneConst { double eta_mass[4], inv_eta_mass[4], nkbt, temperature; bool active; };
+// Lane g's row of the chain constants, picked with compile-time indices: a lane-indexed read of a kernel-argument
+// array would turn into dependent vector loads in the middle of the serial chain (measured: +3 us per launch).
+__device__ __forceinline__ ChainLaneConst chain_lane_const(const NHConst& c, int g) {
+    ChainLaneConst r;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        r.eta_mass[i] = g == 0 ? c.eta_mass[0][i] : g == 1 ? c.eta_mass[1][i] : c.eta_mass[2][i];
+        r.inv_eta_mass[i] = g == 0 ? c.inv_eta_mass[0][i] : g == 1 ? c.inv_eta_mass[1][i] : c.inv_eta_mass[2][i];
+    }
+    r.nkbt = g == 0 ? c.nkbt[0] : g == 1 ? c.nkbt[1] : c.nkbt[2];
+    r.temperature = g == 0 ? c.temperature[0] : g == 1 ? c.temperature[1] : c.temperature[2];
+    r.active = g < c.num_tg && r.eta_mass[0] > 0;                                // HOST:729
+    return r;
+}
+template <int NC>
+__device__ __forceinline__ double propagate_preloaded(const NHConst& c, const ChainLaneConst& lc, double ke2, ChainRegs& r) {
+    // Straight-line on purpose (every lane runs it, inactive groups are masked out by selection at the end) so the
+    // scheduler can interleave this serial fp64 chain with the shuffle-heavy per-particle work around it.
+    ChainRegs n = r;
+    double factor = 1.0;
+    const double ke2_target = lc.nkbt;
+    double expfac = 1.0;
+    const double dt2 = c.step_size / c.loops_per_step / 2;
+    const double dt4 = dt2 / 2;
+    const double dt8 = dt4 / 2;
+    const double kT = ((1.380649e-23 * 6.02214076e23) / 1000.0) * lc.temperature;
+    n.eta_dotdot[0] = (ke2 - ke2_target) * lc.inv_eta_mass[0];
+    for (int iloop = 0; iloop < c.loops_per_step; iloop++) {
+#pragma unroll
+        for (int ich = NC - 1; ich >= 0; ich--) {
+            expfac = chain_exp(-dt8 * n.eta_dot[ich + 1]);
+            n.eta_dot[ich] *= expfac;
+            n.eta_dot[ich] += n.eta_dotdot[ich] * dt4;
+            n.eta_dot[ich] *= expfac;
+        }
+        factor *= chain_exp(-dt2 * n.eta_dot[0]);
+#pragma unroll
+        for (int ich = 0; ich < NC; ich++) n.eta[ich] += dt2 * n.eta_dot[ich];
+        n.eta_dotdot[0] = (ke2 * factor * factor - ke2_target) * lc.inv_eta_mass[0];
+        n.eta_dot[0] *= expfac;                                                  // stale expfac on purpose (quirk Q10)
+        n.eta_dot[0] += n.eta_dotdot[0] * dt4;
+        n.eta_dot[0] *= expfac;
+#pragma unroll
+        for (int ich = 1; ich < NC; ich++) {
+            expfac = chain_exp(-dt8 * n.eta_dot[ich + 1]);
+            n.eta_dot[ich] *= expfac;
+            n.eta_dotdot[ich] = (lc.eta_mass[ich - 1] * n.eta_dot[ich - 1] * n.eta_dot[ich - 1] - kT) * lc.inv_eta_mass[ich];
+            n.eta_dot[ich] += n.eta_dotdot[ich] * dt4;
+            n.eta_dot[ich] *= expfac;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NC; i++) {
+        r.eta[i] = lc.active ? n.eta[i] : r.eta[i];
+        r.eta_dot[i] = lc.active ? n.eta_dot[i] : r.eta_dot[i];
+        r.eta_dotdot[i] = lc.active ? n.eta_dotdot[i] : r.eta_dotdot[i];
+    }
+    return lc.active ? factor : 1.0;
+}
+
+// Kernel B only inlines chain lengths up to 4 (register budget: 8 variants would cost half the occupancy);
+// longer chains take the stand-alone chain launch (vv_api.cpp decides).
+__device__ __forceinline__ double propagate_group_small(const NHConst& c, const ChainLaneConst& lc, double ke2, ChainRegs& r) {
+    switch (c.num_chains) {
+        case 1: return propagate_preloaded<1>(c, lc, ke2, r);
+        case 2: return propagate_preloaded<2>(c, lc, ke2, r);
+        case 3: return propagate_preloaded<3>(c, lc, ke2, r);
+        default: return propagate_preloaded<4>(c, lc, ke2, r);
+    }
+}
+__device__ __forceinline__ double propagate_group(const NHConst& c, int g, double ke2, const NHDevState* in, NHDevState* out) {
+    switch (c.num_chains) {
+        case 1: return propagate_regs<1>(c, g, ke2, in, out);
+        case 2: return propagate_regs<2>(c, g, ke2, in, out);
+        case 3: return propagate_regs<3>(c, g, ke2, in, out);
+        case 4: return propagate_regs<4>(c, g, ke2, in, out);
+        case 5: return propagate_regs<5>(c, g, ke2, in, out);
+        case 6: return propagate_regs<6>(c, g, ke2, in, out);
+        case 7: return propagate_regs<7>(c, g, ke2, in, out);
+        default: return propagate_regs<8>(c, g, ke2, in, out);
+    }
+}
+
+// Stand-alone chain launch (one wave), used by the kernel-interface-level entry points that stop between
+// the reduction and its consumer (vvhip_calc_velocity_bias) and by tests.  Sole reader of the accumulators,
+// so it re-zeroes what it consumed.
+__global__ void __launch_bounds__(64) vv_kernel_chain(const NHConst c, NHDevState* st, unsigned long long* acc) {
+    const int g = threadIdx.x;
+    long long tot[NUM_ACC];
+#pragma unroll
+    for (int k = 0; k < NUM_ACC; k++) tot[k] = acc_total(acc, k, g);
+    double sum = 0;
+#pragma unroll
+    for (int k = 0; k < NUM_ACC; k++)
+        if (g == k) sum = (double) tot[k] * c.acc_inv_scale[k];
+    __syncthreads();
+    for (int j = 0; j < ACC_SLOTS / 64; j++) {
+        if (c.flags & C_CHAIN) { acc[0 * ACC_SLOTS + g + 64 * j] = 0; acc[1 * ACC_SLOTS + g + 64 * j] = 0; acc[2 * ACC_SLOTS + g + 64 * j] = 0; }
+        if (c.flags & C_BIAS) acc[3 * ACC_SLOTS + g + 64 * j] = 0;
+    }
+    if ((c.flags & C_CHAIN) && g < VVHIP_NUM_TG) propagate_group(c, g, sum, st, st);
+    if ((c.flags & C_BIAS) && g == 3) {                                          // K/cosineAccelerate.cu:57-59
         st->s.v_bias = sum * c.inv_mass_total;
         st->scales[3] = sum * c.inv_mass_total;
-        acc[3] = 0;
     }
 }
 
@@ -356,7 +490,7 @@ struct PosIO {
     }
 };
 
-template <class real, class mixed>
+template <class real, class mixed, uint32_t SF>
 __global__ void __launch_bounds__(256) vv_kernel_b(const KArgs a) {
     using real4 = typename Vec<real>::v4;
     using real3 = typename Vec<real>::v3;
@@ -365,7 +499,7 @@ __global__ void __launch_bounds__(256) vv_kernel_b(const KArgs a) {
     using IO = PosIO<real, mixed>;
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint32_t F = a.flags;
+    const uint32_t F = SF ? SF : a.flags;
     if (wave >= a.nwaves) return;
 
     const int2 slot = a.slots[(size_t) wave * 64 + lane];
@@ -383,21 +517,81 @@ __global__ void __launch_bounds__(256) vv_kernel_b(const KArgs a) {
     mixed x = 0, y = 0, z = 0, q = 0;
     real zraw = 0;
     if (act && touches_pos) IO::load(a.posq, a.corr, atom, x, y, z, q, zraw);
+    // thermostat inputs of an inline chain: issue these loads now, next to the particle loads
+    const int cg = lane < VVHIP_NUM_TG ? lane : VVHIP_NUM_TG - 1;
+    ChainRegs cr;
+    long long acc_raw[NUM_ACC][ACC_SLOTS / 64];
+    if (F & B_CHAIN) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) { cr.eta[i] = a.nh->s.eta[cg][i]; cr.eta_dot[i] = a.nh->s.eta_dot[cg][i]; cr.eta_dotdot[i] = a.nh->s.eta_dotdot[cg][i]; }
+        cr.eta_dot[4] = a.nh->s.eta_dot[cg][4];
+#pragma unroll
+        for (int k = 0; k < NUM_ACC; k++)
+#pragma unroll
+            for (int j = 0; j < ACC_SLOTS / 64; j++) acc_raw[k][j] = (long long) a.acc[k * ACC_SLOTS + lane + 64 * j];
+    }
     const mixed4 v_old = v;          // velocity after the kick, before the thermostat (Pos1 uses it)
     bool vel_dirty = false, pos_dirty = false;
+
+    // ---------------- scale factors: advance the NH chain right here (every wave redundantly, while its own
+    // loads above are still in flight) or take them from a previous chain launch
+    double sc0 = 1.0, sc1 = 1.0, sc2 = 1.0, scb = 0.0;
+    if (F & B_CHAIN) {
+        const int wib = threadIdx.x >> 6;
+        long long tot[NUM_ACC];
+#pragma unroll
+        for (int k = 0; k < NUM_ACC; k++) {
+            long long s = 0;
+#pragma unroll
+            for (int j = 0; j < ACC_SLOTS / 64; j++) s += acc_raw[k][j];
+            if (!(F & B_DBG_NOFOLD)) {
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
+                s = __shfl(s, 0, 64);
+            }
+            tot[k] = s;
+        }
+        const int g = cg;
+        double ke2 = 0;
+#pragma unroll
+        for (int k = 0; k < VVHIP_NUM_TG; k++)
+            if (g == k) ke2 = (double) tot[k] * a.chain.acc_inv_scale[k];
+        const bool writer = blockIdx.x == 0 && wib == 0;
+        double factor = 1.0;
+        if (!(F & B_DBG_NOMATH)) factor = propagate_group_small(a.chain, chain_lane_const(a.chain, g), ke2, cr);
+        if (lane < VVHIP_NUM_TG) {
+            if (writer) {
+                NHDevState* out = a.nh_next;
+#pragma unroll
+                for (int i = 0; i < 4; i++) { out->s.eta[g][i] = cr.eta[i]; out->s.eta_dot[g][i] = cr.eta_dot[i]; out->s.eta_dotdot[g][i] = cr.eta_dotdot[i]; }
+                out->s.eta_dot[g][4] = cr.eta_dot[4];
+                out->s.ke2[g] = g < a.chain.num_tg ? ke2 : a.nh->s.ke2[g];
+                out->s.vscale[g] = factor;
+                out->scales[g] = factor;
+            }
+        }
+        sc0 = __shfl(factor, 0, 64); sc1 = __shfl(factor, 1, 64); sc2 = __shfl(factor, 2, 64);
+        scb = (F & B_UNBIAS) ? (double) tot[3] * a.chain.acc_inv_scale[3] * a.chain.inv_mass_total   // K/cosineAccelerate.cu:57-59
+                             : a.nh->scales[3];                                                 // carried over unchanged
+        if (writer && lane == 3) { a.nh_next->s.v_bias = scb; a.nh_next->scales[3] = scb; }
+        if (blockIdx.x == 0)        // the other parity's accumulators are idle during this kernel: clear them for the next A
+            for (int i = threadIdx.x; i < NUM_ACC * ACC_SLOTS; i += blockDim.x) a.acc_next[i] = 0;
+    } else if (F & (B_SCALE | B_UNBIAS | B_BIAS_REMOVE | B_BIAS_RESTORE)) {
+        sc0 = a.nh->scales[0]; sc1 = a.nh->scales[1]; sc2 = a.nh->scales[2]; scb = a.nh->scales[3];
+    }
 
     // ---------------- bias removal (K/cosineAccelerate.cu:63-73); cos uses posq.z (real), all particles
     double cz = 0;
     mixed Vb = 0;
     if (F & (B_UNBIAS | B_BIAS_REMOVE | B_BIAS_RESTORE)) {
-        Vb = (mixed) a.nh->scales[3];
+        Vb = (mixed) scb;
         cz = cos_kz<real>(zraw, (real) a.inv_box_z);
         if ((F & (B_UNBIAS | B_BIAS_REMOVE)) && act) { v.x -= Vb * cz; vel_dirty = true; }
     }
 
     // ---------------- NH velocity scaling (K/drudeNoseHoover.cu:157-209)
     if (F & B_SCALE) {
-        const mixed vscaleAtom = (mixed) a.nh->scales[0], vscaleCOM = (mixed) a.nh->scales[1], vscaleDrude = (mixed) a.nh->scales[2];
+        const mixed vscaleAtom = (mixed) sc0, vscaleCOM = (mixed) sc1, vscaleDrude = (mixed) sc2;
         const bool nh = role == ROLE_NH_NORMAL || role == ROLE_NH_DRUDE || role == ROLE_NH_PARENT;
         const bool use_com = ((meta >> META_SEGFIRST_SHIFT) & 63) != ((meta >> META_SEGLAST_SHIFT) & 63) || (meta & META_COM_LEADER);
         mixed Vx = 0, Vy = 0, Vz = 0, Vw = 0;
@@ -619,7 +813,6 @@ __global__ void __launch_bounds__(256) vv_kernel_images(void* posq_, void* corr_
 template <class real, class mixed>
 __global__ void __launch_bounds__(256) vv_kernel_tether(const TetherArgs t) {
     using real4 = typename Vec<real>::v4;
-    using mixed4 = typename Vec<mixed>::v4;
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (wave >= t.nwaves) return;
@@ -629,11 +822,11 @@ __global__ void __launch_bounds__(256) vv_kernel_tether(const TetherArgs t) {
     const int partner = (meta >> META_PARTNER_SHIFT) & 63;
     const bool act = atom >= 0;
     real4 p = {0, 0, 0, 0}, s = {0, 0, 0, 0};
-    mixed w = 0;
-    if (act) { p = ((const real4*) t.posq)[atom]; s = ((const real4*) t.site)[atom]; w = ((const mixed4*) t.velm)[atom].w; }
+    const bool w = act && (meta & META_MASSIVE);       // == (velm.w != 0) without touching velm
+    if (act) { p = ((const real4*) t.posq)[atom]; s = ((const real4*) t.site)[atom]; }
     const real kt = (real) t.k_tether, kd = (real) t.k_drude, scale = (real) 4294967296.0;
     real fx = 0, fy = 0, fz = 0;
-    if (w != 0) { fx = -kt * (p.x - s.x); fy = -kt * (p.y - s.y); fz = -kt * (p.z - s.z); }
+    if (w) { fx = -kt * (p.x - s.x); fy = -kt * (p.y - s.y); fz = -kt * (p.z - s.z); }
     long long ix = (long long) (fx * scale), iy = (long long) (fy * scale), iz = (long long) (fz * scale);
     const real ox = shfl(p.x, partner), oy = shfl(p.y, partner), oz = shfl(p.z, partner);
     if (act && (meta & META_PAIR)) {
@@ -656,13 +849,30 @@ static inline dim3 grid_for(int nwaves, int block_threads) {
         case VVHIP_MIXED: hipLaunchKernelGGL((KERNEL<float, double>), __VA_ARGS__); break;             \
         default: hipLaunchKernelGGL((KERNEL<double, double>), __VA_ARGS__); break;                     \
     }
+#define VV_DISPATCH_SF(KERNEL, SFV, ...)                                                               \
+    switch (precision) {                                                                               \
+        case VVHIP_SINGLE: hipLaunchKernelGGL((KERNEL<float, float, SFV>), __VA_ARGS__); break;        \
+        case VVHIP_MIXED: hipLaunchKernelGGL((KERNEL<float, double, SFV>), __VA_ARGS__); break;        \
+        default: hipLaunchKernelGGL((KERNEL<double, double, SFV>), __VA_ARGS__); break;                \
+    }
+
+// Stage-bit sets with their own compiled kernel: the fused middle step of a Drude system with / without hard wall
+// (BASELINE configs C3 / C2).  Everything else runs the generic kernel with run-time bits.
+constexpr uint32_t SF_A_MIDDLE = A_KICK_FULL | A_KE;
+constexpr uint32_t SF_B_MIDDLE_HW = B_CHAIN | B_SCALE | B_DRIFT_MIDDLE | B_HARDWALL;
+constexpr uint32_t SF_B_MIDDLE = B_CHAIN | B_SCALE | B_DRIFT_MIDDLE;
 
 hipError_t launch_a(int precision, const KArgs& a, int block_threads, hipStream_t s) {
-    VV_DISPATCH(vv_kernel_a, grid_for(a.nwaves, block_threads), dim3(block_threads), 0, s, a);
+    const dim3 g = grid_for(a.nwaves, block_threads), b(block_threads);
+    if (a.flags == SF_A_MIDDLE) { VV_DISPATCH_SF(vv_kernel_a, SF_A_MIDDLE, g, b, 0, s, a); }
+    else { VV_DISPATCH_SF(vv_kernel_a, 0u, g, b, 0, s, a); }
     return hipGetLastError();
 }
 hipError_t launch_b(int precision, const KArgs& a, int block_threads, hipStream_t s) {
-    VV_DISPATCH(vv_kernel_b, grid_for(a.nwaves, block_threads), dim3(block_threads), 0, s, a);
+    const dim3 g = grid_for(a.nwaves, block_threads), b(block_threads);
+    if (a.flags == SF_B_MIDDLE_HW) { VV_DISPATCH_SF(vv_kernel_b, SF_B_MIDDLE_HW, g, b, 0, s, a); }
+    else if (a.flags == SF_B_MIDDLE) { VV_DISPATCH_SF(vv_kernel_b, SF_B_MIDDLE, g, b, 0, s, a); }
+    else { VV_DISPATCH_SF(vv_kernel_b, 0u, g, b, 0, s, a); }
     return hipGetLastError();
 }
 hipError_t launch_chain(const NHConst& c, NHDevState* st, unsigned long long* acc, hipStream_t s) {

@@ -37,11 +37,18 @@ enum : uint32_t {
     B_VV_POS = 1u << 8,       // x += posDelta; v = posDelta/dt        (K/velocityVerlet.cu:35-68)
     B_HARDWALL = 1u << 9,     // (K/middle.cu:106-221)
     B_IMAGE = 1u << 10,       // mirror copy to the image particle     (K/imageCharge.cu:2-28)
+    B_CHAIN = 1u << 11,       // run the NH chain in the kernel head from the accumulators (else read nh->scales)
+    B_DBG_NOFOLD = 1u << 28,  // timing experiments only: skip the accumulator fold / the chain arithmetic
+    B_DBG_NOMATH = 1u << 29,
 };
 // ---- chain kernel --------------------------------------------------------------------------------
 enum : uint32_t { C_CHAIN = 1u << 0, C_BIAS = 1u << 1 };
 
-constexpr int NUM_ACC = 4;   // fixed-point accumulators: 2KE atom, 2KE com, 2KE drude, bias moment
+constexpr int NUM_ACC = 4;     // fixed-point quantities: 2KE atom, 2KE com, 2KE drude, bias moment
+constexpr int ACC_SLOTS = 256; // each quantity is spread over 256 int64 slots (block b adds into slot b % 256):
+                               // thousands of blocks adding into ONE word serialise at ~10 ns per atomic on MI355X
+                               // (measured: 17 us for kernel A at 1000 blocks); integer sums stay exact and
+                               // order-independent, the chain wave folds the slots.  Layout acc[quantity][slot].
 
 // Device-resident thermostat state (reference keeps it on the host: CudaVVKernels.h:206-215)
 struct NHDevState {
@@ -52,6 +59,7 @@ struct NHDevState {
 // Constants of the chain (HOST:577-594 fixed at init; temperatures read live as API:728 does)
 struct NHConst {
     double eta_mass[VVHIP_NUM_TG][VVHIP_MAX_CHAINS];
+    double inv_eta_mass[VVHIP_NUM_TG][VVHIP_MAX_CHAINS];   // 1/eta_mass (0 where the mass is 0): the chain multiplies instead of dividing
     double nkbt[VVHIP_NUM_TG];
     double temperature[VVHIP_NUM_TG];
     double step_size;
@@ -75,8 +83,11 @@ struct KArgs {
     const int32_t* slot_image;
     const int32_t* slot_rand;
     const float4* random;
-    unsigned long long* acc;
-    const NHDevState* nh;
+    unsigned long long* acc;        // accumulators of the current parity (A adds, B consumes)
+    unsigned long long* acc_next;   // other parity: zeroed by B when it runs the chain inline
+    const NHDevState* nh;           // thermostat state of the current parity
+    NHDevState* nh_next;            // where an inline chain writes the advanced state
+    NHConst chain;                  // chain constants (used by B_CHAIN)
     int32_t padded;
     int32_t nwaves;
     uint32_t flags;

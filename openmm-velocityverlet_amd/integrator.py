@@ -358,6 +358,13 @@ class Context:
         H.check(H.lib.vvhip_timing_read(self.plan, C.byref(a), C.byref(b), C.byref(o), C.byref(n)), self.plan)
         return dict(ms_a=a.value, ms_b=b.value, ms_other=o.value, launches=list(n))
 
+    def time_kernel(self, kernel: int, reps: int = 200) -> float:
+        """Average ms of `reps` back-to-back launches of stage kernel 0 (A) / 1 (B) with the fused step's stage bits.
+        Timing only: the physical state is not meaningful afterwards."""
+        ms = C.c_double()
+        H.check(H.lib.vvhip_time_kernel(self.plan, int(kernel), 0xFFFFFFFF, int(reps), C.byref(ms)), self.plan)
+        return ms.value
+
     def close(self):
         if getattr(self, "plan", None):
             H.lib.vvhip_plan_destroy(self.plan)

@@ -24,8 +24,8 @@ OK, ERR_INVALID, ERR_TOPOLOGY, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE = 0, -1, 
 # stage bits of csrc/vv_kernels.hpp (only the test hooks need them)
 A_FE_LOAD, A_FE_STORE, A_LD, A_EF, A_COS, A_KICK_FULL, A_KICK_HALF, A_POSDELTA_VV, A_POS1, A_BIAS, A_KE, A_UNBIAS_ACC = \
     [1 << i for i in range(12)]
-B_SCALE, B_UNBIAS, B_BIAS_REMOVE, B_BIAS_RESTORE, B_DRIFT_MIDDLE, B_POS2, B_POS3, B_VV_KICK, B_VV_POS, B_HARDWALL, B_IMAGE = \
-    [1 << i for i in range(11)]
+B_SCALE, B_UNBIAS, B_BIAS_REMOVE, B_BIAS_RESTORE, B_DRIFT_MIDDLE, B_POS2, B_POS3, B_VV_KICK, B_VV_POS, B_HARDWALL, B_IMAGE, B_CHAIN = \
+    [1 << i for i in range(12)]
 C_CHAIN, C_BIAS = 1, 2
 
 
@@ -115,6 +115,7 @@ def _load():
         "vvhip_stream_create": [P(vp)], "vvhip_stream_destroy": [vp],
         "vvhip_synth_tether_force": [vp, vp, dbl, dbl],
         "vvhip_run_graph": [vp, C.c_int, C.c_int, vp, dbl, dbl],
+        "vvhip_time_kernel": [vp, C.c_int, u32, C.c_int, P(dbl)],
         "vvhip_timing_enable": [vp, C.c_int], "vvhip_timing_read": [vp, P(dbl), P(dbl), P(dbl), P(i32 * 3)],
         "vvhip_debug_launch": [vp, C.c_int, u32, u32],
         "vvhip_debug_read_accumulators": [vp, P(dbl * 4), C.c_int],
