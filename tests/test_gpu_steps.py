@@ -64,8 +64,11 @@ def test_bulk_drude_il(prec, middle, cos):
         ex, ev = _check(osys, ctx, prec, label=f"bulk/{prec}/middle={middle}/cos={cos}")
         # chain state (device, fp64) against the host-double chain of the oracle
         st, ch = ctx.getNHState(), osys.chain_state()
+        # eta_dot[0] ~ (2KE - target)/Q is a difference of nearly equal numbers: a float KE sum (single mode, ~1e-6
+        # relative, order dependent) is amplified ~1000x; in mixed/double the device chain tracks the host one to ~1e-12
+        rtol = 2e-2 if prec == "single" else 1e-8
         for g in range(3):
-            assert np.allclose(list(st.eta_dot[g])[:3], ch["eta_dot"][g][:3], rtol=5e-4, atol=1e-9)
+            assert np.allclose(list(st.eta_dot[g])[:3], ch["eta_dot"][g][:3], rtol=rtol, atol=1e-12 if prec != "single" else 1e-7)
         if cos != 0:
             v_g, inv_g = it.getViscosity()
             v_o, inv_o = osys.viscosity()
