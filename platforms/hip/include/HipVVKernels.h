@@ -1,0 +1,131 @@
+#ifndef VVHIP_KERNELS_H_
+#define VVHIP_KERNELS_H_
+// OpenMM KernelImpl adapters of the HIP backend.  Each class implements one of the seven interfaces of
+// openmm/VVKernels.h by calling the C ABI of libvvhip (include/vvhip.h); all seven share ONE vvhip_plan per
+// HipContext (the reference shares only forceExtra, through getForceExtra(): CudaVVKernels.h:86-88).
+// Counterpart of platforms/cuda/include/CudaVVKernels.h.
+#include <memory>
+
+#include "HipCompat.h"          // with a real OpenMM: "HipContext.h", "HipArray.h", "HipIntegrationUtilities.h"
+#include "openmm/VVIntegrator.h"
+#include "openmm/VVKernels.h"
+#include "vvhip.h"
+
+namespace OpenMM {
+
+// One plan + the parameters it was last told about.
+class HipVVPlan {
+public:
+    HipVVPlan(HipContext& cu, const System& system, const VVIntegrator& integrator, const DrudeForce* force);
+    ~HipVVPlan();
+    vvhip_plan* get() const { return plan; }
+    void syncParameters(const VVIntegrator& integrator);      // the reference reads the getters at every call
+    void check(int rc) const;                                  // vvhip error -> OpenMMException
+    int numLangevinRandoms() const { return ldRandoms; }
+    bool constraintFree() const { return noConstraints; }
+    static std::shared_ptr<HipVVPlan> find(HipContext& cu);    // the plan the step kernel created for this context
+    static std::shared_ptr<HipVVPlan> create(HipContext& cu, const System&, const VVIntegrator&, const DrudeForce*);
+private:
+    HipContext& cu;
+    vvhip_plan* plan;
+    vvhip_params last;
+    int ldRandoms;
+    bool noConstraints;
+};
+
+class HipVVStepCommon {          // code shared by the two step kernels
+protected:
+    explicit HipVVStepCommon(HipContext& cu) : cu(cu) {}
+    void create(const System& system, const VVIntegrator& integrator, const DrudeForce* force);
+    void advanceClock(const VVIntegrator& integrator);
+    uint32_t nextRandomIndex();
+    HipContext& cu;
+    std::shared_ptr<HipVVPlan> plan;
+};
+
+class HipIntegrateMiddleStepKernel : public IntegrateMiddleStepKernel, public FusedVVStepKernel, private HipVVStepCommon {
+public:
+    HipIntegrateMiddleStepKernel(std::string name, const Platform& platform, HipContext& cu)
+        : IntegrateMiddleStepKernel(name, platform), HipVVStepCommon(cu) {}
+    void initialize(const System& system, const VVIntegrator& integrator, const DrudeForce* force);
+    void firstIntegrate(ContextImpl& context, const VVIntegrator& integrator);
+    void resetExtraForce(ContextImpl& context, const VVIntegrator& integrator);
+    void secondIntegrate(ContextImpl& context, const VVIntegrator& integrator);
+    double computeKineticEnergy(ContextImpl& context, const VVIntegrator& integrator);
+    bool canFuse(ContextImpl& context, const VVIntegrator& integrator) const;
+    void fusedMiddleStep(ContextImpl& context, const VVIntegrator& integrator);
+    void fusedVVFirstHalf(ContextImpl& context, const VVIntegrator& integrator);
+    void fusedVVSecondHalf(ContextImpl& context, const VVIntegrator& integrator);
+};
+
+class HipIntegrateVVStepKernel : public IntegrateVVStepKernel, public FusedVVStepKernel, private HipVVStepCommon {
+public:
+    HipIntegrateVVStepKernel(std::string name, const Platform& platform, HipContext& cu)
+        : IntegrateVVStepKernel(name, platform), HipVVStepCommon(cu) {}
+    void initialize(const System& system, const VVIntegrator& integrator, const DrudeForce* force);
+    void firstIntegrate(ContextImpl& context, const VVIntegrator& integrator);
+    void resetExtraForce(ContextImpl& context, const VVIntegrator& integrator);
+    void secondIntegrate(ContextImpl& context, const VVIntegrator& integrator);
+    double computeKineticEnergy(ContextImpl& context, const VVIntegrator& integrator);
+    bool canFuse(ContextImpl& context, const VVIntegrator& integrator) const;
+    void fusedMiddleStep(ContextImpl& context, const VVIntegrator& integrator);
+    void fusedVVFirstHalf(ContextImpl& context, const VVIntegrator& integrator);
+    void fusedVVSecondHalf(ContextImpl& context, const VVIntegrator& integrator);
+};
+
+class HipModifyDrudeNoseKernel : public ModifyDrudeNoseKernel {
+public:
+    HipModifyDrudeNoseKernel(std::string name, const Platform& platform, HipContext& cu) : ModifyDrudeNoseKernel(name, platform), cu(cu) {}
+    void initialize(const System& system, const VVIntegrator& integrator, const DrudeForce* force);
+    void scaleVelocity(ContextImpl& context, const VVIntegrator& integrator);
+private:
+    HipContext& cu;
+    std::shared_ptr<HipVVPlan> plan;
+};
+
+class HipModifyDrudeLangevinKernel : public ModifyDrudeLangevinKernel {
+public:
+    HipModifyDrudeLangevinKernel(std::string name, const Platform& platform, HipContext& cu) : ModifyDrudeLangevinKernel(name, platform), cu(cu) {}
+    void initialize(const System& system, const VVIntegrator& integrator, const DrudeForce* force, Kernel& vvKernel);
+    void applyLangevinForce(ContextImpl& context, const VVIntegrator& integrator);
+private:
+    HipContext& cu;
+    std::shared_ptr<HipVVPlan> plan;
+};
+
+class HipModifyImageChargeKernel : public ModifyImageChargeKernel {
+public:
+    HipModifyImageChargeKernel(std::string name, const Platform& platform, HipContext& cu) : ModifyImageChargeKernel(name, platform), cu(cu) {}
+    void initialize(const System& system, const VVIntegrator& integrator);
+    void updateImagePositions(ContextImpl& context, const VVIntegrator& integrator);
+private:
+    HipContext& cu;
+    std::shared_ptr<HipVVPlan> plan;
+};
+
+class HipModifyElectricFieldKernel : public ModifyElectricFieldKernel {
+public:
+    HipModifyElectricFieldKernel(std::string name, const Platform& platform, HipContext& cu) : ModifyElectricFieldKernel(name, platform), cu(cu) {}
+    void initialize(const System& system, const VVIntegrator& integrator, Kernel& vvKernel);
+    void applyElectricForce(ContextImpl& context, const VVIntegrator& integrator);
+private:
+    HipContext& cu;
+    std::shared_ptr<HipVVPlan> plan;
+};
+
+class HipModifyCosineAccelerateKernel : public ModifyCosineAccelerateKernel {
+public:
+    HipModifyCosineAccelerateKernel(std::string name, const Platform& platform, HipContext& cu) : ModifyCosineAccelerateKernel(name, platform), cu(cu) {}
+    void initialize(const System& system, const VVIntegrator& integrator, Kernel& vvKernel);
+    void applyCosineForce(ContextImpl& context, const VVIntegrator& integrator);
+    void calcVelocityBias(ContextImpl& context, const VVIntegrator& integrator);
+    void removeVelocityBias(ContextImpl& context, const VVIntegrator& integrator);
+    void restoreVelocityBias(ContextImpl& context, const VVIntegrator& integrator);
+    void calcViscosity(ContextImpl& context, const VVIntegrator& integrator, double& vMax, double& invVis);
+private:
+    HipContext& cu;
+    std::shared_ptr<HipVVPlan> plan;
+};
+
+}  // namespace OpenMM
+#endif

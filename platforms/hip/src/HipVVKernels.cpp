@@ -1,0 +1,227 @@
+// KernelImpl adapters: OpenMM objects in, C ABI calls out.  Counterpart of platforms/cuda/src/CudaVVKernels.cpp
+// ("HOST"), minus everything that moved into libvvhip (table building, launches, the thermostat host round trip).
+#include "HipVVKernels.h"
+
+#include <algorithm>
+#include <iostream>
+#include <map>
+#include <mutex>
+#include <typeinfo>
+
+#include "openmm/CMMotionRemover.h"
+#include "openmm/DrudeForce.h"
+#include "openmm/OpenMMException.h"
+#include "openmm/internal/ContextImpl.h"
+
+using namespace OpenMM;
+
+namespace {
+std::mutex registryLock;
+std::map<HipContext*, std::weak_ptr<HipVVPlan> > registry;
+
+vvhip_params paramsOf(const VVIntegrator& it) {
+    vvhip_params p;
+    p.temperature = it.getTemperature(); p.frequency = it.getFrequency();
+    p.drude_temperature = it.getDrudeTemperature(); p.drude_frequency = it.getDrudeFrequency();
+    p.step_size = it.getStepSize();
+    p.num_nh_chains = it.getNumNHChains(); p.loops_per_step = it.getLoopsPerStep();
+    p.max_drude_distance = it.getMaxDrudeDistance();
+    p.friction = it.getFriction(); p.drude_friction = it.getDrudeFriction();
+    p.mirror_location = it.getMirrorLocation(); p.electric_field = it.getElectricField(); p.cos_acceleration = it.getCosAcceleration();
+    p.use_com_temp_group = it.getUseCOMTempGroup(); p.use_middle_scheme = it.getUseMiddleScheme();
+    p.auto_set_com_temp_group = 0;      // VVIntegrator::initialize has already applied the auto rules
+    p.auto_set_friction = 0;
+    return p;
+}
+bool sameParams(const vvhip_params& a, const vvhip_params& b) {
+    return a.temperature == b.temperature && a.frequency == b.frequency && a.drude_temperature == b.drude_temperature &&
+           a.drude_frequency == b.drude_frequency && a.step_size == b.step_size && a.loops_per_step == b.loops_per_step &&
+           a.max_drude_distance == b.max_drude_distance && a.friction == b.friction && a.drude_friction == b.drude_friction &&
+           a.mirror_location == b.mirror_location && a.electric_field == b.electric_field && a.cos_acceleration == b.cos_acceleration;
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ shared plan
+HipVVPlan::HipVVPlan(HipContext& cu, const System& system, const VVIntegrator& it, const DrudeForce* force) : cu(cu), plan(NULL) {
+    const int n = system.getNumParticles();
+    std::vector<double> masses(n);
+    std::vector<int32_t> molId(n), pairs, cons, ld(it.getParticlesLD().begin(), it.getParticlesLD().end()), img,
+        el(it.getParticlesElectrolyte().begin(), it.getParticlesElectrolyte().end());
+    for (int i = 0; i < n; i++) { masses[i] = system.getParticleMass(i); molId[i] = it.getParticleMolId(i); }
+    if (force != NULL)
+        for (int i = 0; i < force->getNumParticles(); i++) {            // HOST:68-73
+            int p, p1, p2, p3, p4; double q, pol, a12, a34;
+            force->getParticleParameters(i, p, p1, p2, p3, p4, q, pol, a12, a34);
+            pairs.push_back(p); pairs.push_back(p1);
+        }
+    for (int i = 0; i < system.getNumConstraints(); i++) {
+        int a, b; double d;
+        system.getConstraintParameters(i, a, b, d);
+        cons.push_back(a); cons.push_back(b);
+    }
+    bool cmm = false;
+    for (int i = 0; i < system.getNumForces(); i++)                     // HOST:550-558
+        if (dynamic_cast<const CMMotionRemover*>(&system.getForce(i)) != NULL) cmm = true;
+    for (const auto& pr : it.getImagePairs()) { img.push_back(pr.first); img.push_back(pr.second); }
+    vvhip_system_desc d = {};
+    d.num_atoms = n; d.padded_num_atoms = cu.getPaddedNumAtoms();
+    d.masses = masses.data(); d.mol_id = molId.data(); d.num_molecules = it.getNumMolecules();
+    d.num_drude_pairs = (int) pairs.size() / 2; d.drude_pairs = pairs.data();
+    d.num_constraints = (int) cons.size() / 2; d.constraints = cons.data();
+    d.has_cm_motion_remover = cmm;
+    d.num_particles_ld = (int) ld.size(); d.particles_ld = ld.data();
+    d.num_image_pairs = (int) img.size() / 2; d.image_pairs = img.data();
+    d.num_electrolyte = (int) el.size(); d.particles_electrolyte = el.data();
+    last = paramsOf(it);
+    const int precision = cu.getUseDoublePrecision() ? VVHIP_DOUBLE : (cu.getUseMixedPrecision() ? VVHIP_MIXED : VVHIP_SINGLE);
+    char err[512] = "";
+    if (vvhip_plan_create(&d, &last, precision, &plan, err, sizeof(err)) != VVHIP_OK) throw OpenMMException(err);
+    vvhip_plan_info info;
+    vvhip_plan_get_info(plan, &info);
+    ldRandoms = std::max(info.num_normal_ld, 1) + 2 * std::max(info.num_pairs_ld, 1);   // HOST:806-807,863: array sizes are max(n,1)
+    noConstraints = system.getNumConstraints() == 0;
+    HipIntegrationUtilities& integration = cu.getIntegrationUtilities();
+    vvhip_buffers b = {};
+    b.velm = cu.getVelm().getDevicePointer(); b.posq = cu.getPosq().getDevicePointer();
+    b.posq_correction = cu.getUseMixedPrecision() ? cu.getPosqCorrection().getDevicePointer() : NULL;
+    b.force = cu.getForce().getDevicePointer(); b.pos_delta = integration.getPosDelta().getDevicePointer();
+    b.random = integration.getRandom().getDevicePointer(); b.random_size = (uint32_t) integration.getRandom().getSize();
+    b.stream = (void*) cu.getCurrentStream();
+    check(vvhip_bind(plan, &b));
+    check(vvhip_set_box(plan, cu.getPeriodicBoxSize()));
+    std::cerr << "HIP velocity-Verlet plan: " << n << " particles in " << info.num_waves << " waves (" << info.num_slots_used
+              << " lanes used), " << info.num_temp_groups << " temperature group(s), NH pairs " << info.num_pairs_nh
+              << ", Langevin particles " << ld.size() << ", image pairs " << info.num_images << "\n";
+    for (int g = 0; g < info.num_temp_groups; g++)
+        std::cerr << "    DOF[" << g << "]: " << info.dof[g] << ", NkbT[" << g << "]: " << info.nkbt[g] << ", etaMass[" << g
+                  << "]: " << info.eta_mass[g][0] << "\n";
+}
+HipVVPlan::~HipVVPlan() { vvhip_plan_destroy(plan); }
+void HipVVPlan::check(int rc) const { if (rc != VVHIP_OK) throw OpenMMException(vvhip_last_error(plan)); }
+void HipVVPlan::syncParameters(const VVIntegrator& it) {
+    vvhip_params now = paramsOf(it);
+    if (!sameParams(now, last)) { check(vvhip_set_params(plan, &now)); last = now; }
+    check(vvhip_set_box(plan, cu.getPeriodicBoxSize()));
+}
+std::shared_ptr<HipVVPlan> HipVVPlan::create(HipContext& cu, const System& s, const VVIntegrator& it, const DrudeForce* f) {
+    std::shared_ptr<HipVVPlan> p(new HipVVPlan(cu, s, it, f));
+    std::lock_guard<std::mutex> g(registryLock);
+    registry[&cu] = p;
+    return p;
+}
+std::shared_ptr<HipVVPlan> HipVVPlan::find(HipContext& cu) {
+    std::lock_guard<std::mutex> g(registryLock);
+    std::shared_ptr<HipVVPlan> p = registry[&cu].lock();
+    if (!p) throw OpenMMException("the velocity-Verlet step kernel must be initialized before its modifier kernels");
+    return p;
+}
+
+// ------------------------------------------------------------------------------------------ step kernels
+void HipVVStepCommon::create(const System& system, const VVIntegrator& it, const DrudeForce* force) {
+    cu.getIntegrationUtilities().initRandomNumberGenerator((unsigned int) it.getRandomNumberSeed());   // HOST:63
+    plan = HipVVPlan::create(cu, system, it, force);
+}
+void HipVVStepCommon::advanceClock(const VVIntegrator& it) {      // HOST:219-220, 430-431
+    cu.setTime(cu.getTime() + it.getStepSize());
+    cu.setStepCount(cu.getStepCount() + 1);
+}
+uint32_t HipVVStepCommon::nextRandomIndex() { return (uint32_t) cu.getIntegrationUtilities().prepareRandomNumbers(plan->numLangevinRandoms()); }
+
+void HipIntegrateMiddleStepKernel::initialize(const System& s, const VVIntegrator& it, const DrudeForce* f) { create(s, it, f); }
+void HipIntegrateMiddleStepKernel::resetExtraForce(ContextImpl&, const VVIntegrator&) { plan->check(vvhip_reset_extra_force(plan->get())); }
+void HipIntegrateMiddleStepKernel::firstIntegrate(ContextImpl&, const VVIntegrator& it) {              // HOST:129-159
+    cu.setAsCurrent();
+    plan->syncParameters(it);
+    plan->check(vvhip_middle_kick(plan->get()));
+    cu.getIntegrationUtilities().applyVelocityConstraints(it.getConstraintTolerance());
+    plan->check(vvhip_middle_half_drift1(plan->get()));
+}
+void HipIntegrateMiddleStepKernel::secondIntegrate(ContextImpl&, const VVIntegrator& it) {             // HOST:161-231
+    cu.setAsCurrent();
+    plan->check(vvhip_middle_half_drift2(plan->get()));
+    cu.getIntegrationUtilities().applyConstraints(it.getConstraintTolerance());
+    plan->check(vvhip_middle_finish(plan->get()));
+    cu.getIntegrationUtilities().computeVirtualSites();
+    cu.reorderAtoms();
+    advanceClock(it);
+}
+double HipIntegrateMiddleStepKernel::computeKineticEnergy(ContextImpl&, const VVIntegrator&) {
+    return cu.getIntegrationUtilities().computeKineticEnergy(0);                                        // HOST:233-235 (OpenMM's)
+}
+bool HipIntegrateMiddleStepKernel::canFuse(ContextImpl&, const VVIntegrator&) const { return plan->constraintFree(); }
+void HipIntegrateMiddleStepKernel::fusedMiddleStep(ContextImpl&, const VVIntegrator& it) {
+    cu.setAsCurrent();
+    plan->syncParameters(it);
+    plan->check(vvhip_step_middle(plan->get(), it.getParticlesLD().empty() ? 0 : nextRandomIndex()));
+    cu.reorderAtoms();
+    advanceClock(it);
+}
+void HipIntegrateMiddleStepKernel::fusedVVFirstHalf(ContextImpl&, const VVIntegrator&) { throw OpenMMException("middle-scheme kernel asked for a classic step"); }
+void HipIntegrateMiddleStepKernel::fusedVVSecondHalf(ContextImpl&, const VVIntegrator&) { throw OpenMMException("middle-scheme kernel asked for a classic step"); }
+
+void HipIntegrateVVStepKernel::initialize(const System& s, const VVIntegrator& it, const DrudeForce* f) { create(s, it, f); }
+void HipIntegrateVVStepKernel::resetExtraForce(ContextImpl&, const VVIntegrator&) { plan->check(vvhip_reset_extra_force(plan->get())); }
+void HipIntegrateVVStepKernel::firstIntegrate(ContextImpl&, const VVIntegrator& it) {                   // HOST:296-382
+    cu.setAsCurrent();
+    plan->syncParameters(it);
+    plan->check(vvhip_vv_half_kick(plan->get(), 1));
+    cu.getIntegrationUtilities().applyConstraints(it.getConstraintTolerance());
+    plan->check(vvhip_vv_positions(plan->get()));
+    cu.getIntegrationUtilities().computeVirtualSites();
+    cu.reorderAtoms();                                   // after the first half, so Langevin indices stay valid (HOST:376-381)
+}
+void HipIntegrateVVStepKernel::secondIntegrate(ContextImpl&, const VVIntegrator& it) {                  // HOST:395-442
+    cu.setAsCurrent();
+    plan->check(vvhip_vv_half_kick(plan->get(), 0));
+    cu.getIntegrationUtilities().applyVelocityConstraints(it.getConstraintTolerance());
+    advanceClock(it);
+}
+double HipIntegrateVVStepKernel::computeKineticEnergy(ContextImpl&, const VVIntegrator&) { return cu.getIntegrationUtilities().computeKineticEnergy(0); }
+bool HipIntegrateVVStepKernel::canFuse(ContextImpl&, const VVIntegrator&) const { return plan->constraintFree(); }
+void HipIntegrateVVStepKernel::fusedMiddleStep(ContextImpl&, const VVIntegrator&) { throw OpenMMException("classic kernel asked for a middle-scheme step"); }
+void HipIntegrateVVStepKernel::fusedVVFirstHalf(ContextImpl&, const VVIntegrator& it) {
+    cu.setAsCurrent();
+    plan->syncParameters(it);
+    plan->check(vvhip_step_vv_first(plan->get()));
+    cu.reorderAtoms();
+}
+void HipIntegrateVVStepKernel::fusedVVSecondHalf(ContextImpl&, const VVIntegrator& it) {
+    plan->check(vvhip_step_vv_second(plan->get(), it.getParticlesLD().empty() ? 0 : nextRandomIndex()));
+    advanceClock(it);
+}
+
+// ------------------------------------------------------------------------------------------ modifier kernels
+void HipModifyDrudeNoseKernel::initialize(const System&, const VVIntegrator&, const DrudeForce*) { plan = HipVVPlan::find(cu); }
+void HipModifyDrudeNoseKernel::scaleVelocity(ContextImpl&, const VVIntegrator& it) {                    // HOST:670-754
+    plan->syncParameters(it);
+    plan->check(vvhip_scale_velocity(plan->get()));
+}
+
+void HipModifyDrudeLangevinKernel::initialize(const System&, const VVIntegrator&, const DrudeForce*, Kernel&) { plan = HipVVPlan::find(cu); }
+void HipModifyDrudeLangevinKernel::applyLangevinForce(ContextImpl&, const VVIntegrator& it) {            // HOST:826-872
+    plan->syncParameters(it);
+    const int randomIndex = cu.getIntegrationUtilities().prepareRandomNumbers(plan->numLangevinRandoms());
+    plan->check(vvhip_apply_langevin_force(plan->get(), (uint32_t) randomIndex));
+}
+
+void HipModifyImageChargeKernel::initialize(const System&, const VVIntegrator&) { plan = HipVVPlan::find(cu); }
+void HipModifyImageChargeKernel::updateImagePositions(ContextImpl&, const VVIntegrator& it) {            // HOST:904-934
+    plan->syncParameters(it);
+    plan->check(vvhip_update_image_positions(plan->get()));
+}
+
+void HipModifyElectricFieldKernel::initialize(const System&, const VVIntegrator&, Kernel&) { plan = HipVVPlan::find(cu); }
+void HipModifyElectricFieldKernel::applyElectricForce(ContextImpl&, const VVIntegrator& it) {            // HOST:971-992
+    plan->syncParameters(it);
+    plan->check(vvhip_apply_electric_force(plan->get()));
+}
+
+void HipModifyCosineAccelerateKernel::initialize(const System&, const VVIntegrator&, Kernel&) { plan = HipVVPlan::find(cu); }
+void HipModifyCosineAccelerateKernel::applyCosineForce(ContextImpl&, const VVIntegrator& it) { plan->syncParameters(it); plan->check(vvhip_apply_cosine_force(plan->get())); }
+void HipModifyCosineAccelerateKernel::calcVelocityBias(ContextImpl&, const VVIntegrator&) { plan->check(vvhip_calc_velocity_bias(plan->get())); }
+void HipModifyCosineAccelerateKernel::removeVelocityBias(ContextImpl&, const VVIntegrator&) { plan->check(vvhip_remove_velocity_bias(plan->get())); }
+void HipModifyCosineAccelerateKernel::restoreVelocityBias(ContextImpl&, const VVIntegrator&) { plan->check(vvhip_restore_velocity_bias(plan->get())); }
+void HipModifyCosineAccelerateKernel::calcViscosity(ContextImpl&, const VVIntegrator& it, double& vMax, double& invVis) {   // HOST:1112-1134
+    plan->syncParameters(it);
+    plan->check(vvhip_calc_viscosity(plan->get(), &vMax, &invVis));
+}

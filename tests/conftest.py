@@ -14,6 +14,9 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # the oracle is test infrastructure: build it here, never from product code
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "all"], check=True)
+    # the product's native pieces (hipcc / g++ cross-compile without a GPU; no-ops when up to date)
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "openmm-velocityverlet_amd", "csrc")], check=True)
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "platforms", "hip")], check=True)
 
 
 @pytest.fixture(scope="session")

@@ -1,0 +1,163 @@
+// tests/cpp/plugin_driver.cpp -- test code.  Drives the C++ layers the way OpenMM does:
+//   registerHipVVKernelFactories() -> Platform "HIP" -> Context -> VVIntegrator::initialize -> createKernel(...) ->
+//   Hip*Kernel adapters -> libvvhip C ABI -> HIP kernels.
+//   vv_plugin_driver registry                 (no GPU needed) checks registration, names and error behaviour
+//   vv_plugin_driver chain                    (no GPU needed) prints VVIntegrator::propagateNHChain on fixed inputs
+//   vv_plugin_driver run OUT middle cons cos N   (GPU) runs N steps on a small Drude system and dumps system + result
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <vector>
+
+#include "HipVVKernelFactory.h"
+#include "HipVVKernels.h"
+#include "openmm/CMMotionRemover.h"
+#include "openmm/Context.h"
+#include "openmm/DrudeForce.h"
+#include "openmm/VVIntegrator.h"
+#include "openmm/VVKernels.h"
+
+using namespace OpenMM;
+
+static unsigned long long lcg_state = 88172645463325252ull;
+static double uniform() { lcg_state = lcg_state * 6364136223846793005ull + 1442695040888963407ull; return (double) (lcg_state >> 11) / 9007199254740992.0; }
+static double gauss() { double s = 0; for (int i = 0; i < 12; i++) s += uniform(); return s - 6.0; }
+
+struct ProbeIntegrator : VVIntegrator {       // exposes the protected kernel-name list
+    using VVIntegrator::VVIntegrator;
+    std::vector<std::string> names() { return getKernelNames(); }
+};
+
+static int registry() {
+    registerPlatforms();
+    registerHipVVKernelFactories();
+    registerHipVVKernelFactories();            // idempotent: must not add a second platform
+    Platform& hip = Platform::getPlatformByName("HIP");
+    ProbeIntegrator probe(300, 10, 1, 40, 0.001);
+    int ok = 1;
+    for (const std::string& n : probe.names()) {
+        std::printf("kernel %s: %s\n", n.c_str(), hip.hasKernelFactory(n) ? "registered" : "MISSING");
+        ok &= hip.hasKernelFactory(n);
+    }
+    HipVVKernelFactory f;
+    System sys; sys.addParticle(1.0);
+    Context ctx(sys, probe, hip);
+    HipPlatform::PlatformData pd; pd.contexts.push_back(NULL);
+    ctx.getImpl().setPlatformData(&pd);
+    try { hip.createKernel("NoSuchKernel", ctx.getImpl()); ok = 0; } catch (const OpenMMException& e) { std::printf("unknown via platform: %s\n", e.what()); }
+    try { probe.step(1); ok = 0; } catch (const OpenMMException& e) { std::printf("unbound step: %s\n", e.what()); }
+    std::printf(ok ? "REGISTRY OK\n" : "REGISTRY FAILED\n");
+    return ok ? 0 : 1;
+}
+
+static int chain() {
+    ProbeIntegrator it(333.0, 10.0, 1.0, 40.0, 0.001, 3, 2);
+    std::vector<double> eta = {0.01, -0.02, 0.03}, ed = {0.5, -1.5, 2.5, 0.0}, edd = {0.1, 0.2, 0.3}, mass = {4500.0, 0.0277, 0.0277};
+    double scale = 0;
+    it.propagateNHChain(eta, ed, edd, mass, 460000.0, 457000.0, 333.0, scale);
+    std::printf("%.17g", scale);
+    for (double v : eta) std::printf(" %.17g", v);
+    for (double v : ed) std::printf(" %.17g", v);
+    for (double v : edd) std::printf(" %.17g", v);
+    std::printf("\n");
+    return 0;
+}
+
+struct ForceUser { HipContext* cu; HipArray* site; };
+static void tether(ContextImpl&, void* user) {
+    ForceUser* u = (ForceUser*) user;
+    std::shared_ptr<HipVVPlan> plan = HipVVPlan::find(*u->cu);
+    plan->check(vvhip_synth_tether_force(plan->get(), u->site->getDevicePointer(), 1000.0, 209200.0));
+}
+
+template <class T> static void put(std::ofstream& f, const std::vector<T>& v) { long long n = (long long) v.size(); f.write((const char*) &n, 8); f.write((const char*) v.data(), n * sizeof(T)); }
+
+static int run(const char* out, bool middle, bool withConstraint, double cosacc, int nsteps) {
+    registerHipVVKernelFactories();
+    Platform& hip = Platform::getPlatformByName("HIP");
+    const int nmol = 40, per = 8;              // [heavy, drude, heavy, drude, heavy, drude, H, H] per molecule
+    const int n = nmol * per;
+    System system;
+    DrudeForce* drude = new DrudeForce();
+    std::vector<double> masses, charges;
+    std::vector<int> molId;
+    std::vector<std::vector<int> > molecules(nmol);
+    std::vector<int> pairs;
+    for (int m = 0; m < nmol; m++)
+        for (int k = 0; k < per; k++) {
+            const int i = m * per + k;
+            const bool isDrude = k < 6 && (k & 1);
+            const double mass = k >= 6 ? 1.008 : (isDrude ? 0.4 : 11.611 + (k == 0 ? 1.996 : 0.0));
+            system.addParticle(mass);
+            masses.push_back(mass); charges.push_back(isDrude ? -2.0 : (k < 6 ? 2.1 : 0.1)); molId.push_back(m);
+            molecules[m].push_back(i);
+            if (isDrude) { drude->addParticle(i, i - 1, -1, -1, -1, -2.0, 0.001, 1, 1); pairs.push_back(i); pairs.push_back(i - 1); }
+        }
+    system.addForce(drude);
+    system.addForce(new CMMotionRemover());
+    std::vector<int> cons;
+    if (withConstraint) { system.addConstraint(6, 4, 0.1); cons = {6, 4}; }   // only its presence matters here: it forces the un-fused path
+    const double box[3] = {3.0, 3.0, 3.0}, kB = (1.380649e-23 * 6.02214076e23) / 1000.0;
+    std::vector<double> pos(3 * n), vel(3 * n);
+    for (int m = 0; m < nmol; m++) {
+        double c[3] = {uniform() * box[0], uniform() * box[1], uniform() * box[2]};
+        for (int k = 0; k < per; k++) {
+            const int i = m * per + k;
+            const bool isDrude = k < 6 && (k & 1);
+            for (int d = 0; d < 3; d++) {
+                pos[3 * i + d] = isDrude ? pos[3 * (i - 1) + d] + 2e-4 * gauss() : c[d] + 0.15 * (2 * uniform() - 1);
+                vel[3 * i + d] = gauss() * std::sqrt(kB * (isDrude ? 30.0 : 333.0) / masses[i]);
+            }
+        }
+    }
+    ProbeIntegrator it(333.0, 10.0, 1.0, 40.0, 0.001);
+    it.setMaxDrudeDistance(0.02);
+    it.setUseMiddleScheme(middle);
+    it.setCosAcceleration(cosacc);
+    Context ctx(system, it, hip);
+    HipContext cu(n, false, true);             // HipPrecision = mixed
+    cu.setPeriodicBoxSize(box[0], box[1], box[2]);
+    std::vector<double> velm(4 * n);
+    std::vector<float> posq(4 * n), corr(4 * n, 0.f);
+    for (int i = 0; i < n; i++) {
+        for (int d = 0; d < 3; d++) {
+            velm[4 * i + d] = vel[3 * i + d];
+            posq[4 * i + d] = (float) pos[3 * i + d];
+            corr[4 * i + d] = (float) (pos[3 * i + d] - (double) posq[4 * i + d]);
+        }
+        velm[4 * i + 3] = 1.0 / masses[i];
+        posq[4 * i + 3] = (float) charges[i];
+    }
+    cu.getVelm().upload(velm.data()); cu.getPosq().upload(posq.data()); cu.getPosqCorrection().upload(corr.data());
+    HipArray site; site.initialize(n, 16); site.upload(posq.data());
+    HipPlatform::PlatformData pd; pd.contexts.push_back(&cu);
+    ctx.getImpl().setPlatformData(&pd);
+    ctx.getImpl().setMolecules(molecules);
+    ForceUser fu = {&cu, &site};
+    ctx.getImpl().setForceCallback(tether, &fu);
+    ctx.initialize();
+    it.step(nsteps);
+    std::vector<double> vis = it.getViscosity();
+    (void) hipDeviceSynchronize();
+    cu.getVelm().download(velm.data()); cu.getPosq().download(posq.data()); cu.getPosqCorrection().download(corr.data());
+    std::ofstream f(out, std::ios::binary);
+    put(f, masses); put(f, charges); put(f, molId); put(f, pairs); put(f, cons); put(f, pos); put(f, vel);
+    put(f, velm); put(f, posq); put(f, corr); put(f, vis);
+    std::printf("RUN OK steps=%d time=%.6f stepCount=%lld vMax=%.9g\n", nsteps, cu.getTime(), cu.getStepCount(), vis[0]);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    try {
+        if (argc >= 2 && !std::strcmp(argv[1], "registry")) return registry();
+        if (argc >= 2 && !std::strcmp(argv[1], "chain")) return chain();
+        if (argc >= 7 && !std::strcmp(argv[1], "run")) return run(argv[2], std::atoi(argv[3]) != 0, std::atoi(argv[4]) != 0, std::atof(argv[5]), std::atoi(argv[6]));
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "exception: %s\n", e.what());
+        return 2;
+    }
+    std::fprintf(stderr, "usage: vv_plugin_driver registry | chain | run OUT middle cons cos nsteps\n");
+    return 64;
+}
