@@ -1,0 +1,28 @@
+"""N > 1 path: world_size-2 runs over gloo (CPU: the fixed-point exchange protocol; GPU: two ranks sharing the one GPU,
+sharded trajectory vs single process).  On the 8-GPU node the same ShardedStepper runs over nccl (= RCCL, xGMI)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "dist_worker.py")
+
+
+def _launch(mode, port):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), WORKER, mode]
+    return subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+
+
+def test_fixed_point_exchange_protocol_gloo_world2():
+    r = _launch("protocol", 29541)
+    assert r.returncode == 0 and "PROTOCOL OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_sharded_step_equals_single_process_two_ranks_one_gpu():
+    r = _launch("gpu", 29542)
+    assert r.returncode == 0 and "GPU DIST OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
