@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--steps-per-graph", type=int, default=100)
     ap.add_argument("--eager", action="store_true", help="no hipGraph replay (host-launched every step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="take the multi-GPU code path (process group + ShardedStepper) even at N=1")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -51,9 +52,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path is HIP only (no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     pkg = importlib.import_module("openmm-velocityverlet_amd")
     I, S, D = pkg.integrator, pkg.systems, pkg.distributed
@@ -71,11 +74,11 @@ def main():
     if cfg == "C4":
         it.setCosAcceleration(0.02)
     bounds = D.shard_bounds(spec, world)
-    stream = torch.cuda.current_stream().cuda_stream if world > 1 else None
+    stream = torch.cuda.current_stream().cuda_stream if use_dist else None
     ctx = I.Context(spec, it, precision=args.precision, force_provider=args.forces, shard=bounds[rank],
                     device=local_rank, stream=stream)
-    stepper = D.ShardedStepper(ctx) if world > 1 else None
-    use_graph = world == 1 and not args.eager
+    stepper = D.ShardedStepper(ctx) if use_dist else None
+    use_graph = not use_dist and not args.eager
 
     def run(n):
         if stepper is not None:
@@ -88,7 +91,7 @@ def main():
     def fence():
         ctx.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -98,7 +101,7 @@ def main():
     run(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -123,12 +126,12 @@ def main():
                                    f"hard wall 0.02 nm, dt {dt * 1e3:g} fs" + (", cos acceleration 0.02 nm/ps^2" if cfg == "C4" else ""),
                        "force_provider": f"{args.forces} (synthetic, inside the timed region)" if args.forces == "tether" else "static buffer",
                        "launch": "hipGraph replay, %d steps/graph" % args.steps_per_graph if use_graph else "host-launched per step",
-                       "parallelism": "1 GPU" if world == 1 else f"particle shards on molecule boundaries x{world}, int64 all-reduce per thermostat application",
+                       "parallelism": ("1 GPU" + (" (distributed code path forced)" if use_dist else "")) if world == 1 else f"particle shards on molecule boundaries x{world}, int64 all-reduce per thermostat application",
                        "atom_steps_per_s": round(steps_per_s * n, 1)},
         }
 
     # ---- roofline of the dominant kernel, measured live with HIP events on the plan's stream (N = 1 only)
-    if world == 1 and rank == 0:
+    if world == 1 and rank == 0 and not use_dist:
         # two HIP events around 300 back-to-back launches of each stage kernel with the fused step's stage bits
         # (per-launch events in an eager stream starve the GPU and read ~2x high; the rocprofv3 averages under
         # profiles/ are the cross-check).  Runs after the headline measurement: it scrambles the physical state.
@@ -154,7 +157,7 @@ def main():
                            "note": "working set is Infinity-Cache resident at this size; see DESIGN.md"}
 
     # ---- CPU baseline: the oracle (our C restatement of the reference path, OpenMP) on this host's cores, bounded sample
-    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+    if world == 1 and rank == 0 and not args.no_cpu_baseline and not use_dist:
         from oracle import oracle as O
         ncpu = os.cpu_count() or 1
         p = O.Params(temperature=it.getTemperature(), drude_temperature=1.0, step_size=dt, max_drude_distance=it.getMaxDrudeDistance(),
@@ -182,11 +185,17 @@ def main():
         out["cpu_baseline"] = {"value": round(nsteps / cpu_elapsed, 2), "unit": "steps/s", "cores": cores, "kind": "port",
                                "sample": f"{nsteps} steps of the same {cfg} workload ({cpu_elapsed:.1f} s), oracle/vv_oracle.c with OpenMP, "
                                          f"fastest of 1..{min(ncpu, 128)} threads on a {ncpu}-CPU host"}
-    if rank == 0:
-        print(json.dumps(out))
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
+    if rank == 0:          # last thing on stdout (librccl prints a banner of its own when the process group comes up)
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)      # librccl's banner sits in the C stdio buffer until exit otherwise
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
