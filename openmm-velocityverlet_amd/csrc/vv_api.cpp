@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <utility>
@@ -35,6 +36,7 @@ struct vvhip_plan {
     void* d_fextra = nullptr;
     void* d_old_delta = nullptr;
     void* d_pos_delta = nullptr;   // used when the caller does not supply one
+    void* d_comv = nullptr;        // per-segment COM velocities handed from kernel A to kernel B
     unsigned long long* d_acc = nullptr;   // [2 parities][NUM_ACC][ACC_SLOTS]
     vv::NHDevState* d_nh = nullptr;         // [2 parities]
     int parity = 0;                         // which copy the next reduction/consumer pair uses
@@ -108,6 +110,7 @@ vv::KArgs make_args(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
     a.fextra = p->d_fextra;
     a.pos_delta = p->buf.pos_delta ? p->buf.pos_delta : p->d_pos_delta;
     a.old_delta = p->d_old_delta;
+    a.comv = p->d_comv;
     a.slots = p->d_slots;
     a.slot_image = p->d_slot_image;
     a.slot_rand = p->d_slot_rand;
@@ -242,6 +245,10 @@ int vvhip_plan_create(const vvhip_system_desc* system, const vvhip_params* param
         fill_scales(p);
         // small systems: one wave per block spreads the work over more CUs (256 CUs, 8 XCDs)
         p->block_threads = p->hp.info.num_waves >= 2048 ? 256 : (p->hp.info.num_waves >= 512 ? 128 : 64);
+        if (const char* e = std::getenv("VVHIP_BLOCK")) {          // tuning experiments
+            const int b = std::atoi(e);
+            if (b == 64 || b == 128 || b == 192 || b == 256) p->block_threads = b;
+        }
         *plan_out = p;
         return VVHIP_OK;
     } catch (const vv::Error& e) {
@@ -256,7 +263,7 @@ void vvhip_plan_destroy(vvhip_plan* p) {
     if (p->bound) {
         (void) hipStreamSynchronize(p->stream);
         for (void* ptr : {(void*) p->d_slots, (void*) p->d_slot_image, (void*) p->d_slot_rand, (void*) p->d_image_pairs,
-                          p->d_fextra, p->d_old_delta, p->d_pos_delta, (void*) p->d_acc, (void*) p->d_nh})
+                          p->d_fextra, p->d_old_delta, p->d_pos_delta, p->d_comv, (void*) p->d_acc, (void*) p->d_nh})
             if (ptr) (void) hipFree(ptr);
         if (p->graph_exec) (void) hipGraphExecDestroy(p->graph_exec);
         for (auto& v : p->events)
@@ -319,6 +326,8 @@ int vvhip_bind(vvhip_plan* p, const vvhip_buffers* b) {
     HIP_TRY(p, hipMemset(p->d_fextra, 0, nloc * 3 * rs));
     HIP_TRY(p, hipMalloc(&p->d_old_delta, nloc * 4 * ms));
     HIP_TRY(p, hipMemset(p->d_old_delta, 0, nloc * 4 * ms));
+    HIP_TRY(p, hipMalloc(&p->d_comv, nslots * 4 * ms));
+    HIP_TRY(p, hipMemset(p->d_comv, 0, nslots * 4 * ms));
     HIP_TRY(p, hipMalloc(&p->d_pos_delta, nloc * 4 * ms));
     HIP_TRY(p, hipMemset(p->d_pos_delta, 0, nloc * 4 * ms));
     HIP_TRY(p, hipMalloc((void**) &p->d_acc, 2 * kAccN * sizeof(unsigned long long)));

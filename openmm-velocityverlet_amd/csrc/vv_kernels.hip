@@ -68,6 +68,7 @@ __device__ __forceinline__ void block_accumulate(const double (&vals)[NV], const
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
 #pragma unroll
     for (int k = 0; k < NV; k++) {
+        if (!enabled[k]) continue;           // compile-time in the specialised kernels
         double s = wave_sum(vals[k]);
         if (lane == 0) red[w][k] = s;
     }
@@ -246,6 +247,10 @@ __global__ void __launch_bounds__(256) vv_kernel_a(const KArgs a) {
             // the COM stage is wave-uniform on purpose: lanes outside a COM segment scan a 1-lane segment
             com_velocity<real, mixed>(nh && massive && use_com, ux, uy, uz, v.w, lane, meta, Vx, Vy, Vz, Vw);
             if (!use_com) { Vx = 0; Vy = 0; Vz = 0; Vw = 0; }
+            if ((meta & META_COM_LEADER) && use_com) {      // hand the COM velocity to the scaling kernel (the reference's comVelm[id_mol])
+                mixed4 cv = {Vx, Vy, Vz, Vw};
+                ((mixed4*) a.comv)[(size_t) wave * 64 + ((meta >> META_SEGFIRST_SHIFT) & 63)] = cv;
+            }
             if (nh) { ux -= Vx; uy -= Vy; uz -= Vz; }                       // K/drudeNoseHoover.cu:45-47
             const mixed px = shfl(ux, partner), py = shfl(uy, partner), pz = shfl(uz, partner), pw = shfl(v.w, partner);
             if (role == ROLE_NH_NORMAL && massive) {                        // K/drudeNoseHoover.cu:76-83
@@ -491,20 +496,29 @@ struct PosIO {
 };
 
 template <class real, class mixed, uint32_t SF>
-__global__ void __launch_bounds__(256) vv_kernel_b(const KArgs a) {
+__global__ void __launch_bounds__(320) vv_kernel_b(const KArgs a) {
     using real4 = typename Vec<real>::v4;
     using real3 = typename Vec<real>::v3;
     using mixed4 = typename Vec<mixed>::v4;
     using P = Prec<real>;
     using IO = PosIO<real, mixed>;
     const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t F = SF ? SF : a.flags;
-    if (wave >= a.nwaves) return;
+    // Block layout.  With B_CHAIN the LAST wave of every block is the block's thermostat wave: it folds the
+    // accumulators and advances the NH chain (a ~2 us serial fp64 dependency chain) while the other waves of the
+    // block load their particles and do the scale-independent preparation; one barrier joins them.  Without this,
+    // every tile wave pays the chain on its own critical path (measured: 9.7 -> see DESIGN.md §7).
+    const int nwb = blockDim.x >> 6, wib = threadIdx.x >> 6;
+    const bool has_cw = (F & B_CHAIN) != 0;
+    const bool chain_wave = has_cw && wib == nwb - 1;
+    const int tiles_per_block = has_cw ? nwb - 1 : nwb;
+    const int wave = blockIdx.x * tiles_per_block + wib;
+    const bool valid = !chain_wave && wave < a.nwaves;
+    __shared__ double sh_scales[4];
 
-    const int2 slot = a.slots[(size_t) wave * 64 + lane];
-    const int atom = slot.x;
-    const unsigned meta = (unsigned) slot.y;
+    int atom = -1;
+    unsigned meta = 0;
+    if (valid) { const int2 slot = a.slots[(size_t) wave * 64 + lane]; atom = slot.x; meta = (unsigned) slot.y; }
     const unsigned role = meta & META_ROLE_MASK;
     const int partner = (meta >> META_PARTNER_SHIFT) & 63;
     const bool act = atom >= 0;
@@ -517,67 +531,61 @@ __global__ void __launch_bounds__(256) vv_kernel_b(const KArgs a) {
     mixed x = 0, y = 0, z = 0, q = 0;
     real zraw = 0;
     if (act && touches_pos) IO::load(a.posq, a.corr, atom, x, y, z, q, zraw);
-    // thermostat inputs of an inline chain: issue these loads now, next to the particle loads
-    const int cg = lane < VVHIP_NUM_TG ? lane : VVHIP_NUM_TG - 1;
-    ChainRegs cr;
-    long long acc_raw[NUM_ACC][ACC_SLOTS / 64];
-    if (F & B_CHAIN) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) { cr.eta[i] = a.nh->s.eta[cg][i]; cr.eta_dot[i] = a.nh->s.eta_dot[cg][i]; cr.eta_dotdot[i] = a.nh->s.eta_dotdot[cg][i]; }
-        cr.eta_dot[4] = a.nh->s.eta_dot[cg][4];
-#pragma unroll
-        for (int k = 0; k < NUM_ACC; k++)
-#pragma unroll
-            for (int j = 0; j < ACC_SLOTS / 64; j++) acc_raw[k][j] = (long long) a.acc[k * ACC_SLOTS + lane + 64 * j];
-    }
     const mixed4 v_old = v;          // velocity after the kick, before the thermostat (Pos1 uses it)
     bool vel_dirty = false, pos_dirty = false;
 
-    // ---------------- scale factors: advance the NH chain right here (every wave redundantly, while its own
-    // loads above are still in flight) or take them from a previous chain launch
+    const bool nh = role == ROLE_NH_NORMAL || role == ROLE_NH_DRUDE || role == ROLE_NH_PARENT;
+    const bool use_com = ((meta >> META_SEGFIRST_SHIFT) & 63) != ((meta >> META_SEGLAST_SHIFT) & 63) || (meta & META_COM_LEADER);
+    mixed Vx = 0, Vy = 0, Vz = 0, Vw = 0;
+    // COM velocity of this lane's molecule as kernel A's KE stage left it (of the bias-free velocities when a bias is
+    // removed): one 32-byte entry per molecule, the same address for every lane of the segment
+    if ((F & B_SCALE) && nh && use_com) {
+        const mixed4 cv = ((const mixed4*) a.comv)[(size_t) wave * 64 + ((meta >> META_SEGFIRST_SHIFT) & 63)];
+        Vx = cv.x; Vy = cv.y; Vz = cv.z; Vw = cv.w;
+    }
+
+    // ---------------- scale factors
     double sc0 = 1.0, sc1 = 1.0, sc2 = 1.0, scb = 0.0;
-    if (F & B_CHAIN) {
-        const int wib = threadIdx.x >> 6;
-        long long tot[NUM_ACC];
+    if (has_cw) {
+        if (chain_wave) {
+            const int cg = lane < VVHIP_NUM_TG ? lane : VVHIP_NUM_TG - 1;
+            ChainRegs cr;
 #pragma unroll
-        for (int k = 0; k < NUM_ACC; k++) {
-            long long s = 0;
+            for (int i = 0; i < 4; i++) { cr.eta[i] = a.nh->s.eta[cg][i]; cr.eta_dot[i] = a.nh->s.eta_dot[cg][i]; cr.eta_dotdot[i] = a.nh->s.eta_dotdot[cg][i]; }
+            cr.eta_dot[4] = a.nh->s.eta_dot[cg][4];
+            long long tot[NUM_ACC];
 #pragma unroll
-            for (int j = 0; j < ACC_SLOTS / 64; j++) s += acc_raw[k][j];
-            if (!(F & B_DBG_NOFOLD)) {
+            for (int k = 0; k < NUM_ACC; k++) tot[k] = (F & B_DBG_NOFOLD) ? 0 : acc_total(a.acc, k, lane);
+            double ke2 = 0;
 #pragma unroll
-                for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
-                s = __shfl(s, 0, 64);
-            }
-            tot[k] = s;
-        }
-        const int g = cg;
-        double ke2 = 0;
-#pragma unroll
-        for (int k = 0; k < VVHIP_NUM_TG; k++)
-            if (g == k) ke2 = (double) tot[k] * a.chain.acc_inv_scale[k];
-        const bool writer = blockIdx.x == 0 && wib == 0;
-        double factor = 1.0;
-        if (!(F & B_DBG_NOMATH)) factor = propagate_group_small(a.chain, chain_lane_const(a.chain, g), ke2, cr);
-        if (lane < VVHIP_NUM_TG) {
-            if (writer) {
+            for (int k = 0; k < VVHIP_NUM_TG; k++)
+                if (cg == k) ke2 = (double) tot[k] * a.chain.acc_inv_scale[k];
+            double factor = 1.0;
+            if (!(F & B_DBG_NOMATH)) factor = propagate_group_small(a.chain, chain_lane_const(a.chain, cg), ke2, cr);
+            const double bias = (F & B_UNBIAS) ? (double) tot[3] * a.chain.acc_inv_scale[3] * a.chain.inv_mass_total   // K/cosineAccelerate.cu:57-59
+                                               : a.nh->scales[3];                                                 // carried over unchanged
+            if (lane < VVHIP_NUM_TG) sh_scales[lane] = factor;
+            if (lane == 3) sh_scales[3] = bias;
+            if (blockIdx.x == 0) {                    // one block records the advanced thermostat and clears the idle accumulator copy
                 NHDevState* out = a.nh_next;
+                if (lane < VVHIP_NUM_TG) {
 #pragma unroll
-                for (int i = 0; i < 4; i++) { out->s.eta[g][i] = cr.eta[i]; out->s.eta_dot[g][i] = cr.eta_dot[i]; out->s.eta_dotdot[g][i] = cr.eta_dotdot[i]; }
-                out->s.eta_dot[g][4] = cr.eta_dot[4];
-                out->s.ke2[g] = g < a.chain.num_tg ? ke2 : a.nh->s.ke2[g];
-                out->s.vscale[g] = factor;
-                out->scales[g] = factor;
+                    for (int i = 0; i < 4; i++) { out->s.eta[cg][i] = cr.eta[i]; out->s.eta_dot[cg][i] = cr.eta_dot[i]; out->s.eta_dotdot[cg][i] = cr.eta_dotdot[i]; }
+                    out->s.eta_dot[cg][4] = cr.eta_dot[4];
+                    out->s.ke2[cg] = cg < a.chain.num_tg ? ke2 : a.nh->s.ke2[cg];
+                    out->s.vscale[cg] = factor;
+                    out->scales[cg] = factor;
+                }
+                if (lane == 3) { out->s.v_bias = bias; out->scales[3] = bias; }
+                for (int i = lane; i < NUM_ACC * ACC_SLOTS; i += 64) a.acc_next[i] = 0;
             }
         }
-        sc0 = __shfl(factor, 0, 64); sc1 = __shfl(factor, 1, 64); sc2 = __shfl(factor, 2, 64);
-        scb = (F & B_UNBIAS) ? (double) tot[3] * a.chain.acc_inv_scale[3] * a.chain.inv_mass_total   // K/cosineAccelerate.cu:57-59
-                             : a.nh->scales[3];                                                 // carried over unchanged
-        if (writer && lane == 3) { a.nh_next->s.v_bias = scb; a.nh_next->scales[3] = scb; }
-        if (blockIdx.x == 0)        // the other parity's accumulators are idle during this kernel: clear them for the next A
-            for (int i = threadIdx.x; i < NUM_ACC * ACC_SLOTS; i += blockDim.x) a.acc_next[i] = 0;
-    } else if (F & (B_SCALE | B_UNBIAS | B_BIAS_REMOVE | B_BIAS_RESTORE)) {
-        sc0 = a.nh->scales[0]; sc1 = a.nh->scales[1]; sc2 = a.nh->scales[2]; scb = a.nh->scales[3];
+        __syncthreads();
+        if (!valid) return;
+        sc0 = sh_scales[0]; sc1 = sh_scales[1]; sc2 = sh_scales[2]; scb = sh_scales[3];
+    } else {
+        if (!valid) return;
+        if (F & (B_SCALE | B_UNBIAS | B_BIAS_REMOVE | B_BIAS_RESTORE)) { sc0 = a.nh->scales[0]; sc1 = a.nh->scales[1]; sc2 = a.nh->scales[2]; scb = a.nh->scales[3]; }
     }
 
     // ---------------- bias removal (K/cosineAccelerate.cu:63-73); cos uses posq.z (real), all particles
@@ -592,11 +600,6 @@ __global__ void __launch_bounds__(256) vv_kernel_b(const KArgs a) {
     // ---------------- NH velocity scaling (K/drudeNoseHoover.cu:157-209)
     if (F & B_SCALE) {
         const mixed vscaleAtom = (mixed) sc0, vscaleCOM = (mixed) sc1, vscaleDrude = (mixed) sc2;
-        const bool nh = role == ROLE_NH_NORMAL || role == ROLE_NH_DRUDE || role == ROLE_NH_PARENT;
-        const bool use_com = ((meta >> META_SEGFIRST_SHIFT) & 63) != ((meta >> META_SEGLAST_SHIFT) & 63) || (meta & META_COM_LEADER);
-        mixed Vx = 0, Vy = 0, Vz = 0, Vw = 0;
-        com_velocity<real, mixed>(nh && massive && use_com, v.x, v.y, v.z, v.w, lane, meta, Vx, Vy, Vz, Vw);
-        if (!use_com) { Vx = 0; Vy = 0; Vz = 0; }
         mixed ux = v.x, uy = v.y, uz = v.z;
         if (nh) { ux -= Vx; uy -= Vy; uz -= Vz; }
         const mixed px = shfl(ux, partner), py = shfl(uy, partner), pz = shfl(uz, partner), pw = shfl(v.w, partner);
@@ -689,18 +692,21 @@ __global__ void __launch_bounds__(256) vv_kernel_b(const KArgs a) {
     // ---------------- hard wall on Drude pairs (K/middle.cu:106-221); pair.x = Drude = "1", parent = "2"
     if (F & B_HARDWALL) {
         const mixed ox = shfl(x, partner), oy = shfl(y, partner), oz = shfl(z, partner);
-        const mixed ovx = shfl(v.x, partner), ovy = shfl(v.y, partner), ovz = shfl(v.z, partner), ovw = shfl(v.w, partner);
+        const mixed ovw = shfl(v.w, partner);
         if (act && (meta & META_PAIR)) {
             const bool isd = (meta & META_IS_DRUDE) != 0;
             const mixed maxDrudeDistance = (mixed) a.max_drude, hardwallscaleDrude = (mixed) a.hw_scale;
             mixed p1x = isd ? x : ox, p1y = isd ? y : oy, p1z = isd ? z : oz;
             mixed p2x = isd ? ox : x, p2y = isd ? oy : y, p2z = isd ? oz : z;
-            mixed vel1x = isd ? v.x : ovx, vel1y = isd ? v.y : ovy, vel1z = isd ? v.z : ovz, vel1w = isd ? v.w : ovw;
-            mixed vel2x = isd ? ovx : v.x, vel2y = isd ? ovy : v.y, vel2z = isd ? ovz : v.z, vel2w = isd ? ovw : v.w;
+            const mixed vel1w = isd ? v.w : ovw, vel2w = isd ? ovw : v.w;
             const mixed deltax = p1x - p2x, deltay = p1y - p2y, deltaz = p1z - p2z;
             const mixed r = P::SQRT(deltax * deltax + deltay * deltay + deltaz * deltaz);
             const mixed rInv = P::RECIP(r);
             if (rInv * maxDrudeDistance < 1) {
+                // both lanes of a pair see the same r, so both are in here: the partner's velocity is fetched only now
+                const mixed ovx = shfl(v.x, partner), ovy = shfl(v.y, partner), ovz = shfl(v.z, partner);
+                mixed vel1x = isd ? v.x : ovx, vel1y = isd ? v.y : ovy, vel1z = isd ? v.z : ovz;
+                mixed vel2x = isd ? ovx : v.x, vel2y = isd ? ovy : v.y, vel2z = isd ? ovz : v.z;
                 const mixed bx = deltax * rInv, by = deltay * rInv, bz = deltaz * rInv;
                 const mixed mass1 = P::RECIP(vel1w), mass2 = P::RECIP(vel2w);
                 const mixed deltaR = r - maxDrudeDistance;
@@ -869,7 +875,8 @@ hipError_t launch_a(int precision, const KArgs& a, int block_threads, hipStream_
     return hipGetLastError();
 }
 hipError_t launch_b(int precision, const KArgs& a, int block_threads, hipStream_t s) {
-    const dim3 g = grid_for(a.nwaves, block_threads), b(block_threads);
+    // block_threads counts the tile waves; B_CHAIN adds the block's thermostat wave
+    const dim3 g = grid_for(a.nwaves, block_threads), b(block_threads + ((a.flags & B_CHAIN) ? 64 : 0));
     if (a.flags == SF_B_MIDDLE_HW) { VV_DISPATCH_SF(vv_kernel_b, SF_B_MIDDLE_HW, g, b, 0, s, a); }
     else if (a.flags == SF_B_MIDDLE) { VV_DISPATCH_SF(vv_kernel_b, SF_B_MIDDLE, g, b, 0, s, a); }
     else { VV_DISPATCH_SF(vv_kernel_b, 0u, g, b, 0, s, a); }

@@ -79,6 +79,7 @@ struct KArgs {
     void* fextra;
     void* pos_delta;
     void* old_delta;
+    void* comv;                    // mixed4 [64*nwaves]: COM velocity of the segment starting at that lane, written by A_KE, read by B_SCALE
     const int2* slots;
     const int32_t* slot_image;
     const int32_t* slot_rand;
