@@ -40,24 +40,41 @@ template <> struct Prec<double> {
 
 __device__ __forceinline__ float shfl(float x, int src) { return __shfl(x, src, 64); }
 __device__ __forceinline__ double shfl(double x, int src) { return __shfl(x, src, 64); }
-__device__ __forceinline__ float shfl_up(float x, int d) { return __shfl_up(x, d, 64); }
-__device__ __forceinline__ double shfl_up(double x, int d) { return __shfl_up(x, d, 64); }
 
-__device__ __forceinline__ double wave_sum(double x) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) x += __shfl_down(x, d, 64);
-    return x;   // valid in lane 0
+// ---- wave-wide inclusive prefix sum on the DPP network (no LDS round trips): Hillis-Steele inside each 16-lane
+// row (row_shr 1,2,4,8; lanes without a source add 0), then row 0 -> row 1 / row 2 -> row 3 (row_bcast:15) and
+// rows 0+1 -> rows 2,3 (row_bcast:31).  Lane 63 ends up with the wave total.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_fetch(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROW_MASK, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, 0xF, true);
+    return __hiloint2double(hi, lo);
 }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_fetch(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xF, true));
+}
+template <class T>
+__device__ __forceinline__ T wave_scan(T x) {
+    x += dpp_fetch<0x111, 0xF>(x);   // row_shr:1
+    x += dpp_fetch<0x112, 0xF>(x);   // row_shr:2
+    x += dpp_fetch<0x114, 0xF>(x);   // row_shr:4
+    x += dpp_fetch<0x118, 0xF>(x);   // row_shr:8
+    x += dpp_fetch<0x142, 0xA>(x);   // row_bcast:15 into rows 1 and 3
+    x += dpp_fetch<0x143, 0xC>(x);   // row_bcast:31 into rows 2 and 3
+    return x;
+}
+// total of a wave in lane 63
+__device__ __forceinline__ double wave_sum(double x) { return wave_scan(x); }
 
-// Segmented inclusive scan over contiguous lanes [first, last], then broadcast of the segment total.
+// Total of the contiguous lane segment [first, last] for every lane of it: P[last] - P[first-1] on the wave prefix sum.
+// (The prefix runs over at most 64 particles, so the subtraction costs < 3 bits; the reference itself sums serially.)
 template <class T>
 __device__ __forceinline__ T segment_total(T x, int lane, int first, int last) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        T t = shfl_up(x, d);
-        if (lane - d >= first) x += t;
-    }
-    return shfl(x, last);
+    const T P = wave_scan(x);
+    const T hi = shfl(P, last);
+    const T lo = shfl(P, first > 0 ? first - 1 : 0);
+    return first > 0 ? hi - lo : hi;
 }
 
 // Block partials -> fixed-point atomics.  vals[k] is the calling thread's contribution.
@@ -70,7 +87,7 @@ __device__ __forceinline__ void block_accumulate(const double (&vals)[NV], const
     for (int k = 0; k < NV; k++) {
         if (!enabled[k]) continue;           // compile-time in the specialised kernels
         double s = wave_sum(vals[k]);
-        if (lane == 0) red[w][k] = s;
+        if (lane == 63) red[w][k] = s;
     }
     __syncthreads();
     if (threadIdx.x < NV && enabled[threadIdx.x]) {
@@ -81,14 +98,25 @@ __device__ __forceinline__ void block_accumulate(const double (&vals)[NV], const
     }
 }
 
-// Sum of the ACC_SLOTS slots of quantity k (exact integer sum), computed cooperatively by one wave.
+// Sum of the ACC_SLOTS slots of quantity k (exact integer sum), computed cooperatively by one wave (DPP prefix sum,
+// total taken from lane 63).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ long long dpp_fetch_i64(long long x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, (int) (x & 0xFFFFFFFFll), CTRL, ROW_MASK, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int) (x >> 32), CTRL, ROW_MASK, 0xF, true);
+    return ((long long) hi << 32) | (unsigned int) lo;
+}
 __device__ __forceinline__ long long acc_total(const unsigned long long* acc, int k, int lane) {
     long long s = 0;
 #pragma unroll
     for (int j = 0; j < ACC_SLOTS / 64; j++) s += (long long) acc[k * ACC_SLOTS + lane + 64 * j];
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
-    return __shfl(s, 0, 64);
+    s += dpp_fetch_i64<0x111, 0xF>(s);
+    s += dpp_fetch_i64<0x112, 0xF>(s);
+    s += dpp_fetch_i64<0x114, 0xF>(s);
+    s += dpp_fetch_i64<0x118, 0xF>(s);
+    s += dpp_fetch_i64<0x142, 0xA>(s);
+    s += dpp_fetch_i64<0x143, 0xC>(s);
+    return __shfl(s, 63, 64);
 }
 
 template <class real>
