@@ -36,7 +36,9 @@ def main():
     ap.add_argument("--steps-per-graph", type=int, default=100)
     ap.add_argument("--eager", action="store_true", help="no hipGraph replay (host-launched every step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--force-dist", action="store_true", help="take the multi-GPU code path (process group + ShardedStepper) even at N=1")
+    ap.add_argument("--force-dist", action="store_true", help="take the multi-GPU code path (process group + exchange) even at N=1")
+    ap.add_argument("--dist-mode", default="auto", choices=["auto", "graph", "eager", "python"],
+                    help="N>1: graph = RCCL all-reduce captured in the hipGraph; eager = issued from C per step; python = torch.distributed per step")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -74,17 +76,60 @@ def main():
     if cfg == "C4":
         it.setCosAcceleration(0.02)
     bounds = D.shard_bounds(spec, world)
-    stream = torch.cuda.current_stream().cuda_stream if use_dist else None
-    ctx = I.Context(spec, it, precision=args.precision, force_provider=args.forces, shard=bounds[rank],
-                    device=local_rank, stream=stream)
-    stepper = D.ShardedStepper(ctx) if use_dist else None
-    use_graph = not use_dist and not args.eager
+    # N > 1: the plan gets its own RCCL communicator (bootstrap through the torch process group) and then exchanges the
+    # accumulators itself, inside the captured graph if possible; torch.distributed per step is the last resort.
+    dist_mode = None
+    ctx = None
+    if use_dist and args.dist_mode != "python":
+        try:
+            ctx = I.Context(spec, it, precision=args.precision, force_provider=args.forces, shard=bounds[rank], device=local_rank)
+            idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(ctx.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, src=0)
+            ctx.comm_init(bytes(idt.cpu().numpy().tobytes()), world, rank)
+            ok = 1
+        except Exception as e:                                   # noqa: BLE001
+            sys.stderr.write(f"[rank {rank}] in-core RCCL unavailable ({e}); falling back to torch.distributed per step\n")
+            ok = 0
+        flag = torch.tensor([ok], device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            dist_mode = "graph" if args.dist_mode in ("auto", "graph") else "eager"
+            if dist_mode == "graph":                             # every rank must agree that capture works
+                try:
+                    ctx.run_graph(2, 2)
+                    ctx.synchronize()
+                    ok = 1
+                except Exception as e:                           # noqa: BLE001
+                    sys.stderr.write(f"[rank {rank}] graph capture with RCCL failed ({e}); using the C eager loop\n")
+                    ok = 0
+                flag = torch.tensor([ok], device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 0:
+                    dist_mode = "eager"
+        else:
+            if ctx is not None:
+                ctx.close()
+            it._context = None
+            ctx = None
+    stepper = None
+    if ctx is None:
+        stream = torch.cuda.current_stream().cuda_stream if use_dist else None
+        ctx = I.Context(spec, it, precision=args.precision, force_provider=args.forces, shard=bounds[rank],
+                        device=local_rank, stream=stream)
+        if use_dist:
+            stepper = D.ShardedStepper(ctx)
+            dist_mode = "python"
+    use_graph = (not use_dist and not args.eager) or dist_mode == "graph"
 
     def run(n):
         if stepper is not None:
             stepper.step(n)
         elif use_graph:
             ctx.run_graph(n, args.steps_per_graph)
+        elif dist_mode == "eager":
+            ctx.run_eager(n)
         else:
             it.step(n)
 
@@ -126,7 +171,7 @@ def main():
                                    f"hard wall 0.02 nm, dt {dt * 1e3:g} fs" + (", cos acceleration 0.02 nm/ps^2" if cfg == "C4" else ""),
                        "force_provider": f"{args.forces} (synthetic, inside the timed region)" if args.forces == "tether" else "static buffer",
                        "launch": "hipGraph replay, %d steps/graph" % args.steps_per_graph if use_graph else "host-launched per step",
-                       "parallelism": ("1 GPU" + (" (distributed code path forced)" if use_dist else "")) if world == 1 else f"particle shards on molecule boundaries x{world}, int64 all-reduce per thermostat application",
+                       "parallelism": ("1 GPU" + (f" (distributed code path forced: {dist_mode})" if use_dist else "")) if world == 1 else f"particle shards on molecule boundaries x{world}, int64 all-reduce per thermostat application ({dist_mode})",
                        "atom_steps_per_s": round(steps_per_s * n, 1)},
         }
 

@@ -177,6 +177,15 @@ int vvhip_step_middle_phases(const vvhip_plan* plan);
 int vvhip_step_middle_phase(vvhip_plan* plan, int phase, uint32_t random_index);
 int vvhip_accumulators(vvhip_plan* plan, int phase, void** device_ptr, int32_t* count);
 
+/* Built-in exchange.  Instead of running the collective itself, a host may hand the plan an RCCL communicator:
+ * rank 0 calls vvhip_comm_unique_id(), ships the 128 bytes to the other ranks by any means (bench.py uses
+ * torch.distributed), every rank calls vvhip_comm_init(); from then on vvhip_step_middle / vvhip_run_graph /
+ * vvhip_run_eager issue ncclAllReduce(int64, sum) on the plan's stream between the phases themselves, so a whole
+ * sharded step (or a captured graph of steps) needs no host involvement.  librccl is resolved at run time. */
+int vvhip_comm_unique_id(void* id128);
+int vvhip_comm_init(vvhip_plan* plan, const void* id128, int nranks, int rank);
+int vvhip_comm_destroy(vvhip_plan* plan);
+
 /* ---------------------------------------------------------------- kernel-interface level
  * One entry per KernelImpl virtual, for use inside OpenMM where constraint solvers run between them. */
 /* IntegrateMiddleStepKernel (VVKernels.h:50-86; HOST:119-235) */
@@ -224,6 +233,8 @@ int vvhip_synth_tether_force(vvhip_plan* plan, const void* site /* real4[n] */, 
 /* Captures `steps_per_graph` steps (optionally with the synthetic force kernel in front of each) into a
  * hipGraph once and replays it; returns after enqueueing.  Middle scheme only. */
 int vvhip_run_graph(vvhip_plan* plan, int nsteps, int steps_per_graph, const void* site, double k_tether, double k_drude);
+/* The same steps enqueued one by one from C (no graph): fallback when graph capture is not wanted. */
+int vvhip_run_eager(vvhip_plan* plan, int nsteps, const void* site, double k_tether, double k_drude);
 /* HIP-event timing of the dominant kernels on the plan's stream, for bench.py's roofline block. */
 /* Average duration of `reps` back-to-back launches of one stage kernel (0 = A, 1 = B) with the given stage bits,
  * bracketed by two HIP events on the plan's stream.  Destroys the physical state (timing only). */

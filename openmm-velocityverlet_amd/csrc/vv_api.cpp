@@ -10,10 +10,40 @@
 #include <utility>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types and prototypes only: the library is resolved at run time (see rccl_api)
+
 #include "vv_host.hpp"
 #include "vv_kernels.hpp"
 
 namespace {
+// RCCL is looked up lazily so that single-GPU users never need it.  If the process already has a librccl (PyTorch
+// brings its own) that copy is used -- two RCCL builds in one process is asking for trouble.
+struct RcclApi {
+    void* handle = nullptr;
+    decltype(&ncclGetUniqueId) getUniqueId = nullptr;
+    decltype(&ncclCommInitRank) commInitRank = nullptr;
+    decltype(&ncclAllReduce) allReduce = nullptr;
+    decltype(&ncclCommDestroy) commDestroy = nullptr;
+    decltype(&ncclGetErrorString) getErrorString = nullptr;
+    bool ok = false;
+};
+RcclApi& rccl_api() {
+    static RcclApi r;
+    if (r.handle) return r;
+    r.handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    if (!r.handle) r.handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!r.handle) r.handle = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!r.handle) return r;
+    r.getUniqueId = (decltype(r.getUniqueId)) dlsym(r.handle, "ncclGetUniqueId");
+    r.commInitRank = (decltype(r.commInitRank)) dlsym(r.handle, "ncclCommInitRank");
+    r.allReduce = (decltype(r.allReduce)) dlsym(r.handle, "ncclAllReduce");
+    r.commDestroy = (decltype(r.commDestroy)) dlsym(r.handle, "ncclCommDestroy");
+    r.getErrorString = (decltype(r.getErrorString)) dlsym(r.handle, "ncclGetErrorString");
+    r.ok = r.getUniqueId && r.commInitRank && r.allReduce && r.commDestroy;
+    return r;
+}
+
 constexpr double kAvogadro = 6.02214076e23;
 constexpr double kBoltz = (1.380649e-23 * kAvogadro) / 1000.0;
 enum TimerClass { T_A = 0, T_B = 1, T_OTHER = 2 };
@@ -49,6 +79,9 @@ struct vvhip_plan {
     const void* graph_site = nullptr;
     double graph_kt = 0, graph_kd = 0;
     bool capturing = false;
+    // particle sharding over GPUs: RCCL communicator for the accumulator exchange (null = single GPU)
+    ncclComm_t comm = nullptr;
+    int comm_ranks = 1;
 };
 
 namespace {
@@ -266,6 +299,7 @@ void vvhip_plan_destroy(vvhip_plan* p) {
                           p->d_fextra, p->d_old_delta, p->d_pos_delta, p->d_comv, (void*) p->d_acc, (void*) p->d_nh})
             if (ptr) (void) hipFree(ptr);
         if (p->graph_exec) (void) hipGraphExecDestroy(p->graph_exec);
+        if (p->comm) (void) rccl_api().commDestroy(p->comm);
         for (auto& v : p->events)
             for (auto& e : v) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
     }
@@ -411,11 +445,28 @@ int vvhip_accumulators(vvhip_plan* p, int phase, void** device_ptr, int32_t* cou
     return VVHIP_OK;
 }
 
+// Element-wise int64 sum of the accumulators of `phase` over all ranks, on the plan's stream (ncclSum is exact on
+// integers, so every rank continues with identical bits).  No-op without a communicator.
+static int exchange_accumulators(vvhip_plan* p, int phase) {
+    if (!p->comm) return VVHIP_OK;      // a 1-rank communicator still issues the collective (exercises the path on one GPU)
+    void* ptr = nullptr;
+    int32_t count = 0;
+    int rc = vvhip_accumulators(p, phase, &ptr, &count);
+    if (rc != VVHIP_OK) return rc;
+    ScopedTimer t(p, T_OTHER);
+    ncclResult_t e = rccl_api().allReduce(ptr, ptr, (size_t) count, ncclInt64, ncclSum, p->comm, p->stream);
+    if (e != ncclSuccess) return fail(p, VVHIP_ERR_HIP, std::string("ncclAllReduce: ") + (rccl_api().getErrorString ? rccl_api().getErrorString(e) : "error"));
+    return VVHIP_OK;
+}
+
 int vvhip_step_middle(vvhip_plan* p, uint32_t random_index) {
     NEED_BOUND(p);
     if (!p->hp.params.use_middle_scheme) return fail(p, VVHIP_ERR_INVALID, "plan was created for the classic scheme");
     const int n = vvhip_step_middle_phases(p);
-    for (int ph = 0; ph < n; ph++) TRY(vvhip_step_middle_phase(p, ph, random_index));
+    for (int ph = 0; ph < n; ph++) {
+        TRY(vvhip_step_middle_phase(p, ph, random_index));
+        if (ph < n - 1) TRY(exchange_accumulators(p, ph));
+    }
     return VVHIP_OK;
 }
 
@@ -630,6 +681,45 @@ int vvhip_time_kernel(vvhip_plan* p, int kernel, uint32_t flags, int reps, doubl
     (void) hipEventDestroy(e0);
     (void) hipEventDestroy(e1);
     *ms_per_launch = (double) ms / reps;
+    return VVHIP_OK;
+}
+
+int vvhip_comm_unique_id(void* id128) {
+    if (!id128) return VVHIP_ERR_INVALID;
+    RcclApi& r = rccl_api();
+    if (!r.ok) return VVHIP_ERR_UNSUPPORTED;
+    ncclUniqueId id;
+    if (r.getUniqueId(&id) != ncclSuccess) return VVHIP_ERR_HIP;
+    std::memcpy(id128, &id, sizeof(id));
+    return VVHIP_OK;
+}
+int vvhip_comm_init(vvhip_plan* p, const void* id128, int nranks, int rank) {
+    NEED_BOUND(p);
+    if (!id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(p, VVHIP_ERR_INVALID, "bad communicator arguments");
+    RcclApi& r = rccl_api();
+    if (!r.ok) return fail(p, VVHIP_ERR_UNSUPPORTED, "librccl.so.1 could not be loaded");
+    if (p->comm) { (void) r.commDestroy(p->comm); p->comm = nullptr; }
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    ncclResult_t e = r.commInitRank(&p->comm, nranks, id, rank);
+    if (e != ncclSuccess) { p->comm = nullptr; return fail(p, VVHIP_ERR_HIP, std::string("ncclCommInitRank: ") + (r.getErrorString ? r.getErrorString(e) : "error")); }
+    p->comm_ranks = nranks;
+    if (p->graph_exec) { (void) hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
+    return VVHIP_OK;
+}
+int vvhip_comm_destroy(vvhip_plan* p) {
+    if (!p) return VVHIP_ERR_INVALID;
+    if (p->comm) { (void) hipStreamSynchronize(p->stream); (void) rccl_api().commDestroy(p->comm); p->comm = nullptr; p->comm_ranks = 1; }
+    return VVHIP_OK;
+}
+int vvhip_run_eager(vvhip_plan* p, int nsteps, const void* site, double k_tether, double k_drude) {
+    NEED_BOUND(p);
+    if (nsteps < 0) return VVHIP_ERR_INVALID;
+    if (p->hp.has_ld) return fail(p, VVHIP_ERR_UNSUPPORTED, "vvhip_run_eager with Langevin particles needs a per-step random index");
+    for (int i = 0; i < nsteps; i++) {
+        if (site) TRY(vvhip_synth_tether_force(p, site, k_tether, k_drude));
+        TRY(vvhip_step_middle(p, 0));
+    }
     return VVHIP_OK;
 }
 

@@ -344,6 +344,22 @@ class Context:
         site = self.site.ptr if self.force_provider == "tether" else None
         H.check(H.lib.vvhip_run_graph(self.plan, int(steps), int(steps_per_graph), site, self.k_tether, self.k_drude), self.plan)
 
+    def run_eager(self, steps: int):
+        """Middle scheme: the same steps enqueued one by one from C (no per-step Python, no graph)."""
+        site = self.site.ptr if self.force_provider == "tether" else None
+        H.check(H.lib.vvhip_run_eager(self.plan, int(steps), site, self.k_tether, self.k_drude), self.plan)
+
+    def comm_init(self, unique_id: bytes, nranks: int, rank: int):
+        """Give the plan an RCCL communicator (vvhip_comm_init); the id comes from comm_unique_id() on rank 0."""
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        H.check(H.lib.vvhip_comm_init(self.plan, buf, int(nranks), int(rank)), self.plan)
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        H.check(H.lib.vvhip_comm_unique_id(buf), what="ncclGetUniqueId failed (is librccl available?)")
+        return buf.raw
+
     def _viscosity(self):
         v, inv = C.c_double(), C.c_double()
         H.check(H.lib.vvhip_calc_viscosity(self.plan, C.byref(v), C.byref(inv)), self.plan)
@@ -367,6 +383,7 @@ class Context:
 
     def close(self):
         if getattr(self, "plan", None):
+            H.lib.vvhip_comm_destroy(self.plan)
             H.lib.vvhip_plan_destroy(self.plan)
             self.plan = None
             self.integrator._context = None

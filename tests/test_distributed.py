@@ -29,13 +29,15 @@ def test_sharded_step_equals_single_process_two_ranks_one_gpu():
 
 
 @pytest.mark.gpu
-def test_nccl_code_path_world1():
+@pytest.mark.parametrize("mode", ["graph", "eager", "python"])
+def test_nccl_code_path_world1(mode):
     """The exact multi-GPU path of bench.py (process group over nccl = RCCL, accumulator tensor aliasing the plan's
     device memory, all-reduce between kernel A and kernel B on torch's stream) with a single rank."""
     import json
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "300", "--warmup", "30",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--dist-mode", mode, "--steps", "300", "--warmup", "30",
                         "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert line["value"] > 100 and line["n_gpus"] == 1
+    assert mode in line["config"]["parallelism"], line["config"]["parallelism"]
