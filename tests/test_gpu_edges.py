@@ -1,0 +1,144 @@
+"""-m gpu: edge cases of the fused path against the oracle -- chain lengths that take the in-kernel chain (1..4) and the
+stand-alone chain launch (8), several chain loops per step, systems without any NH particle, a single molecule, ragged
+particle counts, parameter changes between steps (the reference re-reads its getters at every call), thermostat
+checkpoint round trip (an extension: the reference loses the chain state on restart)."""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pkg = importlib.import_module("openmm-velocityverlet_amd")
+H, I, systems = pkg.vvhip, pkg.integrator, pkg.systems
+pytestmark = pytest.mark.gpu
+
+
+def _run_pair(spec, nsteps, middle=True, chains=3, loops=1, maxd=0.02, cos=0.0, prec="mixed", T=333.0):
+    p = O.Params(temperature=T, drude_temperature=1.0, max_drude_distance=maxd, cos_acceleration=cos, use_middle_scheme=middle,
+                 num_chains=chains, loops_per_step=loops)
+    osys = O.OracleSystem(spec, p, prec, force_mode=1)
+    it = I.VVIntegrator(T, 10.0, 1.0, 40.0, 0.001, chains, loops)
+    it.setMaxDrudeDistance(maxd)
+    it.setCosAcceleration(cos)
+    it.setUseMiddleScheme(middle)
+    ctx = I.Context(spec, it, precision=prec, force_provider="tether")
+    osys.step(nsteps)
+    it.step(nsteps)
+    return osys, ctx, it
+
+
+def _assert_close(osys, ctx, tol=1e-9):
+    x_o, x_g = osys.positions(), ctx.getPositions()
+    v_o, v_g = osys.velm[:, :3].astype(np.float64), ctx.getVelocities()
+    m = osys.velm[:, 3] != 0
+    ex = np.abs(x_g - x_o).max() / max(np.abs(x_o).max(), 1e-30)
+    ev = np.abs(v_g[m] - v_o[m]).max() / max(np.abs(v_o[m]).max(), 1e-30)
+    assert ex < tol and ev < tol, (ex, ev)
+
+
+@pytest.mark.parametrize("chains", [1, 2, 4, 5, 8])
+@pytest.mark.parametrize("loops", [1, 3])
+@pytest.mark.parametrize("middle", [True, False])
+def test_chain_length_and_loops(chains, loops, middle):
+    spec = systems.drude_il(cells=(1, 1, 1), pairs_per_cell=12, seed=21)
+    osys, ctx, it = _run_pair(spec, 10, middle=middle, chains=chains, loops=loops)
+    try:
+        _assert_close(osys, ctx)
+        st, ch = ctx.getNHState(), osys.chain_state()
+        for g in range(3):
+            assert np.allclose(list(st.eta[g])[:chains], ch["eta"][g][:chains], rtol=1e-8, atol=1e-14)
+            assert np.allclose(list(st.eta_dot[g])[:chains], ch["eta_dot"][g][:chains], rtol=1e-7, atol=1e-12)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("n_pairs", [1, 2, 7])
+def test_tiny_and_ragged_systems(n_pairs):
+    spec = systems.drude_il(cells=(1, 1, 1), pairs_per_cell=n_pairs, seed=3 + n_pairs)
+    osys, ctx, it = _run_pair(spec, 8)
+    try:
+        assert ctx.info.num_waves >= 1 and ctx.info.num_slots_used == spec.num_atoms
+        _assert_close(osys, ctx)
+    finally:
+        ctx.close()
+
+
+def test_single_water_molecule_and_63_65_particles():
+    for nmol in (1, 21, 22):                         # 3, 63 and 66 particles: around one wave
+        spec = systems.spce_water(nmol, seed=nmol)
+        osys, ctx, it = _run_pair(spec, 6, maxd=0.0, T=300.0)
+        try:
+            _assert_close(osys, ctx)
+        finally:
+            ctx.close()
+
+
+def test_all_particles_langevin_no_nh():
+    """No NH particle at all: VVIntegrator.cpp:168 never creates the NH kernel; the fused step has a single phase."""
+    spec = systems.spce_water(30, seed=8)
+    spec.particles_ld = list(range(spec.num_atoms))
+    rnd = np.random.default_rng(5).standard_normal((2048, 4)).astype(np.float32)
+    p = O.Params(temperature=300.0, max_drude_distance=0.0)
+    osys = O.OracleSystem(spec, p, "mixed", random=rnd, force_mode=1)
+    it = I.VVIntegrator(300.0, 10, 1.0, 40, 0.001)
+    ctx = I.Context(spec, it, precision="mixed", random=rnd)
+    try:
+        assert H.lib.vvhip_step_middle_phases(ctx.plan) == 1 and ctx.info.num_particles_nh == 0
+        osys.step(12); it.step(12)
+        _assert_close(osys, ctx)
+    finally:
+        ctx.close()
+
+
+def test_parameters_are_reread_between_steps():
+    spec = systems.drude_il(cells=(1, 1, 1), pairs_per_cell=15, seed=33)
+    osys, ctx, it = _run_pair(spec, 5)
+    try:
+        for T, dt in ((350.0, 0.001), (320.0, 0.0005)):
+            it.setTemperature(T); it.setStepSize(dt)          # reference: getters are read at every kernel call
+            osys.s.temperature, osys.s.dt = T, dt
+            osys.step(5); it.step(5)
+        _assert_close(osys, ctx)
+    finally:
+        ctx.close()
+
+
+def test_thermostat_checkpoint_round_trip():
+    spec = systems.drude_il(cells=(1, 1, 1), pairs_per_cell=15, seed=34)
+    def fresh():
+        it = I.VVIntegrator(333.0, 10, 1.0, 40, 0.001); it.setMaxDrudeDistance(0.02)
+        return it, I.Context(spec, it, precision="mixed")
+    it1, c1 = fresh()
+    it1.step(10)
+    state, velm, posq, corr = c1.getNHState(), c1.getVelm(), c1.getPosq(), c1.getPosqCorrection()
+    it1.step(10)
+    ref = (c1.getPosq(), c1.getVelm())
+    c1.close()
+    it2, c2 = fresh()                                         # "restart": new context, restored particle + thermostat state
+    c2.velm.upload(velm); c2.posq.upload(posq); c2.posq_corr.upload(corr)
+    c2.setNHState(state)
+    it2.step(10)
+    try:
+        assert np.array_equal(c2.getPosq().view(np.uint8), ref[0].view(np.uint8))
+        assert np.array_equal(c2.getVelm().view(np.uint8), ref[1].view(np.uint8))
+    finally:
+        c2.close()
+
+
+def test_molecule_larger_than_a_wave_is_refused_with_com_group_and_works_without():
+    n = 70
+    spec = systems.SystemSpec(name="big", masses=np.full(n, 12.0), charges=np.zeros(n), positions=np.random.default_rng(1).uniform(0, 2, (n, 3)),
+                              velocities=np.random.default_rng(2).normal(0, 0.4, (n, 3)), box=np.array([2.0, 2.0, 2.0]),
+                              mol_id=np.zeros(n, np.int32), drude_pairs=np.zeros((0, 2), np.int32), constraints=np.zeros((0, 2), np.int32))
+    it = I.VVIntegrator(300.0, 10, 1.0, 40, 0.001)
+    it.setUseCOMTempGroup(True)
+    with pytest.raises(H.VVHipError) as e:
+        I.Context(spec, it, precision="mixed")
+    assert e.value.code == H.ERR_UNSUPPORTED
+    osys, ctx, it2 = _run_pair(spec, 5, maxd=0.0, T=300.0)    # auto rule: no Drude => no COM group
+    try:
+        _assert_close(osys, ctx)
+    finally:
+        ctx.close()
