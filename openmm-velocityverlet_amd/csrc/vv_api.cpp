@@ -62,6 +62,8 @@ struct vvhip_plan {
     int2* d_slots = nullptr;
     int32_t* d_slot_image = nullptr;
     int32_t* d_slot_rand = nullptr;
+    int32_t* d_slot_big = nullptr;
+    unsigned long long* d_bigacc = nullptr;
     int2* d_image_pairs = nullptr;
     void* d_fextra = nullptr;
     void* d_old_delta = nullptr;
@@ -147,6 +149,10 @@ vv::KArgs make_args(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
     a.slots = p->d_slots;
     a.slot_image = p->d_slot_image;
     a.slot_rand = p->d_slot_rand;
+    a.slot_big = p->d_slot_big;
+    a.bigacc = p->d_bigacc;
+    a.big_scale = p->hp.big_scale;
+    a.big_inv_scale = 1.0 / p->hp.big_scale;
     a.random = (const float4*) p->buf.random;
     a.acc = p->d_acc + p->parity * kAccN;
     a.acc_next = p->d_acc + (p->parity ^ 1) * kAccN;
@@ -232,6 +238,21 @@ int run_chain(vvhip_plan* p, uint32_t flags) {
     return VVHIP_OK;
 }
 
+// The launch(es) that end in the per-group kinetic energies.  `first` = stage bits that must run before the KE on the
+// same launch if possible (kick, extra forces).  Molecules larger than a wave need their COM summed across waves
+// first (A_COMPART, its own launch after a memset of the small accumulator), so there the stages are split.
+int run_ke(vvhip_plan* p, uint32_t first, uint32_t random_index, bool unbias) {
+    const uint32_t ub = unbias ? vv::A_UNBIAS_ACC : 0;
+    if (p->hp.num_big == 0) {
+        if (unbias && first) { int rc = run_a(p, first, random_index); if (rc != VVHIP_OK) return rc; first = 0; }
+        return run_a(p, first | vv::A_KE | ub, random_index);
+    }
+    if (first) { int rc = run_a(p, first, random_index); if (rc != VVHIP_OK) return rc; }
+    HIP_TRY(p, hipMemsetAsync(p->d_bigacc, 0, (size_t) p->hp.num_big * 4 * sizeof(unsigned long long), p->stream));
+    int rc = run_a(p, vv::A_COMPART | ub, 0);
+    return rc != VVHIP_OK ? rc : run_a(p, vv::A_KE | ub, 0);
+}
+
 // Scaling kernel with the chain in its head (chain length <= 4), or the stand-alone chain launch in front of it.
 int run_chain_and_b(vvhip_plan* p, uint32_t bflags, bool with_bias) {
     if (p->hp.params.num_nh_chains <= 4) return run_b(p, vv::B_CHAIN | bflags);
@@ -295,7 +316,7 @@ void vvhip_plan_destroy(vvhip_plan* p) {
     if (!p) return;
     if (p->bound) {
         (void) hipStreamSynchronize(p->stream);
-        for (void* ptr : {(void*) p->d_slots, (void*) p->d_slot_image, (void*) p->d_slot_rand, (void*) p->d_image_pairs,
+        for (void* ptr : {(void*) p->d_slots, (void*) p->d_slot_image, (void*) p->d_slot_rand, (void*) p->d_slot_big, (void*) p->d_bigacc, (void*) p->d_image_pairs,
                           p->d_fextra, p->d_old_delta, p->d_pos_delta, p->d_comv, (void*) p->d_acc, (void*) p->d_nh})
             if (ptr) (void) hipFree(ptr);
         if (p->graph_exec) (void) hipGraphExecDestroy(p->graph_exec);
@@ -355,6 +376,12 @@ int vvhip_bind(vvhip_plan* p, const vvhip_buffers* b) {
     if (!hp.slot_rand.empty()) {
         HIP_TRY(p, hipMalloc((void**) &p->d_slot_rand, nslots * sizeof(int32_t)));
         HIP_TRY(p, hipMemcpy(p->d_slot_rand, hp.slot_rand.data(), nslots * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    if (!hp.slot_big.empty()) {
+        HIP_TRY(p, hipMalloc((void**) &p->d_slot_big, nslots * sizeof(int32_t)));
+        HIP_TRY(p, hipMemcpy(p->d_slot_big, hp.slot_big.data(), nslots * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(p, hipMalloc((void**) &p->d_bigacc, (size_t) hp.num_big * 4 * sizeof(unsigned long long)));
+        HIP_TRY(p, hipMemset(p->d_bigacc, 0, (size_t) hp.num_big * 4 * sizeof(unsigned long long)));
     }
     HIP_TRY(p, hipMalloc(&p->d_fextra, nloc * 3 * rs));            // zero-initialised like HOST:79-89
     HIP_TRY(p, hipMemset(p->d_fextra, 0, nloc * 3 * rs));
@@ -426,11 +453,11 @@ int vvhip_step_middle_phase(vvhip_plan* p, int phase, uint32_t random_index) {
         return run_b(p, drift);
     }
     if (!cos_on(p)) {
-        if (phase == 0) return run_a(p, kick | vv::A_KE, random_index);
+        if (phase == 0) return run_ke(p, kick, random_index, false);
         if (phase == 1) return run_chain_and_b(p, vv::B_SCALE | drift, false);
     } else {                                               // API:252-259: bias -> remove -> scale -> restore
         if (phase == 0) return run_a(p, kick | vv::A_BIAS, random_index);
-        if (phase == 1) return run_a(p, vv::A_KE | vv::A_UNBIAS_ACC, 0);
+        if (phase == 1) return run_ke(p, 0, 0, true);
         if (phase == 2) return run_chain_and_b(p, vv::B_SCALE | vv::B_UNBIAS | drift, true);
     }
     return fail(p, VVHIP_ERR_INVALID, "phase out of range");
@@ -478,11 +505,11 @@ static int nh_half(vvhip_plan* p, uint32_t a_first, uint32_t random_index, uint3
         return VVHIP_OK;
     }
     if (!cos_on(p)) {
-        TRY(run_a(p, a_first | vv::A_KE, random_index));
+        TRY(run_ke(p, a_first, random_index, false));
         return run_chain_and_b(p, vv::B_SCALE | b_extra, false);
     }
     TRY(run_a(p, a_first | vv::A_BIAS, random_index));
-    TRY(run_a(p, vv::A_KE | vv::A_UNBIAS_ACC, 0));
+    TRY(run_ke(p, 0, 0, true));
     return run_chain_and_b(p, vv::B_SCALE | vv::B_UNBIAS | b_extra, true);
 }
 
@@ -528,7 +555,7 @@ int vvhip_vv_positions(vvhip_plan* p) {
 int vvhip_scale_velocity(vvhip_plan* p) {                  // HOST:670-754 without the download/upload
     NEED_BOUND(p);
     if (!p->hp.has_nh) return VVHIP_OK;
-    TRY(run_a(p, vv::A_KE, 0));
+    TRY(run_ke(p, 0, 0, false));
     return run_chain_and_b(p, vv::B_SCALE, false);
 }
 int vvhip_apply_langevin_force(vvhip_plan* p, uint32_t random_index) {

@@ -19,6 +19,8 @@ struct Cluster {            // particles that must share one wave
     int32_t first;          // smallest particle index (ordering key)
     std::vector<int32_t> members;
     bool com_segment;       // members form one molecular COM segment
+    int32_t big = -1;       // >= 0: chunk of big molecule `big` (a molecule with more than 64 lanes, split over waves)
+    bool big_first = false; // first chunk of that molecule
 };
 }  // namespace
 
@@ -233,6 +235,54 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
         for (int i = 0; i < n; i++)
             if (is_nh[i] && needs_lane(i) && !in_shard(i) && cluster_of_mol[sys.mol_id[i]] >= 0)
                 throw Error(VVHIP_ERR_INVALID, "particle shard cuts a molecule");
+    // A COM cluster larger than a wave is cut into chunks of <= 64 lanes (Drude pairs stay together); the chunks are
+    // ordinary segments for the wave-level scans, the molecule-level sum goes through a small global accumulator.
+    {
+        std::vector<Cluster> out;
+        double max_big_mass = 0;
+        for (Cluster& cl : clusters) {
+            if (!cl.com_segment || cl.members.size() <= 64) { out.push_back(std::move(cl)); continue; }
+            std::sort(cl.members.begin(), cl.members.end());
+            const int big = hp.num_big++;
+            double mtot = 0;
+            for (int i : cl.members) mtot += sys.masses[i];
+            max_big_mass = std::max(max_big_mass, mtot);
+            std::vector<char> taken(cl.members.size(), 0);
+            std::vector<std::vector<int32_t> > units;          // single particles or (Drude, parent) pairs, in index order
+            for (size_t k = 0; k < cl.members.size(); k++) {
+                if (taken[k]) continue;
+                const int i = cl.members[k];
+                std::vector<int32_t> u{i};
+                taken[k] = 1;
+                if (in_pair[i]) {
+                    const int q = partner[i];
+                    auto it = std::lower_bound(cl.members.begin(), cl.members.end(), q);
+                    if (it == cl.members.end() || *it != q) throw Error(VVHIP_ERR_UNSUPPORTED, "a Drude particle and its parent are in different molecules");
+                    taken[it - cl.members.begin()] = 1;
+                    u.push_back(q);
+                }
+                units.push_back(u);
+            }
+            Cluster chunk{units[0][0], {}, true, big, true};
+            for (const auto& u : units) {
+                if (chunk.members.size() + u.size() > 64) {
+                    std::sort(chunk.members.begin(), chunk.members.end());
+                    chunk.first = chunk.members[0];
+                    out.push_back(chunk);
+                    chunk = Cluster{u[0], {}, true, big, false};
+                }
+                chunk.members.insert(chunk.members.end(), u.begin(), u.end());
+            }
+            std::sort(chunk.members.begin(), chunk.members.end());
+            chunk.first = chunk.members[0];
+            out.push_back(chunk);
+        }
+        clusters.swap(out);
+        if (hp.num_big > 0) {       // |sum m v| <= M |v|max with |v|max ~ 50 nm/ps; keep 4x headroom below 2^62
+            const double top = std::ldexp(1.0, 62) / (std::max(max_big_mass, 1.0) * 50.0 * 4.0);
+            hp.big_scale = std::ldexp(1.0, std::max(0, std::min(40, (int) std::floor(std::log2(top)))));
+        }
+    }
     std::stable_sort(clusters.begin(), clusters.end(), [](const Cluster& a, const Cluster& b) { return a.first < b.first; });
     int max_cluster = 0;
     for (auto& c : clusters) {
@@ -240,10 +290,6 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
         max_cluster = std::max(max_cluster, (int) c.members.size());
     }
     info.max_cluster = max_cluster;
-    if (max_cluster > 64)
-        throw Error(VVHIP_ERR_UNSUPPORTED,
-                    "a molecule with more than 64 thermostatted particles cannot use the COM temperature group "
-                    "in this backend yet (setUseCOMTempGroup(false) works)");
 
     // ---- greedy wave packing in particle order
     std::vector<int32_t>& slots = hp.slots;
@@ -285,6 +331,8 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
             if (in_pair[i]) meta |= META_PAIR;
             if (is_drude[i]) meta |= META_IS_DRUDE;
             if (massive) meta |= META_MASSIVE;
+            if (c.big >= 0) meta |= META_BIGMOL;
+            if (c.big >= 0 && c.big_first && (meta & META_COM_LEADER)) meta |= META_BIG_FIRST;
             slots[(size_t) wave * 128 + 2 * lane] = i - sb;
             slots[(size_t) wave * 128 + 2 * lane + 1] = (int32_t) meta;
             used++;
@@ -320,6 +368,17 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
         }
     }
     if (hp.has_ld) hp.slot_rand.assign((size_t) nwaves * 64, -1);
+    if (hp.num_big > 0) {
+        hp.slot_big.assign((size_t) nwaves * 64, -1);
+        std::vector<int32_t> big_of(n, -1);
+        for (const Cluster& cl : clusters)
+            if (cl.big >= 0) for (int i : cl.members) big_of[i] = cl.big;
+        for (int w = 0; w < nwaves; w++)
+            for (int l = 0; l < 64; l++) {
+                const int32_t at = slots[(size_t) w * 128 + 2 * l];
+                if (at >= 0) hp.slot_big[(size_t) w * 64 + l] = big_of[at + sb];
+            }
+    }
     if (hp.has_images || hp.has_ld)
         for (int w = 0; w < nwaves; w++)
             for (int l = 0; l < 64; l++) {

@@ -42,6 +42,8 @@ constexpr uint32_t META_COM_LEADER = 1u << 24; // lane that adds its molecule's 
 constexpr uint32_t META_PAIR = 1u << 25;       // member of a DrudeForce pair (hard wall applies)
 constexpr uint32_t META_IS_DRUDE = 1u << 26;   // the Drude (pair.x) of that pair
 constexpr uint32_t META_MASSIVE = 1u << 27;    // mass != 0 (velm.w != 0)
+constexpr uint32_t META_BIGMOL = 1u << 28;     // lane belongs to a molecule too large for one wave: its COM comes from bigacc
+constexpr uint32_t META_BIG_FIRST = 1u << 29;  // leader of the FIRST chunk of such a molecule (adds M*V^2 once, clears bigacc)
 
 inline uint32_t meta_role(uint32_t m) { return m & META_ROLE_MASK; }
 
@@ -58,6 +60,9 @@ struct HostPlan {
     std::vector<int32_t> slots;
     std::vector<int32_t> slot_image;   // [64*waves] shard-relative image particle of this lane's particle, or -1
     std::vector<int32_t> slot_rand;    // [64*waves] offset into the Langevin slice of the random buffer, or -1
+    std::vector<int32_t> slot_big;     // [64*waves] index of the lane's big molecule, or -1 (empty when there is none)
+    int32_t num_big = 0;               // molecules with more than 64 thermostatted particles (COM temperature group only)
+    double big_scale = 1.0;            // fixed-point scale of their sum(m v) accumulators
     std::vector<int32_t> image_pairs;  // (image, parent) shard-relative, for the stand-alone image kernel
     // reference-style tables, kept for inspection / tests (global particle indices)
     std::vector<int32_t> particles_nh, molecules_nh, normal_nh, pairs_nh, normal_ld, pairs_ld;

@@ -260,6 +260,28 @@ __global__ void __launch_bounds__(256) vv_kernel_a(const KArgs a) {
             k_bias = (double) t;
         }
 
+        // ---------------- molecules larger than a wave: per-chunk partial sums into the molecule's accumulator
+        if ((F & A_COMPART) && a.slot_big) {
+            const bool nhb = (role == ROLE_NH_NORMAL || role == ROLE_NH_DRUDE || role == ROLE_NH_PARENT) && (meta & META_BIGMOL);
+            mixed bx = v.x;
+            if (F & A_UNBIAS_ACC) {
+                const mixed V = (mixed) ((double) acc_total(a.acc, 3, lane) * a.acc_inv_scale[3] * a.inv_mass_total);
+                if (act) bx -= V * cos_kz<real>(pq.z, (real) a.inv_box_z);
+            }
+            const int first = (meta >> META_SEGFIRST_SHIFT) & 63, last = (meta >> META_SEGLAST_SHIFT) & 63;
+            mixed mass = 0, mx = 0, my = 0, mz = 0;
+            if (nhb && massive) { mass = P::RECIP(v.w); mx = bx * mass; my = v.y * mass; mz = v.z * mass; }
+            mx = segment_total(mx, lane, first, last); my = segment_total(my, lane, first, last);
+            mz = segment_total(mz, lane, first, last); mass = segment_total(mass, lane, first, last);
+            if (nhb && (meta & META_COM_LEADER)) {
+                unsigned long long* dst = a.bigacc + 4 * (size_t) a.slot_big[(size_t) wave * 64 + lane];
+                atomicAdd(dst + 0, (unsigned long long) __double2ll_rn((double) mx * a.big_scale));
+                atomicAdd(dst + 1, (unsigned long long) __double2ll_rn((double) my * a.big_scale));
+                atomicAdd(dst + 2, (unsigned long long) __double2ll_rn((double) mz * a.big_scale));
+                atomicAdd(dst + 3, (unsigned long long) __double2ll_rn((double) mass * a.big_scale));
+            }
+        }
+
         // ---------------- kinetic energies of the thermostat groups
         if (F & A_KE) {
             const bool nh = role == ROLE_NH_NORMAL || role == ROLE_NH_DRUDE || role == ROLE_NH_PARENT;
@@ -275,6 +297,13 @@ __global__ void __launch_bounds__(256) vv_kernel_a(const KArgs a) {
             // the COM stage is wave-uniform on purpose: lanes outside a COM segment scan a 1-lane segment
             com_velocity<real, mixed>(nh && massive && use_com, ux, uy, uz, v.w, lane, meta, Vx, Vy, Vz, Vw);
             if (!use_com) { Vx = 0; Vy = 0; Vz = 0; Vw = 0; }
+            if (a.slot_big && (meta & META_BIGMOL) && nh) {     // molecule spread over several waves: totals from the accumulator
+                const unsigned long long* src = a.bigacc + 4 * (size_t) a.slot_big[(size_t) wave * 64 + lane];
+                const mixed sx = (mixed) ((double) (long long) src[0] * a.big_inv_scale), sy = (mixed) ((double) (long long) src[1] * a.big_inv_scale);
+                const mixed sz = (mixed) ((double) (long long) src[2] * a.big_inv_scale), sm = (mixed) ((double) (long long) src[3] * a.big_inv_scale);
+                Vw = P::RECIP(sm);
+                Vx = sx * Vw; Vy = sy * Vw; Vz = sz * Vw;
+            }
             if ((meta & META_COM_LEADER) && use_com) {      // hand the COM velocity to the scaling kernel (the reference's comVelm[id_mol])
                 mixed4 cv = {Vx, Vy, Vz, Vw};
                 ((mixed4*) a.comv)[(size_t) wave * 64 + ((meta >> META_SEGFIRST_SHIFT) & 63)] = cv;
@@ -295,7 +324,7 @@ __global__ void __launch_bounds__(256) vv_kernel_a(const KArgs a) {
                 k_atom = (double) ((cx * cx + cy * cy + cz * cz) * (mass1 + mass2));
                 k_drude = (double) ((rx * rx + ry * ry + rz * rz) / invReducedMass);
             }
-            if ((meta & META_COM_LEADER) && use_com && Vw != 0)             // K/drudeNoseHoover.cu:85-94
+            if ((meta & META_COM_LEADER) && use_com && Vw != 0 && (!(meta & META_BIGMOL) || (meta & META_BIG_FIRST)))   // K/drudeNoseHoover.cu:85-94
                 k_com = (double) ((Vx * Vx + Vy * Vy + Vz * Vz) / Vw);
         }
     }

@@ -23,6 +23,7 @@ enum : uint32_t {
     A_BIAS = 1u << 9,        // accumulate sum m*vx*2cos(kz)       (K/cosineAccelerate.cu:16-61)
     A_KE = 1u << 10,         // molecular COM + per-group sum m v^2 (K/drudeNoseHoover.cu:5-151)
     A_UNBIAS_ACC = 1u << 11, // before the KE, subtract V*cos(kz) with V taken from accumulator 3
+    A_COMPART = 1u << 12,    // molecules larger than a wave: add each chunk's sum(m v), sum(m) to the molecule's accumulator
 };
 // ---- stage flags of kernel B ("consume": starts from the scale factors) -------------------------
 enum : uint32_t {
@@ -83,6 +84,9 @@ struct KArgs {
     const int2* slots;
     const int32_t* slot_image;
     const int32_t* slot_rand;
+    const int32_t* slot_big;        // big-molecule index per lane (only with molecules larger than a wave)
+    unsigned long long* bigacc;     // int64 fixed point [num_big][4]: sum m vx, m vy, m vz, m
+    double big_scale, big_inv_scale;
     const float4* random;
     unsigned long long* acc;        // accumulators of the current parity (A adds, B consumes)
     unsigned long long* acc_next;   // other parity: zeroed by B when it runs the chain inline

@@ -127,18 +127,38 @@ def test_thermostat_checkpoint_round_trip():
         c2.close()
 
 
-def test_molecule_larger_than_a_wave_is_refused_with_com_group_and_works_without():
-    n = 70
-    spec = systems.SystemSpec(name="big", masses=np.full(n, 12.0), charges=np.zeros(n), positions=np.random.default_rng(1).uniform(0, 2, (n, 3)),
-                              velocities=np.random.default_rng(2).normal(0, 0.4, (n, 3)), box=np.array([2.0, 2.0, 2.0]),
-                              mol_id=np.zeros(n, np.int32), drude_pairs=np.zeros((0, 2), np.int32), constraints=np.zeros((0, 2), np.int32))
-    it = I.VVIntegrator(300.0, 10, 1.0, 40, 0.001)
-    it.setUseCOMTempGroup(True)
-    with pytest.raises(H.VVHipError) as e:
-        I.Context(spec, it, precision="mixed")
-    assert e.value.code == H.ERR_UNSUPPORTED
-    osys, ctx, it2 = _run_pair(spec, 5, maxd=0.0, T=300.0)    # auto rule: no Drude => no COM group
+def _big_molecule_system(seed=1):
+    """Two polymers of 150 and 70 particles (with Drude pairs) plus a few small molecules: COM groups larger than a wave."""
+    rng = np.random.default_rng(seed)
+    masses, mol, pairs = [], [], []
+    def polymer(n_heavy, n_h, m):
+        for _ in range(n_heavy):
+            masses.extend([11.611, 0.4]); mol.extend([m, m]); pairs.append((len(masses) - 1, len(masses) - 2))
+        for _ in range(n_h):
+            masses.append(1.008); mol.append(m)
+    polymer(50, 50, 0)
+    polymer(25, 20, 1)
+    for m in range(2, 8):
+        polymer(3, 2, m)
+    n = len(masses)
+    masses = np.array(masses)
+    pos = rng.uniform(0, 3, (n, 3))
+    d = np.array([p[0] for p in pairs])
+    pos[d] = pos[d - 1] + rng.normal(0, 2e-4, (len(d), 3))
+    vel = rng.standard_normal((n, 3)) * np.sqrt(O.BOLTZ * 300.0 / masses)[:, None]
+    return systems.SystemSpec(name="polymers", masses=masses, charges=np.zeros(n), positions=pos, velocities=vel, box=np.array([3.0, 3.0, 3.0]),
+                              mol_id=np.array(mol, np.int32), drude_pairs=np.array(pairs, np.int32), constraints=np.zeros((0, 2), np.int32))
+
+
+@pytest.mark.parametrize("middle", [True, False])
+@pytest.mark.parametrize("cos", [0.0, 0.02])
+def test_molecules_larger_than_a_wave_with_com_group(middle, cos):
+    spec = _big_molecule_system()
+    osys, ctx, it = _run_pair(spec, 10, middle=middle, cos=cos, T=300.0)
     try:
+        assert ctx.info.use_com_temp_group and ctx.info.max_cluster <= 64 and ctx.info.num_temp_groups == 3
         _assert_close(osys, ctx)
+        ke_o, ke_g = osys.ke2(), np.array(list(ctx.getNHState().ke2))
+        assert np.allclose(ke_g, ke_o, rtol=1e-10)
     finally:
         ctx.close()

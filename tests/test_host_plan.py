@@ -127,3 +127,20 @@ def test_no_gpu_means_loud_failure_not_fallback():
     with pytest.raises(H.VVHipError) as e:
         I.Context(systems.make_config("C1"), I.VVIntegrator(300, 10, 1, 40, 0.001))
     assert e.value.code == H.ERR_NO_DEVICE
+
+
+def test_big_molecule_is_cut_into_wave_sized_chunks():
+    n = 150
+    spec = systems.SystemSpec(name="big", masses=np.full(n, 12.0), charges=np.zeros(n), positions=np.zeros((n, 3)), velocities=np.zeros((n, 3)),
+                              box=np.ones(3), mol_id=np.zeros(n, np.int32), drude_pairs=np.zeros((0, 2), np.int32),
+                              constraints=np.zeros((0, 2), np.int32))
+    it = I.VVIntegrator(300, 10, 1, 40, 0.001)
+    it.setUseCOMTempGroup(True)
+    info, slots = I.plan_layout(spec, it)
+    meta = slots[:, 1].astype(np.uint32)
+    used = slots[:, 0] >= 0
+    assert info.num_slots_used == n and info.num_waves == 3 and info.max_cluster <= 64
+    assert ((meta[used] >> 28) & 1).all()                     # every lane knows it belongs to a big molecule
+    assert ((meta >> 29) & 1).sum() == 1                      # exactly one lane adds the molecule's M V^2 / clears nothing twice
+    assert ((meta >> 24) & 1).sum() == 3                      # one chunk leader per wave
+    assert info.dof[1] == 0.0                                 # 3*1 molecule - 3 (CMMotionRemover) = 0 -> no COM group DOF
