@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20000)
     ap.add_argument("--warmup", type=int, default=2000)
-    ap.add_argument("--config", default="C3", choices=["C2", "C3", "C4", "C3x8", "C3x80"])
+    ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C4", "C5", "C3x8", "C3x80"])
     ap.add_argument("--precision", default="mixed", choices=["single", "mixed", "double"])
     ap.add_argument("--forces", default="tether", choices=["tether", "static"])
     ap.add_argument("--steps-per-graph", type=int, default=100)
@@ -71,10 +71,14 @@ def main():
         spec = S.make_config(cfg)
     dt = 0.002 if cfg == "C2" else 0.001
     it = I.VVIntegrator(300.0 if cfg == "C2" else 333.0, 10.0, 1.0, 40.0, dt)
-    if cfg != "C2":
+    if cfg not in ("C1", "C2"):
         it.setMaxDrudeDistance(0.02)
     if cfg == "C4":
         it.setCosAcceleration(0.02)
+    if cfg == "C5":                                   # examples/run-edl.py:82-100: mirror at Lz/2, field V/Lz*2 with V = 2 V
+        lz = float(spec.box[2])
+        it.setMirrorLocation(lz / 2)
+        it.setElectricField(2.0 / lz * 2 * 1.602176634e-22)
     bounds = D.shard_bounds(spec, world)
     # N > 1: the plan gets its own RCCL communicator (bootstrap through the torch process group) and then exchanges the
     # accumulators itself, inside the captured graph if possible; torch.distributed per step is the last resort.
@@ -168,7 +172,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{cfg}: {spec.name}, {n} particles, {spec.num_molecules} molecules, "
                                    f"{len(spec.drude_pairs)} Drude pairs; TGNH thermostat ({ctx.info.num_temp_groups} groups), middle scheme, "
-                                   f"hard wall 0.02 nm, dt {dt * 1e3:g} fs" + (", cos acceleration 0.02 nm/ps^2" if cfg == "C4" else ""),
+                                   f"hard wall 0.02 nm, dt {dt * 1e3:g} fs" + (", cos acceleration 0.02 nm/ps^2" if cfg == "C4" else "")
+                                   + (f", {len(spec.particles_ld)} Langevin particles (device Philox normals), {len(spec.image_pairs)} image pairs, E-field" if cfg == "C5" else ""),
                        "force_provider": f"{args.forces} (synthetic, inside the timed region)" if args.forces == "tether" else "static buffer",
                        "launch": "hipGraph replay, %d steps/graph" % args.steps_per_graph if use_graph else "host-launched per step",
                        "parallelism": ("1 GPU" + (f" (distributed code path forced: {dist_mode})" if use_dist else "")) if world == 1 else f"particle shards on molecule boundaries x{world}, int64 all-reduce per thermostat application ({dist_mode})",

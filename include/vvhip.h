@@ -233,6 +233,11 @@ int vvhip_synth_tether_force(vvhip_plan* plan, const void* site /* real4[n] */, 
 /* Captures `steps_per_graph` steps (optionally with the synthetic force kernel in front of each) into a
  * hipGraph once and replays it; returns after enqueueing.  Middle scheme only. */
 int vvhip_run_graph(vvhip_plan* plan, int nsteps, int steps_per_graph, const void* site, double k_tether, double k_drude);
+/* Device Gaussian generator for stand-alone hosts (inside OpenMM the buffer and its refills are OpenMM's): Philox4x32-10 +
+ * Box-Muller.  vvhip_fill_random refills the bound random buffer; the vvhip_run_* loops refill it themselves whenever a step's
+ * slice (max(normalLD,1) + 2 max(pairsLD,1) float4, HOST:806-807,863) no longer fits, and at the start of every captured graph. */
+int vvhip_set_random_seed(vvhip_plan* plan, uint64_t seed);
+int vvhip_fill_random(vvhip_plan* plan);
 /* The same steps enqueued one by one from C (no graph): fallback when graph capture is not wanted. */
 int vvhip_run_eager(vvhip_plan* plan, int nsteps, const void* site, double k_tether, double k_drude);
 /* HIP-event timing of the dominant kernels on the plan's stream, for bench.py's roofline block. */

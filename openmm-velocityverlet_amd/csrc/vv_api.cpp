@@ -72,6 +72,9 @@ struct vvhip_plan {
     unsigned long long* d_acc = nullptr;   // [2 parities][NUM_ACC][ACC_SLOTS]
     vv::NHDevState* d_nh = nullptr;         // [2 parities]
     int parity = 0;                         // which copy the next reduction/consumer pair uses
+    unsigned long long* d_epoch = nullptr;  // refill counter of the device Gaussian generator
+    uint64_t rng_seed = 0;
+    uint32_t random_pos = 0;                // prepareRandomNumbers cursor for the plan-driven loops (vvhip_run_*)
     // HIP-event timing (eager launches only)
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events[3];
@@ -317,7 +320,7 @@ void vvhip_plan_destroy(vvhip_plan* p) {
     if (p->bound) {
         (void) hipStreamSynchronize(p->stream);
         for (void* ptr : {(void*) p->d_slots, (void*) p->d_slot_image, (void*) p->d_slot_rand, (void*) p->d_slot_big, (void*) p->d_bigacc, (void*) p->d_image_pairs,
-                          p->d_fextra, p->d_old_delta, p->d_pos_delta, p->d_comv, (void*) p->d_acc, (void*) p->d_nh})
+                          p->d_fextra, p->d_old_delta, p->d_pos_delta, p->d_comv, (void*) p->d_epoch, (void*) p->d_acc, (void*) p->d_nh})
             if (ptr) (void) hipFree(ptr);
         if (p->graph_exec) (void) hipGraphExecDestroy(p->graph_exec);
         if (p->comm) (void) rccl_api().commDestroy(p->comm);
@@ -391,6 +394,8 @@ int vvhip_bind(vvhip_plan* p, const vvhip_buffers* b) {
     HIP_TRY(p, hipMemset(p->d_comv, 0, nslots * 4 * ms));
     HIP_TRY(p, hipMalloc(&p->d_pos_delta, nloc * 4 * ms));
     HIP_TRY(p, hipMemset(p->d_pos_delta, 0, nloc * 4 * ms));
+    HIP_TRY(p, hipMalloc((void**) &p->d_epoch, sizeof(unsigned long long)));
+    HIP_TRY(p, hipMemset(p->d_epoch, 0, sizeof(unsigned long long)));
     HIP_TRY(p, hipMalloc((void**) &p->d_acc, 2 * kAccN * sizeof(unsigned long long)));
     HIP_TRY(p, hipMemset(p->d_acc, 0, 2 * kAccN * sizeof(unsigned long long)));
     HIP_TRY(p, hipMalloc((void**) &p->d_nh, 2 * sizeof(vv::NHDevState)));
@@ -646,17 +651,50 @@ int vvhip_synth_tether_force(vvhip_plan* p, const void* site, double k_tether, d
     return VVHIP_OK;
 }
 
+// integration.prepareRandomNumbers(n) for the plan-driven loops: hand out the next slice; when the buffer is exhausted
+// enqueue a refill by the device generator and start over.  `force_refill` starts a graph with fresh numbers.
+static int next_random_slice(vvhip_plan* p, uint32_t* index, bool force_refill) {
+    *index = 0;
+    if (!p->hp.has_ld) return VVHIP_OK;
+    const vvhip_plan_info& in = p->hp.info;
+    const uint32_t need = (uint32_t) std::max(in.num_normal_ld, 1) + 2u * (uint32_t) std::max(in.num_pairs_ld, 1);   // HOST:806-807,863
+    if (need > p->buf.random_size) return fail(p, VVHIP_ERR_INVALID, "random buffer smaller than one step's demand");
+    if (force_refill || p->random_pos + need > p->buf.random_size) {
+        HIP_TRY(p, vv::launch_fill_normals((float4*) p->buf.random, p->buf.random_size, p->rng_seed, p->d_epoch, p->stream));
+        p->random_pos = 0;
+    }
+    *index = p->random_pos;
+    p->random_pos += need;
+    return VVHIP_OK;
+}
+
+int vvhip_set_random_seed(vvhip_plan* p, uint64_t seed) {
+    if (!p) return VVHIP_ERR_INVALID;
+    p->rng_seed = seed;
+    return VVHIP_OK;
+}
+int vvhip_fill_random(vvhip_plan* p) {
+    NEED_BOUND(p);
+    if (!p->buf.random || !p->buf.random_size) return fail(p, VVHIP_ERR_INVALID, "no random buffer bound");
+    HIP_TRY(p, vv::launch_fill_normals((float4*) p->buf.random, p->buf.random_size, p->rng_seed, p->d_epoch, p->stream));
+    p->random_pos = 0;
+    return VVHIP_OK;
+}
+
 int vvhip_run_graph(vvhip_plan* p, int nsteps, int steps_per_graph, const void* site, double k_tether, double k_drude) {
     NEED_BOUND(p);
     if (nsteps < 0 || steps_per_graph < 1) return VVHIP_ERR_INVALID;
     if (steps_per_graph % 2) steps_per_graph += 1;   // the thermostat double-buffers by step parity: a graph must hold an even number of steps
     if (!p->hp.params.use_middle_scheme) return fail(p, VVHIP_ERR_UNSUPPORTED, "graph replay covers the middle scheme only");
-    if (p->hp.has_ld) return fail(p, VVHIP_ERR_UNSUPPORTED, "graph replay with Langevin particles needs a per-step random index");
     hipStream_t s = p->stream;
     if (!s) return fail(p, VVHIP_ERR_INVALID, "graph capture needs a non-null stream in vvhip_buffers.stream");
+    bool first_in_graph = false;
     auto one_step = [&]() -> int {
+        uint32_t ri = 0;
+        TRY(next_random_slice(p, &ri, first_in_graph));      // Langevin: a captured graph begins with a refill, so every replay draws new numbers
+        first_in_graph = false;
         if (site) TRY(vvhip_synth_tether_force(p, site, k_tether, k_drude));
-        return vvhip_step_middle(p, 0);
+        return vvhip_step_middle(p, ri);
     };
     if (!p->graph_exec || p->graph_parity != p->parity || p->graph_steps != steps_per_graph || p->graph_site != site || p->graph_kt != k_tether || p->graph_kd != k_drude) {
         if (p->graph_exec) { (void) hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
@@ -665,6 +703,7 @@ int vvhip_run_graph(vvhip_plan* p, int nsteps, int steps_per_graph, const void* 
         p->capturing = true;
         p->graph_parity = p->parity;
         int rc = VVHIP_OK;
+        first_in_graph = p->hp.has_ld;
         for (int i = 0; i < steps_per_graph && rc == VVHIP_OK; i++) rc = one_step();
         p->capturing = false;
         hipError_t e = hipStreamEndCapture(s, &g);
@@ -742,10 +781,11 @@ int vvhip_comm_destroy(vvhip_plan* p) {
 int vvhip_run_eager(vvhip_plan* p, int nsteps, const void* site, double k_tether, double k_drude) {
     NEED_BOUND(p);
     if (nsteps < 0) return VVHIP_ERR_INVALID;
-    if (p->hp.has_ld) return fail(p, VVHIP_ERR_UNSUPPORTED, "vvhip_run_eager with Langevin particles needs a per-step random index");
     for (int i = 0; i < nsteps; i++) {
+        uint32_t ri = 0;
+        TRY(next_random_slice(p, &ri, false));
         if (site) TRY(vvhip_synth_tether_force(p, site, k_tether, k_drude));
-        TRY(vvhip_step_middle(p, 0));
+        TRY(vvhip_step_middle(p, ri));
     }
     return VVHIP_OK;
 }

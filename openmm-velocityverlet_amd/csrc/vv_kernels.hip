@@ -901,6 +901,36 @@ __global__ void __launch_bounds__(256) vv_kernel_tether(const TetherArgs t) {
     if (act) { t.force[atom] = ix; t.force[atom + t.padded] = iy; t.force[atom + 2 * t.padded] = iz; }
 }
 
+// ================================================================================ device Gaussian random numbers
+// Philox4x32-10 (Salmon et al., SC'11) counter-based generator + Box-Muller; 4 normals per call = one float4 of the
+// buffer the Langevin stage reads.  Not part of the reference (there the buffer is OpenMM's, CudaVVKernels.cpp:63,863).
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], const uint32_t (&k)[2]) {
+    const uint64_t p0 = (uint64_t) 0xD2511F53u * c[0], p1 = (uint64_t) 0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t) (p1 >> 32) ^ c[1] ^ k[0], n1 = (uint32_t) p1, n2 = (uint32_t) (p0 >> 32) ^ c[3] ^ k[1], n3 = (uint32_t) p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__global__ void __launch_bounds__(256) vv_kernel_fill_normals(float4* out, uint32_t count, uint64_t seed, const unsigned long long* epoch) {
+    const unsigned long long ep = *epoch;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += blockDim.x * gridDim.x) {
+        uint32_t c[4] = {i, (uint32_t) ep, (uint32_t) (ep >> 32), 0x5656u};
+        uint32_t key[2] = {(uint32_t) seed, (uint32_t) (seed >> 32)};
+#pragma unroll
+        for (int r = 0; r < 10; r++) {
+            philox_round(c, key);
+            key[0] += 0x9E3779B9u; key[1] += 0xBB67AE85u;
+        }
+        // (0,1] uniforms from the 32-bit words, then two Box-Muller pairs
+        const float u0 = ((float) c[0] + 1.0f) * 2.3283064365386963e-10f, u1 = (float) c[1] * 2.3283064365386963e-10f;
+        const float u2 = ((float) c[2] + 1.0f) * 2.3283064365386963e-10f, u3 = (float) c[3] * 2.3283064365386963e-10f;
+        const float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
+        float s0, c0, s1, c1;
+        sincosf(6.283185307179586f * u1, &s0, &c0);
+        sincosf(6.283185307179586f * u3, &s1, &c1);
+        out[i] = make_float4(r0 * c0, r0 * s0, r1 * c1, r1 * s1);
+    }
+}
+__global__ void vv_kernel_bump_epoch(unsigned long long* epoch) { *epoch += 1; }
+
 // ================================================================================ launchers
 static inline dim3 grid_for(int nwaves, int block_threads) {
     const int wpb = block_threads / 64;
@@ -945,6 +975,13 @@ hipError_t launch_chain(const NHConst& c, NHDevState* st, unsigned long long* ac
 }
 hipError_t launch_tether(int precision, const TetherArgs& t, int block_threads, hipStream_t s) {
     VV_DISPATCH(vv_kernel_tether, grid_for(t.nwaves, block_threads), dim3(block_threads), 0, s, t);
+    return hipGetLastError();
+}
+hipError_t launch_fill_normals(float4* out, uint32_t count, uint64_t seed, unsigned long long* epoch, hipStream_t s) {
+    if (count == 0) return hipSuccess;
+    const unsigned blocks = (count + 255) / 256 > 1024 ? 1024 : (count + 255) / 256;
+    hipLaunchKernelGGL(vv_kernel_fill_normals, dim3(blocks), dim3(256), 0, s, out, count, seed, (const unsigned long long*) epoch);
+    hipLaunchKernelGGL(vv_kernel_bump_epoch, dim3(1), dim3(1), 0, s, epoch);
     return hipGetLastError();
 }
 hipError_t launch_image_pairs(int precision, void* posq, void* corr, const int2* pairs, int npairs, double mirror, hipStream_t s) {

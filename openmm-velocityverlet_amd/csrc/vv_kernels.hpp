@@ -124,6 +124,9 @@ hipError_t launch_a(int precision, const KArgs& a, int block_threads, hipStream_
 hipError_t launch_b(int precision, const KArgs& a, int block_threads, hipStream_t s);
 hipError_t launch_chain(const NHConst& c, NHDevState* st, unsigned long long* acc, hipStream_t s);
 hipError_t launch_tether(int precision, const TetherArgs& t, int block_threads, hipStream_t s);
+// Device Gaussian generator (stand-alone hosts; inside OpenMM the random buffer is OpenMM's): Philox4x32-10 keyed by
+// `seed`, counter = (*epoch, element index); a second 1-thread launch bumps *epoch so that graph replays draw fresh numbers.
+hipError_t launch_fill_normals(float4* out, uint32_t count, uint64_t seed, unsigned long long* epoch, hipStream_t s);
 hipError_t launch_image_pairs(int precision, void* posq, void* corr, const int2* pairs, int npairs, double mirror,
                               hipStream_t s);
 

@@ -19,6 +19,8 @@ def shard_bounds(system, world_size: int) -> List[Tuple[int, int]]:
     systems are single-GPU in the reference's configs (BASELINE.json C5) and are rejected by the plan."""
     mol = np.asarray(system.mol_id)
     n = mol.shape[0]
+    if world_size == 1:
+        return [(0, n)]
     change = np.nonzero(np.diff(mol) != 0)[0] + 1            # indices where a new molecule starts
     if len(np.unique(mol)) != len(change) + 1:
         raise ValueError("molecules are not contiguous in particle index: cannot shard by index range")

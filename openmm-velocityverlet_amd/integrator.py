@@ -340,9 +340,16 @@ class Context:
                 H.check(L.vvhip_step_vv_second(plan, ri), plan)
 
     def run_graph(self, steps: int, steps_per_graph: int = 50):
-        """Middle scheme, no Langevin subset: replay a captured hipGraph of whole steps (force provider included)."""
+        """Middle scheme: replay a captured hipGraph of whole steps (force provider included).  With a Langevin subset the
+        graph starts with a refill of the random buffer by the device generator, so every replay draws fresh numbers."""
         site = self.site.ptr if self.force_provider == "tether" else None
         H.check(H.lib.vvhip_run_graph(self.plan, int(steps), int(steps_per_graph), site, self.k_tether, self.k_drude), self.plan)
+
+    def fill_random(self, seed=None):
+        """Refill the Langevin random buffer with the device generator (Philox4x32-10 + Box-Muller)."""
+        if seed is not None:
+            H.check(H.lib.vvhip_set_random_seed(self.plan, int(seed)), self.plan)
+        H.check(H.lib.vvhip_fill_random(self.plan), self.plan)
 
     def run_eager(self, steps: int):
         """Middle scheme: the same steps enqueued one by one from C (no per-step Python, no graph)."""

@@ -116,6 +116,7 @@ def _load():
         "vvhip_synth_tether_force": [vp, vp, dbl, dbl],
         "vvhip_run_graph": [vp, C.c_int, C.c_int, vp, dbl, dbl],
         "vvhip_run_eager": [vp, C.c_int, vp, dbl, dbl],
+        "vvhip_set_random_seed": [vp, C.c_uint64], "vvhip_fill_random": [vp],
         "vvhip_comm_unique_id": [vp], "vvhip_comm_init": [vp, vp, C.c_int, C.c_int], "vvhip_comm_destroy": [vp],
         "vvhip_time_kernel": [vp, C.c_int, u32, C.c_int, P(dbl)],
         "vvhip_timing_enable": [vp, C.c_int], "vvhip_timing_read": [vp, P(dbl), P(dbl), P(dbl), P(i32 * 3)],

@@ -162,3 +162,31 @@ def test_molecules_larger_than_a_wave_with_com_group(middle, cos):
         assert np.allclose(ke_g, ke_o, rtol=1e-10)
     finally:
         ctx.close()
+
+
+def test_device_gaussian_generator_moments_and_graph_refresh():
+    """Philox4x32-10 + Box-Muller fill of the Langevin buffer: N(0,1) moments, different numbers on every refill, and a
+    Langevin system stepping through graph replay stays finite with a sane temperature."""
+    spec = systems.edl_slab(num_ion_pairs=20, num_electrode=200, seed=9)
+    it = I.VVIntegrator(333.0, 10, 1.0, 40, 0.001)
+    it.setMaxDrudeDistance(0.02)
+    it.setMirrorLocation(float(spec.box[2]) / 2)
+    ctx = I.Context(spec, it, precision="mixed")
+    try:
+        ctx.fill_random(seed=12345)
+        ctx.synchronize()
+        a = ctx.random.download().astype(np.float64).ravel()
+        ctx.fill_random()
+        ctx.synchronize()
+        b = ctx.random.download().astype(np.float64).ravel()
+        n = a.size
+        assert abs(a.mean()) < 5 / np.sqrt(n) and abs(a.var() - 1) < 0.02 and abs((a ** 4).mean() - 3) < 0.1
+        assert abs(np.corrcoef(a[:-1], a[1:])[0, 1]) < 5 / np.sqrt(n)
+        assert not np.array_equal(a, b) and abs(np.corrcoef(a, b)[0, 1]) < 5 / np.sqrt(n)
+        ctx.run_graph(200, steps_per_graph=20)
+        v = ctx.getVelm()
+        el = np.array(spec.particles_ld)
+        T_el = (spec.masses[el, None] * v[el, :3] ** 2).sum() / (3 * len(el)) / O.BOLTZ
+        assert np.isfinite(v).all() and 150 < T_el < 600, T_el
+    finally:
+        ctx.close()
