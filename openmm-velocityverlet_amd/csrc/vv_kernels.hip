@@ -128,7 +128,7 @@ __device__ __forceinline__ double cos_kz(real z, real inv_box_z) {
 // V = (sum m v) * RECIP(sum m), with comVelm.w = RECIP(sum m).
 template <class real, class mixed>
 __device__ __forceinline__ void com_velocity(bool contributes, mixed vx, mixed vy, mixed vz, mixed w, int lane,
-                                             unsigned meta, mixed& Vx, mixed& Vy, mixed& Vz, mixed& Vw) {
+                                             unsigned meta, mixed& Vx, mixed& Vy, mixed& Vz, mixed& Vw, mixed& Vm) {
     const int first = (meta >> META_SEGFIRST_SHIFT) & 63, last = (meta >> META_SEGLAST_SHIFT) & 63;
     mixed mass = 0, mx = 0, my = 0, mz = 0;
     if (contributes) {
@@ -139,6 +139,7 @@ __device__ __forceinline__ void com_velocity(bool contributes, mixed vx, mixed v
     my = segment_total(my, lane, first, last);
     mz = segment_total(mz, lane, first, last);
     mass = segment_total(mass, lane, first, last);
+    Vm = mass;
     Vw = Prec<real>::RECIP(mass);
     Vx = mx * Vw; Vy = my * Vw; Vz = mz * Vw;
 }
@@ -291,16 +292,17 @@ __global__ void __launch_bounds__(256) vv_kernel_a(const KArgs a) {
                 const mixed V = (mixed) ((double) acc_total(a.acc, 3, lane) * a.acc_inv_scale[3] * a.inv_mass_total);
                 if (act) ux -= V * cos_kz<real>(pq.z, (real) a.inv_box_z);
             }
-            mixed Vx = 0, Vy = 0, Vz = 0, Vw = 0;
+            mixed Vx = 0, Vy = 0, Vz = 0, Vw = 0, Vm = 0;
             const bool use_com = ((meta >> META_SEGFIRST_SHIFT) & 63) != ((meta >> META_SEGLAST_SHIFT) & 63) ||
                                  (meta & META_COM_LEADER);
             // the COM stage is wave-uniform on purpose: lanes outside a COM segment scan a 1-lane segment
-            com_velocity<real, mixed>(nh && massive && use_com, ux, uy, uz, v.w, lane, meta, Vx, Vy, Vz, Vw);
+            com_velocity<real, mixed>(nh && massive && use_com, ux, uy, uz, v.w, lane, meta, Vx, Vy, Vz, Vw, Vm);
             if (!use_com) { Vx = 0; Vy = 0; Vz = 0; Vw = 0; }
             if (a.slot_big && (meta & META_BIGMOL) && nh) {     // molecule spread over several waves: totals from the accumulator
                 const unsigned long long* src = a.bigacc + 4 * (size_t) a.slot_big[(size_t) wave * 64 + lane];
                 const mixed sx = (mixed) ((double) (long long) src[0] * a.big_inv_scale), sy = (mixed) ((double) (long long) src[1] * a.big_inv_scale);
                 const mixed sz = (mixed) ((double) (long long) src[2] * a.big_inv_scale), sm = (mixed) ((double) (long long) src[3] * a.big_inv_scale);
+                Vm = sm;
                 Vw = P::RECIP(sm);
                 Vx = sx * Vw; Vy = sy * Vw; Vz = sz * Vw;
             }
@@ -309,23 +311,26 @@ __global__ void __launch_bounds__(256) vv_kernel_a(const KArgs a) {
                 ((mixed4*) a.comv)[(size_t) wave * 64 + ((meta >> META_SEGFIRST_SHIFT) & 63)] = cv;
             }
             if (nh) { ux -= Vx; uy -= Vy; uz -= Vz; }                       // K/drudeNoseHoover.cu:45-47
-            const mixed px = shfl(ux, partner), py = shfl(uy, partner), pz = shfl(uz, partner), pw = shfl(v.w, partner);
+            // Masses: one reciprocal per lane, the partner's comes over the shuffle network.  Where the reference divides by an
+            // inverse mass this multiplies by the mass (<= 1 ulp apart, below the reduction-order noise of these sums).
+            const mixed own_mass = massive ? P::RECIP(v.w) : (mixed) 0;
+            const mixed px = shfl(ux, partner), py = shfl(uy, partner), pz = shfl(uz, partner), pm = shfl(own_mass, partner);
             if (role == ROLE_NH_NORMAL && massive) {                        // K/drudeNoseHoover.cu:76-83
-                k_atom = (double) ((ux * ux + uy * uy + uz * uz) / v.w);
+                k_atom = (double) ((ux * ux + uy * uy + uz * uz) * own_mass);
             } else if (role == ROLE_NH_DRUDE) {                             // K/drudeNoseHoover.cu:97-114, pair.x = Drude
-                const mixed mass1 = P::RECIP(v.w), mass2 = P::RECIP(pw);
+                const mixed mass1 = own_mass, mass2 = pm;
                 const mixed invTotalMass = P::RECIP(mass1 + mass2);
-                const mixed invReducedMass = (mass1 + mass2) * v.w * pw;
+                const mixed reducedMass = mass1 * mass2 * invTotalMass;
                 const mixed mass1fract = invTotalMass * mass1, mass2fract = invTotalMass * mass2;
                 const mixed cx = ux * mass1fract + px * mass2fract;
                 const mixed cy = uy * mass1fract + py * mass2fract;
                 const mixed cz = uz * mass1fract + pz * mass2fract;
                 const mixed rx = ux - px, ry = uy - py, rz = uz - pz;
                 k_atom = (double) ((cx * cx + cy * cy + cz * cz) * (mass1 + mass2));
-                k_drude = (double) ((rx * rx + ry * ry + rz * rz) / invReducedMass);
+                k_drude = (double) ((rx * rx + ry * ry + rz * rz) * reducedMass);
             }
             if ((meta & META_COM_LEADER) && use_com && Vw != 0 && (!(meta & META_BIGMOL) || (meta & META_BIG_FIRST)))   // K/drudeNoseHoover.cu:85-94
-                k_com = (double) ((Vx * Vx + Vy * Vy + Vz * Vz) / Vw);
+                k_com = (double) ((Vx * Vx + Vy * Vy + Vz * Vz) * Vm);
         }
     }
     if (F & (A_KE | A_BIAS)) {
@@ -342,18 +347,14 @@ __global__ void __launch_bounds__(256) vv_kernel_a(const KArgs a) {
 // |x| <= 2^-4 a degree-11 Taylor polynomial (Horner, 11 dependent FMAs) is exact to < 1 ulp (truncation
 // x^12/12! < 1e-23 relative); anything larger goes to the library exp.
 __device__ __forceinline__ double chain_exp(double x) {
-    double p = 1.0 / 39916800.0;
-    p = fma(p, x, 1.0 / 3628800.0);
-    p = fma(p, x, 1.0 / 362880.0);
-    p = fma(p, x, 1.0 / 40320.0);
-    p = fma(p, x, 1.0 / 5040.0);
-    p = fma(p, x, 1.0 / 720.0);
-    p = fma(p, x, 1.0 / 120.0);
-    p = fma(p, x, 1.0 / 24.0);
-    p = fma(p, x, 1.0 / 6.0);
-    p = fma(p, x, 0.5);
-    p = fma(p, x, 1.0);
-    p = fma(p, x, 1.0);
+    // degree-11 Taylor polynomial by Estrin's scheme: the chain is one serial dependency chain executed by three lanes, so
+    // depth (5 levels) matters, not operation count.  exp(x) = sum_{k<=11} x^k/k!, |x| <= 2^-4: truncation < 1e-23 relative.
+    const double x2 = x * x, x4 = x2 * x2, x8 = x4 * x4;
+    const double p01 = fma(x, 1.0, 1.0), p23 = fma(x, 1.0 / 6.0, 0.5), p45 = fma(x, 1.0 / 120.0, 1.0 / 24.0);
+    const double p67 = fma(x, 1.0 / 5040.0, 1.0 / 720.0), p89 = fma(x, 1.0 / 362880.0, 1.0 / 40320.0);
+    const double pab = fma(x, 1.0 / 39916800.0, 1.0 / 3628800.0);
+    const double q0 = fma(x2, p23, p01), q1 = fma(x2, p67, p45), q2 = fma(x2, pab, p89);
+    double p = fma(x8, q2, fma(x4, q1, q0));
     if (__builtin_expect(__any(fabs(x) > 0.0625), 0)) p = fabs(x) > 0.0625 ? exp(x) : p;   // wave-uniform, practically never taken
     return p;
 }
