@@ -69,6 +69,7 @@ struct vvhip_plan {
     void* d_old_delta = nullptr;
     void* d_pos_delta = nullptr;   // used when the caller does not supply one
     void* d_comv = nullptr;        // per-segment COM velocities handed from kernel A to kernel B
+    double* d_cosz = nullptr;      // per-lane cos(2 pi z / Lz) of the current step
     unsigned long long* d_acc = nullptr;   // [2 parities][NUM_ACC][ACC_SLOTS]
     vv::NHDevState* d_nh = nullptr;         // [2 parities]
     int parity = 0;                         // which copy the next reduction/consumer pair uses
@@ -149,6 +150,7 @@ vv::KArgs make_args(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
     a.pos_delta = p->buf.pos_delta ? p->buf.pos_delta : p->d_pos_delta;
     a.old_delta = p->d_old_delta;
     a.comv = p->d_comv;
+    a.cosz = p->d_cosz;
     a.slots = p->d_slots;
     a.slot_image = p->d_slot_image;
     a.slot_rand = p->d_slot_rand;
@@ -245,7 +247,7 @@ int run_chain(vvhip_plan* p, uint32_t flags) {
 // same launch if possible (kick, extra forces).  Molecules larger than a wave need their COM summed across waves
 // first (A_COMPART, its own launch after a memset of the small accumulator), so there the stages are split.
 int run_ke(vvhip_plan* p, uint32_t first, uint32_t random_index, bool unbias) {
-    const uint32_t ub = unbias ? vv::A_UNBIAS_ACC : 0;
+    const uint32_t ub = unbias ? (vv::A_UNBIAS_ACC | vv::A_CZ_LOAD) : 0;    // the bias launch of this step cached cos(kz)
     if (p->hp.num_big == 0) {
         if (unbias && first) { int rc = run_a(p, first, random_index); if (rc != VVHIP_OK) return rc; first = 0; }
         return run_a(p, first | vv::A_KE | ub, random_index);
@@ -320,7 +322,7 @@ void vvhip_plan_destroy(vvhip_plan* p) {
     if (p->bound) {
         (void) hipStreamSynchronize(p->stream);
         for (void* ptr : {(void*) p->d_slots, (void*) p->d_slot_image, (void*) p->d_slot_rand, (void*) p->d_slot_big, (void*) p->d_bigacc, (void*) p->d_image_pairs,
-                          p->d_fextra, p->d_old_delta, p->d_pos_delta, p->d_comv, (void*) p->d_epoch, (void*) p->d_acc, (void*) p->d_nh})
+                          p->d_fextra, p->d_old_delta, p->d_pos_delta, p->d_comv, (void*) p->d_cosz, (void*) p->d_epoch, (void*) p->d_acc, (void*) p->d_nh})
             if (ptr) (void) hipFree(ptr);
         if (p->graph_exec) (void) hipGraphExecDestroy(p->graph_exec);
         if (p->comm) (void) rccl_api().commDestroy(p->comm);
@@ -390,6 +392,8 @@ int vvhip_bind(vvhip_plan* p, const vvhip_buffers* b) {
     HIP_TRY(p, hipMemset(p->d_fextra, 0, nloc * 3 * rs));
     HIP_TRY(p, hipMalloc(&p->d_old_delta, nloc * 4 * ms));
     HIP_TRY(p, hipMemset(p->d_old_delta, 0, nloc * 4 * ms));
+    HIP_TRY(p, hipMalloc((void**) &p->d_cosz, nslots * sizeof(double)));
+    HIP_TRY(p, hipMemset(p->d_cosz, 0, nslots * sizeof(double)));
     HIP_TRY(p, hipMalloc(&p->d_comv, nslots * 4 * ms));
     HIP_TRY(p, hipMemset(p->d_comv, 0, nslots * 4 * ms));
     HIP_TRY(p, hipMalloc(&p->d_pos_delta, nloc * 4 * ms));
@@ -461,9 +465,9 @@ int vvhip_step_middle_phase(vvhip_plan* p, int phase, uint32_t random_index) {
         if (phase == 0) return run_ke(p, kick, random_index, false);
         if (phase == 1) return run_chain_and_b(p, vv::B_SCALE | drift, false);
     } else {                                               // API:252-259: bias -> remove -> scale -> restore
-        if (phase == 0) return run_a(p, kick | vv::A_BIAS, random_index);
+        if (phase == 0) return run_a(p, kick | vv::A_BIAS | vv::A_CZ_STORE, random_index);
         if (phase == 1) return run_ke(p, 0, 0, true);
-        if (phase == 2) return run_chain_and_b(p, vv::B_SCALE | vv::B_UNBIAS | drift, true);
+        if (phase == 2) return run_chain_and_b(p, vv::B_SCALE | vv::B_UNBIAS | vv::B_CZ_LOAD | drift, true);
     }
     return fail(p, VVHIP_ERR_INVALID, "phase out of range");
 }
@@ -513,9 +517,9 @@ static int nh_half(vvhip_plan* p, uint32_t a_first, uint32_t random_index, uint3
         TRY(run_ke(p, a_first, random_index, false));
         return run_chain_and_b(p, vv::B_SCALE | b_extra, false);
     }
-    TRY(run_a(p, a_first | vv::A_BIAS, random_index));
+    TRY(run_a(p, a_first | vv::A_BIAS | vv::A_CZ_STORE, random_index));
     TRY(run_ke(p, 0, 0, true));
-    return run_chain_and_b(p, vv::B_SCALE | vv::B_UNBIAS | b_extra, true);
+    return run_chain_and_b(p, vv::B_SCALE | vv::B_UNBIAS | vv::B_CZ_LOAD | b_extra, true);
 }
 
 int vvhip_step_vv_first(vvhip_plan* p) {                   // API:295-310 (forces for the old positions are in `force`)
@@ -724,8 +728,8 @@ int vvhip_time_kernel(vvhip_plan* p, int kernel, uint32_t flags, int reps, doubl
     NEED_BOUND(p);
     if (reps < 1 || !ms_per_launch) return VVHIP_ERR_INVALID;
     if (flags == 0xFFFFFFFFu) {     // the stage bits vvhip_step_middle uses for this plan
-        if (kernel == 0) flags = vv::A_KICK_FULL | extra_flags(p) | (p->hp.has_nh ? (cos_on(p) ? vv::A_BIAS : vv::A_KE) : 0);
-        else flags = vv::B_DRIFT_MIDDLE | tail_flags(p) | (p->hp.has_nh ? ((p->hp.params.num_nh_chains <= 4 ? vv::B_CHAIN : 0) | vv::B_SCALE | (cos_on(p) ? vv::B_UNBIAS : 0)) : 0);
+        if (kernel == 0) flags = vv::A_KICK_FULL | extra_flags(p) | (p->hp.has_nh ? (cos_on(p) ? (vv::A_BIAS | vv::A_CZ_STORE) : vv::A_KE) : 0);
+        else flags = vv::B_DRIFT_MIDDLE | tail_flags(p) | (p->hp.has_nh ? ((p->hp.params.num_nh_chains <= 4 ? vv::B_CHAIN : 0) | vv::B_SCALE | (cos_on(p) ? (vv::B_UNBIAS | vv::B_CZ_LOAD) : 0)) : 0);
     }
     hipEvent_t e0, e1;
     HIP_TRY(p, hipEventCreate(&e0));

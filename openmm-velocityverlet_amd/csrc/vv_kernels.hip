@@ -170,9 +170,15 @@ __global__ void __launch_bounds__(256) vv_kernel_a(const KArgs a) {
         const mixed stepSize = (mixed) a.dt;
 
         real4 pq = {0, 0, 0, 0};
-        const bool need_pos = (F & (A_COS | A_BIAS | A_UNBIAS_ACC)) || ((F & A_EF) && (meta & META_EFIELD));
+        const bool need_pos = ((F & (A_COS | A_BIAS | A_UNBIAS_ACC)) && !(F & A_CZ_LOAD)) || ((F & A_EF) && (meta & META_EFIELD));
         if (act && need_pos) pq = ((const real4*) a.posq)[atom];
 
+        double czl = 0;          // cos(2 pi z / Lz): evaluated at most once per launch, cached across the launches of a step
+        if (F & (A_COS | A_BIAS | A_UNBIAS_ACC)) {
+            if (F & A_CZ_LOAD) czl = a.cosz[(size_t) wave * 64 + lane];
+            else czl = cos_kz<real>(pq.z, (real) a.inv_box_z);
+            if (F & A_CZ_STORE) a.cosz[(size_t) wave * 64 + lane] = czl;
+        }
         // ---------------- extra force (VVIntegrator.cpp:238-245), accumulated in `real` like forceExtra
         real3 fe = {0, 0, 0};
         if ((F & A_FE_LOAD) && act) fe = ((const real3*) a.fextra)[atom];
@@ -223,7 +229,7 @@ __global__ void __launch_bounds__(256) vv_kernel_a(const KArgs a) {
         if ((F & A_EF) && act && (meta & META_EFIELD))                      // K/electricField.cu:8-10
             fe.z += (real) a.efscale * pq.w;
         if ((F & A_COS) && massive)                                         // K/cosineAccelerate.cu:9
-            fe.x += (real) a.cos_accel * cos_kz<real>(pq.z, (real) a.inv_box_z) * P::RECIP(v.w);
+            fe.x += (real) a.cos_accel * czl * P::RECIP(v.w);
         if ((F & A_FE_STORE) && act) ((real3*) a.fextra)[atom] = fe;
 
         // ---------------- kick
@@ -257,7 +263,7 @@ __global__ void __launch_bounds__(256) vv_kernel_a(const KArgs a) {
 
         // ---------------- periodic bias moment (K/cosineAccelerate.cu:24-27; massless -> 0)
         if ((F & A_BIAS) && massive) {
-            const mixed t = P::RECIP(v.w) * v.x * 2 * cos_kz<real>(pq.z, (real) a.inv_box_z);
+            const mixed t = P::RECIP(v.w) * v.x * 2 * czl;
             k_bias = (double) t;
         }
 
@@ -267,7 +273,7 @@ __global__ void __launch_bounds__(256) vv_kernel_a(const KArgs a) {
             mixed bx = v.x;
             if (F & A_UNBIAS_ACC) {
                 const mixed V = (mixed) ((double) acc_total(a.acc, 3, lane) * a.acc_inv_scale[3] * a.inv_mass_total);
-                if (act) bx -= V * cos_kz<real>(pq.z, (real) a.inv_box_z);
+                if (act) bx -= V * czl;
             }
             const int first = (meta >> META_SEGFIRST_SHIFT) & 63, last = (meta >> META_SEGLAST_SHIFT) & 63;
             mixed mass = 0, mx = 0, my = 0, mz = 0;
@@ -290,7 +296,7 @@ __global__ void __launch_bounds__(256) vv_kernel_a(const KArgs a) {
             if (F & A_UNBIAS_ACC) {                                         // K/cosineAccelerate.cu:53-58, 69-71
                 // same expression as the chain kernel writes to scales[3], so kernel B removes exactly this V
                 const mixed V = (mixed) ((double) acc_total(a.acc, 3, lane) * a.acc_inv_scale[3] * a.inv_mass_total);
-                if (act) ux -= V * cos_kz<real>(pq.z, (real) a.inv_box_z);
+                if (act) ux -= V * czl;
             }
             mixed Vx = 0, Vy = 0, Vz = 0, Vw = 0, Vm = 0;
             const bool use_com = ((meta >> META_SEGFIRST_SHIFT) & 63) != ((meta >> META_SEGLAST_SHIFT) & 63) ||
@@ -651,7 +657,7 @@ __global__ void __launch_bounds__(320) vv_kernel_b(const KArgs a) {
     mixed Vb = 0;
     if (F & (B_UNBIAS | B_BIAS_REMOVE | B_BIAS_RESTORE)) {
         Vb = (mixed) scb;
-        cz = cos_kz<real>(zraw, (real) a.inv_box_z);
+        cz = (F & B_CZ_LOAD) ? a.cosz[(size_t) wave * 64 + lane] : cos_kz<real>(zraw, (real) a.inv_box_z);
         if ((F & (B_UNBIAS | B_BIAS_REMOVE)) && act) { v.x -= Vb * cz; vel_dirty = true; }
     }
 
@@ -953,12 +959,17 @@ static inline dim3 grid_for(int nwaves, int block_threads) {
 // Stage-bit sets with their own compiled kernel: the fused middle step of a Drude system with / without hard wall
 // (BASELINE configs C3 / C2).  Everything else runs the generic kernel with run-time bits.
 constexpr uint32_t SF_A_MIDDLE = A_KICK_FULL | A_KE;
+constexpr uint32_t SF_A_COS1 = A_KICK_FULL | A_COS | A_BIAS | A_CZ_STORE;          // cos acceleration (BASELINE C4): kick + bias moment
+constexpr uint32_t SF_A_COS2 = A_KE | A_UNBIAS_ACC | A_CZ_LOAD;                     // ... kinetic energies of the bias-free velocities
+constexpr uint32_t SF_B_COS_HW = B_CHAIN | B_SCALE | B_UNBIAS | B_CZ_LOAD | B_DRIFT_MIDDLE | B_HARDWALL;
 constexpr uint32_t SF_B_MIDDLE_HW = B_CHAIN | B_SCALE | B_DRIFT_MIDDLE | B_HARDWALL;
 constexpr uint32_t SF_B_MIDDLE = B_CHAIN | B_SCALE | B_DRIFT_MIDDLE;
 
 hipError_t launch_a(int precision, const KArgs& a, int block_threads, hipStream_t s) {
     const dim3 g = grid_for(a.nwaves, block_threads), b(block_threads);
     if (a.flags == SF_A_MIDDLE) { VV_DISPATCH_SF(vv_kernel_a, SF_A_MIDDLE, g, b, 0, s, a); }
+    else if (a.flags == SF_A_COS1) { VV_DISPATCH_SF(vv_kernel_a, SF_A_COS1, g, b, 0, s, a); }
+    else if (a.flags == SF_A_COS2) { VV_DISPATCH_SF(vv_kernel_a, SF_A_COS2, g, b, 0, s, a); }
     else { VV_DISPATCH_SF(vv_kernel_a, 0u, g, b, 0, s, a); }
     return hipGetLastError();
 }
@@ -967,6 +978,7 @@ hipError_t launch_b(int precision, const KArgs& a, int block_threads, hipStream_
     const dim3 g = grid_for(a.nwaves, block_threads), b(block_threads + ((a.flags & B_CHAIN) ? 64 : 0));
     if (a.flags == SF_B_MIDDLE_HW) { VV_DISPATCH_SF(vv_kernel_b, SF_B_MIDDLE_HW, g, b, 0, s, a); }
     else if (a.flags == SF_B_MIDDLE) { VV_DISPATCH_SF(vv_kernel_b, SF_B_MIDDLE, g, b, 0, s, a); }
+    else if (a.flags == SF_B_COS_HW) { VV_DISPATCH_SF(vv_kernel_b, SF_B_COS_HW, g, b, 0, s, a); }
     else { VV_DISPATCH_SF(vv_kernel_b, 0u, g, b, 0, s, a); }
     return hipGetLastError();
 }

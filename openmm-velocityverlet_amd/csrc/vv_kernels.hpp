@@ -24,6 +24,8 @@ enum : uint32_t {
     A_KE = 1u << 10,         // molecular COM + per-group sum m v^2 (K/drudeNoseHoover.cu:5-151)
     A_UNBIAS_ACC = 1u << 11, // before the KE, subtract V*cos(kz) with V taken from accumulator 3
     A_COMPART = 1u << 12,    // molecules larger than a wave: add each chunk's sum(m v), sum(m) to the molecule's accumulator
+    A_CZ_STORE = 1u << 13,   // keep cos(2 pi z / Lz) of every lane for the later kernels of this step (positions do not move in between)
+    A_CZ_LOAD = 1u << 14,    // ... and take it from there instead of evaluating a double-precision cosine again
 };
 // ---- stage flags of kernel B ("consume": starts from the scale factors) -------------------------
 enum : uint32_t {
@@ -39,6 +41,7 @@ enum : uint32_t {
     B_HARDWALL = 1u << 9,     // (K/middle.cu:106-221)
     B_IMAGE = 1u << 10,       // mirror copy to the image particle     (K/imageCharge.cu:2-28)
     B_CHAIN = 1u << 11,       // run the NH chain in the kernel head from the accumulators (else read nh->scales)
+    B_CZ_LOAD = 1u << 12,     // cos(2 pi z / Lz) from the per-lane cache written by kernel A (A_CZ_STORE)
     B_DBG_NOFOLD = 1u << 28,  // timing experiments only: skip the accumulator fold / the chain arithmetic
     B_DBG_NOMATH = 1u << 29,
 };
@@ -80,6 +83,7 @@ struct KArgs {
     void* fextra;
     void* pos_delta;
     void* old_delta;
+    double* cosz;                  // [64*nwaves] per-lane cos(2 pi z / Lz) cache of the current step
     void* comv;                    // mixed4 [64*nwaves]: COM velocity of the segment starting at that lane, written by A_KE, read by B_SCALE
     const int2* slots;
     const int32_t* slot_image;
