@@ -183,6 +183,19 @@ def main():
                        "atom_steps_per_s": round(steps_per_s * n, 1)},
         }
 
+    # ---- the integrator path alone: forces resident in HBM (static buffer), no provider kernel in the loop
+    if world == 1 and rank == 0 and not use_dist and args.forces == "tether" and not args.eager:
+        prov = ctx.force_provider
+        ctx.force_provider = "static"
+        n2 = max(args.steps // 4, 2 * args.steps_per_graph)
+        ctx.run_graph(2 * args.steps_per_graph, args.steps_per_graph)
+        fence()
+        t0 = time.perf_counter()
+        ctx.run_graph(n2, args.steps_per_graph)
+        fence()
+        out["config"]["integrator_only_steps_per_s"] = round(n2 / (time.perf_counter() - t0), 1)
+        ctx.force_provider = prov
+
     # ---- roofline of the dominant kernel, measured live with HIP events on the plan's stream (N = 1 only)
     if world == 1 and rank == 0 and not use_dist:
         # two HIP events around 100 back-to-back launches (x5 batches) of each stage kernel with the fused step's stage bits

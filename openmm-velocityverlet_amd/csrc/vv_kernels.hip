@@ -152,11 +152,13 @@ __global__ void __launch_bounds__(256) vv_kernel_a(const KArgs a) {
     using mixed4 = typename Vec<mixed>::v4;
     using P = Prec<real>;
     const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t F = SF ? SF : a.flags;
     double k_atom = 0, k_com = 0, k_drude = 0, k_bias = 0;
 
-    if (wave < a.nwaves) {
+    // grid-stride over 64-lane tiles (the grid is capped in launch_a): per-lane partial sums run across all tiles of the
+    // block, so the block reduction and its atomics are paid once per block however large the system is
+    const int tile_stride = gridDim.x * (blockDim.x >> 6);
+    for (int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); wave < a.nwaves; wave += tile_stride) {
         const int2 slot = a.slots[(size_t) wave * 64 + lane];
         const int atom = slot.x;
         const unsigned meta = (unsigned) slot.y;
@@ -264,7 +266,7 @@ __global__ void __launch_bounds__(256) vv_kernel_a(const KArgs a) {
         // ---------------- periodic bias moment (K/cosineAccelerate.cu:24-27; massless -> 0)
         if ((F & A_BIAS) && massive) {
             const mixed t = P::RECIP(v.w) * v.x * 2 * czl;
-            k_bias = (double) t;
+            k_bias += (double) t;
         }
 
         // ---------------- molecules larger than a wave: per-chunk partial sums into the molecule's accumulator
@@ -322,7 +324,7 @@ __global__ void __launch_bounds__(256) vv_kernel_a(const KArgs a) {
             const mixed own_mass = massive ? P::RECIP(v.w) : (mixed) 0;
             const mixed px = shfl(ux, partner), py = shfl(uy, partner), pz = shfl(uz, partner), pm = shfl(own_mass, partner);
             if (role == ROLE_NH_NORMAL && massive) {                        // K/drudeNoseHoover.cu:76-83
-                k_atom = (double) ((ux * ux + uy * uy + uz * uz) * own_mass);
+                k_atom += (double) ((ux * ux + uy * uy + uz * uz) * own_mass);
             } else if (role == ROLE_NH_DRUDE) {                             // K/drudeNoseHoover.cu:97-114, pair.x = Drude
                 const mixed mass1 = own_mass, mass2 = pm;
                 const mixed invTotalMass = P::RECIP(mass1 + mass2);
@@ -332,11 +334,11 @@ __global__ void __launch_bounds__(256) vv_kernel_a(const KArgs a) {
                 const mixed cy = uy * mass1fract + py * mass2fract;
                 const mixed cz = uz * mass1fract + pz * mass2fract;
                 const mixed rx = ux - px, ry = uy - py, rz = uz - pz;
-                k_atom = (double) ((cx * cx + cy * cy + cz * cz) * (mass1 + mass2));
-                k_drude = (double) ((rx * rx + ry * ry + rz * rz) * reducedMass);
+                k_atom += (double) ((cx * cx + cy * cy + cz * cz) * (mass1 + mass2));
+                k_drude += (double) ((rx * rx + ry * ry + rz * rz) * reducedMass);
             }
             if ((meta & META_COM_LEADER) && use_com && Vw != 0 && (!(meta & META_BIGMOL) || (meta & META_BIG_FIRST)))   // K/drudeNoseHoover.cu:85-94
-                k_com = (double) ((Vx * Vx + Vy * Vy + Vz * Vz) * Vm);
+                k_com += (double) ((Vx * Vx + Vy * Vy + Vz * Vz) * Vm);
         }
     }
     if (F & (A_KE | A_BIAS)) {
@@ -576,10 +578,52 @@ __global__ void __launch_bounds__(320) vv_kernel_b(const KArgs a) {
     const bool has_cw = (F & B_CHAIN) != 0;
     const bool chain_wave = has_cw && wib == nwb - 1;
     const int tiles_per_block = has_cw ? nwb - 1 : nwb;
-    const int wave = blockIdx.x * tiles_per_block + wib;
-    const bool valid = !chain_wave && wave < a.nwaves;
     __shared__ double sh_scales[4];
+    double sc0 = 1.0, sc1 = 1.0, sc2 = 1.0, scb = 0.0;
 
+    // ---------------- thermostat wave: scale factors for the whole block, then done
+    if (chain_wave) {
+        const int cg = lane < VVHIP_NUM_TG ? lane : VVHIP_NUM_TG - 1;
+        ChainRegs cr;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { cr.eta[i] = a.nh->s.eta[cg][i]; cr.eta_dot[i] = a.nh->s.eta_dot[cg][i]; cr.eta_dotdot[i] = a.nh->s.eta_dotdot[cg][i]; }
+        cr.eta_dot[4] = a.nh->s.eta_dot[cg][4];
+        long long tot[NUM_ACC];
+#pragma unroll
+        for (int k = 0; k < NUM_ACC; k++) tot[k] = (F & B_DBG_NOFOLD) ? 0 : acc_total(a.acc, k, lane);
+        double ke2 = 0;
+#pragma unroll
+        for (int k = 0; k < VVHIP_NUM_TG; k++)
+            if (cg == k) ke2 = (double) tot[k] * a.chain.acc_inv_scale[k];
+        double factor = 1.0;
+        if (!(F & B_DBG_NOMATH)) factor = propagate_group_small(a.chain, chain_lane_const(a.chain, cg), ke2, cr);
+        const double bias = (F & B_UNBIAS) ? (double) tot[3] * a.chain.acc_inv_scale[3] * a.chain.inv_mass_total   // K/cosineAccelerate.cu:57-59
+                                           : a.nh->scales[3];                                                 // carried over unchanged
+        if (lane < VVHIP_NUM_TG) sh_scales[lane] = factor;
+        if (lane == 3) sh_scales[3] = bias;
+        if (blockIdx.x == 0) {                    // one block records the advanced thermostat and clears the idle accumulator copy
+            NHDevState* out = a.nh_next;
+            if (lane < VVHIP_NUM_TG) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) { out->s.eta[cg][i] = cr.eta[i]; out->s.eta_dot[cg][i] = cr.eta_dot[i]; out->s.eta_dotdot[cg][i] = cr.eta_dotdot[i]; }
+                out->s.eta_dot[cg][4] = cr.eta_dot[4];
+                out->s.ke2[cg] = cg < a.chain.num_tg ? ke2 : a.nh->s.ke2[cg];
+                out->s.vscale[cg] = factor;
+                out->scales[cg] = factor;
+            }
+            if (lane == 3) { out->s.v_bias = bias; out->scales[3] = bias; }
+            for (int i = lane; i < NUM_ACC * ACC_SLOTS; i += 64) a.acc_next[i] = 0;
+        }
+        __syncthreads();
+        return;
+    }
+
+    // ---------------- tile waves: grid-stride over 64-lane tiles.  The grid is capped (launch_b), so at large N every block
+    // pays the fold + chain once and then streams many tiles; the first tile's loads overlap the thermostat wave.
+    const int tile_stride = gridDim.x * tiles_per_block;
+    bool need_scales = true;
+    for (int wave = blockIdx.x * tiles_per_block + wib; need_scales || wave < a.nwaves; wave += tile_stride) {
+    const bool valid = wave < a.nwaves;
     int atom = -1;
     unsigned meta = 0;
     if (valid) { const int2 slot = a.slots[(size_t) wave * 64 + lane]; atom = slot.x; meta = (unsigned) slot.y; }
@@ -608,48 +652,15 @@ __global__ void __launch_bounds__(320) vv_kernel_b(const KArgs a) {
         Vx = cv.x; Vy = cv.y; Vz = cv.z; Vw = cv.w;
     }
 
-    // ---------------- scale factors
-    double sc0 = 1.0, sc1 = 1.0, sc2 = 1.0, scb = 0.0;
-    if (has_cw) {
-        if (chain_wave) {
-            const int cg = lane < VVHIP_NUM_TG ? lane : VVHIP_NUM_TG - 1;
-            ChainRegs cr;
-#pragma unroll
-            for (int i = 0; i < 4; i++) { cr.eta[i] = a.nh->s.eta[cg][i]; cr.eta_dot[i] = a.nh->s.eta_dot[cg][i]; cr.eta_dotdot[i] = a.nh->s.eta_dotdot[cg][i]; }
-            cr.eta_dot[4] = a.nh->s.eta_dot[cg][4];
-            long long tot[NUM_ACC];
-#pragma unroll
-            for (int k = 0; k < NUM_ACC; k++) tot[k] = (F & B_DBG_NOFOLD) ? 0 : acc_total(a.acc, k, lane);
-            double ke2 = 0;
-#pragma unroll
-            for (int k = 0; k < VVHIP_NUM_TG; k++)
-                if (cg == k) ke2 = (double) tot[k] * a.chain.acc_inv_scale[k];
-            double factor = 1.0;
-            if (!(F & B_DBG_NOMATH)) factor = propagate_group_small(a.chain, chain_lane_const(a.chain, cg), ke2, cr);
-            const double bias = (F & B_UNBIAS) ? (double) tot[3] * a.chain.acc_inv_scale[3] * a.chain.inv_mass_total   // K/cosineAccelerate.cu:57-59
-                                               : a.nh->scales[3];                                                 // carried over unchanged
-            if (lane < VVHIP_NUM_TG) sh_scales[lane] = factor;
-            if (lane == 3) sh_scales[3] = bias;
-            if (blockIdx.x == 0) {                    // one block records the advanced thermostat and clears the idle accumulator copy
-                NHDevState* out = a.nh_next;
-                if (lane < VVHIP_NUM_TG) {
-#pragma unroll
-                    for (int i = 0; i < 4; i++) { out->s.eta[cg][i] = cr.eta[i]; out->s.eta_dot[cg][i] = cr.eta_dot[i]; out->s.eta_dotdot[cg][i] = cr.eta_dotdot[i]; }
-                    out->s.eta_dot[cg][4] = cr.eta_dot[4];
-                    out->s.ke2[cg] = cg < a.chain.num_tg ? ke2 : a.nh->s.ke2[cg];
-                    out->s.vscale[cg] = factor;
-                    out->scales[cg] = factor;
-                }
-                if (lane == 3) { out->s.v_bias = bias; out->scales[3] = bias; }
-                for (int i = lane; i < NUM_ACC * ACC_SLOTS; i += 64) a.acc_next[i] = 0;
-            }
+    if (need_scales) {
+        need_scales = false;
+        if (has_cw) {
+            __syncthreads();
+            sc0 = sh_scales[0]; sc1 = sh_scales[1]; sc2 = sh_scales[2]; scb = sh_scales[3];
+        } else if (F & (B_SCALE | B_UNBIAS | B_BIAS_REMOVE | B_BIAS_RESTORE)) {
+            sc0 = a.nh->scales[0]; sc1 = a.nh->scales[1]; sc2 = a.nh->scales[2]; scb = a.nh->scales[3];
         }
-        __syncthreads();
-        if (!valid) return;
-        sc0 = sh_scales[0]; sc1 = sh_scales[1]; sc2 = sh_scales[2]; scb = sh_scales[3];
-    } else {
-        if (!valid) return;
-        if (F & (B_SCALE | B_UNBIAS | B_BIAS_REMOVE | B_BIAS_RESTORE)) { sc0 = a.nh->scales[0]; sc1 = a.nh->scales[1]; sc2 = a.nh->scales[2]; scb = a.nh->scales[3]; }
+        if (!valid) break;
     }
 
     // ---------------- bias removal (K/cosineAccelerate.cu:63-73); cos uses posq.z (real), all particles
@@ -846,6 +857,7 @@ __global__ void __launch_bounds__(320) vv_kernel_b(const KArgs a) {
         }
         posq[img] = pi;
     }
+    }   // tile loop
 }
 
 // ================================================================================ stand-alone image kernel
@@ -966,7 +978,9 @@ constexpr uint32_t SF_B_MIDDLE_HW = B_CHAIN | B_SCALE | B_DRIFT_MIDDLE | B_HARDW
 constexpr uint32_t SF_B_MIDDLE = B_CHAIN | B_SCALE | B_DRIFT_MIDDLE;
 
 hipError_t launch_a(int precision, const KArgs& a, int block_threads, hipStream_t s) {
-    const dim3 g = grid_for(a.nwaves, block_threads), b(block_threads);
+    dim3 g = grid_for(a.nwaves, block_threads);
+    if (g.x > 2048) g.x = 2048;          // 8 blocks per CU; beyond that the kernel strides over tiles
+    const dim3 b(block_threads);
     if (a.flags == SF_A_MIDDLE) { VV_DISPATCH_SF(vv_kernel_a, SF_A_MIDDLE, g, b, 0, s, a); }
     else if (a.flags == SF_A_COS1) { VV_DISPATCH_SF(vv_kernel_a, SF_A_COS1, g, b, 0, s, a); }
     else if (a.flags == SF_A_COS2) { VV_DISPATCH_SF(vv_kernel_a, SF_A_COS2, g, b, 0, s, a); }
@@ -974,8 +988,11 @@ hipError_t launch_a(int precision, const KArgs& a, int block_threads, hipStream_
     return hipGetLastError();
 }
 hipError_t launch_b(int precision, const KArgs& a, int block_threads, hipStream_t s) {
-    // block_threads counts the tile waves; B_CHAIN adds the block's thermostat wave
-    const dim3 g = grid_for(a.nwaves, block_threads), b(block_threads + ((a.flags & B_CHAIN) ? 64 : 0));
+    // block_threads counts the tile waves; B_CHAIN adds the block's thermostat wave.  The grid is capped at 1024 blocks
+    // (4 per CU): beyond that the kernel strides over tiles and the per-block thermostat work is amortised.
+    dim3 g = grid_for(a.nwaves, block_threads);
+    if (g.x > 1024) g.x = 1024;
+    const dim3 b(block_threads + ((a.flags & B_CHAIN) ? 64 : 0));
     if (a.flags == SF_B_MIDDLE_HW) { VV_DISPATCH_SF(vv_kernel_b, SF_B_MIDDLE_HW, g, b, 0, s, a); }
     else if (a.flags == SF_B_MIDDLE) { VV_DISPATCH_SF(vv_kernel_b, SF_B_MIDDLE, g, b, 0, s, a); }
     else if (a.flags == SF_B_COS_HW) { VV_DISPATCH_SF(vv_kernel_b, SF_B_COS_HW, g, b, 0, s, a); }
