@@ -444,48 +444,42 @@ __device__ __forceinline__ ChainLaneConst chain_lane_const(const NHConst& c, int
 }
 template <int NC>
 __device__ __forceinline__ double propagate_preloaded(const NHConst& c, const ChainLaneConst& lc, double ke2, ChainRegs& r) {
-    // Straight-line on purpose (every lane runs it, inactive groups are masked out by selection at the end) so the
-    // scheduler can interleave this serial fp64 chain with the shuffle-heavy per-particle work around it.
-    ChainRegs n = r;
+    // Runs in the block's thermostat wave only (lanes 0..2 = the three temperature groups), so a plain branch on
+    // "group is thermostatted" is fine and the state is updated in place (fewer live registers for the whole kernel).
     double factor = 1.0;
+    if (!lc.active) return factor;                                              // HOST:729
     const double ke2_target = lc.nkbt;
     double expfac = 1.0;
     const double dt2 = c.step_size / c.loops_per_step / 2;
     const double dt4 = dt2 / 2;
     const double dt8 = dt4 / 2;
     const double kT = ((1.380649e-23 * 6.02214076e23) / 1000.0) * lc.temperature;
-    n.eta_dotdot[0] = (ke2 - ke2_target) * lc.inv_eta_mass[0];
+    r.eta_dotdot[0] = (ke2 - ke2_target) * lc.inv_eta_mass[0];
     for (int iloop = 0; iloop < c.loops_per_step; iloop++) {
 #pragma unroll
         for (int ich = NC - 1; ich >= 0; ich--) {
-            expfac = chain_exp(-dt8 * n.eta_dot[ich + 1]);
-            n.eta_dot[ich] *= expfac;
-            n.eta_dot[ich] += n.eta_dotdot[ich] * dt4;
-            n.eta_dot[ich] *= expfac;
+            expfac = chain_exp(-dt8 * r.eta_dot[ich + 1]);
+            r.eta_dot[ich] *= expfac;
+            r.eta_dot[ich] += r.eta_dotdot[ich] * dt4;
+            r.eta_dot[ich] *= expfac;
         }
-        factor *= chain_exp(-dt2 * n.eta_dot[0]);
+        factor *= chain_exp(-dt2 * r.eta_dot[0]);
 #pragma unroll
-        for (int ich = 0; ich < NC; ich++) n.eta[ich] += dt2 * n.eta_dot[ich];
-        n.eta_dotdot[0] = (ke2 * factor * factor - ke2_target) * lc.inv_eta_mass[0];
-        n.eta_dot[0] *= expfac;                                                  // stale expfac on purpose (quirk Q10)
-        n.eta_dot[0] += n.eta_dotdot[0] * dt4;
-        n.eta_dot[0] *= expfac;
+        for (int ich = 0; ich < NC; ich++) r.eta[ich] += dt2 * r.eta_dot[ich];
+        r.eta_dotdot[0] = (ke2 * factor * factor - ke2_target) * lc.inv_eta_mass[0];
+        r.eta_dot[0] *= expfac;                                                  // stale expfac on purpose (quirk Q10)
+        r.eta_dot[0] += r.eta_dotdot[0] * dt4;
+        r.eta_dot[0] *= expfac;
 #pragma unroll
         for (int ich = 1; ich < NC; ich++) {
-            expfac = chain_exp(-dt8 * n.eta_dot[ich + 1]);
-            n.eta_dot[ich] *= expfac;
-            n.eta_dotdot[ich] = (lc.eta_mass[ich - 1] * n.eta_dot[ich - 1] * n.eta_dot[ich - 1] - kT) * lc.inv_eta_mass[ich];
-            n.eta_dot[ich] += n.eta_dotdot[ich] * dt4;
-            n.eta_dot[ich] *= expfac;
+            expfac = chain_exp(-dt8 * r.eta_dot[ich + 1]);
+            r.eta_dot[ich] *= expfac;
+            r.eta_dotdot[ich] = (lc.eta_mass[ich - 1] * r.eta_dot[ich - 1] * r.eta_dot[ich - 1] - kT) * lc.inv_eta_mass[ich];
+            r.eta_dot[ich] += r.eta_dotdot[ich] * dt4;
+            r.eta_dot[ich] *= expfac;
         }
     }
-#pragma unroll
-    for (int i = 0; i < NC; i++) {
-        r.eta[i] = lc.active ? n.eta[i] : r.eta[i];
-        r.eta_dot[i] = lc.active ? n.eta_dot[i] : r.eta_dot[i];
-        r.eta_dotdot[i] = lc.active ? n.eta_dotdot[i] : r.eta_dotdot[i];
-    }
-    return lc.active ? factor : 1.0;
+    return factor;
 }
 
 // Kernel B only inlines chain lengths up to 4 (register budget: 8 variants would cost half the occupancy);
