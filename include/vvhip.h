@@ -211,6 +211,9 @@ int vvhip_calc_velocity_bias(vvhip_plan* plan);
 int vvhip_remove_velocity_bias(vvhip_plan* plan);
 int vvhip_restore_velocity_bias(vvhip_plan* plan);
 int vvhip_calc_viscosity(vvhip_plan* plan, double* v_max, double* inv_viscosity);   /* blocks; 8-byte copy */
+/* 1/2 sum m v^2 over all massive particles of this shard (blocks; the reference forwards computeKineticEnergy to OpenMM's
+ * integration utilities, CudaVVKernels.cpp:233-235 -- a stand-alone host has no such service). kJ/mol. */
+int vvhip_compute_kinetic_energy(vvhip_plan* plan, double* kinetic_energy);
 /* Device pointer of the plan-owned forceExtra array (real3[n]); getForceExtra() of the reference
  * (CudaVVKernels.h:86-88). */
 int vvhip_force_extra(vvhip_plan* plan, void** device_ptr);

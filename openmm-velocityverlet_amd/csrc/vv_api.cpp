@@ -90,6 +90,8 @@ struct vvhip_plan {
     int comm_ranks = 1;
 };
 
+extern "C" int vvhip_debug_read_accumulators(vvhip_plan* p, double out[4], int zero_after);
+
 namespace {
 
 int fail(vvhip_plan* p, int code, const std::string& msg) {
@@ -599,6 +601,16 @@ int vvhip_calc_viscosity(vvhip_plan* p, double* v_max, double* inv_vis) {   // H
     if (inv_vis)
         *inv_vis = v * vol * p->hp.info.inv_mass_total / p->hp.params.cos_acceleration * (2 * 3.1415926 / p->box[2]) *
                    (2 * 3.1415926 / p->box[2]);
+    return VVHIP_OK;
+}
+int vvhip_compute_kinetic_energy(vvhip_plan* p, double* kinetic_energy) {   // HOST:233-235 delegates this to OpenMM; stand-alone hosts get it here
+    NEED_BOUND(p);
+    if (!kinetic_energy) return VVHIP_ERR_INVALID;
+    // uses accumulator 0 of the current copy between two steps (it is zero there) and leaves it zero again
+    TRY(run_a(p, vv::A_KE_PLAIN, 0));
+    double acc[vv::NUM_ACC];
+    TRY(vvhip_debug_read_accumulators(p, acc, 1));
+    *kinetic_energy = 0.5 * acc[0];
     return VVHIP_OK;
 }
 int vvhip_update_image_positions(vvhip_plan* p) {          // HOST:904-934

@@ -291,6 +291,9 @@ __global__ void __launch_bounds__(256) vv_kernel_a(const KArgs a) {
             }
         }
 
+        // ---------------- plain kinetic energy of everything massive: sum m v^2 (OpenMM's computeKineticEnergy(0) is half of it)
+        if ((F & A_KE_PLAIN) && massive) k_atom += (double) ((v.x * v.x + v.y * v.y + v.z * v.z) * P::RECIP(v.w));
+
         // ---------------- kinetic energies of the thermostat groups
         if (F & A_KE) {
             const bool nh = role == ROLE_NH_NORMAL || role == ROLE_NH_DRUDE || role == ROLE_NH_PARENT;
@@ -341,9 +344,9 @@ __global__ void __launch_bounds__(256) vv_kernel_a(const KArgs a) {
                 k_com += (double) ((Vx * Vx + Vy * Vy + Vz * Vz) * Vm);
         }
     }
-    if (F & (A_KE | A_BIAS)) {
+    if (F & (A_KE | A_BIAS | A_KE_PLAIN)) {
         const double vals[NUM_ACC] = {k_atom, k_com, k_drude, k_bias};
-        const bool en[NUM_ACC] = {(F & A_KE) != 0, (F & A_KE) != 0, (F & A_KE) != 0, (F & A_BIAS) != 0};
+        const bool en[NUM_ACC] = {(F & (A_KE | A_KE_PLAIN)) != 0, (F & A_KE) != 0, (F & A_KE) != 0, (F & A_BIAS) != 0};
         block_accumulate<NUM_ACC>(vals, en, a.acc, a.acc_scale);
     }
 }
@@ -617,240 +620,240 @@ __global__ void __launch_bounds__(320) vv_kernel_b(const KArgs a) {
     const int tile_stride = gridDim.x * tiles_per_block;
     bool need_scales = true;
     for (int wave = blockIdx.x * tiles_per_block + wib; need_scales || wave < a.nwaves; wave += tile_stride) {
-    const bool valid = wave < a.nwaves;
-    int atom = -1;
-    unsigned meta = 0;
-    if (valid) { const int2 slot = a.slots[(size_t) wave * 64 + lane]; atom = slot.x; meta = (unsigned) slot.y; }
-    const unsigned role = meta & META_ROLE_MASK;
-    const int partner = (meta >> META_PARTNER_SHIFT) & 63;
-    const bool act = atom >= 0;
-    mixed4* velm = (mixed4*) a.velm;
-    mixed4 v = {0, 0, 0, 0};
-    if (act) v = velm[atom];
-    const bool massive = act && v.w != 0;
-    const mixed stepSize = (mixed) a.dt;
-    const bool touches_pos = F & (B_DRIFT_MIDDLE | B_POS3 | B_VV_POS | B_VV_KICK | B_HARDWALL | B_IMAGE | B_UNBIAS | B_BIAS_REMOVE | B_BIAS_RESTORE);
-    mixed x = 0, y = 0, z = 0, q = 0;
-    real zraw = 0;
-    if (act && touches_pos) IO::load(a.posq, a.corr, atom, x, y, z, q, zraw);
-    const mixed4 v_old = v;          // velocity after the kick, before the thermostat (Pos1 uses it)
-    bool vel_dirty = false, pos_dirty = false;
+        const bool valid = wave < a.nwaves;
+        int atom = -1;
+        unsigned meta = 0;
+        if (valid) { const int2 slot = a.slots[(size_t) wave * 64 + lane]; atom = slot.x; meta = (unsigned) slot.y; }
+        const unsigned role = meta & META_ROLE_MASK;
+        const int partner = (meta >> META_PARTNER_SHIFT) & 63;
+        const bool act = atom >= 0;
+        mixed4* velm = (mixed4*) a.velm;
+        mixed4 v = {0, 0, 0, 0};
+        if (act) v = velm[atom];
+        const bool massive = act && v.w != 0;
+        const mixed stepSize = (mixed) a.dt;
+        const bool touches_pos = F & (B_DRIFT_MIDDLE | B_POS3 | B_VV_POS | B_VV_KICK | B_HARDWALL | B_IMAGE | B_UNBIAS | B_BIAS_REMOVE | B_BIAS_RESTORE);
+        mixed x = 0, y = 0, z = 0, q = 0;
+        real zraw = 0;
+        if (act && touches_pos) IO::load(a.posq, a.corr, atom, x, y, z, q, zraw);
+        const mixed4 v_old = v;          // velocity after the kick, before the thermostat (Pos1 uses it)
+        bool vel_dirty = false, pos_dirty = false;
 
-    const bool nh = role == ROLE_NH_NORMAL || role == ROLE_NH_DRUDE || role == ROLE_NH_PARENT;
-    const bool use_com = ((meta >> META_SEGFIRST_SHIFT) & 63) != ((meta >> META_SEGLAST_SHIFT) & 63) || (meta & META_COM_LEADER);
-    mixed Vx = 0, Vy = 0, Vz = 0, Vw = 0;
-    // COM velocity of this lane's molecule as kernel A's KE stage left it (of the bias-free velocities when a bias is
-    // removed): one 32-byte entry per molecule, the same address for every lane of the segment
-    if ((F & B_SCALE) && nh && use_com) {
-        const mixed4 cv = ((const mixed4*) a.comv)[(size_t) wave * 64 + ((meta >> META_SEGFIRST_SHIFT) & 63)];
-        Vx = cv.x; Vy = cv.y; Vz = cv.z; Vw = cv.w;
-    }
-
-    if (need_scales) {
-        need_scales = false;
-        if (has_cw) {
-            __syncthreads();
-            sc0 = sh_scales[0]; sc1 = sh_scales[1]; sc2 = sh_scales[2]; scb = sh_scales[3];
-        } else if (F & (B_SCALE | B_UNBIAS | B_BIAS_REMOVE | B_BIAS_RESTORE)) {
-            sc0 = a.nh->scales[0]; sc1 = a.nh->scales[1]; sc2 = a.nh->scales[2]; scb = a.nh->scales[3];
+        const bool nh = role == ROLE_NH_NORMAL || role == ROLE_NH_DRUDE || role == ROLE_NH_PARENT;
+        const bool use_com = ((meta >> META_SEGFIRST_SHIFT) & 63) != ((meta >> META_SEGLAST_SHIFT) & 63) || (meta & META_COM_LEADER);
+        mixed Vx = 0, Vy = 0, Vz = 0, Vw = 0;
+        // COM velocity of this lane's molecule as kernel A's KE stage left it (of the bias-free velocities when a bias is
+        // removed): one 32-byte entry per molecule, the same address for every lane of the segment
+        if ((F & B_SCALE) && nh && use_com) {
+            const mixed4 cv = ((const mixed4*) a.comv)[(size_t) wave * 64 + ((meta >> META_SEGFIRST_SHIFT) & 63)];
+            Vx = cv.x; Vy = cv.y; Vz = cv.z; Vw = cv.w;
         }
-        if (!valid) break;
-    }
 
-    // ---------------- bias removal (K/cosineAccelerate.cu:63-73); cos uses posq.z (real), all particles
-    double cz = 0;
-    mixed Vb = 0;
-    if (F & (B_UNBIAS | B_BIAS_REMOVE | B_BIAS_RESTORE)) {
-        Vb = (mixed) scb;
-        cz = (F & B_CZ_LOAD) ? a.cosz[(size_t) wave * 64 + lane] : cos_kz<real>(zraw, (real) a.inv_box_z);
-        if ((F & (B_UNBIAS | B_BIAS_REMOVE)) && act) { v.x -= Vb * cz; vel_dirty = true; }
-    }
+        if (need_scales) {
+            need_scales = false;
+            if (has_cw) {
+                __syncthreads();
+                sc0 = sh_scales[0]; sc1 = sh_scales[1]; sc2 = sh_scales[2]; scb = sh_scales[3];
+            } else if (F & (B_SCALE | B_UNBIAS | B_BIAS_REMOVE | B_BIAS_RESTORE)) {
+                sc0 = a.nh->scales[0]; sc1 = a.nh->scales[1]; sc2 = a.nh->scales[2]; scb = a.nh->scales[3];
+            }
+            if (!valid) break;
+        }
 
-    // ---------------- NH velocity scaling (K/drudeNoseHoover.cu:157-209)
-    if (F & B_SCALE) {
-        const mixed vscaleAtom = (mixed) sc0, vscaleCOM = (mixed) sc1, vscaleDrude = (mixed) sc2;
-        mixed ux = v.x, uy = v.y, uz = v.z;
-        if (nh) { ux -= Vx; uy -= Vy; uz -= Vz; }
-        const mixed px = shfl(ux, partner), py = shfl(uy, partner), pz = shfl(uz, partner), pw = shfl(v.w, partner);
-        if (role == ROLE_NH_NORMAL) {
-            if (massive) {
-                v.x = vscaleAtom * ux + vscaleCOM * Vx;
-                v.y = vscaleAtom * uy + vscaleCOM * Vy;
-                v.z = vscaleAtom * uz + vscaleCOM * Vz;
+        // ---------------- bias removal (K/cosineAccelerate.cu:63-73); cos uses posq.z (real), all particles
+        double cz = 0;
+        mixed Vb = 0;
+        if (F & (B_UNBIAS | B_BIAS_REMOVE | B_BIAS_RESTORE)) {
+            Vb = (mixed) scb;
+            cz = (F & B_CZ_LOAD) ? a.cosz[(size_t) wave * 64 + lane] : cos_kz<real>(zraw, (real) a.inv_box_z);
+            if ((F & (B_UNBIAS | B_BIAS_REMOVE)) && act) { v.x -= Vb * cz; vel_dirty = true; }
+        }
+
+        // ---------------- NH velocity scaling (K/drudeNoseHoover.cu:157-209)
+        if (F & B_SCALE) {
+            const mixed vscaleAtom = (mixed) sc0, vscaleCOM = (mixed) sc1, vscaleDrude = (mixed) sc2;
+            mixed ux = v.x, uy = v.y, uz = v.z;
+            if (nh) { ux -= Vx; uy -= Vy; uz -= Vz; }
+            const mixed px = shfl(ux, partner), py = shfl(uy, partner), pz = shfl(uz, partner), pw = shfl(v.w, partner);
+            if (role == ROLE_NH_NORMAL) {
+                if (massive) {
+                    v.x = vscaleAtom * ux + vscaleCOM * Vx;
+                    v.y = vscaleAtom * uy + vscaleCOM * Vy;
+                    v.z = vscaleAtom * uz + vscaleCOM * Vz;
+                    vel_dirty = true;
+                }
+            } else if (role == ROLE_NH_DRUDE || role == ROLE_NH_PARENT) {
+                const bool isd = role == ROLE_NH_DRUDE;      // velAtom1 = Drude (pair.x), velAtom2 = parent
+                const mixed a1x = isd ? ux : px, a1y = isd ? uy : py, a1z = isd ? uz : pz, a1w = isd ? v.w : pw;
+                const mixed a2x = isd ? px : ux, a2y = isd ? py : uy, a2z = isd ? pz : uz, a2w = isd ? pw : v.w;
+                const mixed mass1 = P::RECIP(a1w), mass2 = P::RECIP(a2w);
+                const mixed invTotalMass = P::RECIP(mass1 + mass2);
+                const mixed mass1fract = invTotalMass * mass1, mass2fract = invTotalMass * mass2;
+                mixed cmx = a1x * mass1fract + a2x * mass2fract;
+                mixed cmy = a1y * mass1fract + a2y * mass2fract;
+                mixed cmz = a1z * mass1fract + a2z * mass2fract;
+                mixed rx = a2x - a1x, ry = a2y - a1y, rz = a2z - a1z;
+                cmx = vscaleAtom * cmx; cmy = vscaleAtom * cmy; cmz = vscaleAtom * cmz;
+                rx = vscaleDrude * rx; ry = vscaleDrude * ry; rz = vscaleDrude * rz;
+                if (isd) {
+                    v.x = cmx - rx * mass2fract + vscaleCOM * Vx;
+                    v.y = cmy - ry * mass2fract + vscaleCOM * Vy;
+                    v.z = cmz - rz * mass2fract + vscaleCOM * Vz;
+                } else {
+                    v.x = cmx + rx * mass1fract + vscaleCOM * Vx;
+                    v.y = cmy + ry * mass1fract + vscaleCOM * Vy;
+                    v.z = cmz + rz * mass1fract + vscaleCOM * Vz;
+                }
                 vel_dirty = true;
             }
-        } else if (role == ROLE_NH_DRUDE || role == ROLE_NH_PARENT) {
-            const bool isd = role == ROLE_NH_DRUDE;      // velAtom1 = Drude (pair.x), velAtom2 = parent
-            const mixed a1x = isd ? ux : px, a1y = isd ? uy : py, a1z = isd ? uz : pz, a1w = isd ? v.w : pw;
-            const mixed a2x = isd ? px : ux, a2y = isd ? py : uy, a2z = isd ? pz : uz, a2w = isd ? pw : v.w;
-            const mixed mass1 = P::RECIP(a1w), mass2 = P::RECIP(a2w);
-            const mixed invTotalMass = P::RECIP(mass1 + mass2);
-            const mixed mass1fract = invTotalMass * mass1, mass2fract = invTotalMass * mass2;
-            mixed cmx = a1x * mass1fract + a2x * mass2fract;
-            mixed cmy = a1y * mass1fract + a2y * mass2fract;
-            mixed cmz = a1z * mass1fract + a2z * mass2fract;
-            mixed rx = a2x - a1x, ry = a2y - a1y, rz = a2z - a1z;
-            cmx = vscaleAtom * cmx; cmy = vscaleAtom * cmy; cmz = vscaleAtom * cmz;
-            rx = vscaleDrude * rx; ry = vscaleDrude * ry; rz = vscaleDrude * rz;
-            if (isd) {
-                v.x = cmx - rx * mass2fract + vscaleCOM * Vx;
-                v.y = cmy - ry * mass2fract + vscaleCOM * Vy;
-                v.z = cmz - rz * mass2fract + vscaleCOM * Vz;
-            } else {
-                v.x = cmx + rx * mass1fract + vscaleCOM * Vx;
-                v.y = cmy + ry * mass1fract + vscaleCOM * Vy;
-                v.z = cmz + rz * mass1fract + vscaleCOM * Vz;
-            }
+        }
+        if ((F & (B_UNBIAS | B_BIAS_RESTORE)) && act) { v.x += Vb * cz; vel_dirty = true; }   // K/cosineAccelerate.cu:76-85
+
+        // ---------------- classic VV first half: kick from the stored extra force, then posDelta (K/velocityVerlet.cu:6-29)
+        mixed dx = 0, dy = 0, dz = 0;
+        if ((F & B_VV_KICK) && massive) {
+            const real3 fe = ((const real3*) a.fextra)[atom];
+            const long long fx = a.force[atom], fy = a.force[atom + a.padded], fz = a.force[atom + 2 * a.padded];
+            const mixed fscale = (mixed) a.fscale_vv;
+            v.x += 0.5 * stepSize * v.w * fe.x + fscale * v.w * fx;
+            v.y += 0.5 * stepSize * v.w * fe.y + fscale * v.w * fy;
+            v.z += 0.5 * stepSize * v.w * fe.z + fscale * v.w * fz;
+            dx = stepSize * v.x; dy = stepSize * v.y; dz = stepSize * v.z;
             vel_dirty = true;
         }
-    }
-    if ((F & (B_UNBIAS | B_BIAS_RESTORE)) && act) { v.x += Vb * cz; vel_dirty = true; }   // K/cosineAccelerate.cu:76-85
-
-    // ---------------- classic VV first half: kick from the stored extra force, then posDelta (K/velocityVerlet.cu:6-29)
-    mixed dx = 0, dy = 0, dz = 0;
-    if ((F & B_VV_KICK) && massive) {
-        const real3 fe = ((const real3*) a.fextra)[atom];
-        const long long fx = a.force[atom], fy = a.force[atom + a.padded], fz = a.force[atom + 2 * a.padded];
-        const mixed fscale = (mixed) a.fscale_vv;
-        v.x += 0.5 * stepSize * v.w * fe.x + fscale * v.w * fx;
-        v.y += 0.5 * stepSize * v.w * fe.y + fscale * v.w * fy;
-        v.z += 0.5 * stepSize * v.w * fe.z + fscale * v.w * fz;
-        dx = stepSize * v.x; dy = stepSize * v.y; dz = stepSize * v.z;
-        vel_dirty = true;
-    }
-    // ---------------- position updates
-    if ((F & B_POS2) && massive) {                                          // K/middle.cu:51-58
-        const mixed halfdt = 0.5f * stepSize;
-        mixed4 d = {halfdt * v.x, halfdt * v.y, halfdt * v.z, 0};
-        mixed4 pd = ((mixed4*) a.pos_delta)[atom], od = ((mixed4*) a.old_delta)[atom];
-        pd.x += d.x; pd.y += d.y; pd.z += d.z; pd.w += d.w;
-        od.x += d.x; od.y += d.y; od.z += d.z; od.w += d.w;
-        ((mixed4*) a.pos_delta)[atom] = pd;
-        ((mixed4*) a.old_delta)[atom] = od;
-    }
-    if ((F & B_DRIFT_MIDDLE) && massive) {
-        // Pos1 (K/middle.cu:36-38) with the pre-thermostat velocity, Pos2 (:54-56) with the scaled one,
-        // no constraint solver in between => posDelta == oldDelta and Pos3's velocity correction
-        // (K/middle.cu:77-79) adds (d - d)/dt == 0 exactly.
-        const mixed halfdt = 0.5f * stepSize;
-        mixed ddx = halfdt * v_old.x, ddy = halfdt * v_old.y, ddz = halfdt * v_old.z;
-        ddx += halfdt * v.x; ddy += halfdt * v.y; ddz += halfdt * v.z;
-        const mixed invDt = 1 / stepSize;
-        v.x += (ddx - ddx) * invDt; v.y += (ddy - ddy) * invDt; v.z += (ddz - ddz) * invDt;
-        x += ddx; y += ddy; z += ddz;
-        pos_dirty = true; vel_dirty = true;
-    }
-    if ((F & B_POS3) && massive) {                                          // K/middle.cu:70-96
-        const mixed invDt = 1 / stepSize;
-        const mixed4 d = ((const mixed4*) a.pos_delta)[atom], od = ((const mixed4*) a.old_delta)[atom];
-        v.x += (d.x - od.x) * invDt; v.y += (d.y - od.y) * invDt; v.z += (d.z - od.z) * invDt;
-        x += d.x; y += d.y; z += d.z;
-        pos_dirty = true; vel_dirty = true;
-    }
-    if ((F & (B_VV_POS | B_VV_KICK)) && massive) {                          // K/velocityVerlet.cu:41-66
-        if (!(F & B_VV_KICK)) {
-            const mixed4 d = ((const mixed4*) a.pos_delta)[atom];
-            dx = d.x; dy = d.y; dz = d.z;
+        // ---------------- position updates
+        if ((F & B_POS2) && massive) {                                          // K/middle.cu:51-58
+            const mixed halfdt = 0.5f * stepSize;
+            mixed4 d = {halfdt * v.x, halfdt * v.y, halfdt * v.z, 0};
+            mixed4 pd = ((mixed4*) a.pos_delta)[atom], od = ((mixed4*) a.old_delta)[atom];
+            pd.x += d.x; pd.y += d.y; pd.z += d.z; pd.w += d.w;
+            od.x += d.x; od.y += d.y; od.z += d.z; od.w += d.w;
+            ((mixed4*) a.pos_delta)[atom] = pd;
+            ((mixed4*) a.old_delta)[atom] = od;
         }
-        const mixed invStepSize = 1.0 / stepSize;
-        x += dx; y += dy; z += dz;
-        v.x = (mixed) (invStepSize * dx); v.y = (mixed) (invStepSize * dy); v.z = (mixed) (invStepSize * dz);
-        pos_dirty = true; vel_dirty = true;
-    }
+        if ((F & B_DRIFT_MIDDLE) && massive) {
+            // Pos1 (K/middle.cu:36-38) with the pre-thermostat velocity, Pos2 (:54-56) with the scaled one,
+            // no constraint solver in between => posDelta == oldDelta and Pos3's velocity correction
+            // (K/middle.cu:77-79) adds (d - d)/dt == 0 exactly.
+            const mixed halfdt = 0.5f * stepSize;
+            mixed ddx = halfdt * v_old.x, ddy = halfdt * v_old.y, ddz = halfdt * v_old.z;
+            ddx += halfdt * v.x; ddy += halfdt * v.y; ddz += halfdt * v.z;
+            const mixed invDt = 1 / stepSize;
+            v.x += (ddx - ddx) * invDt; v.y += (ddy - ddy) * invDt; v.z += (ddz - ddz) * invDt;
+            x += ddx; y += ddy; z += ddz;
+            pos_dirty = true; vel_dirty = true;
+        }
+        if ((F & B_POS3) && massive) {                                          // K/middle.cu:70-96
+            const mixed invDt = 1 / stepSize;
+            const mixed4 d = ((const mixed4*) a.pos_delta)[atom], od = ((const mixed4*) a.old_delta)[atom];
+            v.x += (d.x - od.x) * invDt; v.y += (d.y - od.y) * invDt; v.z += (d.z - od.z) * invDt;
+            x += d.x; y += d.y; z += d.z;
+            pos_dirty = true; vel_dirty = true;
+        }
+        if ((F & (B_VV_POS | B_VV_KICK)) && massive) {                          // K/velocityVerlet.cu:41-66
+            if (!(F & B_VV_KICK)) {
+                const mixed4 d = ((const mixed4*) a.pos_delta)[atom];
+                dx = d.x; dy = d.y; dz = d.z;
+            }
+            const mixed invStepSize = 1.0 / stepSize;
+            x += dx; y += dy; z += dz;
+            v.x = (mixed) (invStepSize * dx); v.y = (mixed) (invStepSize * dy); v.z = (mixed) (invStepSize * dz);
+            pos_dirty = true; vel_dirty = true;
+        }
 
-    // ---------------- hard wall on Drude pairs (K/middle.cu:106-221); pair.x = Drude = "1", parent = "2"
-    if (F & B_HARDWALL) {
-        const mixed ox = shfl(x, partner), oy = shfl(y, partner), oz = shfl(z, partner);
-        const mixed ovw = shfl(v.w, partner);
-        if (act && (meta & META_PAIR)) {
-            const bool isd = (meta & META_IS_DRUDE) != 0;
-            const mixed maxDrudeDistance = (mixed) a.max_drude, hardwallscaleDrude = (mixed) a.hw_scale;
-            mixed p1x = isd ? x : ox, p1y = isd ? y : oy, p1z = isd ? z : oz;
-            mixed p2x = isd ? ox : x, p2y = isd ? oy : y, p2z = isd ? oz : z;
-            const mixed vel1w = isd ? v.w : ovw, vel2w = isd ? ovw : v.w;
-            const mixed deltax = p1x - p2x, deltay = p1y - p2y, deltaz = p1z - p2z;
-            const mixed r = P::SQRT(deltax * deltax + deltay * deltay + deltaz * deltaz);
-            const mixed rInv = P::RECIP(r);
-            if (rInv * maxDrudeDistance < 1) {
-                // both lanes of a pair see the same r, so both are in here: the partner's velocity is fetched only now
-                const mixed ovx = shfl(v.x, partner), ovy = shfl(v.y, partner), ovz = shfl(v.z, partner);
-                mixed vel1x = isd ? v.x : ovx, vel1y = isd ? v.y : ovy, vel1z = isd ? v.z : ovz;
-                mixed vel2x = isd ? ovx : v.x, vel2y = isd ? ovy : v.y, vel2z = isd ? ovz : v.z;
-                const mixed bx = deltax * rInv, by = deltay * rInv, bz = deltaz * rInv;
-                const mixed mass1 = P::RECIP(vel1w), mass2 = P::RECIP(vel2w);
-                const mixed deltaR = r - maxDrudeDistance;
-                mixed deltaT = stepSize;
-                mixed dotvr1 = vel1x * bx + vel1y * by + vel1z * bz;
-                const mixed vb1x = bx * dotvr1, vb1y = by * dotvr1, vb1z = bz * dotvr1;
-                const mixed vp1x = vel1x - vb1x, vp1y = vel1y - vb1y, vp1z = vel1z - vb1z;
-                if (vel2w == 0) {                                           // massless parent (K/middle.cu:151-173)
-                    if (dotvr1 != 0) deltaT = deltaR / fabs((double) dotvr1);
-                    if (deltaT > stepSize) deltaT = stepSize;
-                    dotvr1 = -dotvr1 * hardwallscaleDrude / (fabs((double) dotvr1) * P::SQRT(mass1));
-                    const mixed dr = -deltaR + deltaT * dotvr1;
-                    p1x += bx * dr; p1y += by * dr; p1z += bz * dr;
-                    vel1x = vp1x + bx * dotvr1; vel1y = vp1y + by * dotvr1; vel1z = vp1z + bz * dotvr1;
-                    if (isd) { x = p1x; y = p1y; z = p1z; v.x = vel1x; v.y = vel1y; v.z = vel1z; pos_dirty = true; vel_dirty = true; }
-                } else {                                                    // both move (K/middle.cu:174-218)
-                    const mixed invTotalMass = P::RECIP(mass1 + mass2);
-                    mixed dotvr2 = vel2x * bx + vel2y * by + vel2z * bz;
-                    const mixed vb2x = bx * dotvr2, vb2y = by * dotvr2, vb2z = bz * dotvr2;
-                    const mixed vp2x = vel2x - vb2x, vp2y = vel2y - vb2y, vp2z = vel2z - vb2z;
-                    const mixed vbCMass = (mass1 * dotvr1 + mass2 * dotvr2) * invTotalMass;
-                    dotvr1 -= vbCMass;
-                    dotvr2 -= vbCMass;
-                    if (dotvr1 != dotvr2) deltaT = deltaR / fabs((double) (dotvr1 - dotvr2));
-                    if (deltaT > stepSize) deltaT = stepSize;
-                    const mixed vBond = hardwallscaleDrude / P::SQRT(mass1);
-                    dotvr1 = -dotvr1 * vBond * mass2 * invTotalMass / fabs((double) dotvr1);
-                    dotvr2 = -dotvr2 * vBond * mass1 * invTotalMass / fabs((double) dotvr2);
-                    const mixed dr1 = -deltaR * mass2 * invTotalMass + deltaT * dotvr1;
-                    const mixed dr2 = deltaR * mass1 * invTotalMass + deltaT * dotvr2;
-                    dotvr1 += vbCMass;
-                    dotvr2 += vbCMass;
-                    if (isd) {
-                        x = p1x + bx * dr1; y = p1y + by * dr1; z = p1z + bz * dr1;
-                        v.x = vp1x + bx * dotvr1; v.y = vp1y + by * dotvr1; v.z = vp1z + bz * dotvr1;
-                    } else {
-                        x = p2x + bx * dr2; y = p2y + by * dr2; z = p2z + bz * dr2;
-                        v.x = vp2x + bx * dotvr2; v.y = vp2y + by * dotvr2; v.z = vp2z + bz * dotvr2;
+        // ---------------- hard wall on Drude pairs (K/middle.cu:106-221); pair.x = Drude = "1", parent = "2"
+        if (F & B_HARDWALL) {
+            const mixed ox = shfl(x, partner), oy = shfl(y, partner), oz = shfl(z, partner);
+            const mixed ovw = shfl(v.w, partner);
+            if (act && (meta & META_PAIR)) {
+                const bool isd = (meta & META_IS_DRUDE) != 0;
+                const mixed maxDrudeDistance = (mixed) a.max_drude, hardwallscaleDrude = (mixed) a.hw_scale;
+                mixed p1x = isd ? x : ox, p1y = isd ? y : oy, p1z = isd ? z : oz;
+                mixed p2x = isd ? ox : x, p2y = isd ? oy : y, p2z = isd ? oz : z;
+                const mixed vel1w = isd ? v.w : ovw, vel2w = isd ? ovw : v.w;
+                const mixed deltax = p1x - p2x, deltay = p1y - p2y, deltaz = p1z - p2z;
+                const mixed r = P::SQRT(deltax * deltax + deltay * deltay + deltaz * deltaz);
+                const mixed rInv = P::RECIP(r);
+                if (rInv * maxDrudeDistance < 1) {
+                    // both lanes of a pair see the same r, so both are in here: the partner's velocity is fetched only now
+                    const mixed ovx = shfl(v.x, partner), ovy = shfl(v.y, partner), ovz = shfl(v.z, partner);
+                    mixed vel1x = isd ? v.x : ovx, vel1y = isd ? v.y : ovy, vel1z = isd ? v.z : ovz;
+                    mixed vel2x = isd ? ovx : v.x, vel2y = isd ? ovy : v.y, vel2z = isd ? ovz : v.z;
+                    const mixed bx = deltax * rInv, by = deltay * rInv, bz = deltaz * rInv;
+                    const mixed mass1 = P::RECIP(vel1w), mass2 = P::RECIP(vel2w);
+                    const mixed deltaR = r - maxDrudeDistance;
+                    mixed deltaT = stepSize;
+                    mixed dotvr1 = vel1x * bx + vel1y * by + vel1z * bz;
+                    const mixed vb1x = bx * dotvr1, vb1y = by * dotvr1, vb1z = bz * dotvr1;
+                    const mixed vp1x = vel1x - vb1x, vp1y = vel1y - vb1y, vp1z = vel1z - vb1z;
+                    if (vel2w == 0) {                                           // massless parent (K/middle.cu:151-173)
+                        if (dotvr1 != 0) deltaT = deltaR / fabs((double) dotvr1);
+                        if (deltaT > stepSize) deltaT = stepSize;
+                        dotvr1 = -dotvr1 * hardwallscaleDrude / (fabs((double) dotvr1) * P::SQRT(mass1));
+                        const mixed dr = -deltaR + deltaT * dotvr1;
+                        p1x += bx * dr; p1y += by * dr; p1z += bz * dr;
+                        vel1x = vp1x + bx * dotvr1; vel1y = vp1y + by * dotvr1; vel1z = vp1z + bz * dotvr1;
+                        if (isd) { x = p1x; y = p1y; z = p1z; v.x = vel1x; v.y = vel1y; v.z = vel1z; pos_dirty = true; vel_dirty = true; }
+                    } else {                                                    // both move (K/middle.cu:174-218)
+                        const mixed invTotalMass = P::RECIP(mass1 + mass2);
+                        mixed dotvr2 = vel2x * bx + vel2y * by + vel2z * bz;
+                        const mixed vb2x = bx * dotvr2, vb2y = by * dotvr2, vb2z = bz * dotvr2;
+                        const mixed vp2x = vel2x - vb2x, vp2y = vel2y - vb2y, vp2z = vel2z - vb2z;
+                        const mixed vbCMass = (mass1 * dotvr1 + mass2 * dotvr2) * invTotalMass;
+                        dotvr1 -= vbCMass;
+                        dotvr2 -= vbCMass;
+                        if (dotvr1 != dotvr2) deltaT = deltaR / fabs((double) (dotvr1 - dotvr2));
+                        if (deltaT > stepSize) deltaT = stepSize;
+                        const mixed vBond = hardwallscaleDrude / P::SQRT(mass1);
+                        dotvr1 = -dotvr1 * vBond * mass2 * invTotalMass / fabs((double) dotvr1);
+                        dotvr2 = -dotvr2 * vBond * mass1 * invTotalMass / fabs((double) dotvr2);
+                        const mixed dr1 = -deltaR * mass2 * invTotalMass + deltaT * dotvr1;
+                        const mixed dr2 = deltaR * mass1 * invTotalMass + deltaT * dotvr2;
+                        dotvr1 += vbCMass;
+                        dotvr2 += vbCMass;
+                        if (isd) {
+                            x = p1x + bx * dr1; y = p1y + by * dr1; z = p1z + bz * dr1;
+                            v.x = vp1x + bx * dotvr1; v.y = vp1y + by * dotvr1; v.z = vp1z + bz * dotvr1;
+                        } else {
+                            x = p2x + bx * dr2; y = p2y + by * dr2; z = p2z + bz * dr2;
+                            v.x = vp2x + bx * dotvr2; v.y = vp2y + by * dotvr2; v.z = vp2z + bz * dotvr2;
+                        }
+                        pos_dirty = true; vel_dirty = true;
                     }
-                    pos_dirty = true; vel_dirty = true;
                 }
             }
         }
-    }
 
-    // ---------------- write back
-    if (act && vel_dirty) velm[atom] = v;
-    if (act && pos_dirty) IO::store(a.posq, a.corr, atom, x, y, z, q);
-    if ((F & B_VV_KICK) && massive) {
-        mixed4 d = {dx, dy, dz, 0};
-        if (a.pos_delta) ((mixed4*) a.pos_delta)[atom] = d;
-    }
-
-    // ---------------- image charges (K/imageCharge.cu:10-26): x, y are bit copies, z is mirrored
-    if ((F & B_IMAGE) && act && (meta & META_HAS_IMAGE)) {
-        const int img = a.slot_image[(size_t) wave * 64 + lane];
-        real4* posq = (real4*) a.posq;
-        const real4 pp = posq[atom];       // re-read what was just stored: the copy must be of the stored bits
-        real4 pi = posq[img];
-        pi.x = pp.x; pi.y = pp.y;
-        if (IO::kMixed) {
-            real4* corr = (real4*) a.corr;
-            const real4 cp = corr[atom];
-            real4 ci = corr[img];
-            ci.x = cp.x; ci.y = cp.y;
-            mixed zz = (mixed) pp.z + (mixed) cp.z;
-            zz = (mixed) a.mirror * 2 - zz;
-            pi.z = (real) zz;
-            ci.z = (real) (zz - (real) zz);
-            corr[img] = ci;
-        } else {
-            pi.z = 2 * (mixed) a.mirror - pp.z;
+        // ---------------- write back
+        if (act && vel_dirty) velm[atom] = v;
+        if (act && pos_dirty) IO::store(a.posq, a.corr, atom, x, y, z, q);
+        if ((F & B_VV_KICK) && massive) {
+            mixed4 d = {dx, dy, dz, 0};
+            if (a.pos_delta) ((mixed4*) a.pos_delta)[atom] = d;
         }
-        posq[img] = pi;
-    }
+
+        // ---------------- image charges (K/imageCharge.cu:10-26): x, y are bit copies, z is mirrored
+        if ((F & B_IMAGE) && act && (meta & META_HAS_IMAGE)) {
+            const int img = a.slot_image[(size_t) wave * 64 + lane];
+            real4* posq = (real4*) a.posq;
+            const real4 pp = posq[atom];       // re-read what was just stored: the copy must be of the stored bits
+            real4 pi = posq[img];
+            pi.x = pp.x; pi.y = pp.y;
+            if (IO::kMixed) {
+                real4* corr = (real4*) a.corr;
+                const real4 cp = corr[atom];
+                real4 ci = corr[img];
+                ci.x = cp.x; ci.y = cp.y;
+                mixed zz = (mixed) pp.z + (mixed) cp.z;
+                zz = (mixed) a.mirror * 2 - zz;
+                pi.z = (real) zz;
+                ci.z = (real) (zz - (real) zz);
+                corr[img] = ci;
+            } else {
+                pi.z = 2 * (mixed) a.mirror - pp.z;
+            }
+            posq[img] = pi;
+        }
     }   // tile loop
 }
 

@@ -26,6 +26,7 @@ enum : uint32_t {
     A_COMPART = 1u << 12,    // molecules larger than a wave: add each chunk's sum(m v), sum(m) to the molecule's accumulator
     A_CZ_STORE = 1u << 13,   // keep cos(2 pi z / Lz) of every lane for the later kernels of this step (positions do not move in between)
     A_CZ_LOAD = 1u << 14,    // ... and take it from there instead of evaluating a double-precision cosine again
+    A_KE_PLAIN = 1u << 15,   // sum m v^2 over every massive particle into accumulator 0 (kinetic-energy query)
 };
 // ---- stage flags of kernel B ("consume": starts from the scale factors) -------------------------
 enum : uint32_t {

@@ -290,6 +290,19 @@ class Context:
         self.velm.upload(velm)
         self.forces_valid = False                               # VVIntegrator.h:447-449 stateChanged
 
+    def getKineticEnergy(self) -> float:
+        """1/2 sum m v^2 [kJ/mol] (what State.getKineticEnergy() returns through VVIntegrator::computeKineticEnergy)."""
+        ke = C.c_double()
+        H.check(H.lib.vvhip_compute_kinetic_energy(self.plan, C.byref(ke)), self.plan)
+        return ke.value
+
+    def getGroupTemperatures(self):
+        """Temperatures of the thermostat groups [atom, COM, Drude] at the last thermostat application: 2KE_g / (dof_g kB) --
+        the quantities examples/ommhelper/reporter/drudetemperaturereporter.py:98-133 recomputes on the host in NumPy."""
+        st = self.getNHState()
+        kb = 8.31446261815324e-3
+        return [st.ke2[g] / (self.info.dof[g] * kb) if self.info.dof[g] > 0 else 0.0 for g in range(3)]
+
     def getNHState(self) -> H.NHState:
         s = H.NHState()
         H.check(H.lib.vvhip_get_nh_state(self.plan, C.byref(s)), self.plan)

@@ -107,7 +107,7 @@ def _load():
         "vvhip_apply_langevin_force": [vp, u32], "vvhip_update_image_positions": [vp],
         "vvhip_apply_electric_force": [vp], "vvhip_apply_cosine_force": [vp], "vvhip_calc_velocity_bias": [vp],
         "vvhip_remove_velocity_bias": [vp], "vvhip_restore_velocity_bias": [vp],
-        "vvhip_calc_viscosity": [vp, P(dbl), P(dbl)], "vvhip_force_extra": [vp, P(vp)],
+        "vvhip_calc_viscosity": [vp, P(dbl), P(dbl)], "vvhip_compute_kinetic_energy": [vp, P(dbl)], "vvhip_force_extra": [vp, P(vp)],
         "vvhip_device_count": [P(C.c_int)], "vvhip_set_device": [C.c_int],
         "vvhip_malloc": [P(vp), C.c_size_t], "vvhip_free": [vp],
         "vvhip_memcpy_h2d": [vp, vp, C.c_size_t], "vvhip_memcpy_d2h": [vp, vp, C.c_size_t],

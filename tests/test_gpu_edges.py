@@ -190,3 +190,24 @@ def test_device_gaussian_generator_moments_and_graph_refresh():
         assert np.isfinite(v).all() and 150 < T_el < 600, T_el
     finally:
         ctx.close()
+
+
+def test_kinetic_energy_and_group_temperatures():
+    spec = systems.drude_il(cells=(1, 1, 1), pairs_per_cell=50, seed=17)
+    it = I.VVIntegrator(333.0, 10, 1.0, 40, 0.001)
+    it.setMaxDrudeDistance(0.02)
+    ctx = I.Context(spec, it, precision="mixed")
+    try:
+        ke0 = 0.5 * (spec.masses[:, None] * spec.velocities ** 2).sum()
+        assert ctx.getKineticEnergy() == pytest.approx(ke0, rel=1e-12)
+        it.step(5)
+        v = ctx.getVelocities()
+        assert ctx.getKineticEnergy() == pytest.approx(0.5 * (spec.masses[:, None] * v ** 2).sum(), rel=1e-12)
+        T = ctx.getGroupTemperatures()
+        assert 200 < T[0] < 500 and 100 < T[1] < 700 and 0.05 < T[2] < 100
+        it.step(5)                                  # the query must not disturb the thermostat accumulators
+        p = O.Params(temperature=333.0, drude_temperature=1.0, max_drude_distance=0.02)
+        osys = O.OracleSystem(spec, p, "mixed"); osys.step(10)
+        assert np.abs(ctx.getPositions() - osys.positions()).max() < 1e-11
+    finally:
+        ctx.close()
