@@ -635,3 +635,57 @@ class Kernels:
         else:
             self._sizes(num_images=len(image_pairs))
             self.L.updateImagePositions(_p(posq), _p(corr), _p(image_pairs), self.cm(mirror))
+
+
+# ----------------------------------------------------------------------------------------------
+# the reference's kernels on the GPU (oracle/_ref/libvvref_gpu_mixed_tg{1,3}.so, built by `make refgpu`)
+# ----------------------------------------------------------------------------------------------
+def have_ref_gpu() -> bool:
+    return all(os.path.exists(os.path.join(HERE, "_ref", f"libvvref_gpu_mixed_tg{t}.so")) for t in (1, 3))
+
+
+class RefGpuSystem:
+    """The reference's own kernel sequence (middle scheme, mixed precision) on the GPU: see ref_gpu_driver.cpp.
+    Covers NH / TGNH + hard wall + cos acceleration (BASELINE C2, C3, C4); no Langevin / image kernels."""
+
+    def __init__(self, spec, params: Params, k_tether: float = 1000.0, k_drude: float = 209200.0):
+        t = build_tables(spec, params)
+        p = t["params"]
+        if t["num_tg"] == 2 or not p.use_middle_scheme or len(spec.particles_ld) or len(spec.image_pairs):
+            raise ValueError("RefGpuSystem covers the middle scheme with 1 or 3 temperature groups, no Langevin / images")
+        self.L = C.CDLL(os.path.join(HERE, "_ref", f"libvvref_gpu_mixed_tg{t['num_tg']}.so"))
+        self.L.vvrefgpu_create.restype = C.c_void_p
+        st = make_state(spec, "mixed")
+        self.n = n = spec.num_atoms
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        self._keep = [st["velm"], st["posq"], st["posq_corr"], i32(spec.drude_pairs).reshape(-1, 2), i32(t["particles_nh"]), i32(t["molecules_nh"]),
+                      i32(t["normal_nh"]), i32(t["pairs_nh"]).reshape(-1, 2), i32(t["particle_mol_id"]), i32(t["particles_in_molecules"]),
+                      i32(t["particles_sorted_by_mol_id"]), np.ascontiguousarray(t["eta_mass"], dtype=np.float64),
+                      np.ascontiguousarray(t["nkbt"], dtype=np.float64), np.ascontiguousarray(spec.box, dtype=np.float64)]
+        k = self._keep
+        d = C.c_double
+        self.h = C.c_void_p(self.L.vvrefgpu_create(
+            n, padded(n), spec.num_molecules, _p(k[0]), _p(k[1]), _p(k[2]), _p(k[3]), len(k[3]), _p(k[4]), len(k[4]), _p(k[5]), len(k[5]),
+            _p(k[6]), len(k[6]), _p(k[7]), len(k[7]), _p(k[8]), _p(k[9]), _p(k[10]), int(t["num_tg"]), int(p.use_com_temp_group),
+            int(p.num_chains), int(p.loops_per_step), _p(k[11]), _p(k[12]), d(p.step_size), d(p.temperature), d(p.drude_temperature),
+            d(p.max_drude_distance), d(p.cos_acceleration), d(t["inv_mass_total"]), _p(k[13]), d(k_tether), d(k_drude)))
+
+    def step(self, n):
+        self.L.vvrefgpu_step(self.h, int(n))
+
+    def sync(self):
+        self.L.vvrefgpu_sync(self.h)
+
+    def download(self):
+        velm = np.zeros((self.n, 4), np.float64)
+        posq = np.zeros((self.n, 4), np.float32)
+        corr = np.zeros((self.n, 4), np.float32)
+        ke2, vs = (C.c_double * 3)(), (C.c_double * 3)()
+        self.L.vvrefgpu_download(self.h, _p(velm), _p(posq), _p(corr), ke2, vs)
+        return dict(velm=velm, posq=posq, posq_corr=corr, ke2=np.array(list(ke2)), vscale=np.array(list(vs)),
+                    positions=posq[:, :3].astype(np.float64) + corr[:, :3].astype(np.float64))
+
+    def close(self):
+        if self.h:
+            self.L.vvrefgpu_destroy(self.h)
+            self.h = None
