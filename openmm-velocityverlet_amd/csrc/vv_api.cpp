@@ -58,6 +58,7 @@ struct vvhip_plan {
     double box[3] = {1, 1, 1};
     double acc_scale[vv::NUM_ACC], acc_inv_scale[vv::NUM_ACC];
     int block_threads = 256;
+    bool wt_stores = false;        // write-through stores in the fused kernels (VVHIP_WT=1; tuning experiment)
     // plan-owned device state
     int2* d_slots = nullptr;
     int32_t* d_slot_image = nullptr;
@@ -229,11 +230,13 @@ struct ScopedTimer {
 };
 
 int run_a(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
+    if (p->wt_stores && (flags & (vv::A_KICK_FULL | vv::A_KICK_HALF))) flags |= vv::A_WT_STORES;
     ScopedTimer t(p, T_A);
     HIP_TRY(p, vv::launch_a(p->hp.precision, make_args(p, flags, random_index), p->block_threads, p->stream));
     return VVHIP_OK;
 }
 int run_b(vvhip_plan* p, uint32_t flags) {
+    if (p->wt_stores) flags |= vv::B_WT_STORES;
     ScopedTimer t(p, T_B);
     HIP_TRY(p, vv::launch_b(p->hp.precision, make_args(p, flags, 0), p->block_threads, p->stream));
     if (flags & vv::B_CHAIN) p->parity ^= 1;     // the advanced thermostat state now lives in the other copy
@@ -306,6 +309,7 @@ int vvhip_plan_create(const vvhip_system_desc* system, const vvhip_params* param
         fill_scales(p);
         // small systems: one wave per block spreads the work over more CUs (256 CUs, 8 XCDs)
         p->block_threads = p->hp.info.num_waves >= 2048 ? 256 : (p->hp.info.num_waves >= 512 ? 128 : 64);
+        if (const char* e = std::getenv("VVHIP_WT")) p->wt_stores = std::atoi(e) != 0;
         if (const char* e = std::getenv("VVHIP_BLOCK")) {          // tuning experiments
             const int b = std::atoi(e);
             if (b == 64 || b == 128 || b == 192 || b == 256) p->block_threads = b;

@@ -291,21 +291,44 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
     }
     info.max_cluster = max_cluster;
 
-    // ---- greedy wave packing in particle order
+    // ---- wave packing: clusters are visited in particle order and placed best-fit -- into the open wave whose free lanes
+    // they fill most tightly, else into a new wave.  Visiting in order keeps neighbouring molecules in neighbouring waves
+    // (coalescing, L2 locality); best-fit lets e.g. a 10-particle anion complete a wave that two 27-particle cations left at 54
+    // lanes (C3: 87 % -> 99 % lane use, 13 % fewer waves).  O(64) per cluster via free-lane buckets.
     std::vector<int32_t>& slots = hp.slots;
-    int lane = 0, wave = -1;
+    int lane = 0, wave = -1, num_waves_alloc = 0;
+    std::vector<int32_t> fill;                          // lanes used per wave
+    std::vector<std::vector<int32_t> > open_by_free(65);  // waves with exactly f free lanes (stacks)
     auto new_wave = [&]() {
-        wave++;
-        lane = 0;
-        slots.resize((size_t) (wave + 1) * 128);
-        for (int l = 0; l < 64; l++) { slots[(size_t) wave * 128 + 2 * l] = -1; slots[(size_t) wave * 128 + 2 * l + 1] = 0; }
+        const int w = num_waves_alloc++;
+        fill.push_back(0);
+        slots.resize((size_t) (w + 1) * 128);
+        for (int l = 0; l < 64; l++) { slots[(size_t) w * 128 + 2 * l] = -1; slots[(size_t) w * 128 + 2 * l + 1] = 0; }
+        return w;
     };
-    new_wave();
     std::vector<int32_t> lane_of(n, -1), wave_of(n, -1);
     int used = 0;
+    // Measured on MI355X: best-fit wins while the working set is cache resident (111 k particles: +3 %, 0.9 M: +4 %) and loses
+    // once the kernels are HBM bound (8.9 M: -5 %, segments from distant index ranges cost partial cache lines), so very large
+    // systems keep plain in-order filling.
+    size_t total_lanes = 0;
+    for (const Cluster& c : clusters) total_lanes += c.members.size();
+    const bool best_fit = total_lanes < ((size_t) 1 << 20);
+    int last_wave = -1;
     for (const Cluster& c : clusters) {
         const int sz = (int) c.members.size();
-        if (lane + sz > 64) new_wave();
+        wave = -1;
+        if (best_fit) {
+            for (int f = sz; f <= 63 && wave < 0; f++)
+                if (!open_by_free[f].empty()) { wave = open_by_free[f].back(); open_by_free[f].pop_back(); }
+        } else if (last_wave >= 0 && fill[last_wave] + sz <= 64) {
+            wave = last_wave;
+        }
+        if (wave < 0) wave = new_wave();
+        last_wave = wave;
+        lane = fill[wave];
+        fill[wave] += sz;
+        if (best_fit && fill[wave] < 64) open_by_free[64 - fill[wave]].push_back(wave);
         const int first_lane = lane, last_lane = lane + sz - 1;
         for (int k = 0; k < sz; k++) { lane_of[c.members[k]] = lane + k; wave_of[c.members[k]] = wave; }
         bool leader_set = false;
@@ -339,7 +362,8 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
         }
     }
     // partner lanes were only known for the earlier member of each pair: fix them up
-    const int nwaves = wave + 1;
+    const int nwaves = std::max(num_waves_alloc, 1);
+    if (num_waves_alloc == 0) new_wave();
     for (int w = 0; w < nwaves; w++)
         for (int l = 0; l < 64; l++) {
             int32_t a = slots[(size_t) w * 128 + 2 * l];

@@ -38,6 +38,23 @@ template <> struct Prec<double> {
     static __device__ __forceinline__ double RECIP(double x) { return 1.0 / x; }
 };
 
+// 16-byte write-through store (buffer_store_dwordx4 ... sc1): the line goes to memory now instead of staying dirty in the
+// XCD's L2 until the end-of-kernel write-back (MI355X_MICROARCH.md "publish-large").  `base` must be wave-uniform.
+typedef unsigned int vv_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16_wt(void* base, unsigned byte_offset, const void* src) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0xFFFFFFFF, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(*(const vv_u4*) src, rsrc, (int) byte_offset, 0, 16);
+}
+template <class V>
+__device__ __forceinline__ void store_vec(V* base, int index, const V& val, bool write_through) {
+    if (write_through) {
+#pragma unroll
+        for (unsigned o = 0; o < sizeof(V); o += 16) store16_wt((void*) base, (unsigned) index * (unsigned) sizeof(V) + o, (const char*) &val + o);
+    } else {
+        base[index] = val;
+    }
+}
+
 __device__ __forceinline__ float shfl(float x, int src) { return __shfl(x, src, 64); }
 __device__ __forceinline__ double shfl(double x, int src) { return __shfl(x, src, 64); }
 
@@ -249,7 +266,7 @@ __global__ void __launch_bounds__(256) vv_kernel_a(const KArgs a) {
                     v.y += 0.5 * stepSize * v.w * fe.y + fscale * v.w * fy;
                     v.z += 0.5 * stepSize * v.w * fe.z + fscale * v.w * fz;
                 }
-                velm[atom] = v;
+                store_vec(velm, atom, v, (F & A_WT_STORES) != 0);
                 if (F & A_POSDELTA_VV) {                                    // K/velocityVerlet.cu:24-26
                     mixed4 d = {stepSize * v.x, stepSize * v.y, stepSize * v.z, 0};
                     ((mixed4*) a.pos_delta)[atom] = d;
@@ -548,12 +565,12 @@ struct PosIO {
             x = p1.x; y = p1.y; z = p1.z; w = p1.w;
         }
     }
-    static __device__ __forceinline__ void store(void* posq, void* corr, int i, mixed x, mixed y, mixed z, mixed w) {
+    static __device__ __forceinline__ void store(void* posq, void* corr, int i, mixed x, mixed y, mixed z, mixed w, bool wt = false) {
         real4 p = {(real) x, (real) y, (real) z, (real) w};
-        ((real4*) posq)[i] = p;
+        store_vec((real4*) posq, i, p, wt);
         if (kMixed) {
             real4 c = {(real) (x - (real) x), (real) (y - (real) y), (real) (z - (real) z), 0};
-            ((real4*) corr)[i] = c;
+            store_vec((real4*) corr, i, c, wt);
         }
     }
 };
@@ -825,8 +842,8 @@ __global__ void __launch_bounds__(320) vv_kernel_b(const KArgs a) {
         }
 
         // ---------------- write back
-        if (act && vel_dirty) velm[atom] = v;
-        if (act && pos_dirty) IO::store(a.posq, a.corr, atom, x, y, z, q);
+        if (act && vel_dirty) store_vec(velm, atom, v, (F & B_WT_STORES) != 0);
+        if (act && pos_dirty) IO::store(a.posq, a.corr, atom, x, y, z, q, (F & B_WT_STORES) != 0);
         if ((F & B_VV_KICK) && massive) {
             mixed4 d = {dx, dy, dz, 0};
             if (a.pos_delta) ((mixed4*) a.pos_delta)[atom] = d;
@@ -968,10 +985,12 @@ static inline dim3 grid_for(int nwaves, int block_threads) {
 // Stage-bit sets with their own compiled kernel: the fused middle step of a Drude system with / without hard wall
 // (BASELINE configs C3 / C2).  Everything else runs the generic kernel with run-time bits.
 constexpr uint32_t SF_A_MIDDLE = A_KICK_FULL | A_KE;
+constexpr uint32_t SF_A_MIDDLE_WT = SF_A_MIDDLE | A_WT_STORES;
 constexpr uint32_t SF_A_COS1 = A_KICK_FULL | A_COS | A_BIAS | A_CZ_STORE;          // cos acceleration (BASELINE C4): kick + bias moment
 constexpr uint32_t SF_A_COS2 = A_KE | A_UNBIAS_ACC | A_CZ_LOAD;                     // ... kinetic energies of the bias-free velocities
 constexpr uint32_t SF_B_COS_HW = B_CHAIN | B_SCALE | B_UNBIAS | B_CZ_LOAD | B_DRIFT_MIDDLE | B_HARDWALL;
 constexpr uint32_t SF_B_MIDDLE_HW = B_CHAIN | B_SCALE | B_DRIFT_MIDDLE | B_HARDWALL;
+constexpr uint32_t SF_B_MIDDLE_HW_WT = SF_B_MIDDLE_HW | B_WT_STORES;
 constexpr uint32_t SF_B_MIDDLE = B_CHAIN | B_SCALE | B_DRIFT_MIDDLE;
 
 hipError_t launch_a(int precision, const KArgs& a, int block_threads, hipStream_t s) {
@@ -979,6 +998,7 @@ hipError_t launch_a(int precision, const KArgs& a, int block_threads, hipStream_
     if (g.x > 2048) g.x = 2048;          // 8 blocks per CU; beyond that the kernel strides over tiles
     const dim3 b(block_threads);
     if (a.flags == SF_A_MIDDLE) { VV_DISPATCH_SF(vv_kernel_a, SF_A_MIDDLE, g, b, 0, s, a); }
+    else if (a.flags == SF_A_MIDDLE_WT) { VV_DISPATCH_SF(vv_kernel_a, SF_A_MIDDLE_WT, g, b, 0, s, a); }
     else if (a.flags == SF_A_COS1) { VV_DISPATCH_SF(vv_kernel_a, SF_A_COS1, g, b, 0, s, a); }
     else if (a.flags == SF_A_COS2) { VV_DISPATCH_SF(vv_kernel_a, SF_A_COS2, g, b, 0, s, a); }
     else { VV_DISPATCH_SF(vv_kernel_a, 0u, g, b, 0, s, a); }
@@ -991,6 +1011,7 @@ hipError_t launch_b(int precision, const KArgs& a, int block_threads, hipStream_
     if (g.x > 1024) g.x = 1024;
     const dim3 b(block_threads + ((a.flags & B_CHAIN) ? 64 : 0));
     if (a.flags == SF_B_MIDDLE_HW) { VV_DISPATCH_SF(vv_kernel_b, SF_B_MIDDLE_HW, g, b, 0, s, a); }
+    else if (a.flags == SF_B_MIDDLE_HW_WT) { VV_DISPATCH_SF(vv_kernel_b, SF_B_MIDDLE_HW_WT, g, b, 0, s, a); }
     else if (a.flags == SF_B_MIDDLE) { VV_DISPATCH_SF(vv_kernel_b, SF_B_MIDDLE, g, b, 0, s, a); }
     else if (a.flags == SF_B_COS_HW) { VV_DISPATCH_SF(vv_kernel_b, SF_B_COS_HW, g, b, 0, s, a); }
     else { VV_DISPATCH_SF(vv_kernel_b, 0u, g, b, 0, s, a); }

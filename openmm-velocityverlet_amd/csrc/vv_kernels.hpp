@@ -26,6 +26,7 @@ enum : uint32_t {
     A_COMPART = 1u << 12,    // molecules larger than a wave: add each chunk's sum(m v), sum(m) to the molecule's accumulator
     A_CZ_STORE = 1u << 13,   // keep cos(2 pi z / Lz) of every lane for the later kernels of this step (positions do not move in between)
     A_CZ_LOAD = 1u << 14,    // ... and take it from there instead of evaluating a double-precision cosine again
+    A_WT_STORES = 1u << 27,  // write-through (sc1) store of the kicked velocities
     A_KE_PLAIN = 1u << 15,   // sum m v^2 over every massive particle into accumulator 0 (kinetic-energy query)
 };
 // ---- stage flags of kernel B ("consume": starts from the scale factors) -------------------------
@@ -43,6 +44,7 @@ enum : uint32_t {
     B_IMAGE = 1u << 10,       // mirror copy to the image particle     (K/imageCharge.cu:2-28)
     B_CHAIN = 1u << 11,       // run the NH chain in the kernel head from the accumulators (else read nh->scales)
     B_CZ_LOAD = 1u << 12,     // cos(2 pi z / Lz) from the per-lane cache written by kernel A (A_CZ_STORE)
+    B_WT_STORES = 1u << 27,   // write-through (sc1) stores for the particle arrays: the dirty lines leave L2 during the kernel, not at its end
     B_DBG_NOFOLD = 1u << 28,  // timing experiments only: skip the accumulator fold / the chain arithmetic
     B_DBG_NOMATH = 1u << 29,
 };
