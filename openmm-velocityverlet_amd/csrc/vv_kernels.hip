@@ -666,6 +666,30 @@ __global__ void __launch_bounds__(320) vv_kernel_b(const KArgs a) {
             Vx = cv.x; Vy = cv.y; Vz = cv.z; Vw = cv.w;
         }
 
+        // Factor-independent half of the scaling: velocities relative to the molecular COM, the Drude partner's over the shuffle
+        // network, mass fractions, COM / relative split of the pair.  Without a bias to remove first it runs here, i.e. while
+        // the tile waves of the first iteration wait for the thermostat wave.
+        mixed ux = 0, uy = 0, uz = 0, cmx = 0, cmy = 0, cmz = 0, rx = 0, ry = 0, rz = 0, mass1fract = 0, mass2fract = 0;
+        auto scale_prep = [&]() {
+            ux = v.x; uy = v.y; uz = v.z;
+            if (nh) { ux -= Vx; uy -= Vy; uz -= Vz; }
+            const mixed px = shfl(ux, partner), py = shfl(uy, partner), pz = shfl(uz, partner), pw = shfl(v.w, partner);
+            if (role == ROLE_NH_DRUDE || role == ROLE_NH_PARENT) {
+                const bool isd = role == ROLE_NH_DRUDE;      // velAtom1 = Drude (pair.x), velAtom2 = parent
+                const mixed a1x = isd ? ux : px, a1y = isd ? uy : py, a1z = isd ? uz : pz, a1w = isd ? v.w : pw;
+                const mixed a2x = isd ? px : ux, a2y = isd ? py : uy, a2z = isd ? pz : uz, a2w = isd ? pw : v.w;
+                const mixed mass1 = P::RECIP(a1w), mass2 = P::RECIP(a2w);
+                const mixed invTotalMass = P::RECIP(mass1 + mass2);
+                mass1fract = invTotalMass * mass1; mass2fract = invTotalMass * mass2;
+                cmx = a1x * mass1fract + a2x * mass2fract;
+                cmy = a1y * mass1fract + a2y * mass2fract;
+                cmz = a1z * mass1fract + a2z * mass2fract;
+                rx = a2x - a1x; ry = a2y - a1y; rz = a2z - a1z;
+            }
+        };
+        const bool prep_early = (F & B_SCALE) && !(F & (B_UNBIAS | B_BIAS_REMOVE));
+        if (prep_early) scale_prep();
+
         if (need_scales) {
             need_scales = false;
             if (has_cw) {
@@ -686,12 +710,10 @@ __global__ void __launch_bounds__(320) vv_kernel_b(const KArgs a) {
             if ((F & (B_UNBIAS | B_BIAS_REMOVE)) && act) { v.x -= Vb * cz; vel_dirty = true; }
         }
 
-        // ---------------- NH velocity scaling (K/drudeNoseHoover.cu:157-209)
+        // ---------------- NH velocity scaling (K/drudeNoseHoover.cu:157-209): the factor-independent half was prepared above
         if (F & B_SCALE) {
+            if (!prep_early) scale_prep();
             const mixed vscaleAtom = (mixed) sc0, vscaleCOM = (mixed) sc1, vscaleDrude = (mixed) sc2;
-            mixed ux = v.x, uy = v.y, uz = v.z;
-            if (nh) { ux -= Vx; uy -= Vy; uz -= Vz; }
-            const mixed px = shfl(ux, partner), py = shfl(uy, partner), pz = shfl(uz, partner), pw = shfl(v.w, partner);
             if (role == ROLE_NH_NORMAL) {
                 if (massive) {
                     v.x = vscaleAtom * ux + vscaleCOM * Vx;
@@ -700,26 +722,16 @@ __global__ void __launch_bounds__(320) vv_kernel_b(const KArgs a) {
                     vel_dirty = true;
                 }
             } else if (role == ROLE_NH_DRUDE || role == ROLE_NH_PARENT) {
-                const bool isd = role == ROLE_NH_DRUDE;      // velAtom1 = Drude (pair.x), velAtom2 = parent
-                const mixed a1x = isd ? ux : px, a1y = isd ? uy : py, a1z = isd ? uz : pz, a1w = isd ? v.w : pw;
-                const mixed a2x = isd ? px : ux, a2y = isd ? py : uy, a2z = isd ? pz : uz, a2w = isd ? pw : v.w;
-                const mixed mass1 = P::RECIP(a1w), mass2 = P::RECIP(a2w);
-                const mixed invTotalMass = P::RECIP(mass1 + mass2);
-                const mixed mass1fract = invTotalMass * mass1, mass2fract = invTotalMass * mass2;
-                mixed cmx = a1x * mass1fract + a2x * mass2fract;
-                mixed cmy = a1y * mass1fract + a2y * mass2fract;
-                mixed cmz = a1z * mass1fract + a2z * mass2fract;
-                mixed rx = a2x - a1x, ry = a2y - a1y, rz = a2z - a1z;
-                cmx = vscaleAtom * cmx; cmy = vscaleAtom * cmy; cmz = vscaleAtom * cmz;
-                rx = vscaleDrude * rx; ry = vscaleDrude * ry; rz = vscaleDrude * rz;
-                if (isd) {
-                    v.x = cmx - rx * mass2fract + vscaleCOM * Vx;
-                    v.y = cmy - ry * mass2fract + vscaleCOM * Vy;
-                    v.z = cmz - rz * mass2fract + vscaleCOM * Vz;
+                const mixed sx = vscaleAtom * cmx, sy = vscaleAtom * cmy, sz = vscaleAtom * cmz;
+                const mixed tx = vscaleDrude * rx, ty = vscaleDrude * ry, tz = vscaleDrude * rz;
+                if (role == ROLE_NH_DRUDE) {
+                    v.x = sx - tx * mass2fract + vscaleCOM * Vx;
+                    v.y = sy - ty * mass2fract + vscaleCOM * Vy;
+                    v.z = sz - tz * mass2fract + vscaleCOM * Vz;
                 } else {
-                    v.x = cmx + rx * mass1fract + vscaleCOM * Vx;
-                    v.y = cmy + ry * mass1fract + vscaleCOM * Vy;
-                    v.z = cmz + rz * mass1fract + vscaleCOM * Vz;
+                    v.x = sx + tx * mass1fract + vscaleCOM * Vx;
+                    v.y = sy + ty * mass1fract + vscaleCOM * Vy;
+                    v.z = sz + tz * mass1fract + vscaleCOM * Vz;
                 }
                 vel_dirty = true;
             }
