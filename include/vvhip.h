@@ -70,6 +70,11 @@ typedef struct {
      * above; must not cut a molecule or a Drude pair.  Device arrays passed to vvhip_bind are indexed
      * from shard_begin.  0,0 = the whole system. */
     int32_t shard_begin, shard_end;
+    /* Optional.  System::getConstraintParameters distances [num_constraints] (nm).  When given and every constraint belongs to a
+     * SHAKE-able cluster (one central particle + up to three peripheral particles of equal mass and distance: what OpenMM's own
+     * SHAKE kernel takes, e.g. all X-H bonds), the fused steps solve the constraints inside kernels A and B.  NULL: constraints
+     * only enter the DOF count and the fused steps refuse to run if there are any (use the split entry points around the host's solver). */
+    const double* constraint_distances;
 } vvhip_system_desc;
 
 /* VVIntegrator's parameters (openmmapi/include/openmm/VVIntegrator.h:70-431).  The reference reads
@@ -86,6 +91,7 @@ typedef struct {
     int32_t use_com_temp_group, use_middle_scheme;
     int32_t auto_set_com_temp_group;   /* 1 = constructor default not overridden (API:67,106-121)    */
     int32_t auto_set_friction;
+    double constraint_tolerance;       /* Integrator::getConstraintTolerance (relative, 1e-5 by default); used by the in-kernel SHAKE */
 } vvhip_params;
 
 /* Device arrays owned by the caller (OpenMM's HipContext / HipIntegrationUtilities in the plugin). */
@@ -112,6 +118,8 @@ typedef struct {
     double inv_mass_total;                       /* HOST:1028-1031 */
     int32_t num_waves, num_slots_used;           /* work-item layout: 64 slots per wave */
     int32_t max_cluster;                         /* largest set of particles that must share a wave */
+    int32_t num_shake_clusters;                  /* constraint clusters solved in-kernel (0 if none / not possible) */
+    int32_t constraints_fused;                   /* 1: no constraints, or all of them are handled in-kernel => fused steps are valid */
 } vvhip_plan_info;
 
 /* Nose-Hoover chain state + last reduction results (HOST: CudaVVKernels.h:206-215).  The reference

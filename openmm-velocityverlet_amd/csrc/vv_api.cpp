@@ -64,6 +64,8 @@ struct vvhip_plan {
     int32_t* d_slot_image = nullptr;
     int32_t* d_slot_rand = nullptr;
     int32_t* d_slot_big = nullptr;
+    int32_t* d_slot_shake = nullptr;
+    float4* d_slot_shake_param = nullptr;
     unsigned long long* d_bigacc = nullptr;
     int2* d_image_pairs = nullptr;
     void* d_fextra = nullptr;
@@ -157,6 +159,9 @@ vv::KArgs make_args(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
     a.slots = p->d_slots;
     a.slot_image = p->d_slot_image;
     a.slot_rand = p->d_slot_rand;
+    a.slot_shake = p->d_slot_shake;
+    a.slot_shake_param = p->d_slot_shake_param;
+    a.shake_tol = q.constraint_tolerance > 0 ? q.constraint_tolerance : 1e-5;
     a.slot_big = p->d_slot_big;
     a.bigacc = p->d_bigacc;
     a.big_scale = p->hp.big_scale;
@@ -284,6 +289,12 @@ uint32_t tail_flags(const vvhip_plan* p) {      // what follows every position u
     return f;
 }
 bool cos_on(const vvhip_plan* p) { return p->hp.params.cos_acceleration != 0; }
+bool shake_on(const vvhip_plan* p) { return !p->hp.slot_shake.empty(); }
+#define NEED_FUSABLE(p)                                                                                                   \
+    do {                                                                                                                \
+        if (!(p)->hp.info.constraints_fused)                                                                            \
+            return fail(p, VVHIP_ERR_UNSUPPORTED, "the System has constraints this backend cannot solve in-kernel: use the split entry points around the host's constraint solver"); \
+    } while (0)
 
 #define TRY(x)                       \
     do {                             \
@@ -327,7 +338,7 @@ void vvhip_plan_destroy(vvhip_plan* p) {
     if (!p) return;
     if (p->bound) {
         (void) hipStreamSynchronize(p->stream);
-        for (void* ptr : {(void*) p->d_slots, (void*) p->d_slot_image, (void*) p->d_slot_rand, (void*) p->d_slot_big, (void*) p->d_bigacc, (void*) p->d_image_pairs,
+        for (void* ptr : {(void*) p->d_slots, (void*) p->d_slot_image, (void*) p->d_slot_rand, (void*) p->d_slot_shake, (void*) p->d_slot_shake_param, (void*) p->d_slot_big, (void*) p->d_bigacc, (void*) p->d_image_pairs,
                           p->d_fextra, p->d_old_delta, p->d_pos_delta, p->d_comv, (void*) p->d_cosz, (void*) p->d_epoch, (void*) p->d_acc, (void*) p->d_nh})
             if (ptr) (void) hipFree(ptr);
         if (p->graph_exec) (void) hipGraphExecDestroy(p->graph_exec);
@@ -387,6 +398,12 @@ int vvhip_bind(vvhip_plan* p, const vvhip_buffers* b) {
     if (!hp.slot_rand.empty()) {
         HIP_TRY(p, hipMalloc((void**) &p->d_slot_rand, nslots * sizeof(int32_t)));
         HIP_TRY(p, hipMemcpy(p->d_slot_rand, hp.slot_rand.data(), nslots * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    if (!hp.slot_shake.empty()) {
+        HIP_TRY(p, hipMalloc((void**) &p->d_slot_shake, nslots * sizeof(int32_t)));
+        HIP_TRY(p, hipMemcpy(p->d_slot_shake, hp.slot_shake.data(), nslots * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(p, hipMalloc((void**) &p->d_slot_shake_param, nslots * sizeof(float4)));
+        HIP_TRY(p, hipMemcpy(p->d_slot_shake_param, hp.slot_shake_param.data(), nslots * sizeof(float4), hipMemcpyHostToDevice));
     }
     if (!hp.slot_big.empty()) {
         HIP_TRY(p, hipMalloc((void**) &p->d_slot_big, nslots * sizeof(int32_t)));
@@ -460,8 +477,9 @@ int vvhip_step_middle_phases(const vvhip_plan* p) {
 
 int vvhip_step_middle_phase(vvhip_plan* p, int phase, uint32_t random_index) {
     NEED_BOUND(p);
-    const uint32_t kick = vv::A_KICK_FULL | extra_flags(p);
-    const uint32_t drift = vv::B_DRIFT_MIDDLE | tail_flags(p);
+    NEED_FUSABLE(p);
+    const uint32_t kick = vv::A_KICK_FULL | extra_flags(p) | (shake_on(p) ? vv::A_SHAKE_V : 0);
+    const uint32_t drift = vv::B_DRIFT_MIDDLE | tail_flags(p) | (shake_on(p) ? vv::B_SHAKE : 0);
     if (!p->hp.has_nh) {                                   // API:251: no NH particles, nothing to reduce
         if (phase != 0) return fail(p, VVHIP_ERR_INVALID, "phase out of range");
         TRY(run_a(p, kick, random_index));
@@ -530,14 +548,16 @@ static int nh_half(vvhip_plan* p, uint32_t a_first, uint32_t random_index, uint3
 
 int vvhip_step_vv_first(vvhip_plan* p) {                   // API:295-310 (forces for the old positions are in `force`)
     NEED_BOUND(p);
-    return nh_half(p, 0, 0, vv::B_VV_KICK | tail_flags(p));
+    NEED_FUSABLE(p);
+    return nh_half(p, 0, 0, vv::B_VV_KICK | tail_flags(p) | (shake_on(p) ? vv::B_SHAKE : 0));
 }
 
 int vvhip_step_vv_second(vvhip_plan* p, uint32_t random_index) {   // API:316-336 (forces for the new positions)
     NEED_BOUND(p);
     uint32_t ex = extra_flags(p);
     if (ex) ex |= vv::A_FE_STORE;                          // the first half of the NEXT step kicks with these (API:316-323)
-    return nh_half(p, vv::A_KICK_HALF | ex, random_index, 0);
+    NEED_FUSABLE(p);
+    return nh_half(p, vv::A_KICK_HALF | ex | (shake_on(p) ? vv::A_SHAKE_V : 0), random_index, 0);
 }
 
 // ------------------------------------------------------------------------------------------ kernel-interface level
@@ -744,8 +764,8 @@ int vvhip_time_kernel(vvhip_plan* p, int kernel, uint32_t flags, int reps, doubl
     NEED_BOUND(p);
     if (reps < 1 || !ms_per_launch) return VVHIP_ERR_INVALID;
     if (flags == 0xFFFFFFFFu) {     // the stage bits vvhip_step_middle uses for this plan
-        if (kernel == 0) flags = vv::A_KICK_FULL | extra_flags(p) | (p->hp.has_nh ? (cos_on(p) ? (vv::A_BIAS | vv::A_CZ_STORE) : vv::A_KE) : 0);
-        else flags = vv::B_DRIFT_MIDDLE | tail_flags(p) | (p->hp.has_nh ? ((p->hp.params.num_nh_chains <= 4 ? vv::B_CHAIN : 0) | vv::B_SCALE | (cos_on(p) ? (vv::B_UNBIAS | vv::B_CZ_LOAD) : 0)) : 0);
+        if (kernel == 0) flags = vv::A_KICK_FULL | extra_flags(p) | (shake_on(p) ? vv::A_SHAKE_V : 0) | (p->hp.has_nh ? (cos_on(p) ? (vv::A_BIAS | vv::A_CZ_STORE) : vv::A_KE) : 0);
+        else flags = vv::B_DRIFT_MIDDLE | tail_flags(p) | (shake_on(p) ? vv::B_SHAKE : 0) | (p->hp.has_nh ? ((p->hp.params.num_nh_chains <= 4 ? vv::B_CHAIN : 0) | vv::B_SCALE | (cos_on(p) ? (vv::B_UNBIAS | vv::B_CZ_LOAD) : 0)) : 0);
     }
     hipEvent_t e0, e1;
     HIP_TRY(p, hipEventCreate(&e0));

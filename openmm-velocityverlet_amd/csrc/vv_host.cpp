@@ -195,6 +195,34 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
     for (size_t i = 0; i < hp.pairs_ld.size() / 2; i++)
         rand_of[hp.pairs_ld[2 * i]] = rand_of[hp.pairs_ld[2 * i + 1]] = (int32_t) (hp.normal_ld.size() + 2 * i);
 
+    // ---- constraint clusters for the in-kernel SHAKE (same admission rule as OpenMM's SHAKE kernel: a central particle with
+    // one to three peripheral particles of identical mass and distance, every peripheral in exactly one constraint)
+    struct Shake { int32_t center; std::vector<int32_t> periph; double d; };
+    std::vector<Shake> shakes;
+    std::vector<int32_t> shake_of(n, -1);
+    bool constraints_fused = sys.num_constraints == 0;
+    if (sys.num_constraints > 0 && sys.constraint_distances) {
+        std::vector<int> deg(n, 0);
+        for (int k = 0; k < sys.num_constraints; k++) { deg[sys.constraints[2 * k]]++; deg[sys.constraints[2 * k + 1]]++; }
+        bool ok = true;
+        for (int k = 0; k < sys.num_constraints && ok; k++) {
+            int a = sys.constraints[2 * k], b = sys.constraints[2 * k + 1];
+            const double d = sys.constraint_distances[k];
+            // the central particle is the one with several constraints; for an isolated pair, the heavier one
+            int ctr = deg[a] > 1 ? a : (deg[b] > 1 ? b : (sys.masses[a] >= sys.masses[b] ? a : b));
+            int per = ctr == a ? b : a;
+            if (deg[per] != 1 || sys.masses[ctr] == 0 || sys.masses[per] == 0 ) { ok = false; break; }
+            if (shake_of[ctr] < 0) { shake_of[ctr] = (int32_t) shakes.size(); shakes.push_back(Shake{ctr, {}, d}); }
+            Shake& s = shakes[shake_of[ctr]];
+            if (s.center != ctr || s.periph.size() >= 3 || s.d != d || (!s.periph.empty() && sys.masses[s.periph[0]] != sys.masses[per])) { ok = false; break; }
+            if (shake_of[per] >= 0) { ok = false; break; }
+            s.periph.push_back(per);
+            shake_of[per] = shake_of[ctr];
+        }
+        if (ok) constraints_fused = true;
+        else { shakes.clear(); std::fill(shake_of.begin(), shake_of.end(), -1); }
+    }
+
     // ---- which particles need a lane, and which must share a wave
     auto needs_lane = [&](int i) {
         if (sys.masses[i] != 0.0) return true;      // anything massive is integrated
@@ -217,16 +245,29 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
             clusters[cluster_of_mol[m]].members.push_back(i);
             done[i] = 1;
         } else {
-            Cluster c{i, {i}, false};
+            // closure of {Drude partner, SHAKE cluster mates}: a handful of particles at most
+            Cluster c{i, {}, false};
+            std::vector<int32_t> todo{i};
             done[i] = 1;
-            if (in_pair[i]) {
-                int q = partner[i];
-                if (!in_shard(q)) throw Error(VVHIP_ERR_INVALID, "particle shard cuts a Drude pair");
-                c.members.push_back(q);
-                done[q] = 1;
-                std::sort(c.members.begin(), c.members.end());
-                c.first = c.members[0];
+            while (!todo.empty()) {
+                const int j = todo.back();
+                todo.pop_back();
+                c.members.push_back(j);
+                auto visit = [&](int q) {
+                    if (q < 0 || done[q]) return;
+                    if (!in_shard(q)) throw Error(VVHIP_ERR_INVALID, "particle shard cuts a Drude pair or a constraint cluster");
+                    done[q] = 1;
+                    todo.push_back(q);
+                };
+                if (in_pair[j]) visit(partner[j]);
+                if (shake_of[j] >= 0) {
+                    const Shake& s = shakes[shake_of[j]];
+                    visit(s.center);
+                    for (int q : s.periph) visit(q);
+                }
             }
+            std::sort(c.members.begin(), c.members.end());
+            c.first = c.members[0];
             clusters.push_back(c);
         }
     }
@@ -392,6 +433,28 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
         }
     }
     if (hp.has_ld) hp.slot_rand.assign((size_t) nwaves * 64, -1);
+    info.constraints_fused = constraints_fused ? 1 : 0;
+    info.num_shake_clusters = 0;
+    if (!shakes.empty()) {
+        hp.slot_shake.assign((size_t) nwaves * 64, 0);
+        hp.slot_shake_param.assign((size_t) nwaves * 64 * 4, 0.0f);
+        for (const Shake& s : shakes) {
+            if (!in_shard(s.center)) continue;
+            const int w = wave_of[s.center], lc = lane_of[s.center];
+            uint32_t word = 1u | ((uint32_t) s.periph.size() << 2);
+            for (size_t k = 0; k < s.periph.size(); k++) {
+                const int q = s.periph[k];
+                if (wave_of[q] != w) throw Error(VVHIP_ERR_UNSUPPORTED, "a constraint cluster does not fit into one wave with its molecule");
+                word |= (uint32_t) lane_of[q] << (4 + 6 * k);
+                hp.slot_shake[(size_t) w * 64 + lane_of[q]] = (int32_t) (2u | ((uint32_t) k << 2) | ((uint32_t) lc << 4));
+            }
+            hp.slot_shake[(size_t) w * 64 + lc] = (int32_t) word;
+            const double imc = 1.0 / sys.masses[s.center], imp = 1.0 / sys.masses[s.periph[0]];
+            float* prm = &hp.slot_shake_param[((size_t) w * 64 + lc) * 4];
+            prm[0] = (float) imc; prm[1] = (float) (0.5 / (imc + imp)); prm[2] = (float) (s.d * s.d); prm[3] = (float) imp;
+            info.num_shake_clusters++;
+        }
+    }
     if (hp.num_big > 0) {
         hp.slot_big.assign((size_t) nwaves * 64, -1);
         std::vector<int32_t> big_of(n, -1);

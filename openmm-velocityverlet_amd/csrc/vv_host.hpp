@@ -60,6 +60,12 @@ struct HostPlan {
     std::vector<int32_t> slots;
     std::vector<int32_t> slot_image;   // [64*waves] shard-relative image particle of this lane's particle, or -1
     std::vector<int32_t> slot_rand;    // [64*waves] offset into the Langevin slice of the random buffer, or -1
+    // in-kernel SHAKE (hydrogen-type clusters): per lane a packed word and, for central lanes, OpenMM-style cluster parameters
+    //   word: bit0 central, bit1 peripheral, bits2-3 = #peripherals (central) or own index (peripheral),
+    //         bits 4-9 / 10-15 / 16-21 = lanes of the peripherals (central) or bits 4-9 = lane of the central (peripheral)
+    //   param float4: x = 1/m_central, y = 0.5/(1/m_central + 1/m_peripheral), z = d^2, w = 1/m_peripheral
+    std::vector<int32_t> slot_shake;
+    std::vector<float> slot_shake_param;
     std::vector<int32_t> slot_big;     // [64*waves] index of the lane's big molecule, or -1 (empty when there is none)
     int32_t num_big = 0;               // molecules with more than 64 thermostatted particles (COM temperature group only)
     double big_scale = 1.0;            // fixed-point scale of their sum(m v) accumulators

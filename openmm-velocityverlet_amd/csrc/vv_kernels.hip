@@ -161,6 +161,146 @@ __device__ __forceinline__ void com_velocity(bool contributes, mixed vx, mixed v
     Vx = mx * Vw; Vy = my * Vw; Vz = mz * Vw;
 }
 
+// positions are posq (+ posqCorrection in mixed mode): K/middle.cu:81-96
+template <class real, class mixed>
+struct PosIO {
+    using real4 = typename Vec<real>::v4;
+    static constexpr bool kMixed = sizeof(real) != sizeof(mixed);
+    // K/middle.cu:81-96: positions are posq (+ posqCorrection in mixed mode)
+    static __device__ __forceinline__ void load(const void* posq, const void* corr, int i, mixed& x, mixed& y, mixed& z, mixed& w, real& zraw) {
+        const real4 p1 = ((const real4*) posq)[i];
+        zraw = p1.z;
+        if (kMixed) {
+            const real4 p2 = ((const real4*) corr)[i];
+            x = p1.x + (mixed) p2.x; y = p1.y + (mixed) p2.y; z = p1.z + (mixed) p2.z; w = p1.w;
+        } else {
+            x = p1.x; y = p1.y; z = p1.z; w = p1.w;
+        }
+    }
+    static __device__ __forceinline__ void store(void* posq, void* corr, int i, mixed x, mixed y, mixed z, mixed w, bool wt = false) {
+        real4 p = {(real) x, (real) y, (real) z, (real) w};
+        store_vec((real4*) posq, i, p, wt);
+        if (kMixed) {
+            real4 c = {(real) (x - (real) x), (real) (y - (real) y), (real) (z - (real) z), 0};
+            store_vec((real4*) corr, i, c, wt);
+        }
+    }
+};
+
+// ================================================================================ in-kernel SHAKE
+// Constraint clusters of the kind OpenMM's SHAKE kernels take: one central particle, up to three peripheral particles of
+// equal mass at equal distance.  A cluster always lies inside one wave (vv_host.cpp), so the peripherals hand their state
+// to the central lane through a per-wave LDS page, the central lane iterates exactly like OpenMM's applyShakeToPositions /
+// applyShakeToVelocities (Gauss-Seidel over the cluster, <= 15 sweeps, float cluster parameters, `mixed` arithmetic), and
+// the peripherals pick their result up again.  OpenMM's source is not under /root/reference: this follows its published
+// algorithm, parity with OpenMM itself is unpinned; the CPU oracle carries the same statement.
+template <class mixed>
+__device__ __forceinline__ void shake_positions(int lane, unsigned word, float4 prm, mixed tol, mixed x, mixed y, mixed z,
+                                                mixed& dx, mixed& dy, mixed& dz, mixed (*page)[6]) {
+    if (word & 2u) { page[lane][0] = x; page[lane][1] = y; page[lane][2] = z; page[lane][3] = dx; page[lane][4] = dy; page[lane][5] = dz; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (word & 1u) {
+        const int np = (int) ((word >> 2) & 3u);
+        const mixed invMassCentral = prm.x, avgMass = prm.y, d2 = prm.z, invMassPeripheral = prm.w;
+        mixed rij[3][3], rijsq[3], ld[3], xpj[3][3];
+        int pl[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            pl[k] = (int) ((word >> (4 + 6 * k)) & 63u);
+            if (k < np) {
+                rij[k][0] = x - page[pl[k]][0]; rij[k][1] = y - page[pl[k]][1]; rij[k][2] = z - page[pl[k]][2];
+                xpj[k][0] = page[pl[k]][3]; xpj[k][1] = page[pl[k]][4]; xpj[k][2] = page[pl[k]][5];
+            } else {
+                rij[k][0] = rij[k][1] = rij[k][2] = 0; xpj[k][0] = xpj[k][1] = xpj[k][2] = 0;
+            }
+            rijsq[k] = rij[k][0] * rij[k][0] + rij[k][1] * rij[k][1] + rij[k][2] * rij[k][2];
+            ld[k] = d2 - rijsq[k];
+        }
+        mixed xpi[3] = {dx, dy, dz};
+        bool converged = false;
+        for (int iteration = 0; iteration < 15 && !converged; iteration++) {
+            converged = true;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                if (k < np) {
+                    const mixed rp0 = xpi[0] - xpj[k][0], rp1 = xpi[1] - xpj[k][1], rp2 = xpi[2] - xpj[k][2];
+                    const mixed rpsqij = rp0 * rp0 + rp1 * rp1 + rp2 * rp2;
+                    const mixed rrpr = rij[k][0] * rp0 + rij[k][1] * rp1 + rij[k][2] * rp2;
+                    const mixed diff = fabs(ld[k] - 2.0f * rrpr - rpsqij) / (d2 * tol);
+                    if (diff >= 1.0f) {
+                        const mixed acor = (ld[k] - 2.0f * rrpr - rpsqij) * avgMass / (rrpr + rijsq[k]);
+                        const mixed d0 = rij[k][0] * acor, d1 = rij[k][1] * acor, d2v = rij[k][2] * acor;
+                        xpi[0] += d0 * invMassCentral; xpi[1] += d1 * invMassCentral; xpi[2] += d2v * invMassCentral;
+                        xpj[k][0] -= d0 * invMassPeripheral; xpj[k][1] -= d1 * invMassPeripheral; xpj[k][2] -= d2v * invMassPeripheral;
+                        converged = false;
+                    }
+                }
+            }
+        }
+        dx = xpi[0]; dy = xpi[1]; dz = xpi[2];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            if (k < np) { page[pl[k]][3] = xpj[k][0]; page[pl[k]][4] = xpj[k][1]; page[pl[k]][5] = xpj[k][2]; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (word & 2u) { dx = page[lane][3]; dy = page[lane][4]; dz = page[lane][5]; }
+}
+
+template <class mixed>
+__device__ __forceinline__ void shake_velocities(int lane, unsigned word, float4 prm, mixed tol, mixed x, mixed y, mixed z,
+                                                 mixed& vx, mixed& vy, mixed& vz, mixed (*page)[6]) {
+    if (word & 2u) { page[lane][0] = x; page[lane][1] = y; page[lane][2] = z; page[lane][3] = vx; page[lane][4] = vy; page[lane][5] = vz; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (word & 1u) {
+        const int np = (int) ((word >> 2) & 3u);
+        const mixed invMassCentral = prm.x, avgMass = prm.y, invMassPeripheral = prm.w;
+        mixed rij[3][3], rijsq[3], vj[3][3];
+        int pl[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            pl[k] = (int) ((word >> (4 + 6 * k)) & 63u);
+            if (k < np) {
+                rij[k][0] = x - page[pl[k]][0]; rij[k][1] = y - page[pl[k]][1]; rij[k][2] = z - page[pl[k]][2];
+                vj[k][0] = page[pl[k]][3]; vj[k][1] = page[pl[k]][4]; vj[k][2] = page[pl[k]][5];
+            } else {
+                rij[k][0] = rij[k][1] = rij[k][2] = 0; vj[k][0] = vj[k][1] = vj[k][2] = 0;
+            }
+            rijsq[k] = rij[k][0] * rij[k][0] + rij[k][1] * rij[k][1] + rij[k][2] * rij[k][2];
+        }
+        mixed vi[3] = {vx, vy, vz};
+        bool converged = false;
+        for (int iteration = 0; iteration < 15 && !converged; iteration++) {
+            converged = true;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                if (k < np) {
+                    const mixed rp0 = vi[0] - vj[k][0], rp1 = vi[1] - vj[k][1], rp2 = vi[2] - vj[k][2];
+                    const mixed rrpr = rp0 * rij[k][0] + rp1 * rij[k][1] + rp2 * rij[k][2];
+                    const mixed delta = -2.0f * avgMass * rrpr / rijsq[k];
+                    const mixed d0 = rij[k][0] * delta, d1 = rij[k][1] * delta, d2v = rij[k][2] * delta;
+                    vi[0] += d0 * invMassCentral; vi[1] += d1 * invMassCentral; vi[2] += d2v * invMassCentral;
+                    vj[k][0] -= d0 * invMassPeripheral; vj[k][1] -= d1 * invMassPeripheral; vj[k][2] -= d2v * invMassPeripheral;
+                    if (fabs(delta) > tol) converged = false;
+                }
+            }
+        }
+        vx = vi[0]; vy = vi[1]; vz = vi[2];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            if (k < np) { page[pl[k]][3] = vj[k][0]; page[pl[k]][4] = vj[k][1]; page[pl[k]][5] = vj[k][2]; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (word & 2u) { vx = page[lane][3]; vy = page[lane][4]; vz = page[lane][5]; }
+}
+
 // ================================================================================ kernel A
 template <class real, class mixed, uint32_t SF>   // SF != 0: the stage bits are a compile-time constant (hot paths)
 __global__ void __launch_bounds__(256) vv_kernel_a(const KArgs a) {
@@ -266,12 +406,22 @@ __global__ void __launch_bounds__(256) vv_kernel_a(const KArgs a) {
                     v.y += 0.5 * stepSize * v.w * fe.y + fscale * v.w * fy;
                     v.z += 0.5 * stepSize * v.w * fe.z + fscale * v.w * fz;
                 }
-                store_vec(velm, atom, v, (F & A_WT_STORES) != 0);
+                if (!(F & A_SHAKE_V)) store_vec(velm, atom, v, (F & A_WT_STORES) != 0);
                 if (F & A_POSDELTA_VV) {                                    // K/velocityVerlet.cu:24-26
                     mixed4 d = {stepSize * v.x, stepSize * v.y, stepSize * v.z, 0};
                     ((mixed4*) a.pos_delta)[atom] = d;
                 }
             }
+        }
+        if (F & A_SHAKE_V) {                   // integration.applyVelocityConstraints(tol) (HOST:151, 427), clusters solved in the wave
+            __shared__ mixed shake_page_a[4][64][6];
+            const unsigned word = act ? (unsigned) a.slot_shake[(size_t) wave * 64 + lane] : 0u;
+            const float4 prm = (word & 1u) ? a.slot_shake_param[(size_t) wave * 64 + lane] : make_float4(0, 0, 0, 0);
+            mixed sx = 0, sy = 0, sz = 0, sq = 0;
+            real sraw = 0;
+            if (word & 3u) PosIO<real, mixed>::load(a.posq, a.corr, atom, sx, sy, sz, sq, sraw);
+            shake_velocities<mixed>(lane, word, prm, (mixed) a.shake_tol, sx, sy, sz, v.x, v.y, v.z, shake_page_a[threadIdx.x >> 6]);
+            if (massive) store_vec(velm, atom, v, (F & A_WT_STORES) != 0);
         }
         if ((F & A_POS1) && massive) {                                      // K/middle.cu:33-40
             const mixed halfdt = 0.5f * stepSize;
@@ -550,30 +700,6 @@ __global__ void __launch_bounds__(64) vv_kernel_chain(const NHConst c, NHDevStat
 }
 
 // ================================================================================ kernel B
-template <class real, class mixed>
-struct PosIO {
-    using real4 = typename Vec<real>::v4;
-    static constexpr bool kMixed = sizeof(real) != sizeof(mixed);
-    // K/middle.cu:81-96: positions are posq (+ posqCorrection in mixed mode)
-    static __device__ __forceinline__ void load(const void* posq, const void* corr, int i, mixed& x, mixed& y, mixed& z, mixed& w, real& zraw) {
-        const real4 p1 = ((const real4*) posq)[i];
-        zraw = p1.z;
-        if (kMixed) {
-            const real4 p2 = ((const real4*) corr)[i];
-            x = p1.x + (mixed) p2.x; y = p1.y + (mixed) p2.y; z = p1.z + (mixed) p2.z; w = p1.w;
-        } else {
-            x = p1.x; y = p1.y; z = p1.z; w = p1.w;
-        }
-    }
-    static __device__ __forceinline__ void store(void* posq, void* corr, int i, mixed x, mixed y, mixed z, mixed w, bool wt = false) {
-        real4 p = {(real) x, (real) y, (real) z, (real) w};
-        store_vec((real4*) posq, i, p, wt);
-        if (kMixed) {
-            real4 c = {(real) (x - (real) x), (real) (y - (real) y), (real) (z - (real) z), 0};
-            store_vec((real4*) corr, i, c, wt);
-        }
-    }
-};
 
 template <class real, class mixed, uint32_t SF>
 __global__ void __launch_bounds__(320) vv_kernel_b(const KArgs a) {
@@ -760,17 +886,33 @@ __global__ void __launch_bounds__(320) vv_kernel_b(const KArgs a) {
             ((mixed4*) a.pos_delta)[atom] = pd;
             ((mixed4*) a.old_delta)[atom] = od;
         }
-        if ((F & B_DRIFT_MIDDLE) && massive) {
-            // Pos1 (K/middle.cu:36-38) with the pre-thermostat velocity, Pos2 (:54-56) with the scaled one,
-            // no constraint solver in between => posDelta == oldDelta and Pos3's velocity correction
-            // (K/middle.cu:77-79) adds (d - d)/dt == 0 exactly.
+        // per-wave LDS page and cluster word of the in-kernel SHAKE (collective over the wave: every lane walks through it)
+        __shared__ mixed shake_page_b[4][64][6];
+        unsigned shake_word = 0;
+        float4 shake_prm = make_float4(0, 0, 0, 0);
+        if ((F & B_SHAKE) && act) {
+            shake_word = (unsigned) a.slot_shake[(size_t) wave * 64 + lane];
+            if (shake_word & 1u) shake_prm = a.slot_shake_param[(size_t) wave * 64 + lane];
+        }
+        if (F & B_DRIFT_MIDDLE) {
+            // Pos1 (K/middle.cu:36-38) with the pre-thermostat velocity, Pos2 (:54-56) with the scaled one.  Without constraints
+            // posDelta == oldDelta and Pos3's velocity correction (K/middle.cu:77-79) adds (d - d)/dt == 0 exactly; with the
+            // in-kernel SHAKE the constrained displacement differs and the correction is the constraint force's kick.
             const mixed halfdt = 0.5f * stepSize;
-            mixed ddx = halfdt * v_old.x, ddy = halfdt * v_old.y, ddz = halfdt * v_old.z;
-            ddx += halfdt * v.x; ddy += halfdt * v.y; ddz += halfdt * v.z;
-            const mixed invDt = 1 / stepSize;
-            v.x += (ddx - ddx) * invDt; v.y += (ddy - ddy) * invDt; v.z += (ddz - ddz) * invDt;
-            x += ddx; y += ddy; z += ddz;
-            pos_dirty = true; vel_dirty = true;
+            mixed ddx = 0, ddy = 0, ddz = 0;
+            if (massive) {
+                ddx = halfdt * v_old.x; ddy = halfdt * v_old.y; ddz = halfdt * v_old.z;
+                ddx += halfdt * v.x; ddy += halfdt * v.y; ddz += halfdt * v.z;
+            }
+            const mixed odx = ddx, ody = ddy, odz = ddz;
+            if (F & B_SHAKE)                                                       // integration.applyConstraints(tol), HOST:176
+                shake_positions<mixed>(lane, shake_word, shake_prm, (mixed) a.shake_tol, x, y, z, ddx, ddy, ddz, shake_page_b[wib]);
+            if (massive) {
+                const mixed invDt = 1 / stepSize;
+                v.x += (ddx - odx) * invDt; v.y += (ddy - ody) * invDt; v.z += (ddz - odz) * invDt;
+                x += ddx; y += ddy; z += ddz;
+                pos_dirty = true; vel_dirty = true;
+            }
         }
         if ((F & B_POS3) && massive) {                                          // K/middle.cu:70-96
             const mixed invDt = 1 / stepSize;
@@ -779,15 +921,19 @@ __global__ void __launch_bounds__(320) vv_kernel_b(const KArgs a) {
             x += d.x; y += d.y; z += d.z;
             pos_dirty = true; vel_dirty = true;
         }
-        if ((F & (B_VV_POS | B_VV_KICK)) && massive) {                          // K/velocityVerlet.cu:41-66
-            if (!(F & B_VV_KICK)) {
+        if (F & (B_VV_POS | B_VV_KICK)) {                                       // K/velocityVerlet.cu:41-66
+            if (!(F & B_VV_KICK) && massive) {
                 const mixed4 d = ((const mixed4*) a.pos_delta)[atom];
                 dx = d.x; dy = d.y; dz = d.z;
             }
-            const mixed invStepSize = 1.0 / stepSize;
-            x += dx; y += dy; z += dz;
-            v.x = (mixed) (invStepSize * dx); v.y = (mixed) (invStepSize * dy); v.z = (mixed) (invStepSize * dz);
-            pos_dirty = true; vel_dirty = true;
+            if (F & B_SHAKE)                                                       // integration.applyConstraints(tol), HOST:351
+                shake_positions<mixed>(lane, shake_word, shake_prm, (mixed) a.shake_tol, x, y, z, dx, dy, dz, shake_page_b[wib]);
+            if (massive) {
+                const mixed invStepSize = 1.0 / stepSize;
+                x += dx; y += dy; z += dz;
+                v.x = (mixed) (invStepSize * dx); v.y = (mixed) (invStepSize * dy); v.z = (mixed) (invStepSize * dz);
+                pos_dirty = true; vel_dirty = true;
+            }
         }
 
         // ---------------- hard wall on Drude pairs (K/middle.cu:106-221); pair.x = Drude = "1", parent = "2"

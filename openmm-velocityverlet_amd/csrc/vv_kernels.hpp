@@ -26,6 +26,7 @@ enum : uint32_t {
     A_COMPART = 1u << 12,    // molecules larger than a wave: add each chunk's sum(m v), sum(m) to the molecule's accumulator
     A_CZ_STORE = 1u << 13,   // keep cos(2 pi z / Lz) of every lane for the later kernels of this step (positions do not move in between)
     A_CZ_LOAD = 1u << 14,    // ... and take it from there instead of evaluating a double-precision cosine again
+    A_SHAKE_V = 1u << 16,    // velocity constraints of the SHAKE clusters right after the kick (OpenMM applyVelocityConstraints)
     A_WT_STORES = 1u << 27,  // write-through (sc1) store of the kicked velocities
     A_KE_PLAIN = 1u << 15,   // sum m v^2 over every massive particle into accumulator 0 (kinetic-energy query)
 };
@@ -44,6 +45,7 @@ enum : uint32_t {
     B_IMAGE = 1u << 10,       // mirror copy to the image particle     (K/imageCharge.cu:2-28)
     B_CHAIN = 1u << 11,       // run the NH chain in the kernel head from the accumulators (else read nh->scales)
     B_CZ_LOAD = 1u << 12,     // cos(2 pi z / Lz) from the per-lane cache written by kernel A (A_CZ_STORE)
+    B_SHAKE = 1u << 13,       // position constraints of the SHAKE clusters on the step's displacement (OpenMM applyConstraints)
     B_WT_STORES = 1u << 27,   // write-through (sc1) stores for the particle arrays: the dirty lines leave L2 during the kernel, not at its end
     B_DBG_NOFOLD = 1u << 28,  // timing experiments only: skip the accumulator fold / the chain arithmetic
     B_DBG_NOMATH = 1u << 29,
@@ -91,6 +93,9 @@ struct KArgs {
     const int2* slots;
     const int32_t* slot_image;
     const int32_t* slot_rand;
+    const int32_t* slot_shake;      // packed SHAKE cluster word per lane (vv_host.hpp), NULL without in-kernel constraints
+    const float4* slot_shake_param; // central lanes: 1/m_c, 0.5/(1/m_c+1/m_p), d^2, 1/m_p
+    double shake_tol;
     const int32_t* slot_big;        // big-molecule index per lane (only with molecules larger than a wave)
     unsigned long long* bigacc;     // int64 fixed point [num_big][4]: sum m vx, m vy, m vz, m
     double big_scale, big_inv_scale;

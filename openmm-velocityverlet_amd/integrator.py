@@ -143,7 +143,7 @@ class VVIntegrator:
         return H.Params(self._temperature, self._frequency, self._drudeTemperature, self._drudeFrequency, self._stepSize,
                         self._numNHChains, self._loopsPerStep, self._maxDrudeDistance, self._friction, self._drudeFriction,
                         self._mirrorLocation, self._electricField, self._cosAcceleration, int(self._useCOMTempGroup),
-                        int(self._useMiddleScheme), int(self._autoSetCOMTempGroup), int(self._autoSetFriction))
+                        int(self._useMiddleScheme), int(self._autoSetCOMTempGroup), int(self._autoSetFriction), self._constraintTolerance)
 
     def _push(self):
         if self._context is not None:
@@ -165,12 +165,15 @@ def create_plan(system: SystemSpec, integrator: "VVIntegrator", precision: str =
         cons=np.ascontiguousarray(system.constraints, dtype=np.int32).reshape(-1),
         ld=np.ascontiguousarray(particles_ld, dtype=np.int32),
         img=np.ascontiguousarray(image_pairs, dtype=np.int32).reshape(-1),
-        el=np.ascontiguousarray(electrolyte, dtype=np.int32))
+        el=np.ascontiguousarray(electrolyte, dtype=np.int32),
+        cdist=np.ascontiguousarray(getattr(system, "constraint_distances", None) if getattr(system, "constraint_distances", None) is not None else [], dtype=np.float64))
+    if k["cdist"].size not in (0, k["cons"].size // 2):
+        raise ValueError("constraint_distances must have one entry per constraint")
     ptr = lambda a: a.ctypes.data if a.size else None
     desc = H.SystemDesc(n, padded(n), ptr(k["masses"]), ptr(k["mol_id"]), system.num_molecules,
                         k["drude"].size // 2, ptr(k["drude"]), k["cons"].size // 2, ptr(k["cons"]),
                         int(system.has_cm_motion_remover), k["ld"].size, ptr(k["ld"]), k["img"].size // 2, ptr(k["img"]),
-                        k["el"].size, ptr(k["el"]), int(shard[0]), int(shard[1]))
+                        k["el"].size, ptr(k["el"]), int(shard[0]), int(shard[1]), ptr(k["cdist"]))
     plan = C.c_void_p()
     err = C.create_string_buffer(512)
     rc = H.lib.vvhip_plan_create(C.byref(desc), C.byref(integrator._params()), H.PRECISION[precision], C.byref(plan), err, 512)

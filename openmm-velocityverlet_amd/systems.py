@@ -62,7 +62,8 @@ class SystemSpec:
     box: np.ndarray               # float64 [3] nm (orthorhombic)
     mol_id: np.ndarray            # int32 [N]  (ContextImpl::getMolecules())
     drude_pairs: np.ndarray       # int32 [Np,2] (drude, parent)  (DrudeForce::getParticleParameters p, p1)
-    constraints: np.ndarray       # int32 [Nc,2]  DOF accounting only; the solvers are OpenMM's
+    constraints: np.ndarray       # int32 [Nc,2]  System constraints (pairs)
+    constraint_distances: np.ndarray = None   # float64 [Nc] nm; given => hydrogen-type clusters are solved in-kernel (SHAKE)
     has_cm_motion_remover: bool = True
     particles_ld: List[int] = field(default_factory=list)
     image_pairs: List[Tuple[int, int]] = field(default_factory=list)   # (image, parent)
@@ -216,6 +217,33 @@ def edl_slab(num_ion_pairs=511, num_electrode=2496, T=333.0, T_drude=1.0, seed=S
     spec.image_pairs = [(o_img + i, o_il + i) for i in range(n_il)]
     spec.particles_electrolyte = list(range(o_il, o_il + n_il))
     assert nmol_il + num_electrode == spec.num_molecules
+    return spec
+
+
+def constrain_hydrogens(spec: SystemSpec, distance: float = 0.109) -> SystemSpec:
+    """HBonds constraints as examples/ommhelper/oplspsffile.py:952-955 asks of OpenMM: every H (mass 1.008 here) is constrained to
+    the heavy particle in front of it in its molecule (the generator lists a heavy atom, its Drude, then its hydrogens), and the
+    hydrogens are put at exactly `distance` from it so the initial state satisfies the constraints."""
+    m = spec.masses
+    cons = []
+    heavy = -1
+    for i in range(spec.num_atoms):
+        if i > 0 and spec.mol_id[i] != spec.mol_id[i - 1]:
+            heavy = -1
+        if m[i] > 1.5:
+            heavy = i
+        elif abs(m[i] - 1.008) < 1e-9 and heavy >= 0 and len([c for c in cons if c[1] == heavy]) < 3:
+            cons.append((i, heavy))
+    cons = np.array(cons, dtype=np.int32).reshape(-1, 2)
+    rng = np.random.default_rng(SEED + 7)
+    u = rng.standard_normal((len(cons), 3))
+    u /= np.linalg.norm(u, axis=1)[:, None]
+    spec.positions[cons[:, 0]] = spec.positions[cons[:, 1]] + distance * u
+    # remove the velocity component along each bond (relative velocity), so the start also satisfies the velocity constraints
+    rel = spec.velocities[cons[:, 0]] - spec.velocities[cons[:, 1]]
+    spec.velocities[cons[:, 0]] -= (rel * u).sum(1)[:, None] * u
+    spec.constraints = cons
+    spec.constraint_distances = np.full(len(cons), distance)
     return spec
 
 

@@ -45,7 +45,7 @@ class SystemDesc(C.Structure):
                 ("num_particles_ld", C.c_int32), ("particles_ld", C.c_void_p),
                 ("num_image_pairs", C.c_int32), ("image_pairs", C.c_void_p),
                 ("num_electrolyte", C.c_int32), ("particles_electrolyte", C.c_void_p),
-                ("shard_begin", C.c_int32), ("shard_end", C.c_int32)]
+                ("shard_begin", C.c_int32), ("shard_end", C.c_int32), ("constraint_distances", C.c_void_p)]
 
 
 class Params(C.Structure):
@@ -55,7 +55,7 @@ class Params(C.Structure):
                 ("max_drude_distance", C.c_double), ("friction", C.c_double), ("drude_friction", C.c_double),
                 ("mirror_location", C.c_double), ("electric_field", C.c_double), ("cos_acceleration", C.c_double),
                 ("use_com_temp_group", C.c_int32), ("use_middle_scheme", C.c_int32),
-                ("auto_set_com_temp_group", C.c_int32), ("auto_set_friction", C.c_int32)]
+                ("auto_set_com_temp_group", C.c_int32), ("auto_set_friction", C.c_int32), ("constraint_tolerance", C.c_double)]
 
 
 class Buffers(C.Structure):
@@ -70,7 +70,7 @@ class PlanInfo(C.Structure):
                 ("use_com_temp_group", C.c_int32), ("friction", C.c_double),
                 ("dof", C.c_double * 3), ("nkbt", C.c_double * 3), ("eta_mass", (C.c_double * MAX_CHAINS) * 3),
                 ("inv_mass_total", C.c_double), ("num_waves", C.c_int32), ("num_slots_used", C.c_int32),
-                ("max_cluster", C.c_int32)]
+                ("max_cluster", C.c_int32), ("num_shake_clusters", C.c_int32), ("constraints_fused", C.c_int32)]
 
 
 class NHState(C.Structure):

@@ -190,6 +190,31 @@ def build_tables(spec, params: Params) -> Dict:
 # ----------------------------------------------------------------------------------------------
 # array layouts shared by oracle, _ref and the product's host mirror
 # ----------------------------------------------------------------------------------------------
+def build_shake(spec):
+    """SHAKE clusters from the System's constraints with OpenMM's admission rule (central particle + <= 3 peripherals of equal mass
+    and distance, each peripheral in one constraint only).  Returns (atoms int32 [n,4], params float32 [n,4]) or None."""
+    cons = np.asarray(spec.constraints).reshape(-1, 2)
+    dist = getattr(spec, "constraint_distances", None)
+    if dist is None or len(cons) == 0:
+        return None
+    deg = np.bincount(cons.reshape(-1), minlength=spec.num_atoms)
+    clusters = {}
+    for (a, b), d in zip(cons, dist):
+        ctr = a if deg[a] > 1 else (b if deg[b] > 1 else (a if spec.masses[a] >= spec.masses[b] else b))
+        per = b if ctr == a else a
+        if deg[per] != 1:
+            raise OracleError("constraint topology is not a set of hydrogen-type clusters")
+        clusters.setdefault(int(ctr), []).append((int(per), float(d)))
+    atoms, params = [], []
+    for ctr, lst in clusters.items():
+        if len(lst) > 3 or len({d for _, d in lst}) != 1 or len({spec.masses[p] for p, _ in lst}) != 1:
+            raise OracleError("constraint topology is not a set of hydrogen-type clusters")
+        imc, imp, d = 1.0 / spec.masses[ctr], 1.0 / spec.masses[lst[0][0]], lst[0][1]
+        atoms.append([ctr] + [p for p, _ in lst] + [-1] * (3 - len(lst)))
+        params.append([imc, 0.5 / (imc + imp), d * d, imp])
+    return np.array(atoms, dtype=np.int32), np.array(params, dtype=np.float32)
+
+
 def padded(n: int) -> int:
     return (n + 31) // 32 * 32          # OpenMM pads the atom count to a multiple of its tile size
 
@@ -251,6 +276,7 @@ class _System(C.Structure):
         ("use_middle", C.c_int),
         ("force_mode", C.c_int), ("site", C.c_void_p), ("k_tether", C.c_double), ("k_drude", C.c_double),
         ("forces_valid", C.c_int), ("num_threads", C.c_int),
+        ("num_shake", C.c_int), ("shake_atoms", C.c_void_p), ("shake_params", C.c_void_p), ("constraint_tolerance", C.c_double),
     ]
 
 
@@ -342,6 +368,10 @@ class OracleSystem:
         s.use_middle = int(p.use_middle_scheme)
         s.force_mode, s.site, s.k_tether, s.k_drude = force_mode, _p(self.site), k_tether, k_drude
         s.forces_valid, s.num_threads = 0, num_threads
+        self.shake = build_shake(spec)
+        s.constraint_tolerance = 1e-5
+        if self.shake is not None:
+            s.num_shake, s.shake_atoms, s.shake_params = len(self.shake[0]), _p(self.shake[0]), _p(self.shake[1])
 
     def step(self, n: int = 1):
         self.L.vvo_step(C.byref(self.s), n)

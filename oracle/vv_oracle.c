@@ -601,6 +601,98 @@ void vvo_update_image_positions(int n_img, real4* posq, real4* posq_corr, const 
     }
 }
 
+/* ------------------------------------------------------------------ OpenMM-style SHAKE clusters (see vv_oracle.h)
+ * One central particle i, up to three peripherals j of equal mass and distance; Gauss-Seidel sweeps (<= 15) until every
+ * constraint of the cluster is within tol (relative, on d^2) resp. every velocity correction is below tol. */
+void vvo_shake_positions(int nclusters, const int* atoms, const float* params, mixed tol, const real4* posq,
+                         const real4* posq_corr, mixed4* pos_delta) {
+    PAR_FOR
+    for (int c = 0; c < nclusters; c++) {
+        const int ic = atoms[4 * c];
+        const mixed invMassCentral = params[4 * c], avgMass = params[4 * c + 1], d2 = params[4 * c + 2], invMassPeripheral = params[4 * c + 3];
+        mixed x, y, z, w;
+        load_pos(posq, posq_corr, ic, &x, &y, &z, &w);
+        mixed rij[3][3], rijsq[3], ld[3], xpj[3][3];
+        int np = 0;
+        for (int k = 0; k < 3; k++) {
+            const int j = atoms[4 * c + 1 + k];
+            if (j < 0) break;
+            mixed px, py, pz, pw;
+            load_pos(posq, posq_corr, j, &px, &py, &pz, &pw);
+            rij[k][0] = x - px; rij[k][1] = y - py; rij[k][2] = z - pz;
+            xpj[k][0] = pos_delta[j].x; xpj[k][1] = pos_delta[j].y; xpj[k][2] = pos_delta[j].z;
+            rijsq[k] = rij[k][0] * rij[k][0] + rij[k][1] * rij[k][1] + rij[k][2] * rij[k][2];
+            ld[k] = d2 - rijsq[k];
+            np++;
+        }
+        mixed xpi[3] = { pos_delta[ic].x, pos_delta[ic].y, pos_delta[ic].z };
+        int converged = 0;
+        for (int iteration = 0; iteration < 15 && !converged; iteration++) {
+            converged = 1;
+            for (int k = 0; k < np; k++) {
+                const mixed rp0 = xpi[0] - xpj[k][0], rp1 = xpi[1] - xpj[k][1], rp2 = xpi[2] - xpj[k][2];
+                const mixed rpsqij = rp0 * rp0 + rp1 * rp1 + rp2 * rp2;
+                const mixed rrpr = rij[k][0] * rp0 + rij[k][1] * rp1 + rij[k][2] * rp2;
+                const mixed diff = fabs(ld[k] - 2.0f * rrpr - rpsqij) / (d2 * tol);
+                if (diff >= 1.0f) {
+                    const mixed acor = (ld[k] - 2.0f * rrpr - rpsqij) * avgMass / (rrpr + rijsq[k]);
+                    const mixed d0 = rij[k][0] * acor, d1 = rij[k][1] * acor, d2v = rij[k][2] * acor;
+                    xpi[0] += d0 * invMassCentral; xpi[1] += d1 * invMassCentral; xpi[2] += d2v * invMassCentral;
+                    xpj[k][0] -= d0 * invMassPeripheral; xpj[k][1] -= d1 * invMassPeripheral; xpj[k][2] -= d2v * invMassPeripheral;
+                    converged = 0;
+                }
+            }
+        }
+        pos_delta[ic].x = xpi[0]; pos_delta[ic].y = xpi[1]; pos_delta[ic].z = xpi[2];
+        for (int k = 0; k < np; k++) {
+            const int j = atoms[4 * c + 1 + k];
+            pos_delta[j].x = xpj[k][0]; pos_delta[j].y = xpj[k][1]; pos_delta[j].z = xpj[k][2];
+        }
+    }
+}
+
+void vvo_shake_velocities(int nclusters, const int* atoms, const float* params, mixed tol, const real4* posq,
+                          const real4* posq_corr, mixed4* velm) {
+    PAR_FOR
+    for (int c = 0; c < nclusters; c++) {
+        const int ic = atoms[4 * c];
+        const mixed invMassCentral = params[4 * c], avgMass = params[4 * c + 1], invMassPeripheral = params[4 * c + 3];
+        mixed x, y, z, w;
+        load_pos(posq, posq_corr, ic, &x, &y, &z, &w);
+        mixed rij[3][3], rijsq[3], vj[3][3];
+        int np = 0;
+        for (int k = 0; k < 3; k++) {
+            const int j = atoms[4 * c + 1 + k];
+            if (j < 0) break;
+            mixed px, py, pz, pw;
+            load_pos(posq, posq_corr, j, &px, &py, &pz, &pw);
+            rij[k][0] = x - px; rij[k][1] = y - py; rij[k][2] = z - pz;
+            vj[k][0] = velm[j].x; vj[k][1] = velm[j].y; vj[k][2] = velm[j].z;
+            rijsq[k] = rij[k][0] * rij[k][0] + rij[k][1] * rij[k][1] + rij[k][2] * rij[k][2];
+            np++;
+        }
+        mixed vi[3] = { velm[ic].x, velm[ic].y, velm[ic].z };
+        int converged = 0;
+        for (int iteration = 0; iteration < 15 && !converged; iteration++) {
+            converged = 1;
+            for (int k = 0; k < np; k++) {
+                const mixed rp0 = vi[0] - vj[k][0], rp1 = vi[1] - vj[k][1], rp2 = vi[2] - vj[k][2];
+                const mixed rrpr = rp0 * rij[k][0] + rp1 * rij[k][1] + rp2 * rij[k][2];
+                const mixed delta = -2.0f * avgMass * rrpr / rijsq[k];
+                const mixed d0 = rij[k][0] * delta, d1 = rij[k][1] * delta, d2v = rij[k][2] * delta;
+                vi[0] += d0 * invMassCentral; vi[1] += d1 * invMassCentral; vi[2] += d2v * invMassCentral;
+                vj[k][0] -= d0 * invMassPeripheral; vj[k][1] -= d1 * invMassPeripheral; vj[k][2] -= d2v * invMassPeripheral;
+                if (fabs(delta) > tol) converged = 0;
+            }
+        }
+        velm[ic].x = vi[0]; velm[ic].y = vi[1]; velm[ic].z = vi[2];
+        for (int k = 0; k < np; k++) {
+            const int j = atoms[4 * c + 1 + k];
+            velm[j].x = vj[k][0]; velm[j].y = vj[k][1]; velm[j].z = vj[k][2];
+        }
+    }
+}
+
 /* ------------------------------------------------------------------ API:340-376 (host, double) */
 void vvo_propagate_nh_chain(int numNHChains, int loopsPerStep, double stepSize, double* eta, double* eta_dot,
                             double* eta_dotdot, const double* eta_mass, double ke2, double ke2_target,
@@ -765,9 +857,13 @@ static void step_middle(vvo_system* s) {           /* API:232-270; constraints/v
     calc_forces(s);
     apply_extra_forces(s);
     vvo_integrate_middle_vel(n, s->padded_num_atoms, s->velm, s->force, s->force_extra, (mixed) s->dt);  /* HOST:144-148 */
+    if (s->num_shake > 0)   /* integration.applyVelocityConstraints, HOST:151 */
+        vvo_shake_velocities(s->num_shake, s->shake_atoms, s->shake_params, (mixed) s->constraint_tolerance, s->posq, s->posq_corr, s->velm);
     vvo_integrate_middle_pos1(n, s->velm, s->pos_delta, s->old_delta, (mixed) s->dt);                     /* HOST:154-158 */
     nh_half(s);
     vvo_integrate_middle_pos2(n, s->velm, s->pos_delta, s->old_delta, (mixed) s->dt);                     /* HOST:169-173 */
+    if (s->num_shake > 0)   /* integration.applyConstraints, HOST:176 */
+        vvo_shake_positions(s->num_shake, s->shake_atoms, s->shake_params, (mixed) s->constraint_tolerance, s->posq, s->posq_corr, s->pos_delta);
     vvo_integrate_middle_pos3(n, s->posq, s->posq_corr, s->pos_delta, s->old_delta, s->velm, (mixed) s->dt); /* HOST:179-185 */
     hard_wall(s);
     if (s->num_images > 0)
@@ -783,6 +879,8 @@ static void step_vv(vvo_system* s) {               /* API:272-338 */
     double fscale = 0.5 * s->dt / (double) 0x100000000;                                                   /* HOST:306 */
     vvo_vv_integrate_velocities(n, s->padded_num_atoms, s->velm, s->force, s->force_extra, s->pos_delta,
                                 (mixed) s->dt, (mixed) fscale, 1);                                        /* HOST:341-348 */
+    if (s->num_shake > 0)   /* HOST:351 */
+        vvo_shake_positions(s->num_shake, s->shake_atoms, s->shake_params, (mixed) s->constraint_tolerance, s->posq, s->posq_corr, s->pos_delta);
     vvo_vv_integrate_positions(n, s->posq, s->posq_corr, s->pos_delta, s->velm, (mixed) s->dt);           /* HOST:355-360 */
     hard_wall(s);
     if (s->num_images > 0)
@@ -792,6 +890,8 @@ static void step_vv(vvo_system* s) {               /* API:272-338 */
     apply_extra_forces(s);
     vvo_vv_integrate_velocities(n, s->padded_num_atoms, s->velm, s->force, s->force_extra, s->pos_delta,
                                 (mixed) s->dt, (mixed) fscale, 0);                                        /* HOST:417-424 */
+    if (s->num_shake > 0)   /* HOST:427 */
+        vvo_shake_velocities(s->num_shake, s->shake_atoms, s->shake_params, (mixed) s->constraint_tolerance, s->posq, s->posq_corr, s->velm);
     nh_half(s);
 }
 void vvo_step(vvo_system* s, int steps) {

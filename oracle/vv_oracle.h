@@ -101,6 +101,10 @@ typedef struct {
     /* classic-VV bookkeeping (VVIntegrator.cpp:286-292) */
     int forces_valid;
     int num_threads;                       /* OpenMP threads for the step drivers */
+    /* constraints solved on the path: OpenMM-style SHAKE clusters, see vvo_shake_positions */
+    int num_shake;  const int* shake_atoms;   /* [4*n]: central, up to three peripherals (-1 = none) */
+    const float* shake_params;                /* [4*n]: 1/m_c, 0.5/(1/m_c + 1/m_p), d^2, 1/m_p       */
+    double constraint_tolerance;
 } vvo_system;
 
 #ifdef __cplusplus
@@ -156,6 +160,13 @@ void vvo_update_image_positions(int n_img, vvo_real4* posq, vvo_real4* posq_corr
                                 vvo_mixed mirror);
 
 /* ---- host-side restatements ---- */
+/* OpenMM's SHAKE for hydrogen-type clusters (applyShakeToPositions / applyShakeToVelocities of its integration utilities; that
+ * source is NOT under /root/reference, so this follows the published algorithm from the call sites HOST:151,176,351,427 and is
+ * not pinned against OpenMM itself).  Positions: acts on the step displacement posDelta, old positions from posq(+corr). */
+void vvo_shake_positions(int nclusters, const int* atoms, const float* params, vvo_mixed tol, const vvo_real4* posq,
+                         const vvo_real4* posq_corr, vvo_mixed4* pos_delta);
+void vvo_shake_velocities(int nclusters, const int* atoms, const float* params, vvo_mixed tol, const vvo_real4* posq,
+                          const vvo_real4* posq_corr, vvo_mixed4* velm);
 void vvo_propagate_nh_chain(int num_chains, int loops_per_step, double step_size, double* eta, double* eta_dot,
                             double* eta_dotdot, const double* eta_mass, double ke2, double ke2_target,
                             double t_target, double* factor);

@@ -31,6 +31,7 @@ vvhip_params paramsOf(const VVIntegrator& it) {
     p.use_com_temp_group = it.getUseCOMTempGroup(); p.use_middle_scheme = it.getUseMiddleScheme();
     p.auto_set_com_temp_group = 0;      // VVIntegrator::initialize has already applied the auto rules
     p.auto_set_friction = 0;
+    p.constraint_tolerance = it.getConstraintTolerance();
     return p;
 }
 bool sameParams(const vvhip_params& a, const vvhip_params& b) {
@@ -45,6 +46,7 @@ bool sameParams(const vvhip_params& a, const vvhip_params& b) {
 HipVVPlan::HipVVPlan(HipContext& cu, const System& system, const VVIntegrator& it, const DrudeForce* force) : cu(cu), plan(NULL) {
     const int n = system.getNumParticles();
     std::vector<double> masses(n);
+    std::vector<double> consDist;
     std::vector<int32_t> molId(n), pairs, cons, ld(it.getParticlesLD().begin(), it.getParticlesLD().end()), img,
         el(it.getParticlesElectrolyte().begin(), it.getParticlesElectrolyte().end());
     for (int i = 0; i < n; i++) { masses[i] = system.getParticleMass(i); molId[i] = it.getParticleMolId(i); }
@@ -58,6 +60,7 @@ HipVVPlan::HipVVPlan(HipContext& cu, const System& system, const VVIntegrator& i
         int a, b; double d;
         system.getConstraintParameters(i, a, b, d);
         cons.push_back(a); cons.push_back(b);
+        consDist.push_back(d);
     }
     bool cmm = false;
     for (int i = 0; i < system.getNumForces(); i++)                     // HOST:550-558
@@ -67,7 +70,7 @@ HipVVPlan::HipVVPlan(HipContext& cu, const System& system, const VVIntegrator& i
     d.num_atoms = n; d.padded_num_atoms = cu.getPaddedNumAtoms();
     d.masses = masses.data(); d.mol_id = molId.data(); d.num_molecules = it.getNumMolecules();
     d.num_drude_pairs = (int) pairs.size() / 2; d.drude_pairs = pairs.data();
-    d.num_constraints = (int) cons.size() / 2; d.constraints = cons.data();
+    d.num_constraints = (int) cons.size() / 2; d.constraints = cons.data(); d.constraint_distances = consDist.empty() ? NULL : consDist.data();
     d.has_cm_motion_remover = cmm;
     d.num_particles_ld = (int) ld.size(); d.particles_ld = ld.data();
     d.num_image_pairs = (int) img.size() / 2; d.image_pairs = img.data();
@@ -79,7 +82,7 @@ HipVVPlan::HipVVPlan(HipContext& cu, const System& system, const VVIntegrator& i
     vvhip_plan_info info;
     vvhip_plan_get_info(plan, &info);
     ldRandoms = std::max(info.num_normal_ld, 1) + 2 * std::max(info.num_pairs_ld, 1);   // HOST:806-807,863: array sizes are max(n,1)
-    noConstraints = system.getNumConstraints() == 0;
+    noConstraints = info.constraints_fused != 0;      // no constraints at all, or all of them solved inside the kernels
     HipIntegrationUtilities& integration = cu.getIntegrationUtilities();
     vvhip_buffers b = {};
     b.velm = cu.getVelm().getDevicePointer(); b.posq = cu.getPosq().getDevicePointer();

@@ -74,7 +74,7 @@ static void tether(ContextImpl&, void* user) {
 
 template <class T> static void put(std::ofstream& f, const std::vector<T>& v) { long long n = (long long) v.size(); f.write((const char*) &n, 8); f.write((const char*) v.data(), n * sizeof(T)); }
 
-static int run(const char* out, bool middle, bool withConstraint, double cosacc, int nsteps) {
+static int run(const char* out, bool middle, int consMode, double cosacc, int nsteps) {
     registerHipVVKernelFactories();
     Platform& hip = Platform::getPlatformByName("HIP");
     const int nmol = 40, per = 8;              // [heavy, drude, heavy, drude, heavy, drude, H, H] per molecule
@@ -97,8 +97,15 @@ static int run(const char* out, bool middle, bool withConstraint, double cosacc,
         }
     system.addForce(drude);
     system.addForce(new CMMotionRemover());
+    // consMode 1: a rigid triangle in molecule 0 -- not a hydrogen-type cluster, so the plan leaves constraints to OpenMM's solver
+    //             and VVIntegrator takes the un-fused path (the stand-in solver is a no-op; only the path and the DOF matter);
+    // consMode 2: both hydrogens of every molecule constrained to the heavy particle 4 -- solved inside the fused kernels.
     std::vector<int> cons;
-    if (withConstraint) { system.addConstraint(6, 4, 0.1); cons = {6, 4}; }   // only its presence matters here: it forces the un-fused path
+    std::vector<double> consDist;
+    auto addCons = [&](int a, int b, double d) { system.addConstraint(a, b, d); cons.push_back(a); cons.push_back(b); consDist.push_back(d); };
+    if (consMode == 1) { addCons(6, 4, 0.1); addCons(7, 4, 0.1); addCons(6, 7, 0.16); }
+    if (consMode == 2)
+        for (int m = 0; m < nmol; m++) { addCons(m * per + 6, m * per + 4, 0.1); addCons(m * per + 7, m * per + 4, 0.1); }
     const double box[3] = {3.0, 3.0, 3.0}, kB = (1.380649e-23 * 6.02214076e23) / 1000.0;
     std::vector<double> pos(3 * n), vel(3 * n);
     for (int m = 0; m < nmol; m++) {
@@ -112,6 +119,15 @@ static int run(const char* out, bool middle, bool withConstraint, double cosacc,
             }
         }
     }
+    if (consMode == 2)                          // start on the constraint manifold: |r| = d, no relative velocity along the bond
+        for (size_t c = 0; c < consDist.size(); c++) {
+            const int h = cons[2 * c], o = cons[2 * c + 1];
+            double u[3], len = 0, along = 0;
+            for (int d = 0; d < 3; d++) { u[d] = pos[3 * h + d] - pos[3 * o + d]; len += u[d] * u[d]; }
+            len = std::sqrt(len);
+            for (int d = 0; d < 3; d++) { u[d] /= len; pos[3 * h + d] = pos[3 * o + d] + consDist[c] * u[d]; along += (vel[3 * h + d] - vel[3 * o + d]) * u[d]; }
+            for (int d = 0; d < 3; d++) vel[3 * h + d] -= along * u[d];
+        }
     ProbeIntegrator it(333.0, 10.0, 1.0, 40.0, 0.001);
     it.setMaxDrudeDistance(0.02);
     it.setUseMiddleScheme(middle);
@@ -144,7 +160,7 @@ static int run(const char* out, bool middle, bool withConstraint, double cosacc,
     cu.getVelm().download(velm.data()); cu.getPosq().download(posq.data()); cu.getPosqCorrection().download(corr.data());
     std::ofstream f(out, std::ios::binary);
     put(f, masses); put(f, charges); put(f, molId); put(f, pairs); put(f, cons); put(f, pos); put(f, vel);
-    put(f, velm); put(f, posq); put(f, corr); put(f, vis);
+    put(f, velm); put(f, posq); put(f, corr); put(f, vis); put(f, consDist);
     std::printf("RUN OK steps=%d time=%.6f stepCount=%lld vMax=%.9g\n", nsteps, cu.getTime(), cu.getStepCount(), vis[0]);
     return 0;
 }
@@ -153,7 +169,7 @@ int main(int argc, char** argv) {
     try {
         if (argc >= 2 && !std::strcmp(argv[1], "registry")) return registry();
         if (argc >= 2 && !std::strcmp(argv[1], "chain")) return chain();
-        if (argc >= 7 && !std::strcmp(argv[1], "run")) return run(argv[2], std::atoi(argv[3]) != 0, std::atoi(argv[4]) != 0, std::atof(argv[5]), std::atoi(argv[6]));
+        if (argc >= 7 && !std::strcmp(argv[1], "run")) return run(argv[2], std::atoi(argv[3]) != 0, std::atoi(argv[4]), std::atof(argv[5]), std::atoi(argv[6]));
     } catch (const std::exception& e) {
         std::fprintf(stderr, "exception: %s\n", e.what());
         return 2;

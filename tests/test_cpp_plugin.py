@@ -46,7 +46,7 @@ def _read(path):
     raw = open(path, "rb").read()
     off = 0
     out = []
-    for dt in ("f8", "f8", "i4", "i4", "i4", "f8", "f8", "f8", "f4", "f4", "f8"):
+    for dt in ("f8", "f8", "i4", "i4", "i4", "f8", "f8", "f8", "f4", "f4", "f8", "f8"):
         (n,) = struct.unpack_from("<q", raw, off)
         off += 8
         a = np.frombuffer(raw, dtype=dt, count=n, offset=off).copy()
@@ -56,18 +56,21 @@ def _read(path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("middle,cons,cos", [(1, 0, 0.0), (1, 1, 0.0), (1, 0, 0.02), (1, 1, 0.02), (0, 0, 0.0), (0, 1, 0.02)])
+@pytest.mark.parametrize("middle,cons,cos", [(1, 0, 0.0), (1, 1, 0.0), (1, 0, 0.02), (1, 1, 0.02), (0, 0, 0.0), (0, 1, 0.02),
+                                             (1, 2, 0.0), (1, 2, 0.02), (0, 2, 0.0)])
 def test_cpp_integrator_through_plugin_matches_oracle(tmp_path, middle, cons, cos):
     nsteps = 12
     dump = str(tmp_path / "run.bin")
     r = subprocess.run([DRIVER, "run", dump, str(middle), str(cons), str(cos), str(nsteps)], capture_output=True, text=True)
     assert r.returncode == 0 and "RUN OK" in r.stdout, r.stdout + r.stderr
     assert f"stepCount={nsteps}" in r.stdout
-    masses, charges, mol, pairs, cns, pos, vel, velm, posq, corr, vis = _read(dump)
+    masses, charges, mol, pairs, cns, pos, vel, velm, posq, corr, vis, cdist = _read(dump)
     n = masses.shape[0]
     spec = systems.SystemSpec(name="cpp", masses=masses, charges=charges, positions=pos.reshape(n, 3), velocities=vel.reshape(n, 3),
                               box=np.array([3.0, 3.0, 3.0]), mol_id=mol, drude_pairs=pairs.reshape(-1, 2),
                               constraints=cns.reshape(-1, 2), has_cm_motion_remover=True)
+    if cons == 2:       # hydrogen-type clusters: solved in the fused kernels, and by the oracle's SHAKE (cons == 1: see the driver)
+        spec.constraint_distances = cdist
     p = O.Params(temperature=333.0, drude_temperature=1.0, max_drude_distance=0.02, cos_acceleration=cos, use_middle_scheme=bool(middle))
     osys = O.OracleSystem(spec, p, "mixed", force_mode=1)
     osys.step(nsteps)
@@ -78,3 +81,7 @@ def test_cpp_integrator_through_plugin_matches_oracle(tmp_path, middle, cons, co
     assert ex < 1e-5 and ev < 1e-5, (ex, ev)
     if cos != 0:
         assert vis[0] == pytest.approx(osys.viscosity()[0], rel=1e-6, abs=1e-12)
+    if cons == 2:
+        c = cns.reshape(-1, 2)
+        r = np.linalg.norm(x_g[c[:, 0]] - x_g[c[:, 1]], axis=1)
+        assert np.abs(r * r - cdist ** 2).max() < 2e-5 * cdist[0] ** 2, np.abs(r - cdist).max()

@@ -1,0 +1,155 @@
+"""-m gpu: constraints solved on the path.  Hydrogen-type constraint clusters are SHAKEn inside the
+fused kernels (A: velocities after the kick; B: the step displacement before the position update) at the points where the
+reference calls OpenMM's applyVelocityConstraints / applyConstraints (CudaVVKernels.cpp:151,176,351,427).  Checked against the
+oracle's CPU statement of the same algorithm on the same seeded inputs (1e-5 relative, as for the unconstrained steps) and
+through the constraint invariants themselves, which do not depend on the oracle:
+  |r_ij|^2 = d^2 within the solver tolerance after every step, bond-parallel relative velocity ~ 0 after a classic-VV step."""
+import importlib
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pkg = importlib.import_module("openmm-velocityverlet_amd")
+H, I, systems = pkg.vvhip, pkg.integrator, pkg.systems
+pytestmark = pytest.mark.gpu
+
+NSTEPS = {"single": 2, "mixed": 20, "double": 20}
+TOL = 1e-5          # VVIntegrator's default constraint tolerance (OpenMM Integrator default)
+
+
+def _pair(spec, prec, middle, nsteps, maxd=0.02, T=333.0, dt=0.001, use_com=None):
+    p = O.Params(temperature=T, drude_temperature=1.0, step_size=dt, max_drude_distance=maxd, use_middle_scheme=middle)
+    if use_com is not None:                 # explicit choice switches the automatic one off (VVIntegrator.h:147-150)
+        p.use_com_temp_group, p.auto_set_com_temp_group = use_com, False
+    osys = O.OracleSystem(spec, p, prec, force_mode=1)
+    it = I.VVIntegrator(T, 10.0, 1.0, 40.0, dt)
+    it.setMaxDrudeDistance(maxd)
+    it.setUseMiddleScheme(middle)
+    if use_com is not None:
+        it.setUseCOMTempGroup(use_com)
+    ctx = I.Context(spec, it, precision=prec, force_provider="tether")
+    osys.step(nsteps)
+    it.step(nsteps)
+    return osys, ctx, it
+
+
+def _invariants(spec, ctx, prec, middle, label):
+    x, v = ctx.getPositions(), ctx.getVelocities()
+    c, d = np.asarray(spec.constraints), np.asarray(spec.constraint_distances)
+    r = x[c[:, 0]] - x[c[:, 1]]
+    r2 = (r * r).sum(1)
+    # positions come back through real4 (+ correction in mixed mode): single precision adds ~1e-7 * |x| / d on top of the tolerance
+    slack = 2.0 * TOL + (4e-5 if prec == "single" else 1e-9)
+    assert np.abs(r2 - d * d).max() < slack * (d * d).max(), f"{label}: |r^2 - d^2|/d^2 = {np.abs(r2 - d * d).max() / (d * d).max():.2e}"
+    if not middle:      # the classic scheme ends with the velocity constraints; the middle scheme ends with a position update
+        rel = ((v[c[:, 0]] - v[c[:, 1]]) * r).sum(1) / np.sqrt(r2)
+        assert np.abs(rel).max() < 1e-3, f"{label}: bond-parallel relative velocity {np.abs(rel).max():.2e} nm/ps"
+
+
+def _parity(osys, ctx, prec, label, tol=1e-5):
+    x_o, x_g = osys.positions(), ctx.getPositions()
+    v_o, v_g = osys.velm[:, :3].astype(np.float64), ctx.getVelocities()
+    ex = np.abs(x_g - x_o).max() / np.abs(x_o).max()
+    ev = np.abs(v_g - v_o).max() / np.abs(v_o).max()
+    assert np.isfinite(x_g).all() and np.isfinite(v_g).all(), label
+    assert ex < tol and ev < tol, f"{label}: rel err pos {ex:.2e} vel {ev:.2e}"
+    print(f"{label}: rel err pos {ex:.2e} vel {ev:.2e}")
+
+
+@pytest.mark.parametrize("prec", O.PRECISIONS)
+@pytest.mark.parametrize("middle", [True, False])
+def test_water_oh_constraints(prec, middle):
+    """3-site water, both O-H bonds constrained (two peripherals per cluster), plain NH (non-COM layout)."""
+    spec = systems.constrain_hydrogens(systems.spce_water(300, seed=5), distance=0.1)
+    assert len(spec.constraints) == 600
+    osys, ctx, it = _pair(spec, prec, middle, NSTEPS[prec], maxd=0.0, T=300.0, dt=0.002)
+    try:
+        assert ctx.info.constraints_fused and ctx.info.num_shake_clusters == 300
+        assert list(ctx.info.dof)[0] == 3 * 900 - 600 - 3
+        _parity(osys, ctx, prec, f"water-shake/{prec}/middle={middle}")
+        _invariants(spec, ctx, prec, middle, f"water-shake/{prec}/middle={middle}")
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("prec", O.PRECISIONS)
+@pytest.mark.parametrize("middle", [True, False])
+@pytest.mark.parametrize("use_com", [True, False])
+def test_drude_il_hbonds(prec, middle, use_com):
+    """Polarisable ionic liquid with HBonds constraints (examples/ommhelper/oplspsffile.py:952-955): clusters of 1-3 hydrogens
+    next to Drude pairs; with the COM group whole molecules share a wave, without it Drude pairs and SHAKE mates are merged."""
+    spec = systems.constrain_hydrogens(systems.drude_il(cells=(1, 1, 1), pairs_per_cell=40, seed=7))
+    osys, ctx, it = _pair(spec, prec, middle, NSTEPS[prec], use_com=use_com)
+    try:
+        assert ctx.info.constraints_fused and ctx.info.num_shake_clusters > 0
+        _parity(osys, ctx, prec, f"il-shake/{prec}/middle={middle}/com={use_com}")
+        _invariants(spec, ctx, prec, middle, f"il-shake/{prec}/middle={middle}/com={use_com}")
+        st = ctx.getNHState()
+        assert np.allclose(np.array(list(st.ke2))[:osys.s.num_tg], osys.ke2()[:osys.s.num_tg], rtol=2e-4)
+    finally:
+        ctx.close()
+
+
+def test_constraints_hold_over_a_long_run_and_graph_replay_is_identical():
+    spec = systems.constrain_hydrogens(systems.drude_il(cells=(1, 1, 1), pairs_per_cell=60, seed=11))
+    res = []
+    for mode in ("eager", "graph"):
+        it = I.VVIntegrator(333.0, 10, 1.0, 40, 0.001)
+        it.setMaxDrudeDistance(0.02)
+        ctx = I.Context(spec, it, precision="mixed", force_provider="tether")
+        if mode == "eager":
+            it.step(400)
+            _invariants(spec, ctx, "mixed", True, "il-shake/long")
+        else:
+            ctx.run_graph(400, steps_per_graph=8)
+        res.append((ctx.getPosq(), ctx.getVelm()))
+        ctx.close()
+    assert np.array_equal(res[0][0].view(np.uint8), res[1][0].view(np.uint8))
+    assert np.array_equal(res[0][1].view(np.uint8), res[1][1].view(np.uint8))
+
+
+def test_unfusable_topology_is_left_to_the_host_solver():
+    """A rigid triangle (three mutual constraints) is not a hydrogen-type cluster: the plan reports constraints_fused = 0, refuses
+    the fused step (so a caller cannot silently run unconstrained) and the split entry points stay available."""
+    spec = systems.spce_water(50, seed=3)
+    cons, dist = [], []
+    for m in range(50):
+        o = 3 * m
+        cons += [(o + 1, o), (o + 2, o), (o + 1, o + 2)]
+        dist += [0.1, 0.1, 0.1633]
+    spec.constraints = np.array(cons, dtype=np.int32)
+    spec.constraint_distances = np.array(dist)
+    it = I.VVIntegrator(300.0, 10, 1.0, 40, 0.002)
+    it.setMaxDrudeDistance(0.0)
+    ctx = I.Context(spec, it, precision="mixed", force_provider="tether")
+    try:
+        assert not ctx.info.constraints_fused and ctx.info.num_shake_clusters == 0
+        assert list(ctx.info.dof)[0] == 3 * 150 - 150 - 3
+        ctx.calcForces()
+        rc = H.lib.vvhip_step_middle(ctx.plan, 0)
+        assert rc != 0 and b"constraint" in H.lib.vvhip_last_error(ctx.plan)
+        for fn in (H.lib.vvhip_reset_extra_force, H.lib.vvhip_middle_kick, H.lib.vvhip_middle_half_drift1):
+            H.check(fn(ctx.plan), ctx.plan)
+    finally:
+        ctx.close()
+
+
+def test_full_size_c3_with_hbonds():
+    """BASELINE.json C3 (111 000 particles) with HBonds constraints, size-independent properties only."""
+    spec = systems.constrain_hydrogens(systems.make_config("C3"))
+    it = I.VVIntegrator(333.0, 10, 1.0, 40, 0.001)
+    it.setMaxDrudeDistance(0.02)
+    ctx = I.Context(spec, it, precision="mixed", force_provider="tether")
+    try:
+        assert ctx.info.constraints_fused and ctx.info.num_shake_clusters == 9000 and len(spec.constraints) == 21000
+        ctx.run_graph(64, steps_per_graph=8)
+        _invariants(spec, ctx, "mixed", True, "C3-shake")
+        st = ctx.getNHState()
+        T = np.array(list(st.ke2)) / np.array(list(ctx.info.dof)) / O.BOLTZ
+        # 64 fs into a run on harmonic tethers: kinetic energy has partly gone into the tethers, the thermostat (10/ps) has not
+        # answered yet -- only sanity bounds here, parity is covered at oracle sizes above
+        assert 50 < T[0] < 420 and 50 < T[1] < 420, T
+    finally:
+        ctx.close()

@@ -144,3 +144,32 @@ def test_big_molecule_is_cut_into_wave_sized_chunks():
     assert ((meta >> 29) & 1).sum() == 1                      # exactly one lane adds the molecule's M V^2 / clears nothing twice
     assert ((meta >> 24) & 1).sum() == 3                      # one chunk leader per wave
     assert info.dof[1] == 0.0                                 # 3*1 molecule - 3 (CMMotionRemover) = 0 -> no COM group DOF
+
+
+@pytest.mark.parametrize("use_com", [None, False])
+def test_constraint_clusters_share_a_wave(use_com):
+    """In-kernel SHAKE needs every constraint cluster inside one 64-lane wave (and, without the COM group, together with the
+    Drude pairs hanging off its members).  Cluster admission follows OpenMM's SHAKE rule; the oracle restates it independently."""
+    spec = systems.constrain_hydrogens(systems.drude_il(cells=(1, 1, 1), pairs_per_cell=25, seed=2))
+    it = I.VVIntegrator(333.0, 10, 1.0, 40, 0.001)
+    if use_com is not None:
+        it.setUseCOMTempGroup(use_com)
+    info, slots = I.plan_layout(spec, it)
+    atoms, params = O.build_shake(spec)
+    assert info.constraints_fused and info.num_shake_clusters == len(atoms)
+    wave_of = np.full(spec.num_atoms, -1)
+    live = slots[:, 0] >= 0
+    wave_of[slots[live, 0]] = np.nonzero(live)[0] // 64
+    for row in atoms:
+        members = row[row >= 0]
+        assert len(set(wave_of[members])) == 1 and wave_of[members[0]] >= 0
+    for d, par in np.asarray(spec.drude_pairs):
+        assert wave_of[d] == wave_of[par]
+    # a rigid triangle is not such a cluster: reported, not silently dropped
+    spec2 = systems.spce_water(4)
+    spec2.constraints = np.array([(1, 0), (2, 0), (1, 2)], dtype=np.int32)
+    spec2.constraint_distances = np.array([0.1, 0.1, 0.16])
+    info2, _ = I.plan_layout(spec2, I.VVIntegrator(300.0, 10, 1.0, 40, 0.001))
+    assert not info2.constraints_fused and info2.num_shake_clusters == 0
+    with pytest.raises(O.OracleError):
+        O.build_shake(spec2)
