@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--dist-mode", default="auto", choices=["auto", "graph", "eager", "python"],
                     help="N>1: graph = RCCL all-reduce captured in the hipGraph; eager = issued from C per step; python = torch.distributed per step")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--hbonds", action="store_true", help="constrain every hydrogen to its heavy atom (HBonds), solved in-kernel (not the headline workload)")
     args = ap.parse_args()
 
     import numpy as np
@@ -69,6 +70,8 @@ def main():
         spec = S.make_config("C3", float(cfg[3:]))
     else:
         spec = S.make_config(cfg)
+    if args.hbonds:
+        spec = S.constrain_hydrogens(spec, 0.1 if cfg == "C2" else 0.109)
     dt = 0.002 if cfg == "C2" else 0.001
     it = I.VVIntegrator(300.0 if cfg == "C2" else 333.0, 10.0, 1.0, 40.0, dt)
     if cfg not in ("C1", "C2"):
@@ -176,6 +179,7 @@ def main():
             "config": {"workload": f"{cfg}: {spec.name}, {n} particles, {spec.num_molecules} molecules, "
                                    f"{len(spec.drude_pairs)} Drude pairs; TGNH thermostat ({ctx.info.num_temp_groups} groups), middle scheme, "
                                    f"hard wall 0.02 nm, dt {dt * 1e3:g} fs" + (", cos acceleration 0.02 nm/ps^2" if cfg == "C4" else "")
+                                   + (f", {len(spec.constraints)} HBonds constraints in {ctx.info.num_shake_clusters} clusters (in-kernel SHAKE)" if args.hbonds else "")
                                    + (f", {len(spec.particles_ld)} Langevin particles (device Philox normals), {len(spec.image_pairs)} image pairs, E-field" if cfg == "C5" else ""),
                        "force_provider": f"{args.forces} (synthetic, inside the timed region)" if args.forces == "tether" else "static buffer",
                        "launch": "hipGraph replay, %d steps/graph" % args.steps_per_graph if use_graph else "host-launched per step",
@@ -253,7 +257,7 @@ def main():
                                "sample": f"{nsteps} steps of the same {cfg} workload ({cpu_elapsed:.1f} s), oracle/vv_oracle.c with OpenMP, "
                                          f"fastest of 1..{min(ncpu, 128)} threads on a {ncpu}-CPU host"}
     # ---- the reference's own kernel sequence on this GPU (oracle/_ref GPU build; present only if built where /root/reference exists)
-    if world == 1 and rank == 0 and not use_dist and cfg in ("C2", "C3", "C4") and args.precision == "mixed" and args.forces == "tether":
+    if world == 1 and rank == 0 and not use_dist and cfg in ("C2", "C3", "C4") and args.precision == "mixed" and args.forces == "tether" and not args.hbonds:
         try:
             from oracle import oracle as O
             if O.have_ref_gpu():

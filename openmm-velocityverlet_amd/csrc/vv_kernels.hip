@@ -228,9 +228,10 @@ __device__ __forceinline__ void shake_positions(int lane, unsigned word, float4 
                     const mixed rp0 = xpi[0] - xpj[k][0], rp1 = xpi[1] - xpj[k][1], rp2 = xpi[2] - xpj[k][2];
                     const mixed rpsqij = rp0 * rp0 + rp1 * rp1 + rp2 * rp2;
                     const mixed rrpr = rij[k][0] * rp0 + rij[k][1] * rp1 + rij[k][2] * rp2;
+                    // both quotients are started together (the wave is latency-bound here); values as in the branchy statement
                     const mixed diff = fabs(ld[k] - 2.0f * rrpr - rpsqij) / (d2 * tol);
+                    const mixed acor = (ld[k] - 2.0f * rrpr - rpsqij) * avgMass / (rrpr + rijsq[k]);
                     if (diff >= 1.0f) {
-                        const mixed acor = (ld[k] - 2.0f * rrpr - rpsqij) * avgMass / (rrpr + rijsq[k]);
                         const mixed d0 = rij[k][0] * acor, d1 = rij[k][1] * acor, d2v = rij[k][2] * acor;
                         xpi[0] += d0 * invMassCentral; xpi[1] += d1 * invMassCentral; xpi[2] += d2v * invMassCentral;
                         xpj[k][0] -= d0 * invMassPeripheral; xpj[k][1] -= d1 * invMassPeripheral; xpj[k][2] -= d2v * invMassPeripheral;
@@ -1150,6 +1151,9 @@ constexpr uint32_t SF_B_COS_HW = B_CHAIN | B_SCALE | B_UNBIAS | B_CZ_LOAD | B_DR
 constexpr uint32_t SF_B_MIDDLE_HW = B_CHAIN | B_SCALE | B_DRIFT_MIDDLE | B_HARDWALL;
 constexpr uint32_t SF_B_MIDDLE_HW_WT = SF_B_MIDDLE_HW | B_WT_STORES;
 constexpr uint32_t SF_B_MIDDLE = B_CHAIN | B_SCALE | B_DRIFT_MIDDLE;
+constexpr uint32_t SF_A_MIDDLE_SHAKE = SF_A_MIDDLE | A_SHAKE_V;                         // HBonds constraints solved in-kernel
+constexpr uint32_t SF_B_MIDDLE_HW_SHAKE = SF_B_MIDDLE_HW | B_SHAKE;
+constexpr uint32_t SF_B_MIDDLE_SHAKE = SF_B_MIDDLE | B_SHAKE;
 
 hipError_t launch_a(int precision, const KArgs& a, int block_threads, hipStream_t s) {
     dim3 g = grid_for(a.nwaves, block_threads);
@@ -1158,6 +1162,7 @@ hipError_t launch_a(int precision, const KArgs& a, int block_threads, hipStream_
     if (a.flags == SF_A_MIDDLE) { VV_DISPATCH_SF(vv_kernel_a, SF_A_MIDDLE, g, b, 0, s, a); }
     else if (a.flags == SF_A_MIDDLE_WT) { VV_DISPATCH_SF(vv_kernel_a, SF_A_MIDDLE_WT, g, b, 0, s, a); }
     else if (a.flags == SF_A_COS1) { VV_DISPATCH_SF(vv_kernel_a, SF_A_COS1, g, b, 0, s, a); }
+    else if (a.flags == SF_A_MIDDLE_SHAKE) { VV_DISPATCH_SF(vv_kernel_a, SF_A_MIDDLE_SHAKE, g, b, 0, s, a); }
     else if (a.flags == SF_A_COS2) { VV_DISPATCH_SF(vv_kernel_a, SF_A_COS2, g, b, 0, s, a); }
     else { VV_DISPATCH_SF(vv_kernel_a, 0u, g, b, 0, s, a); }
     return hipGetLastError();
@@ -1172,6 +1177,8 @@ hipError_t launch_b(int precision, const KArgs& a, int block_threads, hipStream_
     else if (a.flags == SF_B_MIDDLE_HW_WT) { VV_DISPATCH_SF(vv_kernel_b, SF_B_MIDDLE_HW_WT, g, b, 0, s, a); }
     else if (a.flags == SF_B_MIDDLE) { VV_DISPATCH_SF(vv_kernel_b, SF_B_MIDDLE, g, b, 0, s, a); }
     else if (a.flags == SF_B_COS_HW) { VV_DISPATCH_SF(vv_kernel_b, SF_B_COS_HW, g, b, 0, s, a); }
+    else if (a.flags == SF_B_MIDDLE_HW_SHAKE) { VV_DISPATCH_SF(vv_kernel_b, SF_B_MIDDLE_HW_SHAKE, g, b, 0, s, a); }
+    else if (a.flags == SF_B_MIDDLE_SHAKE) { VV_DISPATCH_SF(vv_kernel_b, SF_B_MIDDLE_SHAKE, g, b, 0, s, a); }
     else { VV_DISPATCH_SF(vv_kernel_b, 0u, g, b, 0, s, a); }
     return hipGetLastError();
 }
