@@ -37,8 +37,11 @@ def main():
     ap.add_argument("--eager", action="store_true", help="no hipGraph replay (host-launched every step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-GPU code path (process group + exchange) even at N=1")
-    ap.add_argument("--dist-mode", default="auto", choices=["auto", "graph", "eager", "python"],
-                    help="N>1: graph = RCCL all-reduce captured in the hipGraph; eager = issued from C per step; python = torch.distributed per step")
+    ap.add_argument("--dist-mode", default="auto", choices=["auto", "mailbox", "graph", "eager", "python"],
+                    help="N>1: mailbox = totals stored into the peers over xGMI by the kernels themselves (default when its trial run passes); "
+                         "graph = RCCL all-reduce captured in the hipGraph; eager = RCCL issued from C per step; python = torch.distributed per step")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (gloo + --share-device: tests on a one-GPU box)")
+    ap.add_argument("--share-device", action="store_true", help="all ranks use GPU 0 (tests only)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--hbonds", action="store_true", help="constrain every hydrogen to its heavy atom (HBonds), solved in-kernel (not the headline workload)")
     args = ap.parse_args()
@@ -54,12 +57,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path is HIP only (no CPU fallback)")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     pkg = importlib.import_module("openmm-velocityverlet_amd")
     I, S, D = pkg.integrator, pkg.systems, pkg.distributed
@@ -83,55 +91,98 @@ def main():
         it.setMirrorLocation(lz / 2)
         it.setElectricField(2.0 / lz * 2 * 1.602176634e-22)
     bounds = D.shard_bounds(spec, world)
-    # N > 1: the plan gets its own RCCL communicator (bootstrap through the torch process group) and then exchanges the
-    # accumulators itself, inside the captured graph if possible; torch.distributed per step is the last resort.
+    # N > 1, in order of preference (each step down only if the one above cannot be set up or fails its trial run on any rank):
+    #   mailbox  kernel A's last block stores the rank's int64 totals into every peer's box over xGMI (hipIpc mappings), kernel B's
+    #            thermostat wave collects them: no collective launch, the sharded step stays two launches inside the hipGraph;
+    #   eager    in-core RCCL: ncclAllReduce enqueued from C between kernel A and kernel B of every step (graph = captured; opt-in,
+    #            multi-rank capture cannot be tried in the build environment);
+    #   python   torch.distributed all-reduce per step.
     dist_mode = None
     ctx = None
-    if use_dist and args.dist_mode != "python":
+
+    def agree(ok):
+        flag = torch.tensor([1 if ok else 0], device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return int(flag.item()) == 1
+
+    def fresh_context(stream=None):
+        it._context = None
+        return I.Context(spec, it, precision=args.precision, force_provider=args.forces, shard=bounds[rank], device=local_rank, stream=stream)
+
+    if use_dist and args.dist_mode in ("auto", "mailbox") and cfg != "C4":
+        ok = True
         try:
-            ctx = I.Context(spec, it, precision=args.precision, force_provider=args.forces, shard=bounds[rank], device=local_rank)
+            ctx = fresh_context()
+            mine = torch.frombuffer(bytearray(ctx.mailbox_create(world, rank)), dtype=torch.uint8).cuda()
+            allh = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(allh, mine)
+            ctx.mailbox_connect(b"".join(bytes(h.cpu().numpy().tobytes()) for h in allh))
+        except Exception as e:                                   # noqa: BLE001
+            sys.stderr.write(f"[rank {rank}] mailbox exchange unavailable ({e})\n")
+            ok = False
+        if agree(ok):
+            try:                                                 # trial: eager steps, then a replayed graph; all ranks must end up
+                it.step(4)                                       # with the very same thermostat bits and no wait may have run out
+                if not ctx.mailbox_status()[1]:
+                    ctx.run_graph(2 * args.steps_per_graph, args.steps_per_graph)
+                ctx.synchronize()
+                active, timed_out = ctx.mailbox_status()
+                st = ctx.getNHState()
+                mine = torch.tensor(list(st.ke2) + list(st.vscale), dtype=torch.float64, device="cuda")
+                every = [torch.empty_like(mine) for _ in range(world)]
+                dist.all_gather(every, mine)
+                ok = active and not timed_out and all(torch.equal(e.view(torch.int64), mine.view(torch.int64)) for e in every) \
+                    and bool(torch.isfinite(mine).all())
+            except Exception as e:                               # noqa: BLE001
+                sys.stderr.write(f"[rank {rank}] mailbox trial failed ({e})\n")
+                ok = False
+            if agree(ok):
+                dist_mode = "mailbox"
+        if dist_mode is None:
+            if rank == 0:
+                sys.stderr.write("mailbox exchange not usable here; falling back to RCCL\n")
+            if ctx is not None:
+                try:
+                    ctx.close()
+                except Exception:                                # noqa: BLE001
+                    pass
+            ctx = None
+    if use_dist and dist_mode is None and args.dist_mode != "python":
+        try:
+            ctx = fresh_context()
             idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
             if rank == 0:
                 idt.copy_(torch.frombuffer(bytearray(ctx.comm_unique_id()), dtype=torch.uint8))
             dist.broadcast(idt, src=0)
             ctx.comm_init(bytes(idt.cpu().numpy().tobytes()), world, rank)
-            ok = 1
+            ok = True
         except Exception as e:                                   # noqa: BLE001
             sys.stderr.write(f"[rank {rank}] in-core RCCL unavailable ({e}); falling back to torch.distributed per step\n")
-            ok = 0
-        flag = torch.tensor([ok], device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 1:
-            # auto = eager: ncclAllReduce enqueued from C between kernel A and kernel B of every step (plain RCCL usage).
-            # Capturing a multi-rank RCCL collective in a hipGraph works with one rank here but cannot be tried on more
-            # than one GPU in the build environment, so it stays opt-in (--dist-mode graph).
+            ok = False
+        if agree(ok):
             dist_mode = "graph" if args.dist_mode == "graph" else "eager"
             if dist_mode == "graph":                             # every rank must agree that capture works
                 try:
                     ctx.run_graph(2, 2)
                     ctx.synchronize()
-                    ok = 1
+                    ok = True
                 except Exception as e:                           # noqa: BLE001
                     sys.stderr.write(f"[rank {rank}] graph capture with RCCL failed ({e}); using the C eager loop\n")
-                    ok = 0
-                flag = torch.tensor([ok], device="cuda")
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                if int(flag.item()) == 0:
+                    ok = False
+                if not agree(ok):
                     dist_mode = "eager"
         else:
             if ctx is not None:
                 ctx.close()
-            it._context = None
             ctx = None
     stepper = None
     if ctx is None:
         stream = torch.cuda.current_stream().cuda_stream if use_dist else None
-        ctx = I.Context(spec, it, precision=args.precision, force_provider=args.forces, shard=bounds[rank],
-                        device=local_rank, stream=stream)
+        ctx = fresh_context(stream)
         if use_dist:
             stepper = D.ShardedStepper(ctx)
             dist_mode = "python"
-    use_graph = (not use_dist and not args.eager) or dist_mode == "graph"
+    use_graph = (not use_dist and not args.eager) or dist_mode in ("graph", "mailbox")
 
     def run(n):
         if stepper is not None:
@@ -183,7 +234,7 @@ def main():
                                    + (f", {len(spec.particles_ld)} Langevin particles (device Philox normals), {len(spec.image_pairs)} image pairs, E-field" if cfg == "C5" else ""),
                        "force_provider": f"{args.forces} (synthetic, inside the timed region)" if args.forces == "tether" else "static buffer",
                        "launch": "hipGraph replay, %d steps/graph" % args.steps_per_graph if use_graph else "host-launched per step",
-                       "parallelism": ("1 GPU" + (f" (distributed code path forced: {dist_mode})" if use_dist else "")) if world == 1 else f"particle shards on molecule boundaries x{world}, int64 all-reduce per thermostat application ({dist_mode})",
+                       "parallelism": ("1 GPU" + (f" (distributed code path forced: {dist_mode})" if use_dist else "")) if world == 1 else f"particle shards on molecule boundaries x{world}, int64 totals exchanged per thermostat application ({dist_mode})",
                        "atom_steps_per_s": round(steps_per_s * n, 1)},
         }
 

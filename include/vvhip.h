@@ -194,6 +194,20 @@ int vvhip_comm_unique_id(void* id128);
 int vvhip_comm_init(vvhip_plan* plan, const void* id128, int nranks, int rank);
 int vvhip_comm_destroy(vvhip_plan* plan);
 
+/* Exchange without a collective launch, for the ranks of ONE node ("mailbox" over xGMI peer mappings).  Every rank calls
+ * vvhip_mailbox_create (allocates its uncached box, returns a 64-byte hipIpc handle), the host gathers all handles in rank
+ * order (ranks * 64 bytes, any transport) and every rank calls vvhip_mailbox_connect.  From then on kernel A's last block stores
+ * the rank's int64 totals into every peer's box and kernel B's thermostat wave sums them in rank order: a sharded step stays two
+ * launches, replayable from a hipGraph, and all ranks continue with identical bits.  Used for the kinetic-energy reduction of
+ * steps without cos acceleration and chain length <= 4 (vvhip_mailbox_status: active); everything else keeps using the RCCL
+ * communicator if one is set.  A rank that does not hear from its peers within ~5 s raises `timed_out` and carries on with
+ * wrong sums instead of hanging the GPU: hosts check vvhip_mailbox_status after a trial run and fall back to vvhip_comm_*.
+ * No reference counterpart (the reference is single-GPU: CudaVVKernelFactory.cpp:68). */
+int vvhip_mailbox_create(vvhip_plan* plan, int nranks, int rank, void* handle64);
+int vvhip_mailbox_connect(vvhip_plan* plan, const void* handles);
+int vvhip_mailbox_status(vvhip_plan* plan, int32_t* active, int32_t* timed_out);
+int vvhip_mailbox_destroy(vvhip_plan* plan);
+
 /* ---------------------------------------------------------------- kernel-interface level
  * One entry per KernelImpl virtual, for use inside OpenMM where constraint solvers run between them. */
 /* IntegrateMiddleStepKernel (VVKernels.h:50-86; HOST:119-235) */

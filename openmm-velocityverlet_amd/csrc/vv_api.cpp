@@ -91,6 +91,13 @@ struct vvhip_plan {
     // particle sharding over GPUs: RCCL communicator for the accumulator exchange (null = single GPU)
     ncclComm_t comm = nullptr;
     int comm_ranks = 1;
+    // ... or the xGMI mailbox (vv_kernels.hpp: Mailbox): no collective launch, works inside a captured graph
+    unsigned long long* mb_local = nullptr;       // uncached, exported through hipIpc
+    unsigned long long** d_mb_peers = nullptr;    // device array of the peers' mappings
+    unsigned int* d_mb_ctl = nullptr;
+    std::vector<void*> mb_opened;                 // hipIpcOpenMemHandle mappings to close
+    int mb_ranks = 0, mb_rank = 0;
+    bool mb_on = false;
 };
 
 extern "C" int vvhip_debug_read_accumulators(vvhip_plan* p, double out[4], int zero_after);
@@ -172,6 +179,11 @@ vv::KArgs make_args(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
     a.nh = p->d_nh + p->parity;
     a.nh_next = p->d_nh + (p->parity ^ 1);
     a.chain = make_chain(p, 0);
+    a.mb.local = p->mb_local;
+    a.mb.peers = p->d_mb_peers;
+    a.mb.ctl = p->d_mb_ctl;
+    a.mb.ranks = p->mb_ranks;
+    a.mb.rank = p->mb_rank;
     a.padded = p->hp.padded_num_atoms;
     a.nwaves = p->hp.info.num_waves;
     a.flags = flags;
@@ -253,6 +265,12 @@ int run_chain(vvhip_plan* p, uint32_t flags) {
     return VVHIP_OK;
 }
 
+// The mailbox carries the kinetic-energy totals between the ranks' kernel-B heads (inline chain); the bias moment of the cos
+// perturbation (consumed by another kernel A) and the stand-alone chain kernel still go through the collective.
+bool use_mailbox(const vvhip_plan* p) {
+    return p->mb_on && p->hp.params.cos_acceleration == 0 && p->hp.params.num_nh_chains <= 4;
+}
+
 // The launch(es) that end in the per-group kinetic energies.  `first` = stage bits that must run before the KE on the
 // same launch if possible (kick, extra forces).  Molecules larger than a wave need their COM summed across waves
 // first (A_COMPART, its own launch after a memset of the small accumulator), so there the stages are split.
@@ -270,7 +288,7 @@ int run_ke(vvhip_plan* p, uint32_t first, uint32_t random_index, bool unbias) {
 
 // Scaling kernel with the chain in its head (chain length <= 4), or the stand-alone chain launch in front of it.
 int run_chain_and_b(vvhip_plan* p, uint32_t bflags, bool with_bias) {
-    if (p->hp.params.num_nh_chains <= 4) return run_b(p, vv::B_CHAIN | bflags);
+    if (p->hp.params.num_nh_chains <= 4) return run_b(p, vv::B_CHAIN | bflags | (use_mailbox(p) ? vv::B_MAILBOX : 0));
     int rc = run_chain(p, vv::C_CHAIN | (with_bias ? vv::C_BIAS : 0));
     return rc != VVHIP_OK ? rc : run_b(p, bflags);
 }
@@ -305,6 +323,8 @@ bool shake_on(const vvhip_plan* p) { return !p->hp.slot_shake.empty(); }
 }  // namespace
 
 extern "C" {
+
+static void mailbox_release(vvhip_plan* p);
 
 // ------------------------------------------------------------------------------------------ life cycle
 int vvhip_plan_create(const vvhip_system_desc* system, const vvhip_params* params, int precision, vvhip_plan** plan_out,
@@ -343,6 +363,7 @@ void vvhip_plan_destroy(vvhip_plan* p) {
             if (ptr) (void) hipFree(ptr);
         if (p->graph_exec) (void) hipGraphExecDestroy(p->graph_exec);
         if (p->comm) (void) rccl_api().commDestroy(p->comm);
+        mailbox_release(p);
         for (auto& v : p->events)
             for (auto& e : v) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
     }
@@ -508,6 +529,7 @@ int vvhip_accumulators(vvhip_plan* p, int phase, void** device_ptr, int32_t* cou
 // Element-wise int64 sum of the accumulators of `phase` over all ranks, on the plan's stream (ncclSum is exact on
 // integers, so every rank continues with identical bits).  No-op without a communicator.
 static int exchange_accumulators(vvhip_plan* p, int phase) {
+    if (use_mailbox(p)) return VVHIP_OK;   // kernel B exchanges the totals itself
     if (!p->comm) return VVHIP_OK;      // a 1-rank communicator still issues the collective (exercises the path on one GPU)
     void* ptr = nullptr;
     int32_t count = 0;
@@ -539,10 +561,13 @@ static int nh_half(vvhip_plan* p, uint32_t a_first, uint32_t random_index, uint3
     }
     if (!cos_on(p)) {
         TRY(run_ke(p, a_first, random_index, false));
+        TRY(exchange_accumulators(p, 0));
         return run_chain_and_b(p, vv::B_SCALE | b_extra, false);
     }
     TRY(run_a(p, a_first | vv::A_BIAS | vv::A_CZ_STORE, random_index));
+    TRY(exchange_accumulators(p, 0));
     TRY(run_ke(p, 0, 0, true));
+    TRY(exchange_accumulators(p, 1));
     return run_chain_and_b(p, vv::B_SCALE | vv::B_UNBIAS | vv::B_CZ_LOAD | b_extra, true);
 }
 
@@ -813,6 +838,78 @@ int vvhip_comm_init(vvhip_plan* p, const void* id128, int nranks, int rank) {
     if (p->graph_exec) { (void) hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
     return VVHIP_OK;
 }
+// ---- xGMI mailbox (include/vvhip.h): create -> exchange the 64-byte handles by any means -> connect
+static void mailbox_release(vvhip_plan* p) {
+    p->mb_on = false;
+    for (void* m : p->mb_opened) (void) hipIpcCloseMemHandle(m);
+    p->mb_opened.clear();
+    if (p->d_mb_peers) { (void) hipFree(p->d_mb_peers); p->d_mb_peers = nullptr; }
+    if (p->d_mb_ctl) { (void) hipFree(p->d_mb_ctl); p->d_mb_ctl = nullptr; }
+    if (p->mb_local) { (void) hipFree(p->mb_local); p->mb_local = nullptr; }
+    p->mb_ranks = 0;
+}
+int vvhip_mailbox_create(vvhip_plan* p, int nranks, int rank, void* handle64) {
+    NEED_BOUND(p);
+    if (!handle64 || nranks < 1 || nranks > vv::MB_MAX_RANKS || rank < 0 || rank >= nranks)
+        return fail(p, VVHIP_ERR_INVALID, "mailbox: 1 <= ranks <= 16, 0 <= rank < ranks");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "the C ABI hands the IPC handle over as 64 bytes");
+    HIP_TRY(p, hipStreamSynchronize(p->stream));
+    mailbox_release(p);
+    if (p->graph_exec) { (void) hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
+    const size_t bytes = (size_t) 2 * nranks * vv::MB_WORDS * sizeof(unsigned long long);
+    // uncached: peers' stores land in this GPU's memory over xGMI and must be seen by loads that would otherwise hit in L2
+    HIP_TRY(p, hipExtMallocWithFlags((void**) &p->mb_local, std::max(bytes, (size_t) 4096), hipDeviceMallocUncached));
+    HIP_TRY(p, hipMemset(p->mb_local, 0, std::max(bytes, (size_t) 4096)));
+    HIP_TRY(p, hipMalloc((void**) &p->d_mb_ctl, 4 * sizeof(unsigned int)));
+    HIP_TRY(p, hipMemset(p->d_mb_ctl, 0, 4 * sizeof(unsigned int)));
+    HIP_TRY(p, hipDeviceSynchronize());
+    hipIpcMemHandle_t h;
+    HIP_TRY(p, hipIpcGetMemHandle(&h, p->mb_local));
+    std::memcpy(handle64, &h, 64);
+    p->mb_ranks = nranks;
+    p->mb_rank = rank;
+    return VVHIP_OK;
+}
+int vvhip_mailbox_connect(vvhip_plan* p, const void* handles) {
+    NEED_BOUND(p);
+    if (!p->mb_local || !handles) return fail(p, VVHIP_ERR_INVALID, "vvhip_mailbox_create has not been called");
+    std::vector<unsigned long long*> peers((size_t) p->mb_ranks, nullptr);
+    for (int r = 0; r < p->mb_ranks; r++) {
+        if (r == p->mb_rank) { peers[r] = p->mb_local; continue; }
+        hipIpcMemHandle_t h;
+        std::memcpy(&h, (const char*) handles + (size_t) r * 64, 64);
+        void* m = nullptr;
+        HIP_TRY(p, hipIpcOpenMemHandle(&m, h, hipIpcMemLazyEnablePeerAccess));
+        p->mb_opened.push_back(m);
+        peers[r] = (unsigned long long*) m;
+    }
+    HIP_TRY(p, hipMalloc((void**) &p->d_mb_peers, peers.size() * sizeof(void*)));
+    HIP_TRY(p, hipMemcpy(p->d_mb_peers, peers.data(), peers.size() * sizeof(void*), hipMemcpyHostToDevice));
+    p->mb_on = true;
+    return VVHIP_OK;
+}
+int vvhip_mailbox_status(vvhip_plan* p, int32_t* active, int32_t* timed_out) {
+    NEED_BOUND(p);
+    if (active) *active = use_mailbox(p) ? 1 : 0;
+    if (timed_out) {
+        *timed_out = 0;
+        if (p->d_mb_ctl) {
+            unsigned int ctl[4];
+            HIP_TRY(p, hipStreamSynchronize(p->stream));
+            HIP_TRY(p, hipMemcpy(ctl, p->d_mb_ctl, sizeof ctl, hipMemcpyDeviceToHost));
+            *timed_out = (int32_t) ctl[0];
+        }
+    }
+    return VVHIP_OK;
+}
+int vvhip_mailbox_destroy(vvhip_plan* p) {
+    NEED_BOUND(p);
+    HIP_TRY(p, hipStreamSynchronize(p->stream));
+    if (p->graph_exec) { (void) hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
+    mailbox_release(p);
+    return VVHIP_OK;
+}
+
 int vvhip_comm_destroy(vvhip_plan* p) {
     if (!p) return VVHIP_ERR_INVALID;
     if (p->comm) { (void) hipStreamSynchronize(p->stream); (void) rccl_api().commDestroy(p->comm); p->comm = nullptr; p->comm_ranks = 1; }

@@ -99,6 +99,7 @@ template <int NV>
 __device__ __forceinline__ void block_accumulate(const double (&vals)[NV], const bool (&enabled)[NV],
                                                  unsigned long long* acc, const double* scale) {
     __shared__ double red[16][NV];
+
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
 #pragma unroll
     for (int k = 0; k < NV; k++) {
@@ -300,6 +301,53 @@ __device__ __forceinline__ void shake_velocities(int lane, unsigned word, float4
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (word & 2u) { vx = page[lane][3]; vy = page[lane][4]; vz = page[lane][5]; }
+}
+
+// ================================================================================ multi-GPU mailbox (vv_kernels.hpp: Mailbox)
+// Head of kernel B, thermostat waves.  Every wave has just folded this rank's accumulators (complete: kernel A ended); block 0's
+// stores the totals into slot [seq & 1][rank] of every OTHER rank's box; then every block's wave polls its own box until the other
+// ranks' words carry the sequence number and adds them (int64: any order gives the same bits).  Bounded wait: after ~5 s without the peers' words the wave raises
+// ctl[0] and carries on (the host reports the failure; nothing ever hangs the GPU).
+__device__ __forceinline__ void mailbox_exchange(const KArgs& a, int lane, unsigned int seq, unsigned int* words, long long (&tot)[NUM_ACC]) {
+    const int par = (int) (seq & 1u);
+    const int nwords = a.mb.ranks * MB_WORDS;
+    if (blockIdx.x == 0) {
+        for (int i = lane; i < nwords; i += 64) {
+            const int peer = i / MB_WORDS, w = i % MB_WORDS;
+            if (peer == a.mb.rank) continue;
+            long long t = 0;
+#pragma unroll
+            for (int k = 0; k < NUM_ACC; k++) if ((w >> 1) == k) t = tot[k];
+            const unsigned int payload = (w & 1) ? (unsigned int) ((unsigned long long) t >> 32) : (unsigned int) t;
+            unsigned long long* box = a.mb.peers[peer];
+            __hip_atomic_store(&box[((size_t) par * a.mb.ranks + a.mb.rank) * MB_WORDS + w], ((unsigned long long) seq << 32) | payload,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    const unsigned long long* box = a.mb.local + (size_t) par * nwords;
+    const long long t0 = wall_clock64();
+    const bool dead = a.mb.ctl[0] != 0;            // an earlier wait ran out: the run is void, do not wait again
+    for (int i = lane; i < nwords; i += 64) {
+        unsigned long long v;
+        if (i / MB_WORDS == a.mb.rank) continue;
+        for (;;) {
+            v = __hip_atomic_load(&box[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((unsigned int) (v >> 32) == seq) break;
+            if (dead || wall_clock64() - t0 > 500000000LL) { a.mb.ctl[0] = 1u; break; }      // 100 MHz counter
+            __builtin_amdgcn_s_sleep(1);
+        }
+        words[i] = (unsigned int) v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int k = 0; k < NUM_ACC; k++) {
+        long long s = tot[k];                      // this rank's own total never leaves the registers
+        for (int r = 0; r < a.mb.ranks; r++)
+            if (r != a.mb.rank) s += (long long) ((unsigned long long) words[r * MB_WORDS + 2 * k] | ((unsigned long long) words[r * MB_WORDS + 2 * k + 1] << 32));
+        tot[k] = s;
+    }
 }
 
 // ================================================================================ kernel A
@@ -731,7 +779,12 @@ __global__ void __launch_bounds__(320) vv_kernel_b(const KArgs a) {
         cr.eta_dot[4] = a.nh->s.eta_dot[cg][4];
         long long tot[NUM_ACC];
 #pragma unroll
-        for (int k = 0; k < NUM_ACC; k++) tot[k] = (F & B_DBG_NOFOLD) ? 0 : acc_total(a.acc, k, lane);
+        for (int k = 0; k < NUM_ACC; k++)
+            tot[k] = (F & B_DBG_NOFOLD) ? 0 : acc_total(a.acc, k, lane);
+        if (F & B_MAILBOX) {                      // multi-GPU: block 0 publishes this rank's totals, every block collects all ranks'
+            __shared__ unsigned int mb_words[MB_MAX_RANKS * MB_WORDS];
+            mailbox_exchange(a, lane, a.nh->mb_seq + 1u, mb_words, tot);
+        }
         double ke2 = 0;
 #pragma unroll
         for (int k = 0; k < VVHIP_NUM_TG; k++)
@@ -753,6 +806,7 @@ __global__ void __launch_bounds__(320) vv_kernel_b(const KArgs a) {
                 out->scales[cg] = factor;
             }
             if (lane == 3) { out->s.v_bias = bias; out->scales[3] = bias; }
+            if (lane == 4) out->mb_seq = a.nh->mb_seq + ((F & B_MAILBOX) ? 1u : 0u);
             for (int i = lane; i < NUM_ACC * ACC_SLOTS; i += 64) a.acc_next[i] = 0;
         }
         __syncthreads();
@@ -1151,6 +1205,7 @@ constexpr uint32_t SF_B_COS_HW = B_CHAIN | B_SCALE | B_UNBIAS | B_CZ_LOAD | B_DR
 constexpr uint32_t SF_B_MIDDLE_HW = B_CHAIN | B_SCALE | B_DRIFT_MIDDLE | B_HARDWALL;
 constexpr uint32_t SF_B_MIDDLE_HW_WT = SF_B_MIDDLE_HW | B_WT_STORES;
 constexpr uint32_t SF_B_MIDDLE = B_CHAIN | B_SCALE | B_DRIFT_MIDDLE;
+constexpr uint32_t SF_B_MIDDLE_HW_MB = SF_B_MIDDLE_HW | B_MAILBOX;
 constexpr uint32_t SF_A_MIDDLE_SHAKE = SF_A_MIDDLE | A_SHAKE_V;                         // HBonds constraints solved in-kernel
 constexpr uint32_t SF_B_MIDDLE_HW_SHAKE = SF_B_MIDDLE_HW | B_SHAKE;
 constexpr uint32_t SF_B_MIDDLE_SHAKE = SF_B_MIDDLE | B_SHAKE;
@@ -1177,6 +1232,7 @@ hipError_t launch_b(int precision, const KArgs& a, int block_threads, hipStream_
     else if (a.flags == SF_B_MIDDLE_HW_WT) { VV_DISPATCH_SF(vv_kernel_b, SF_B_MIDDLE_HW_WT, g, b, 0, s, a); }
     else if (a.flags == SF_B_MIDDLE) { VV_DISPATCH_SF(vv_kernel_b, SF_B_MIDDLE, g, b, 0, s, a); }
     else if (a.flags == SF_B_COS_HW) { VV_DISPATCH_SF(vv_kernel_b, SF_B_COS_HW, g, b, 0, s, a); }
+    else if (a.flags == SF_B_MIDDLE_HW_MB) { VV_DISPATCH_SF(vv_kernel_b, SF_B_MIDDLE_HW_MB, g, b, 0, s, a); }
     else if (a.flags == SF_B_MIDDLE_HW_SHAKE) { VV_DISPATCH_SF(vv_kernel_b, SF_B_MIDDLE_HW_SHAKE, g, b, 0, s, a); }
     else if (a.flags == SF_B_MIDDLE_SHAKE) { VV_DISPATCH_SF(vv_kernel_b, SF_B_MIDDLE_SHAKE, g, b, 0, s, a); }
     else { VV_DISPATCH_SF(vv_kernel_b, 0u, g, b, 0, s, a); }

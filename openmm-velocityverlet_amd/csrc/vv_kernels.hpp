@@ -46,6 +46,7 @@ enum : uint32_t {
     B_CHAIN = 1u << 11,       // run the NH chain in the kernel head from the accumulators (else read nh->scales)
     B_CZ_LOAD = 1u << 12,     // cos(2 pi z / Lz) from the per-lane cache written by kernel A (A_CZ_STORE)
     B_SHAKE = 1u << 13,       // position constraints of the SHAKE clusters on the step's displacement (OpenMM applyConstraints)
+    B_MAILBOX = 1u << 14,     // multi-GPU mailbox: block 0's thermostat wave stores this rank's totals into every peer, all blocks sum all ranks' totals
     B_WT_STORES = 1u << 27,   // write-through (sc1) stores for the particle arrays: the dirty lines leave L2 during the kernel, not at its end
     B_DBG_NOFOLD = 1u << 28,  // timing experiments only: skip the accumulator fold / the chain arithmetic
     B_DBG_NOMATH = 1u << 29,
@@ -59,10 +60,30 @@ constexpr int ACC_SLOTS = 256; // each quantity is spread over 256 int64 slots (
                                // (measured: 17 us for kernel A at 1000 blocks); integer sums stay exact and
                                // order-independent, the chain wave folds the slots.  Layout acc[quantity][slot].
 
+// Multi-GPU accumulator exchange without a collective launch ("mailbox", one node over xGMI).  Every rank owns an UNCACHED
+// device allocation box[2 parities][ranks][MB_WORDS] of 8-byte words {sequence number : 32 | payload : 32} that all peers
+// have mapped through hipIpc.  At the start of kernel B the thermostat wave of block 0 -- which has just folded the rank's
+// accumulators, complete since kernel A ended -- writes the NUM_ACC int64 totals as 2*NUM_ACC words into slot [seq & 1][rank] of
+// every OTHER rank's box (one 8-byte store each: payload and flag travel in the same atomic word, the LL idea of RCCL).  The
+// thermostat wave of every block then polls the rank's own box until the other ranks' words carry the current sequence number
+// and adds them to its own fold of the local accumulators -- integers, so all ranks continue with identical bits.  Nothing is added to kernel A, no launch is
+// added to the step.  Two parities suffice: a rank can only be one exchange ahead of the slowest one (it needs everybody's
+// words of exchange n to finish its kernel B of exchange n).  The sequence number lives in the double-buffered NHDevState.
+constexpr int MB_WORDS = 2 * NUM_ACC;
+constexpr int MB_MAX_RANKS = 16;
+struct Mailbox {
+    unsigned long long* local;            // this rank's box
+    unsigned long long* const* peers;     // device array [ranks] of every rank's box as mapped here (own entry = local)
+    unsigned int* ctl;                    // [0] set when a wait on the peers ran out
+    int32_t ranks, rank;
+};
+
 // Device-resident thermostat state (reference keeps it on the host: CudaVVKernels.h:206-215)
 struct NHDevState {
     vvhip_nh_state s;
     double scales[4];        // what kernel B consumes: vscale[3] and the periodic bias V
+    unsigned int mb_seq;     // mailbox exchanges done so far (advanced with the state by a B_MAILBOX launch)
+    unsigned int pad_;
 };
 
 // Constants of the chain (HOST:577-594 fixed at init; temperatures read live as API:728 does)
@@ -105,6 +126,7 @@ struct KArgs {
     const NHDevState* nh;           // thermostat state of the current parity
     NHDevState* nh_next;            // where an inline chain writes the advanced state
     NHConst chain;                  // chain constants (used by B_CHAIN)
+    Mailbox mb;                     // B_MAILBOX
     int32_t padded;
     int32_t nwaves;
     uint32_t flags;

@@ -377,6 +377,26 @@ class Context:
         buf = C.create_string_buffer(bytes(unique_id), 128)
         H.check(H.lib.vvhip_comm_init(self.plan, buf, int(nranks), int(rank)), self.plan)
 
+    def mailbox_create(self, nranks: int, rank: int) -> bytes:
+        """xGMI mailbox exchange (vvhip_mailbox_*): returns this rank's 64-byte IPC handle; gather all ranks' handles in rank
+        order and pass them to mailbox_connect()."""
+        buf = C.create_string_buffer(64)
+        H.check(H.lib.vvhip_mailbox_create(self.plan, int(nranks), int(rank), buf), self.plan)
+        return buf.raw
+
+    def mailbox_connect(self, handles: bytes):
+        buf = C.create_string_buffer(bytes(handles), len(handles))
+        H.check(H.lib.vvhip_mailbox_connect(self.plan, buf), self.plan)
+
+    def mailbox_status(self):
+        """(active, timed_out): whether the fused steps use the mailbox, and whether a wait on the peers ever ran out."""
+        a, t = C.c_int32(0), C.c_int32(0)
+        H.check(H.lib.vvhip_mailbox_status(self.plan, C.byref(a), C.byref(t)), self.plan)
+        return bool(a.value), bool(t.value)
+
+    def mailbox_destroy(self):
+        H.check(H.lib.vvhip_mailbox_destroy(self.plan), self.plan)
+
     @staticmethod
     def comm_unique_id() -> bytes:
         buf = C.create_string_buffer(128)

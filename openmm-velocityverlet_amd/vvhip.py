@@ -118,6 +118,8 @@ def _load():
         "vvhip_run_eager": [vp, C.c_int, vp, dbl, dbl],
         "vvhip_set_random_seed": [vp, C.c_uint64], "vvhip_fill_random": [vp],
         "vvhip_comm_unique_id": [vp], "vvhip_comm_init": [vp, vp, C.c_int, C.c_int], "vvhip_comm_destroy": [vp],
+        "vvhip_mailbox_create": [vp, C.c_int, C.c_int, vp], "vvhip_mailbox_connect": [vp, vp],
+        "vvhip_mailbox_status": [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)], "vvhip_mailbox_destroy": [vp],
         "vvhip_time_kernel": [vp, C.c_int, u32, C.c_int, P(dbl)],
         "vvhip_timing_enable": [vp, C.c_int], "vvhip_timing_read": [vp, P(dbl), P(dbl), P(dbl), P(i32 * 3)],
         "vvhip_debug_launch": [vp, C.c_int, u32, u32],
