@@ -1,3 +1,5 @@
+// Probe used while designing the multi-GPU mailbox: two processes share an uncached device allocation through
+// hipIpc and ping-pong through it from kernels.  Build: hipcc --offload-arch=gfx950 -O2 -o ipc_probe ipc_probe.cpp
 // probe: can two processes share an uncached device allocation through hipIpc* and ping-pong through it from kernels?
 #include <hip/hip_runtime.h>
 #include <cstdio>
