@@ -118,8 +118,10 @@ typedef struct {
     double inv_mass_total;                       /* HOST:1028-1031 */
     int32_t num_waves, num_slots_used;           /* work-item layout: 64 slots per wave */
     int32_t max_cluster;                         /* largest set of particles that must share a wave */
-    int32_t num_shake_clusters;                  /* constraint clusters solved in-kernel (0 if none / not possible) */
+    int32_t num_shake_clusters;                  /* hydrogen-type constraint clusters solved in-kernel (SHAKE; 0 if none / not possible) */
     int32_t constraints_fused;                   /* 1: no constraints, or all of them are handled in-kernel => fused steps are valid */
+    int32_t num_settle_clusters;                 /* rigid three-site molecules solved in-kernel (SETTLE) */
+    int32_t reserved_;
 } vvhip_plan_info;
 
 /* Nose-Hoover chain state + last reduction results (HOST: CudaVVKernels.h:206-215).  The reference

@@ -197,7 +197,7 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
 
     // ---- constraint clusters for the in-kernel SHAKE (same admission rule as OpenMM's SHAKE kernel: a central particle with
     // one to three peripheral particles of identical mass and distance, every peripheral in exactly one constraint)
-    struct Shake { int32_t center; std::vector<int32_t> periph; double d; };
+    struct Shake { int32_t center; std::vector<int32_t> periph; double d; bool settle = false; double d_pp = 0; };
     std::vector<Shake> shakes;
     std::vector<int32_t> shake_of(n, -1);
     bool constraints_fused = sys.num_constraints == 0;
@@ -205,7 +205,46 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
         std::vector<int> deg(n, 0);
         for (int k = 0; k < sys.num_constraints; k++) { deg[sys.constraints[2 * k]]++; deg[sys.constraints[2 * k + 1]]++; }
         bool ok = true;
+        // rigid three-site molecules first (what OpenMM hands to SETTLE): three particles, three mutual constraints and nothing
+        // else; the apex is the particle whose two distances are equal and whose two partners have equal masses
+        std::vector<char> used(sys.num_constraints, 0);
+        {
+            std::vector<std::vector<std::pair<int, int> > > adj(n);      // (other particle, constraint index)
+            for (int k = 0; k < sys.num_constraints; k++) {
+                const int a = sys.constraints[2 * k], b = sys.constraints[2 * k + 1];
+                if (deg[a] == 2 && deg[b] == 2) { adj[a].push_back({b, k}); adj[b].push_back({a, k}); }
+            }
+            for (int a = 0; a < n && ok; a++) {
+                if (adj[a].size() != 2 || shake_of[a] >= 0) continue;
+                const int b = adj[a][0].first, c = adj[a][1].first;
+                if (b == c || adj[b].size() != 2 || adj[c].size() != 2) continue;
+                int kbc = -1;
+                for (auto& e : adj[b]) if (e.first == c) kbc = e.second;
+                if (kbc < 0) continue;                                    // a chain, not a triangle: left to the rule below (which refuses it)
+                const int tri[3] = {a, b, c};
+                const double dist[3] = {sys.constraint_distances[adj[a][0].second], sys.constraint_distances[adj[a][1].second], sys.constraint_distances[kbc]};   // ab, ac, bc
+                // apex candidates: a (ab == ac, m_b == m_c), b (ab == bc, m_a == m_c), c (ac == bc, m_a == m_b)
+                int apex = -1;
+                if (dist[0] == dist[1] && sys.masses[b] == sys.masses[c]) apex = 0;
+                else if (dist[0] == dist[2] && sys.masses[a] == sys.masses[c]) apex = 1;
+                else if (dist[1] == dist[2] && sys.masses[a] == sys.masses[b]) apex = 2;
+                if (apex < 0 || sys.masses[a] == 0 || sys.masses[b] == 0 || sys.masses[c] == 0) { ok = false; break; }
+                Shake st;
+                st.settle = true;
+                st.center = tri[apex];
+                for (int t = 0; t < 3; t++) if (t != apex) st.periph.push_back(tri[t]);
+                std::sort(st.periph.begin(), st.periph.end());
+                st.d = apex == 0 ? dist[0] : (apex == 1 ? dist[0] : dist[1]);
+                st.d_pp = apex == 0 ? dist[2] : (apex == 1 ? dist[1] : dist[0]);
+                for (int t = 0; t < 3; t++) shake_of[tri[t]] = (int32_t) shakes.size();
+                shakes.push_back(st);
+                used[adj[a][0].second] = used[adj[a][1].second] = used[kbc] = 1;
+            }
+        }
+        // everything else must be hydrogen-type clusters (same admission rule as OpenMM's SHAKE kernel: a central particle with
+        // one to three peripheral particles of identical mass and distance, every peripheral in exactly one constraint)
         for (int k = 0; k < sys.num_constraints && ok; k++) {
+            if (used[k]) continue;
             int a = sys.constraints[2 * k], b = sys.constraints[2 * k + 1];
             const double d = sys.constraint_distances[k];
             // the central particle is the one with several constraints; for an isolated pair, the heavier one
@@ -214,7 +253,7 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
             if (deg[per] != 1 || sys.masses[ctr] == 0 || sys.masses[per] == 0 ) { ok = false; break; }
             if (shake_of[ctr] < 0) { shake_of[ctr] = (int32_t) shakes.size(); shakes.push_back(Shake{ctr, {}, d}); }
             Shake& s = shakes[shake_of[ctr]];
-            if (s.center != ctr || s.periph.size() >= 3 || s.d != d || (!s.periph.empty() && sys.masses[s.periph[0]] != sys.masses[per])) { ok = false; break; }
+            if (s.settle || s.center != ctr || s.periph.size() >= 3 || s.d != d || (!s.periph.empty() && sys.masses[s.periph[0]] != sys.masses[per])) { ok = false; break; }
             if (shake_of[per] >= 0) { ok = false; break; }
             s.periph.push_back(per);
             shake_of[per] = shake_of[ctr];
@@ -289,19 +328,25 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
             for (int i : cl.members) mtot += sys.masses[i];
             max_big_mass = std::max(max_big_mass, mtot);
             std::vector<char> taken(cl.members.size(), 0);
-            std::vector<std::vector<int32_t> > units;          // single particles or (Drude, parent) pairs, in index order
+            std::vector<std::vector<int32_t> > units;          // particles that must stay in one wave (Drude pairs, constraint clusters), in index order
+            auto index_in = [&](int q) {
+                auto it = std::lower_bound(cl.members.begin(), cl.members.end(), q);
+                if (it == cl.members.end() || *it != q) throw Error(VVHIP_ERR_UNSUPPORTED, "a Drude pair or a constraint cluster spans two molecules");
+                return (size_t) (it - cl.members.begin());
+            };
             for (size_t k = 0; k < cl.members.size(); k++) {
                 if (taken[k]) continue;
-                const int i = cl.members[k];
-                std::vector<int32_t> u{i};
+                std::vector<int32_t> u, todo{cl.members[k]};
                 taken[k] = 1;
-                if (in_pair[i]) {
-                    const int q = partner[i];
-                    auto it = std::lower_bound(cl.members.begin(), cl.members.end(), q);
-                    if (it == cl.members.end() || *it != q) throw Error(VVHIP_ERR_UNSUPPORTED, "a Drude particle and its parent are in different molecules");
-                    taken[it - cl.members.begin()] = 1;
-                    u.push_back(q);
+                while (!todo.empty()) {
+                    const int j = todo.back();
+                    todo.pop_back();
+                    u.push_back(j);
+                    auto visit = [&](int q) { const size_t t = index_in(q); if (!taken[t]) { taken[t] = 1; todo.push_back(q); } };
+                    if (in_pair[j]) visit(partner[j]);
+                    if (shake_of[j] >= 0) { visit(shakes[shake_of[j]].center); for (int q : shakes[shake_of[j]].periph) visit(q); }
                 }
+                std::sort(u.begin(), u.end());
                 units.push_back(u);
             }
             Cluster chunk{units[0][0], {}, true, big, true};
@@ -435,13 +480,14 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
     if (hp.has_ld) hp.slot_rand.assign((size_t) nwaves * 64, -1);
     info.constraints_fused = constraints_fused ? 1 : 0;
     info.num_shake_clusters = 0;
+    info.num_settle_clusters = 0;
     if (!shakes.empty()) {
         hp.slot_shake.assign((size_t) nwaves * 64, 0);
         hp.slot_shake_param.assign((size_t) nwaves * 64 * 4, 0.0f);
         for (const Shake& s : shakes) {
             if (!in_shard(s.center)) continue;
             const int w = wave_of[s.center], lc = lane_of[s.center];
-            uint32_t word = 1u | ((uint32_t) s.periph.size() << 2);
+            uint32_t word = 1u | ((uint32_t) s.periph.size() << 2) | (s.settle ? vv::SHAKE_WORD_SETTLE : 0u);
             for (size_t k = 0; k < s.periph.size(); k++) {
                 const int q = s.periph[k];
                 if (wave_of[q] != w) throw Error(VVHIP_ERR_UNSUPPORTED, "a constraint cluster does not fit into one wave with its molecule");
@@ -451,8 +497,8 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
             hp.slot_shake[(size_t) w * 64 + lc] = (int32_t) word;
             const double imc = 1.0 / sys.masses[s.center], imp = 1.0 / sys.masses[s.periph[0]];
             float* prm = &hp.slot_shake_param[((size_t) w * 64 + lc) * 4];
-            prm[0] = (float) imc; prm[1] = (float) (0.5 / (imc + imp)); prm[2] = (float) (s.d * s.d); prm[3] = (float) imp;
-            info.num_shake_clusters++;
+            if (s.settle) { prm[0] = (float) s.d; prm[1] = (float) s.d_pp; prm[2] = 0; prm[3] = 0; info.num_settle_clusters++; }   // apex-partner and partner-partner distance
+            else { prm[0] = (float) imc; prm[1] = (float) (0.5 / (imc + imp)); prm[2] = (float) (s.d * s.d); prm[3] = (float) imp; info.num_shake_clusters++; }
         }
     }
     if (hp.num_big > 0) {

@@ -43,6 +43,7 @@ constexpr uint32_t META_PAIR = 1u << 25;       // member of a DrudeForce pair (h
 constexpr uint32_t META_IS_DRUDE = 1u << 26;   // the Drude (pair.x) of that pair
 constexpr uint32_t META_MASSIVE = 1u << 27;    // mass != 0 (velm.w != 0)
 constexpr uint32_t META_BIGMOL = 1u << 28;     // lane belongs to a molecule too large for one wave: its COM comes from bigacc
+constexpr uint32_t SHAKE_WORD_SETTLE = 1u << 30;  // slot_shake word of an apex lane: the cluster is a rigid triangle (SETTLE)
 constexpr uint32_t META_BIG_FIRST = 1u << 29;  // leader of the FIRST chunk of such a molecule (adds M*V^2 once, clears bigacc)
 
 inline uint32_t meta_role(uint32_t m) { return m & META_ROLE_MASK; }
@@ -64,6 +65,8 @@ struct HostPlan {
     //   word: bit0 central, bit1 peripheral, bits2-3 = #peripherals (central) or own index (peripheral),
     //         bits 4-9 / 10-15 / 16-21 = lanes of the peripherals (central) or bits 4-9 = lane of the central (peripheral)
     //   param float4: x = 1/m_central, y = 0.5/(1/m_central + 1/m_peripheral), z = d^2, w = 1/m_peripheral
+    //   rigid three-site molecules (SETTLE): bit 30 set on the apex' word, two peripherals; param x = apex-partner distance,
+    //   y = partner-partner distance (masses are taken from velm.w)
     std::vector<int32_t> slot_shake;
     std::vector<float> slot_shake_param;
     std::vector<int32_t> slot_big;     // [64*waves] index of the lane's big molecule, or -1 (empty when there is none)

@@ -195,14 +195,121 @@ struct PosIO {
 // applyShakeToVelocities (Gauss-Seidel over the cluster, <= 15 sweeps, float cluster parameters, `mixed` arithmetic), and
 // the peripherals pick their result up again.  OpenMM's source is not under /root/reference: this follows its published
 // algorithm, parity with OpenMM itself is unpinned; the CPU oracle carries the same statement.
+// Rigid three-site molecules (what OpenMM hands to SETTLE): analytic, no iteration.  Same unpinned status as the SHAKE clusters:
+// OpenMM's source is not under /root/reference; the formulas below were checked numerically (|r_ij| = d_ij, r_ij.v_ij = 0 and
+// conservation of the molecule's momentum to 1e-15) and the CPU oracle carries an independently written statement.
 template <class mixed>
-__device__ __forceinline__ void shake_positions(int lane, unsigned word, float4 prm, mixed tol, mixed x, mixed y, mixed z,
-                                                mixed& dx, mixed& dy, mixed& dz, mixed (*page)[6]) {
-    if (word & 2u) { page[lane][0] = x; page[lane][1] = y; page[lane][2] = z; page[lane][3] = dx; page[lane][4] = dy; page[lane][5] = dz; }
+__device__ __forceinline__ void settle_positions_math(mixed m0, mixed m1, mixed distAB, mixed distBB,
+        mixed apos0x, mixed apos0y, mixed apos0z, mixed apos1x, mixed apos1y, mixed apos1z, mixed apos2x, mixed apos2y, mixed apos2z,
+        mixed& xp0x, mixed& xp0y, mixed& xp0z, mixed& xp1x, mixed& xp1y, mixed& xp1z, mixed& xp2x, mixed& xp2y, mixed& xp2z) {
+        // Miyamoto & Kollman's SETTLE as OpenMM's settle kernel applies it to the step displacement: apos* old positions, xp* displacements,
+        // particle 0 = apex (mass m0), particles 1, 2 = the two equal partners (mass m1 each); distAB apex-partner, distBB partner-partner.
+        const mixed xb0 = apos1x - apos0x, yb0 = apos1y - apos0y, zb0 = apos1z - apos0z;
+        const mixed xc0 = apos2x - apos0x, yc0 = apos2y - apos0y, zc0 = apos2z - apos0z;
+        const mixed invTotalMass = 1 / (m0 + m1 + m1);
+        const mixed xcom = (xp0x * m0 + (xb0 + xp1x) * m1 + (xc0 + xp2x) * m1) * invTotalMass;
+        const mixed ycom = (xp0y * m0 + (yb0 + xp1y) * m1 + (yc0 + xp2y) * m1) * invTotalMass;
+        const mixed zcom = (xp0z * m0 + (zb0 + xp1z) * m1 + (zc0 + xp2z) * m1) * invTotalMass;
+        const mixed xa1 = xp0x - xcom, ya1 = xp0y - ycom, za1 = xp0z - zcom;
+        const mixed xb1 = xb0 + xp1x - xcom, yb1 = yb0 + xp1y - ycom, zb1 = zb0 + xp1z - zcom;
+        const mixed xc1 = xc0 + xp2x - xcom, yc1 = yc0 + xp2y - ycom, zc1 = zc0 + xp2z - zcom;
+        const mixed xaksZd = yb0 * zc0 - zb0 * yc0, yaksZd = zb0 * xc0 - xb0 * zc0, zaksZd = xb0 * yc0 - yb0 * xc0;
+        const mixed xaksXd = ya1 * zaksZd - za1 * yaksZd, yaksXd = za1 * xaksZd - xa1 * zaksZd, zaksXd = xa1 * yaksZd - ya1 * xaksZd;
+        const mixed xaksYd = yaksZd * zaksXd - zaksZd * yaksXd, yaksYd = zaksZd * xaksXd - xaksZd * zaksXd, zaksYd = xaksZd * yaksXd - yaksZd * xaksXd;
+        const mixed axlng = sqrt(xaksXd * xaksXd + yaksXd * yaksXd + zaksXd * zaksXd);
+        const mixed aylng = sqrt(xaksYd * xaksYd + yaksYd * yaksYd + zaksYd * zaksYd);
+        const mixed azlng = sqrt(xaksZd * xaksZd + yaksZd * yaksZd + zaksZd * zaksZd);
+        const mixed trns11 = xaksXd / axlng, trns21 = yaksXd / axlng, trns31 = zaksXd / axlng;
+        const mixed trns12 = xaksYd / aylng, trns22 = yaksYd / aylng, trns32 = zaksYd / aylng;
+        const mixed trns13 = xaksZd / azlng, trns23 = yaksZd / azlng, trns33 = zaksZd / azlng;
+        const mixed xb0d = trns11 * xb0 + trns21 * yb0 + trns31 * zb0, yb0d = trns12 * xb0 + trns22 * yb0 + trns32 * zb0;
+        const mixed xc0d = trns11 * xc0 + trns21 * yc0 + trns31 * zc0, yc0d = trns12 * xc0 + trns22 * yc0 + trns32 * zc0;
+        const mixed za1d = trns13 * xa1 + trns23 * ya1 + trns33 * za1;
+        const mixed xb1d = trns11 * xb1 + trns21 * yb1 + trns31 * zb1, yb1d = trns12 * xb1 + trns22 * yb1 + trns32 * zb1, zb1d = trns13 * xb1 + trns23 * yb1 + trns33 * zb1;
+        const mixed xc1d = trns11 * xc1 + trns21 * yc1 + trns31 * zc1, yc1d = trns12 * xc1 + trns22 * yc1 + trns32 * zc1, zc1d = trns13 * xc1 + trns23 * yc1 + trns33 * zc1;
+        // step 1: A2'
+        const mixed rc = 0.5f * distBB;
+        mixed rb = sqrt(distAB * distAB - rc * rc);
+        const mixed ra = rb * (m1 + m1) * invTotalMass;
+        rb -= ra;
+        const mixed sinphi = za1d / ra;
+        const mixed cosphi = sqrt(1 - sinphi * sinphi);
+        const mixed sinpsi = (zb1d - zc1d) / (2 * rc * cosphi);
+        const mixed cospsi = sqrt(1 - sinpsi * sinpsi);
+        const mixed ya2d = ra * cosphi;
+        mixed xb2d = -rc * cospsi;
+        const mixed yb2d = -rb * cosphi - rc * sinpsi * sinphi;
+        const mixed yc2d = -rb * cosphi + rc * sinpsi * sinphi;
+        const mixed xb2d2 = xb2d * xb2d;
+        const mixed hh2 = 4.0f * xb2d2 + (yb2d - yc2d) * (yb2d - yc2d) + (zb1d - zc1d) * (zb1d - zc1d);
+        const mixed deltx = 2.0f * xb2d + sqrt(4.0f * xb2d2 - hh2 + distBB * distBB);
+        xb2d -= deltx * 0.5f;
+        // step 2: A3'
+        const mixed alpha = xb2d * (xb0d - xc0d) + yb0d * yb2d + yc0d * yc2d;
+        const mixed beta = xb2d * (yc0d - yb0d) + xb0d * yb2d + xc0d * yc2d;
+        const mixed gamma = xb0d * yb1d - xb1d * yb0d + xc0d * yc1d - xc1d * yc0d;
+        const mixed al2be2 = alpha * alpha + beta * beta;
+        const mixed sintheta = (alpha * gamma - beta * sqrt(al2be2 - gamma * gamma)) / al2be2;
+        // step 3: A3
+        const mixed costheta = sqrt(1 - sintheta * sintheta);
+        const mixed xa3d = -ya2d * sintheta, ya3d = ya2d * costheta, za3d = za1d;
+        const mixed xb3d = xb2d * costheta - yb2d * sintheta, yb3d = xb2d * sintheta + yb2d * costheta, zb3d = zb1d;
+        const mixed xc3d = -xb2d * costheta - yc2d * sintheta, yc3d = -xb2d * sintheta + yc2d * costheta, zc3d = zc1d;
+        // step 4: back to the lab frame
+        const mixed xa3 = trns11 * xa3d + trns12 * ya3d + trns13 * za3d, ya3 = trns21 * xa3d + trns22 * ya3d + trns23 * za3d, za3 = trns31 * xa3d + trns32 * ya3d + trns33 * za3d;
+        const mixed xb3 = trns11 * xb3d + trns12 * yb3d + trns13 * zb3d, yb3 = trns21 * xb3d + trns22 * yb3d + trns23 * zb3d, zb3 = trns31 * xb3d + trns32 * yb3d + trns33 * zb3d;
+        const mixed xc3 = trns11 * xc3d + trns12 * yc3d + trns13 * zc3d, yc3 = trns21 * xc3d + trns22 * yc3d + trns23 * zc3d, zc3 = trns31 * xc3d + trns32 * yc3d + trns33 * zc3d;
+        xp0x = xcom + xa3; xp0y = ycom + ya3; xp0z = zcom + za3;
+        xp1x = xcom + xb3 - xb0; xp1y = ycom + yb3 - yb0; xp1z = zcom + zb3 - zb0;
+        xp2x = xcom + xc3 - xc0; xp2y = ycom + yc3 - yc0; xp2z = zcom + zc3 - zc0;
+}
+template <class mixed>
+__device__ __forceinline__ void settle_velocities_math(mixed m0, mixed m1,
+        mixed apos0x, mixed apos0y, mixed apos0z, mixed apos1x, mixed apos1y, mixed apos1z, mixed apos2x, mixed apos2y, mixed apos2z,
+        mixed& v0x, mixed& v0y, mixed& v0z, mixed& v1x, mixed& v1y, mixed& v1z, mixed& v2x, mixed& v2y, mixed& v2z) {
+        // Velocity constraints of the rigid triangle: one multiplier per bond, d/dt |r_ij|^2 = 0 for the three bonds at once.
+        // With e_ij the unit bond vectors and v_ij = (v_j - v_i).e_ij the system is linear 3x3 in (tab, tbc, tca) and is solved in closed
+        // form; particle 0 = apex A (mass mA), 1 = B, 2 = C (mass mB = mC).
+        mixed eABx = apos1x - apos0x, eABy = apos1y - apos0y, eABz = apos1z - apos0z;
+        mixed eBCx = apos2x - apos1x, eBCy = apos2y - apos1y, eBCz = apos2z - apos1z;
+        mixed eCAx = apos0x - apos2x, eCAy = apos0y - apos2y, eCAz = apos0z - apos2z;
+        const mixed nAB = 1 / sqrt(eABx * eABx + eABy * eABy + eABz * eABz);
+        const mixed nBC = 1 / sqrt(eBCx * eBCx + eBCy * eBCy + eBCz * eBCz);
+        const mixed nCA = 1 / sqrt(eCAx * eCAx + eCAy * eCAy + eCAz * eCAz);
+        eABx *= nAB; eABy *= nAB; eABz *= nAB; eBCx *= nBC; eBCy *= nBC; eBCz *= nBC; eCAx *= nCA; eCAy *= nCA; eCAz *= nCA;
+        const mixed vAB = (v1x - v0x) * eABx + (v1y - v0y) * eABy + (v1z - v0z) * eABz;
+        const mixed vBC = (v2x - v1x) * eBCx + (v2y - v1y) * eBCy + (v2z - v1z) * eBCz;
+        const mixed vCA = (v0x - v2x) * eCAx + (v0y - v2y) * eCAy + (v0z - v2z) * eCAz;
+        const mixed cA = -(eABx * eCAx + eABy * eCAy + eABz * eCAz);
+        const mixed cB = -(eABx * eBCx + eABy * eBCy + eABz * eBCz);
+        const mixed cC = -(eBCx * eCAx + eBCy * eCAy + eBCz * eCAz);
+        const mixed s2A = 1 - cA * cA, s2B = 1 - cB * cB, s2C = 1 - cC * cC;
+        const mixed mA = m0, mB = m1, mC = m1;
+        const mixed mABCinv = 1 / (mA * mB * mC);
+        const mixed denom = (((s2A * mB + s2B * mA) * mC + (s2A * mB * mB + 2 * (cA * cB * cC + 1) * mA * mB + s2B * mA * mA)) * mC + s2C * mA * mB * (mA + mB)) * mABCinv;
+        const mixed tab = ((cB * cC * mA - cA * mB - cA * mC) * vCA + (cA * cC * mB - cB * mC - cB * mA) * vBC + (s2C * mA * mA * mB * mB * mABCinv + (mA + mB + mC)) * vAB) / denom;
+        const mixed tbc = ((cA * cB * mC - cC * mB - cC * mA) * vCA + (s2A * mB * mB * mC * mC * mABCinv + (mA + mB + mC)) * vBC + (cA * cC * mB - cB * mA - cB * mC) * vAB) / denom;
+        const mixed tca = ((s2B * mA * mA * mC * mC * mABCinv + (mA + mB + mC)) * vCA + (cA * cB * mC - cC * mB - cC * mA) * vBC + (cB * cC * mA - cA * mB - cA * mC) * vAB) / denom;
+        const mixed iA = 1 / mA, iB = 1 / mB, iC = 1 / mC;
+        v0x += (eABx * tab - eCAx * tca) * iA; v0y += (eABy * tab - eCAy * tca) * iA; v0z += (eABz * tab - eCAz * tca) * iA;
+        v1x += (eBCx * tbc - eABx * tab) * iB; v1y += (eBCy * tbc - eABy * tab) * iB; v1z += (eBCz * tbc - eABz * tab) * iB;
+        v2x += (eCAx * tca - eBCx * tbc) * iC; v2y += (eCAy * tca - eBCy * tbc) * iC; v2z += (eCAz * tca - eBCz * tbc) * iC;
+}
+
+template <class mixed>
+__device__ __forceinline__ void shake_positions(int lane, unsigned word, float4 prm, mixed tol, mixed x, mixed y, mixed z, mixed invm,
+                                                mixed& dx, mixed& dy, mixed& dz, mixed (*page)[7]) {
+    if (word & 2u) { page[lane][0] = x; page[lane][1] = y; page[lane][2] = z; page[lane][3] = dx; page[lane][4] = dy; page[lane][5] = dz; page[lane][6] = invm; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (word & 1u) {
+    if ((word & 1u) && (word & SHAKE_WORD_SETTLE)) {
+        const int l1 = (int) ((word >> 4) & 63u), l2 = (int) ((word >> 10) & 63u);
+        mixed d1x = page[l1][3], d1y = page[l1][4], d1z = page[l1][5], d2x = page[l2][3], d2y = page[l2][4], d2z = page[l2][5];
+        settle_positions_math<mixed>((mixed) 1 / invm, (mixed) 1 / page[l1][6], (mixed) prm.x, (mixed) prm.y, x, y, z,
+                                     page[l1][0], page[l1][1], page[l1][2], page[l2][0], page[l2][1], page[l2][2], dx, dy, dz, d1x, d1y, d1z, d2x, d2y, d2z);
+        page[l1][3] = d1x; page[l1][4] = d1y; page[l1][5] = d1z; page[l2][3] = d2x; page[l2][4] = d2y; page[l2][5] = d2z;
+    } else if (word & 1u) {
         const int np = (int) ((word >> 2) & 3u);
         const mixed invMassCentral = prm.x, avgMass = prm.y, d2 = prm.z, invMassPeripheral = prm.w;
         mixed rij[3][3], rijsq[3], ld[3], xpj[3][3];
@@ -253,13 +360,19 @@ __device__ __forceinline__ void shake_positions(int lane, unsigned word, float4 
 }
 
 template <class mixed>
-__device__ __forceinline__ void shake_velocities(int lane, unsigned word, float4 prm, mixed tol, mixed x, mixed y, mixed z,
-                                                 mixed& vx, mixed& vy, mixed& vz, mixed (*page)[6]) {
-    if (word & 2u) { page[lane][0] = x; page[lane][1] = y; page[lane][2] = z; page[lane][3] = vx; page[lane][4] = vy; page[lane][5] = vz; }
+__device__ __forceinline__ void shake_velocities(int lane, unsigned word, float4 prm, mixed tol, mixed x, mixed y, mixed z, mixed invm,
+                                                 mixed& vx, mixed& vy, mixed& vz, mixed (*page)[7]) {
+    if (word & 2u) { page[lane][0] = x; page[lane][1] = y; page[lane][2] = z; page[lane][3] = vx; page[lane][4] = vy; page[lane][5] = vz; page[lane][6] = invm; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (word & 1u) {
+    if ((word & 1u) && (word & SHAKE_WORD_SETTLE)) {
+        const int l1 = (int) ((word >> 4) & 63u), l2 = (int) ((word >> 10) & 63u);
+        mixed u1x = page[l1][3], u1y = page[l1][4], u1z = page[l1][5], u2x = page[l2][3], u2y = page[l2][4], u2z = page[l2][5];
+        settle_velocities_math<mixed>((mixed) 1 / invm, (mixed) 1 / page[l1][6], x, y, z,
+                                      page[l1][0], page[l1][1], page[l1][2], page[l2][0], page[l2][1], page[l2][2], vx, vy, vz, u1x, u1y, u1z, u2x, u2y, u2z);
+        page[l1][3] = u1x; page[l1][4] = u1y; page[l1][5] = u1z; page[l2][3] = u2x; page[l2][4] = u2y; page[l2][5] = u2z;
+    } else if (word & 1u) {
         const int np = (int) ((word >> 2) & 3u);
         const mixed invMassCentral = prm.x, avgMass = prm.y, invMassPeripheral = prm.w;
         mixed rij[3][3], rijsq[3], vj[3][3];
@@ -463,13 +576,13 @@ __global__ void __launch_bounds__(256) vv_kernel_a(const KArgs a) {
             }
         }
         if (F & A_SHAKE_V) {                   // integration.applyVelocityConstraints(tol) (HOST:151, 427), clusters solved in the wave
-            __shared__ mixed shake_page_a[4][64][6];
+            __shared__ mixed shake_page_a[4][64][7];
             const unsigned word = act ? (unsigned) a.slot_shake[(size_t) wave * 64 + lane] : 0u;
             const float4 prm = (word & 1u) ? a.slot_shake_param[(size_t) wave * 64 + lane] : make_float4(0, 0, 0, 0);
             mixed sx = 0, sy = 0, sz = 0, sq = 0;
             real sraw = 0;
             if (word & 3u) PosIO<real, mixed>::load(a.posq, a.corr, atom, sx, sy, sz, sq, sraw);
-            shake_velocities<mixed>(lane, word, prm, (mixed) a.shake_tol, sx, sy, sz, v.x, v.y, v.z, shake_page_a[threadIdx.x >> 6]);
+            shake_velocities<mixed>(lane, word, prm, (mixed) a.shake_tol, sx, sy, sz, v.w, v.x, v.y, v.z, shake_page_a[threadIdx.x >> 6]);
             if (massive) store_vec(velm, atom, v, (F & A_WT_STORES) != 0);
         }
         if ((F & A_POS1) && massive) {                                      // K/middle.cu:33-40
@@ -942,7 +1055,7 @@ __global__ void __launch_bounds__(320) vv_kernel_b(const KArgs a) {
             ((mixed4*) a.old_delta)[atom] = od;
         }
         // per-wave LDS page and cluster word of the in-kernel SHAKE (collective over the wave: every lane walks through it)
-        __shared__ mixed shake_page_b[4][64][6];
+        __shared__ mixed shake_page_b[4][64][7];
         unsigned shake_word = 0;
         float4 shake_prm = make_float4(0, 0, 0, 0);
         if ((F & B_SHAKE) && act) {
@@ -961,7 +1074,7 @@ __global__ void __launch_bounds__(320) vv_kernel_b(const KArgs a) {
             }
             const mixed odx = ddx, ody = ddy, odz = ddz;
             if (F & B_SHAKE)                                                       // integration.applyConstraints(tol), HOST:176
-                shake_positions<mixed>(lane, shake_word, shake_prm, (mixed) a.shake_tol, x, y, z, ddx, ddy, ddz, shake_page_b[wib]);
+                shake_positions<mixed>(lane, shake_word, shake_prm, (mixed) a.shake_tol, x, y, z, v.w, ddx, ddy, ddz, shake_page_b[wib]);
             if (massive) {
                 const mixed invDt = 1 / stepSize;
                 v.x += (ddx - odx) * invDt; v.y += (ddy - ody) * invDt; v.z += (ddz - odz) * invDt;
@@ -982,7 +1095,7 @@ __global__ void __launch_bounds__(320) vv_kernel_b(const KArgs a) {
                 dx = d.x; dy = d.y; dz = d.z;
             }
             if (F & B_SHAKE)                                                       // integration.applyConstraints(tol), HOST:351
-                shake_positions<mixed>(lane, shake_word, shake_prm, (mixed) a.shake_tol, x, y, z, dx, dy, dz, shake_page_b[wib]);
+                shake_positions<mixed>(lane, shake_word, shake_prm, (mixed) a.shake_tol, x, y, z, v.w, dx, dy, dz, shake_page_b[wib]);
             if (massive) {
                 const mixed invStepSize = 1.0 / stepSize;
                 x += dx; y += dy; z += dz;

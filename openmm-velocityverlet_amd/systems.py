@@ -247,6 +247,34 @@ def constrain_hydrogens(spec: SystemSpec, distance: float = 0.109) -> SystemSpec
     return spec
 
 
+def rigid_water(spec: SystemSpec, d_oh: float = 0.1, d_hh: float = 0.1633) -> SystemSpec:
+    """Rigid three-site water as OpenMM's rigidWater=True asks for it: O-H, O-H and H-H constrained in every (O, H, H) molecule
+    of `spec`; the hydrogens are put on the rigid geometry and the molecule's velocity is made rigid-body compatible (the
+    bond-parallel relative velocities are removed), so the start lies on the constraint manifold."""
+    n = spec.num_atoms
+    assert n % 3 == 0
+    o = np.arange(0, n, 3)
+    rng = np.random.default_rng(SEED + 11)
+    u = rng.standard_normal((len(o), 3)); u /= np.linalg.norm(u, axis=1)[:, None]
+    w = rng.standard_normal((len(o), 3)); w -= (w * u).sum(1)[:, None] * u; w /= np.linalg.norm(w, axis=1)[:, None]
+    half = np.arcsin(0.5 * d_hh / d_oh)
+    spec.positions[o + 1] = spec.positions[o] + d_oh * (np.cos(half) * u + np.sin(half) * w)
+    spec.positions[o + 2] = spec.positions[o] + d_oh * (np.cos(half) * u - np.sin(half) * w)
+    cons = np.stack([np.stack([o + 1, o], 1), np.stack([o + 2, o], 1), np.stack([o + 1, o + 2], 1)], 1).reshape(-1, 2)
+    dist = np.tile([d_oh, d_oh, d_hh], len(o))
+    # rigid-body velocities: v_i = V_com + omega x (r_i - r_com), with V_com the molecule's COM velocity and a random omega
+    m = spec.masses.reshape(-1, 3)
+    x = spec.positions.reshape(-1, 3, 3)
+    v = spec.velocities.reshape(-1, 3, 3)
+    com = (m[:, :, None] * x).sum(1) / m.sum(1)[:, None]
+    vcom = (m[:, :, None] * v).sum(1) / m.sum(1)[:, None]
+    omega = rng.standard_normal((len(o), 3)) * 10.0
+    spec.velocities = (vcom[:, None, :] + np.cross(omega[:, None, :], x - com[:, None, :])).reshape(-1, 3)
+    spec.constraints = cons.astype(np.int32)
+    spec.constraint_distances = dist
+    return spec
+
+
 def make_config(name: str, scale: float = 1.0) -> SystemSpec:
     """BASELINE.json configs by id.  `scale` < 1 gives a reduced copy for fast parity tests."""
     if name == "C1":

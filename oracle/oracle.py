@@ -190,29 +190,69 @@ def build_tables(spec, params: Params) -> Dict:
 # ----------------------------------------------------------------------------------------------
 # array layouts shared by oracle, _ref and the product's host mirror
 # ----------------------------------------------------------------------------------------------
-def build_shake(spec):
-    """SHAKE clusters from the System's constraints with OpenMM's admission rule (central particle + <= 3 peripherals of equal mass
-    and distance, each peripheral in one constraint only).  Returns (atoms int32 [n,4], params float32 [n,4]) or None."""
+def build_constraint_clusters(spec):
+    """The System's constraints sorted into what the in-kernel solvers take, by OpenMM's admission rules:
+    rigid three-site molecules (three mutual constraints, an apex with two equal distances to two equal-mass partners) -> SETTLE;
+    everything else must be hydrogen-type clusters (central particle + <= 3 peripherals of equal mass and distance, each
+    peripheral in one constraint only) -> SHAKE.  Returns None without constraint distances, else a dict of
+    shake_atoms int32 [n,4], shake_params float32 [n,4], settle_atoms int32 [m,3], settle_params float32 [m,2]."""
     cons = np.asarray(spec.constraints).reshape(-1, 2)
     dist = getattr(spec, "constraint_distances", None)
     if dist is None or len(cons) == 0:
         return None
+    m = spec.masses
     deg = np.bincount(cons.reshape(-1), minlength=spec.num_atoms)
+    dmap = {}
+    for (a, b), d in zip(cons, dist):
+        dmap[(min(a, b), max(a, b))] = float(d)
+    nbr = {}
+    for a, b in cons:
+        nbr.setdefault(int(a), []).append(int(b))
+        nbr.setdefault(int(b), []).append(int(a))
+    settle_atoms, settle_params, in_settle = [], [], set()
+    for a in sorted(nbr):
+        if a in in_settle or deg[a] != 2:
+            continue
+        b, c = nbr[a]
+        if deg[b] != 2 or deg[c] != 2 or (min(b, c), max(b, c)) not in dmap:
+            continue
+        tri = (a, b, c)
+        dd = {(i, j): dmap[(min(i, j), max(i, j))] for i in tri for j in tri if i != j}
+        apex = None
+        for x in tri:
+            y, z = [t for t in tri if t != x]
+            if dd[(x, y)] == dd[(x, z)] and m[y] == m[z]:
+                apex = (x, min(y, z), max(y, z))
+                break
+        if apex is None:
+            raise OracleError("a rigid triangle without an apex of two equal bonds to equal partners")
+        settle_atoms.append(list(apex))
+        settle_params.append([dd[(apex[0], apex[1])], dd[(apex[1], apex[2])]])
+        in_settle.update(tri)
     clusters = {}
     for (a, b), d in zip(cons, dist):
-        ctr = a if deg[a] > 1 else (b if deg[b] > 1 else (a if spec.masses[a] >= spec.masses[b] else b))
+        if int(a) in in_settle:
+            continue
+        ctr = a if deg[a] > 1 else (b if deg[b] > 1 else (a if m[a] >= m[b] else b))
         per = b if ctr == a else a
         if deg[per] != 1:
-            raise OracleError("constraint topology is not a set of hydrogen-type clusters")
+            raise OracleError("constraint topology is neither rigid triangles nor hydrogen-type clusters")
         clusters.setdefault(int(ctr), []).append((int(per), float(d)))
     atoms, params = [], []
     for ctr, lst in clusters.items():
-        if len(lst) > 3 or len({d for _, d in lst}) != 1 or len({spec.masses[p] for p, _ in lst}) != 1:
-            raise OracleError("constraint topology is not a set of hydrogen-type clusters")
-        imc, imp, d = 1.0 / spec.masses[ctr], 1.0 / spec.masses[lst[0][0]], lst[0][1]
+        if len(lst) > 3 or len({d for _, d in lst}) != 1 or len({m[p] for p, _ in lst}) != 1:
+            raise OracleError("constraint topology is neither rigid triangles nor hydrogen-type clusters")
+        imc, imp, d = 1.0 / m[ctr], 1.0 / m[lst[0][0]], lst[0][1]
         atoms.append([ctr] + [p for p, _ in lst] + [-1] * (3 - len(lst)))
         params.append([imc, 0.5 / (imc + imp), d * d, imp])
-    return np.array(atoms, dtype=np.int32), np.array(params, dtype=np.float32)
+    return dict(shake_atoms=np.array(atoms, dtype=np.int32).reshape(-1, 4), shake_params=np.array(params, dtype=np.float32).reshape(-1, 4),
+                settle_atoms=np.array(settle_atoms, dtype=np.int32).reshape(-1, 3), settle_params=np.array(settle_params, dtype=np.float32).reshape(-1, 2))
+
+
+def build_shake(spec):
+    """(atoms, params) of the SHAKE clusters only; None without constraint distances."""
+    c = build_constraint_clusters(spec)
+    return None if c is None else (c["shake_atoms"], c["shake_params"])
 
 
 def padded(n: int) -> int:
@@ -277,6 +317,7 @@ class _System(C.Structure):
         ("force_mode", C.c_int), ("site", C.c_void_p), ("k_tether", C.c_double), ("k_drude", C.c_double),
         ("forces_valid", C.c_int), ("num_threads", C.c_int),
         ("num_shake", C.c_int), ("shake_atoms", C.c_void_p), ("shake_params", C.c_void_p), ("constraint_tolerance", C.c_double),
+        ("num_settle", C.c_int), ("settle_atoms", C.c_void_p), ("settle_params", C.c_void_p),
     ]
 
 
@@ -368,10 +409,14 @@ class OracleSystem:
         s.use_middle = int(p.use_middle_scheme)
         s.force_mode, s.site, s.k_tether, s.k_drude = force_mode, _p(self.site), k_tether, k_drude
         s.forces_valid, s.num_threads = 0, num_threads
-        self.shake = build_shake(spec)
+        self.clusters = build_constraint_clusters(spec)
         s.constraint_tolerance = 1e-5
-        if self.shake is not None:
-            s.num_shake, s.shake_atoms, s.shake_params = len(self.shake[0]), _p(self.shake[0]), _p(self.shake[1])
+        if self.clusters is not None:
+            cl = self.clusters
+            if len(cl["shake_atoms"]):
+                s.num_shake, s.shake_atoms, s.shake_params = len(cl["shake_atoms"]), _p(cl["shake_atoms"]), _p(cl["shake_params"])
+            if len(cl["settle_atoms"]):
+                s.num_settle, s.settle_atoms, s.settle_params = len(cl["settle_atoms"]), _p(cl["settle_atoms"]), _p(cl["settle_params"])
 
     def step(self, n: int = 1):
         self.L.vvo_step(C.byref(self.s), n)

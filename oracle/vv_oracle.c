@@ -693,6 +693,99 @@ void vvo_shake_velocities(int nclusters, const int* atoms, const float* params, 
     }
 }
 
+/* ------------------------------------------------------------------ SETTLE for rigid three-site molecules (see vv_oracle.h) */
+typedef struct { mixed x, y, z; } v3;
+static inline v3 v3_make(mixed x, mixed y, mixed z) { v3 r = { x, y, z }; return r; }
+static inline v3 v3_add(v3 a, v3 b) { return v3_make(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 v3_sub(v3 a, v3 b) { return v3_make(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 v3_scale(v3 a, mixed s) { return v3_make(a.x * s, a.y * s, a.z * s); }
+static inline mixed v3_dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline v3 v3_cross(v3 a, v3 b) { return v3_make(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+static inline v3 v3_unit(v3 a) { return v3_scale(a, 1 / sqrt(v3_dot(a, a))); }
+static inline v3 v3_pos(const real4* posq, const real4* corr, int i) { mixed x, y, z, w; load_pos(posq, corr, i, &x, &y, &z, &w); return v3_make(x, y, z); }
+
+void vvo_settle_positions(int n, const int* atoms, const float* params, const real4* posq, const real4* posq_corr,
+                          const mixed4* velm, mixed4* pos_delta) {
+    PAR_FOR
+    for (int c = 0; c < n; c++) {
+        const int ia = atoms[3 * c], ib = atoms[3 * c + 1], ic = atoms[3 * c + 2];
+        const mixed dAB = params[2 * c], dBB = params[2 * c + 1];
+        const mixed mA = 1 / velm[ia].w, mB = 1 / velm[ib].w;
+        const mixed invM = 1 / (mA + mB + mB);
+        const v3 a0 = v3_pos(posq, posq_corr, ia);
+        const v3 b0 = v3_sub(v3_pos(posq, posq_corr, ib), a0), c0 = v3_sub(v3_pos(posq, posq_corr, ic), a0);
+        const v3 da = v3_make(pos_delta[ia].x, pos_delta[ia].y, pos_delta[ia].z);
+        const v3 db = v3_make(pos_delta[ib].x, pos_delta[ib].y, pos_delta[ib].z);
+        const v3 dc = v3_make(pos_delta[ic].x, pos_delta[ic].y, pos_delta[ic].z);
+        /* unconstrained new positions relative to the old apex, and their centre of mass */
+        const v3 pa = da, pb = v3_add(b0, db), pc = v3_add(c0, dc);
+        const v3 com = v3_scale(v3_add(v3_scale(pa, mA), v3_scale(v3_add(pb, pc), mB)), invM);
+        const v3 a1 = v3_sub(pa, com), b1 = v3_sub(pb, com), c1 = v3_sub(pc, com);
+        /* frame: z normal to the OLD triangle, x normal to z and to the new apex vector, y completes it */
+        const v3 zax = v3_cross(b0, c0), xax = v3_cross(a1, zax), yax = v3_cross(zax, xax);
+        const v3 ex = v3_unit(xax), ey = v3_unit(yax), ez = v3_unit(zax);
+        const mixed xb0d = v3_dot(ex, b0), yb0d = v3_dot(ey, b0), xc0d = v3_dot(ex, c0), yc0d = v3_dot(ey, c0);
+        const mixed za1d = v3_dot(ez, a1);
+        const mixed xb1d = v3_dot(ex, b1), yb1d = v3_dot(ey, b1), zb1d = v3_dot(ez, b1);
+        const mixed xc1d = v3_dot(ex, c1), yc1d = v3_dot(ey, c1), zc1d = v3_dot(ez, c1);
+        /* canonical triangle: apex at (0, ra), partners at (-+rc, -rb) */
+        const mixed rc = dBB / 2;
+        const mixed height = sqrt(dAB * dAB - rc * rc);
+        const mixed ra = height * (mB + mB) * invM, rb = height - ra;
+        /* tilt angles phi, psi from the z displacements */
+        const mixed sinphi = za1d / ra, cosphi = sqrt(1 - sinphi * sinphi);
+        const mixed sinpsi = (zb1d - zc1d) / (2 * rc * cosphi), cospsi = sqrt(1 - sinpsi * sinpsi);
+        const mixed ya2d = ra * cosphi;
+        mixed xb2d = -rc * cospsi;
+        const mixed yb2d = -rb * cosphi - rc * sinpsi * sinphi, yc2d = -rb * cosphi + rc * sinpsi * sinphi;
+        const mixed hh2 = 4 * xb2d * xb2d + (yb2d - yc2d) * (yb2d - yc2d) + (zb1d - zc1d) * (zb1d - zc1d);
+        xb2d -= (2 * xb2d + sqrt(4 * xb2d * xb2d - hh2 + dBB * dBB)) / 2;
+        /* in-plane rotation theta from the angular-momentum condition */
+        const mixed alpha = xb2d * (xb0d - xc0d) + yb0d * yb2d + yc0d * yc2d;
+        const mixed beta = xb2d * (yc0d - yb0d) + xb0d * yb2d + xc0d * yc2d;
+        const mixed gamma = xb0d * yb1d - xb1d * yb0d + xc0d * yc1d - xc1d * yc0d;
+        const mixed ab2 = alpha * alpha + beta * beta;
+        const mixed sintheta = (alpha * gamma - beta * sqrt(ab2 - gamma * gamma)) / ab2, costheta = sqrt(1 - sintheta * sintheta);
+        const v3 a3d = v3_make(-ya2d * sintheta, ya2d * costheta, za1d);
+        const v3 b3d = v3_make(xb2d * costheta - yb2d * sintheta, xb2d * sintheta + yb2d * costheta, zb1d);
+        const v3 c3d = v3_make(-xb2d * costheta - yc2d * sintheta, -xb2d * sintheta + yc2d * costheta, zc1d);
+        const v3 a3 = v3_add(v3_add(v3_scale(ex, a3d.x), v3_scale(ey, a3d.y)), v3_scale(ez, a3d.z));
+        const v3 b3 = v3_add(v3_add(v3_scale(ex, b3d.x), v3_scale(ey, b3d.y)), v3_scale(ez, b3d.z));
+        const v3 c3 = v3_add(v3_add(v3_scale(ex, c3d.x), v3_scale(ey, c3d.y)), v3_scale(ez, c3d.z));
+        const v3 na = v3_add(com, a3), nb = v3_sub(v3_add(com, b3), b0), nc = v3_sub(v3_add(com, c3), c0);
+        pos_delta[ia].x = na.x; pos_delta[ia].y = na.y; pos_delta[ia].z = na.z;
+        pos_delta[ib].x = nb.x; pos_delta[ib].y = nb.y; pos_delta[ib].z = nb.z;
+        pos_delta[ic].x = nc.x; pos_delta[ic].y = nc.y; pos_delta[ic].z = nc.z;
+    }
+}
+
+void vvo_settle_velocities(int n, const int* atoms, const real4* posq, const real4* posq_corr, mixed4* velm) {
+    PAR_FOR
+    for (int c = 0; c < n; c++) {
+        const int ia = atoms[3 * c], ib = atoms[3 * c + 1], ic = atoms[3 * c + 2];
+        const mixed wA = velm[ia].w, wB = velm[ib].w, wC = velm[ic].w;                 /* inverse masses */
+        const v3 pa = v3_pos(posq, posq_corr, ia), pb = v3_pos(posq, posq_corr, ib), pc = v3_pos(posq, posq_corr, ic);
+        const v3 eAB = v3_unit(v3_sub(pb, pa)), eBC = v3_unit(v3_sub(pc, pb)), eCA = v3_unit(v3_sub(pa, pc));
+        v3 va = v3_make(velm[ia].x, velm[ia].y, velm[ia].z), vb = v3_make(velm[ib].x, velm[ib].y, velm[ib].z), vc = v3_make(velm[ic].x, velm[ic].y, velm[ic].z);
+        const mixed rAB = v3_dot(v3_sub(vb, va), eAB), rBC = v3_dot(v3_sub(vc, vb), eBC), rCA = v3_dot(v3_sub(va, vc), eCA);
+        const mixed cA = -v3_dot(eAB, eCA), cB = -v3_dot(eAB, eBC), cC = -v3_dot(eBC, eCA);
+        /* [ wA+wB  cB wB  cA wA ] [tab]   [rAB]
+         * [ cB wB  wB+wC  cC wC ] [tbc] = [rBC]      (symmetric; solved by Cramer's rule)
+         * [ cA wA  cC wC  wC+wA ] [tca]   [rCA] */
+        const mixed m11 = wA + wB, m12 = cB * wB, m13 = cA * wA, m22 = wB + wC, m23 = cC * wC, m33 = wC + wA;
+        const mixed det = m11 * (m22 * m33 - m23 * m23) - m12 * (m12 * m33 - m23 * m13) + m13 * (m12 * m23 - m22 * m13);
+        const mixed tab = (rAB * (m22 * m33 - m23 * m23) - m12 * (rBC * m33 - m23 * rCA) + m13 * (rBC * m23 - m22 * rCA)) / det;
+        const mixed tbc = (m11 * (rBC * m33 - m23 * rCA) - rAB * (m12 * m33 - m23 * m13) + m13 * (m12 * rCA - rBC * m13)) / det;
+        const mixed tca = (m11 * (m22 * rCA - rBC * m23) - m12 * (m12 * rCA - rBC * m13) + rAB * (m12 * m23 - m22 * m13)) / det;
+        va = v3_add(va, v3_scale(v3_sub(v3_scale(eAB, tab), v3_scale(eCA, tca)), wA));
+        vb = v3_add(vb, v3_scale(v3_sub(v3_scale(eBC, tbc), v3_scale(eAB, tab)), wB));
+        vc = v3_add(vc, v3_scale(v3_sub(v3_scale(eCA, tca), v3_scale(eBC, tbc)), wC));
+        velm[ia].x = va.x; velm[ia].y = va.y; velm[ia].z = va.z;
+        velm[ib].x = vb.x; velm[ib].y = vb.y; velm[ib].z = vb.z;
+        velm[ic].x = vc.x; velm[ic].y = vc.y; velm[ic].z = vc.z;
+    }
+}
+
 /* ------------------------------------------------------------------ API:340-376 (host, double) */
 void vvo_propagate_nh_chain(int numNHChains, int loopsPerStep, double stepSize, double* eta, double* eta_dot,
                             double* eta_dotdot, const double* eta_mass, double ke2, double ke2_target,
@@ -859,11 +952,13 @@ static void step_middle(vvo_system* s) {           /* API:232-270; constraints/v
     vvo_integrate_middle_vel(n, s->padded_num_atoms, s->velm, s->force, s->force_extra, (mixed) s->dt);  /* HOST:144-148 */
     if (s->num_shake > 0)   /* integration.applyVelocityConstraints, HOST:151 */
         vvo_shake_velocities(s->num_shake, s->shake_atoms, s->shake_params, (mixed) s->constraint_tolerance, s->posq, s->posq_corr, s->velm);
+    if (s->num_settle > 0) vvo_settle_velocities(s->num_settle, s->settle_atoms, s->posq, s->posq_corr, s->velm);
     vvo_integrate_middle_pos1(n, s->velm, s->pos_delta, s->old_delta, (mixed) s->dt);                     /* HOST:154-158 */
     nh_half(s);
     vvo_integrate_middle_pos2(n, s->velm, s->pos_delta, s->old_delta, (mixed) s->dt);                     /* HOST:169-173 */
     if (s->num_shake > 0)   /* integration.applyConstraints, HOST:176 */
         vvo_shake_positions(s->num_shake, s->shake_atoms, s->shake_params, (mixed) s->constraint_tolerance, s->posq, s->posq_corr, s->pos_delta);
+    if (s->num_settle > 0) vvo_settle_positions(s->num_settle, s->settle_atoms, s->settle_params, s->posq, s->posq_corr, s->velm, s->pos_delta);
     vvo_integrate_middle_pos3(n, s->posq, s->posq_corr, s->pos_delta, s->old_delta, s->velm, (mixed) s->dt); /* HOST:179-185 */
     hard_wall(s);
     if (s->num_images > 0)
@@ -881,6 +976,7 @@ static void step_vv(vvo_system* s) {               /* API:272-338 */
                                 (mixed) s->dt, (mixed) fscale, 1);                                        /* HOST:341-348 */
     if (s->num_shake > 0)   /* HOST:351 */
         vvo_shake_positions(s->num_shake, s->shake_atoms, s->shake_params, (mixed) s->constraint_tolerance, s->posq, s->posq_corr, s->pos_delta);
+    if (s->num_settle > 0) vvo_settle_positions(s->num_settle, s->settle_atoms, s->settle_params, s->posq, s->posq_corr, s->velm, s->pos_delta);
     vvo_vv_integrate_positions(n, s->posq, s->posq_corr, s->pos_delta, s->velm, (mixed) s->dt);           /* HOST:355-360 */
     hard_wall(s);
     if (s->num_images > 0)
@@ -892,6 +988,7 @@ static void step_vv(vvo_system* s) {               /* API:272-338 */
                                 (mixed) s->dt, (mixed) fscale, 0);                                        /* HOST:417-424 */
     if (s->num_shake > 0)   /* HOST:427 */
         vvo_shake_velocities(s->num_shake, s->shake_atoms, s->shake_params, (mixed) s->constraint_tolerance, s->posq, s->posq_corr, s->velm);
+    if (s->num_settle > 0) vvo_settle_velocities(s->num_settle, s->settle_atoms, s->posq, s->posq_corr, s->velm);
     nh_half(s);
 }
 void vvo_step(vvo_system* s, int steps) {

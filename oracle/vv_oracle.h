@@ -105,6 +105,9 @@ typedef struct {
     int num_shake;  const int* shake_atoms;   /* [4*n]: central, up to three peripherals (-1 = none) */
     const float* shake_params;                /* [4*n]: 1/m_c, 0.5/(1/m_c + 1/m_p), d^2, 1/m_p       */
     double constraint_tolerance;
+    /* rigid three-site molecules (SETTLE), see vvo_settle_positions */
+    int num_settle; const int* settle_atoms;  /* [3*n]: apex, partner, partner */
+    const float* settle_params;               /* [2*n]: apex-partner distance, partner-partner distance */
 } vvo_system;
 
 #ifdef __cplusplus
@@ -167,6 +170,12 @@ void vvo_shake_positions(int nclusters, const int* atoms, const float* params, v
                          const vvo_real4* posq_corr, vvo_mixed4* pos_delta);
 void vvo_shake_velocities(int nclusters, const int* atoms, const float* params, vvo_mixed tol, const vvo_real4* posq,
                           const vvo_real4* posq_corr, vvo_mixed4* velm);
+/* SETTLE (Miyamoto & Kollman 1992) for rigid three-site molecules, on the step displacement / on the velocities; masses from
+ * velm.w.  Written independently of the device code (vector form, the velocity multipliers by Cramer's rule); same unpinned status
+ * as vvo_shake_*: OpenMM's source is not under /root/reference. */
+void vvo_settle_positions(int n, const int* atoms, const float* params, const vvo_real4* posq, const vvo_real4* posq_corr,
+                          const vvo_mixed4* velm, vvo_mixed4* pos_delta);
+void vvo_settle_velocities(int n, const int* atoms, const vvo_real4* posq, const vvo_real4* posq_corr, vvo_mixed4* velm);
 void vvo_propagate_nh_chain(int num_chains, int loops_per_step, double step_size, double* eta, double* eta_dot,
                             double* eta_dotdot, const double* eta_mass, double ke2, double ke2_target,
                             double t_target, double* factor);

@@ -97,13 +97,13 @@ static int run(const char* out, bool middle, int consMode, double cosacc, int ns
         }
     system.addForce(drude);
     system.addForce(new CMMotionRemover());
-    // consMode 1: a rigid triangle in molecule 0 -- not a hydrogen-type cluster, so the plan leaves constraints to OpenMM's solver
+    // consMode 1: a chain H-heavy-H-H in molecule 0 -- neither a hydrogen-type cluster nor a rigid triangle, so the plan leaves constraints to OpenMM's solver
     //             and VVIntegrator takes the un-fused path (the stand-in solver is a no-op; only the path and the DOF matter);
     // consMode 2: both hydrogens of every molecule constrained to the heavy particle 4 -- solved inside the fused kernels.
     std::vector<int> cons;
     std::vector<double> consDist;
     auto addCons = [&](int a, int b, double d) { system.addConstraint(a, b, d); cons.push_back(a); cons.push_back(b); consDist.push_back(d); };
-    if (consMode == 1) { addCons(6, 4, 0.1); addCons(7, 4, 0.1); addCons(6, 7, 0.16); }
+    if (consMode == 1) { addCons(6, 4, 0.1); addCons(7, 6, 0.16); }
     if (consMode == 2)
         for (int m = 0; m < nmol; m++) { addCons(m * per + 6, m * per + 4, 0.1); addCons(m * per + 7, m * per + 4, 0.1); }
     const double box[3] = {3.0, 3.0, 3.0}, kB = (1.380649e-23 * 6.02214076e23) / 1000.0;

@@ -165,11 +165,29 @@ def test_constraint_clusters_share_a_wave(use_com):
         assert len(set(wave_of[members])) == 1 and wave_of[members[0]] >= 0
     for d, par in np.asarray(spec.drude_pairs):
         assert wave_of[d] == wave_of[par]
-    # a rigid triangle is not such a cluster: reported, not silently dropped
+    # a chain of constraints (H-O-H plus a fourth particle hanging off one H) is neither a triangle nor such a cluster: reported,
+    # not silently dropped
     spec2 = systems.spce_water(4)
-    spec2.constraints = np.array([(1, 0), (2, 0), (1, 2)], dtype=np.int32)
+    spec2.constraints = np.array([(1, 0), (2, 0), (2, 3)], dtype=np.int32)
     spec2.constraint_distances = np.array([0.1, 0.1, 0.16])
     info2, _ = I.plan_layout(spec2, I.VVIntegrator(300.0, 10, 1.0, 40, 0.001))
-    assert not info2.constraints_fused and info2.num_shake_clusters == 0
+    assert not info2.constraints_fused and info2.num_shake_clusters == 0 and info2.num_settle_clusters == 0
     with pytest.raises(O.OracleError):
-        O.build_shake(spec2)
+        O.build_constraint_clusters(spec2)
+
+
+def test_rigid_water_is_recognised_as_settle_clusters():
+    spec = systems.rigid_water(systems.spce_water(40, seed=2))
+    info, slots = I.plan_layout(spec, I.VVIntegrator(300.0, 10, 1.0, 40, 0.002))
+    cl = O.build_constraint_clusters(spec)
+    assert info.constraints_fused and info.num_settle_clusters == 40 == len(cl["settle_atoms"]) and info.num_shake_clusters == 0
+    assert np.array_equal(cl["settle_atoms"][:, 0] % 3, np.zeros(40, int))            # the oxygen is the apex
+    assert list(info.dof)[0] == 3 * 120 - 120 - 3
+    wave_of = np.full(spec.num_atoms, -1)
+    live = slots[:, 0] >= 0
+    wave_of[slots[live, 0]] = np.nonzero(live)[0] // 64
+    assert all(len(set(wave_of[row])) == 1 for row in cl["settle_atoms"])
+    # water + a solute with HBonds in one System: both kinds side by side
+    mix = systems.constrain_hydrogens(systems.drude_il(cells=(1, 1, 1), pairs_per_cell=3, seed=2))
+    cm = O.build_constraint_clusters(mix)
+    assert len(cm["settle_atoms"]) == 0 and len(cm["shake_atoms"]) > 0
