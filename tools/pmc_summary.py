@@ -1,0 +1,29 @@
+"""HBM traffic per launch of the fused kernels from rocprofv3 counter CSVs (tools/profile_round.sh).
+Corrections as /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section) prescribes for gfx950: FETCH_SIZE and WRITE_SIZE are
+in KB; FETCH_SIZE reads exactly half of a wide coalesced streaming read -> doubled; WRITE_SIZE as is."""
+import csv, glob, json, os, sys
+
+out_dir, tag = sys.argv[1], sys.argv[2]
+names = {"vv_kernel_a": "A", "vv_kernel_b": "B", "vv_kernel_tether": "tether"}
+raw = {}
+for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    files = glob.glob(os.path.join(out_dir, f"pmc_{counter}", "**", "*counter_collection.csv"), recursive=True)
+    for f in files:
+        for row in csv.DictReader(open(f)):
+            if row.get("Counter_Name") != counter:
+                continue
+            for key, short in names.items():
+                if key in row["Kernel_Name"]:
+                    rec = raw.setdefault(short, {}).setdefault(counter, [0.0, 0])
+                    rec[0] += float(row["Counter_Value"]); rec[1] += 1
+res = {"config": "C3", "precision": "mixed", "round": tag,
+       "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 400 --warmup 100 --no-cpu-baseline (two separate passes; tools/profile_round.sh)",
+       "correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE (KB) reads exactly half of a wide coalesced streaming read on gfx950 -> doubled; WRITE_SIZE (KB) as is; x1024 for bytes",
+       "raw_kb": {}}
+for short, d in raw.items():
+    res["raw_kb"][short] = {c: round(v[0] / max(v[1], 1), 1) for c, v in d.items()}
+    res["raw_kb"][short]["dispatches"] = max(v[1] for v in d.values())
+    f = d.get("FETCH_SIZE", [0, 1]); w = d.get("WRITE_SIZE", [0, 1])
+    res[f"hbm_bytes_per_launch_{short}"] = int(round((2 * f[0] / max(f[1], 1) + w[0] / max(w[1], 1)) * 1024))
+res["algorithmic_bytes_per_launch"] = {"A": 94 * 111000, "B": 134 * 111000}
+print(json.dumps(res, indent=1))
