@@ -1318,6 +1318,7 @@ constexpr uint32_t SF_B_COS_HW = B_CHAIN | B_SCALE | B_UNBIAS | B_CZ_LOAD | B_DR
 constexpr uint32_t SF_B_MIDDLE_HW = B_CHAIN | B_SCALE | B_DRIFT_MIDDLE | B_HARDWALL;
 constexpr uint32_t SF_B_MIDDLE_HW_WT = SF_B_MIDDLE_HW | B_WT_STORES;
 constexpr uint32_t SF_B_MIDDLE = B_CHAIN | B_SCALE | B_DRIFT_MIDDLE;
+constexpr uint32_t SF_B_MIDDLE_HW_NC = B_SCALE | B_DRIFT_MIDDLE | B_HARDWALL;                // large systems: the chain runs as its own 1-wave launch in front
 constexpr uint32_t SF_B_MIDDLE_HW_MB = SF_B_MIDDLE_HW | B_MAILBOX;
 constexpr uint32_t SF_A_MIDDLE_SHAKE = SF_A_MIDDLE | A_SHAKE_V;                         // HBonds constraints solved in-kernel
 constexpr uint32_t SF_B_MIDDLE_HW_SHAKE = SF_B_MIDDLE_HW | B_SHAKE;
@@ -1345,6 +1346,7 @@ hipError_t launch_b(int precision, const KArgs& a, int block_threads, hipStream_
     else if (a.flags == SF_B_MIDDLE_HW_WT) { VV_DISPATCH_SF(vv_kernel_b, SF_B_MIDDLE_HW_WT, g, b, 0, s, a); }
     else if (a.flags == SF_B_MIDDLE) { VV_DISPATCH_SF(vv_kernel_b, SF_B_MIDDLE, g, b, 0, s, a); }
     else if (a.flags == SF_B_COS_HW) { VV_DISPATCH_SF(vv_kernel_b, SF_B_COS_HW, g, b, 0, s, a); }
+    else if (a.flags == SF_B_MIDDLE_HW_NC) { VV_DISPATCH_SF(vv_kernel_b, SF_B_MIDDLE_HW_NC, g, b, 0, s, a); }
     else if (a.flags == SF_B_MIDDLE_HW_MB) { VV_DISPATCH_SF(vv_kernel_b, SF_B_MIDDLE_HW_MB, g, b, 0, s, a); }
     else if (a.flags == SF_B_MIDDLE_HW_SHAKE) { VV_DISPATCH_SF(vv_kernel_b, SF_B_MIDDLE_HW_SHAKE, g, b, 0, s, a); }
     else if (a.flags == SF_B_MIDDLE_SHAKE) { VV_DISPATCH_SF(vv_kernel_b, SF_B_MIDDLE_SHAKE, g, b, 0, s, a); }
