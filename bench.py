@@ -93,65 +93,40 @@ def main():
         it.setMirrorLocation(lz / 2)
         it.setElectricField(2.0 / lz * 2 * 1.602176634e-22)
     bounds = D.shard_bounds(spec, world)
-    # N > 1, in order of preference (each step down only if the one above cannot be set up or fails its trial run on any rank):
-    #   mailbox  kernel A's last block stores the rank's int64 totals into every peer's box over xGMI (hipIpc mappings), kernel B's
-    #            thermostat wave collects them: no collective launch, the sharded step stays two launches inside the hipGraph;
+    # N > 1: three ways to exchange the thermostat sums.  Unless --dist-mode names one, the bench sets up what it
+    # can, times a short run of each candidate on all ranks and keeps the faster one:
+    #   mailbox  kernel B's head stores the rank's int64 totals into every peer's box over xGMI (hipIpc mappings) and collects
+    #            the peers': no collective launch, the sharded step stays two launches inside the hipGraph;
     #   eager    in-core RCCL: ncclAllReduce enqueued from C between kernel A and kernel B of every step (graph = captured; opt-in,
     #            multi-rank capture cannot be tried in the build environment);
-    #   python   torch.distributed all-reduce per step.
+    #   python   torch.distributed all-reduce per step (last resort).
     dist_mode = None
     ctx = None
+    candidates = {}
 
     def agree(ok):
         flag = torch.tensor([1 if ok else 0], device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         return int(flag.item()) == 1
 
+    def slowest(seconds):
+        t = torch.tensor([seconds], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     def fresh_context(stream=None):
         it._context = None
         return I.Context(spec, it, precision=args.precision, force_provider=args.forces, shard=bounds[rank], device=local_rank, stream=stream)
 
-    if use_dist and args.dist_mode in ("auto", "mailbox") and cfg != "C4":
-        ok = True
+    def timed(fn, n):
+        ctx.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        fn(n)
+        ctx.synchronize()
+        return slowest(time.perf_counter() - t0) / n * 1e6
+
+    def setup_rccl():
         try:
-            ctx = fresh_context()
-            mine = torch.frombuffer(bytearray(ctx.mailbox_create(world, rank)), dtype=torch.uint8).cuda()
-            allh = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(allh, mine)
-            ctx.mailbox_connect(b"".join(bytes(h.cpu().numpy().tobytes()) for h in allh))
-        except Exception as e:                                   # noqa: BLE001
-            sys.stderr.write(f"[rank {rank}] mailbox exchange unavailable ({e})\n")
-            ok = False
-        if agree(ok):
-            try:                                                 # trial: eager steps, then a replayed graph; all ranks must end up
-                it.step(4)                                       # with the very same thermostat bits and no wait may have run out
-                if not ctx.mailbox_status()[1]:
-                    ctx.run_graph(2 * args.steps_per_graph, args.steps_per_graph)
-                ctx.synchronize()
-                active, timed_out = ctx.mailbox_status()
-                st = ctx.getNHState()
-                mine = torch.tensor(list(st.ke2) + list(st.vscale), dtype=torch.float64, device="cuda")
-                every = [torch.empty_like(mine) for _ in range(world)]
-                dist.all_gather(every, mine)
-                ok = active and not timed_out and all(torch.equal(e.view(torch.int64), mine.view(torch.int64)) for e in every) \
-                    and bool(torch.isfinite(mine).all())
-            except Exception as e:                               # noqa: BLE001
-                sys.stderr.write(f"[rank {rank}] mailbox trial failed ({e})\n")
-                ok = False
-            if agree(ok):
-                dist_mode = "mailbox"
-        if dist_mode is None:
-            if rank == 0:
-                sys.stderr.write("mailbox exchange not usable here; falling back to RCCL\n")
-            if ctx is not None:
-                try:
-                    ctx.close()
-                except Exception:                                # noqa: BLE001
-                    pass
-            ctx = None
-    if use_dist and dist_mode is None and args.dist_mode != "python":
-        try:
-            ctx = fresh_context()
             idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
             if rank == 0:
                 idt.copy_(torch.frombuffer(bytearray(ctx.comm_unique_id()), dtype=torch.uint8))
@@ -159,10 +134,67 @@ def main():
             ctx.comm_init(bytes(idt.cpu().numpy().tobytes()), world, rank)
             ok = True
         except Exception as e:                                   # noqa: BLE001
-            sys.stderr.write(f"[rank {rank}] in-core RCCL unavailable ({e}); falling back to torch.distributed per step\n")
+            sys.stderr.write(f"[rank {rank}] in-core RCCL unavailable ({e})\n")
             ok = False
-        if agree(ok):
-            dist_mode = "graph" if args.dist_mode == "graph" else "eager"
+        return agree(ok)
+
+    def setup_mailbox():
+        ok = True
+        try:
+            mine = torch.frombuffer(bytearray(ctx.mailbox_create(world, rank)), dtype=torch.uint8).cuda()
+            allh = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(allh, mine)
+            ctx.mailbox_connect(b"".join(bytes(h.cpu().numpy().tobytes()) for h in allh))
+        except Exception as e:                                   # noqa: BLE001
+            sys.stderr.write(f"[rank {rank}] mailbox exchange unavailable ({e})\n")
+            ok = False
+        if not agree(ok):
+            return False
+        try:                                                     # trial: eager steps, then a replayed graph; all ranks must end up
+            it.step(4)                                           # with the very same thermostat bits and no wait may have run out
+            if not ctx.mailbox_status()[1]:
+                ctx.run_graph(2 * args.steps_per_graph, args.steps_per_graph)
+            ctx.synchronize()
+            active, timed_out = ctx.mailbox_status()
+            st = ctx.getNHState()
+            mine = torch.tensor(list(st.ke2) + list(st.vscale), dtype=torch.float64, device="cuda")
+            every = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            ok = active and not timed_out and all(torch.equal(e.view(torch.int64), mine.view(torch.int64)) for e in every) \
+                and bool(torch.isfinite(mine).all())
+        except Exception as e:                                   # noqa: BLE001
+            sys.stderr.write(f"[rank {rank}] mailbox trial failed ({e})\n")
+            ok = False
+        return agree(ok)
+
+    if use_dist and args.dist_mode != "python":
+        want = args.dist_mode
+        ctx = fresh_context()
+        have_rccl = setup_rccl() if want in ("auto", "eager", "graph") else False
+        if have_rccl and want == "auto":
+            ctx.run_eager(100)
+            candidates["rccl_eager_us_per_step"] = round(timed(ctx.run_eager, 300), 2)
+        have_mb = False
+        if want in ("auto", "mailbox") and cfg != "C4":          # (the bias moment of the cos perturbation goes through the collective)
+            have_mb = setup_mailbox()
+            if have_mb and want == "auto":
+                candidates["mailbox_graph_us_per_step"] = round(timed(lambda n: ctx.run_graph(n, args.steps_per_graph), 3 * args.steps_per_graph), 2)
+            if not have_mb:                                       # a failed trial leaves a void state behind: start over
+                if rank == 0:
+                    sys.stderr.write("mailbox exchange not usable here\n")
+                try:
+                    ctx.close()
+                except Exception:                                # noqa: BLE001
+                    pass
+                ctx = fresh_context()
+                have_rccl = setup_rccl() if want in ("auto", "eager", "graph") else False
+        if have_mb and (not have_rccl or want == "mailbox" or
+                        candidates.get("mailbox_graph_us_per_step", 0.0) <= candidates.get("rccl_eager_us_per_step", float("inf"))):
+            dist_mode = "mailbox"
+        elif have_rccl:
+            if have_mb:
+                ctx.mailbox_destroy()
+            dist_mode = "graph" if want == "graph" else "eager"
             if dist_mode == "graph":                             # every rank must agree that capture works
                 try:
                     ctx.run_graph(2, 2)
@@ -174,8 +206,7 @@ def main():
                 if not agree(ok):
                     dist_mode = "eager"
         else:
-            if ctx is not None:
-                ctx.close()
+            ctx.close()
             ctx = None
     stepper = None
     if ctx is None:
@@ -239,6 +270,8 @@ def main():
                        "parallelism": ("1 GPU" + (f" (distributed code path forced: {dist_mode})" if use_dist else "")) if world == 1 else f"particle shards on molecule boundaries x{world}, int64 totals exchanged per thermostat application ({dist_mode})",
                        "atom_steps_per_s": round(steps_per_s * n, 1)},
         }
+        if candidates:
+            out["config"]["exchange_candidates"] = candidates
 
     # ---- the integrator path alone: forces resident in HBM (static buffer), no provider kernel in the loop
     if world == 1 and rank == 0 and not use_dist and args.forces == "tether" and not args.eager:
