@@ -99,6 +99,11 @@ struct vvhip_plan {
     std::vector<void*> mb_opened;                 // hipIpcOpenMemHandle mappings to close
     int mb_ranks = 0, mb_rank = 0;
     bool mb_on = false;
+    vv::ChainLaneBlock* d_lane_const = nullptr;   // [3] chain constants per temperature group (kernel B's thermostat wave)
+    vv::ChainLaneBlock lane_const_host[VVHIP_NUM_TG] = {};
+    bool lane_const_valid = false;
+    long long* d_dbg = nullptr;                   // instrumented build only (vvhip_debug_timestamps)
+    int dbg_block = 0;
 };
 
 extern "C" int vvhip_debug_read_accumulators(vvhip_plan* p, double out[4], int zero_after);
@@ -180,11 +185,14 @@ vv::KArgs make_args(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
     a.nh = p->d_nh + p->parity;
     a.nh_next = p->d_nh + (p->parity ^ 1);
     a.chain = make_chain(p, 0);
+    a.lane_const = p->d_lane_const;
     a.mb.local = p->mb_local;
     a.mb.peers = p->d_mb_peers;
     a.mb.ctl = p->d_mb_ctl;
     a.mb.ranks = p->mb_ranks;
     a.mb.rank = p->mb_rank;
+    a.dbg = p->d_dbg;
+    a.dbg_block = p->dbg_block;
     a.padded = p->hp.padded_num_atoms;
     a.nwaves = p->hp.info.num_waves;
     a.flags = flags;
@@ -225,6 +233,36 @@ vv::NHConst make_chain(vvhip_plan* p, uint32_t flags) {
     c.num_tg = in.num_temp_groups;
     c.flags = flags;
     return c;
+}
+
+// Chain constants per temperature group for kernel B's thermostat wave; the temperatures are read live (HOST:728), so this is
+// refreshed whenever the parameters change.
+int upload_lane_const(vvhip_plan* p) {
+    if (!p->d_lane_const) return VVHIP_OK;
+    const vvhip_params& q = p->hp.params;
+    const vvhip_plan_info& in = p->hp.info;
+    vv::ChainLaneBlock b[VVHIP_NUM_TG] = {};
+    for (int g = 0; g < VVHIP_NUM_TG; g++) {
+        for (int i = 0; i < 4; i++) {
+            b[g].eta_mass[i] = in.eta_mass[g][i];
+            b[g].inv_eta_mass[i] = in.eta_mass[g][i] > 0 ? 1.0 / in.eta_mass[g][i] : 0.0;
+        }
+        b[g].nkbt = in.nkbt[g];
+        b[g].kT = kBoltz * (g == 2 ? q.drude_temperature : q.temperature);
+        b[g].acc_inv_scale = p->acc_inv_scale[g];
+        b[g].active = (g < in.num_temp_groups && in.eta_mass[g][0] > 0) ? 1.0 : 0.0;
+        b[g].dt2 = q.step_size / q.loops_per_step / 2;                            // API:343-345
+        b[g].dt4 = b[g].dt2 / 2;
+        b[g].dt8 = b[g].dt4 / 2;
+    }
+    // hosts re-send their parameters every step (the reference re-reads the getters every step): only a real change costs a copy
+    if (p->lane_const_valid && std::memcmp(p->lane_const_host, b, sizeof(b)) == 0) return VVHIP_OK;
+    (void) hipStreamSynchronize(p->stream);
+    hipError_t e = hipMemcpy(p->d_lane_const, b, sizeof(b), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return hip_fail(p, e, "hipMemcpy(chain constants)");
+    std::memcpy(p->lane_const_host, b, sizeof(b));
+    p->lane_const_valid = true;
+    return VVHIP_OK;
 }
 
 struct ScopedTimer {
@@ -364,7 +402,7 @@ void vvhip_plan_destroy(vvhip_plan* p) {
     if (p->bound) {
         (void) hipStreamSynchronize(p->stream);
         for (void* ptr : {(void*) p->d_slots, (void*) p->d_slot_image, (void*) p->d_slot_rand, (void*) p->d_slot_shake, (void*) p->d_slot_shake_param, (void*) p->d_slot_big, (void*) p->d_bigacc, (void*) p->d_image_pairs,
-                          p->d_fextra, p->d_old_delta, p->d_pos_delta, p->d_comv, (void*) p->d_cosz, (void*) p->d_epoch, (void*) p->d_acc, (void*) p->d_nh})
+                          p->d_fextra, p->d_old_delta, p->d_pos_delta, p->d_comv, (void*) p->d_cosz, (void*) p->d_epoch, (void*) p->d_acc, (void*) p->d_nh, (void*) p->d_lane_const, (void*) p->d_dbg})
             if (ptr) (void) hipFree(ptr);
         if (p->graph_exec) (void) hipGraphExecDestroy(p->graph_exec);
         if (p->comm) (void) rccl_api().commDestroy(p->comm);
@@ -456,8 +494,9 @@ int vvhip_bind(vvhip_plan* p, const vvhip_buffers* b) {
     for (int c = 0; c < 2; c++)
         for (int g = 0; g < 3; g++) { init[c].s.vscale[g] = 1.0; init[c].scales[g] = 1.0; }
     HIP_TRY(p, hipMemcpy(p->d_nh, init, sizeof(init), hipMemcpyHostToDevice));
+    HIP_TRY(p, hipMalloc((void**) &p->d_lane_const, VVHIP_NUM_TG * sizeof(vv::ChainLaneBlock)));
     p->bound = true;
-    return VVHIP_OK;
+    return upload_lane_const(p);
 }
 
 int vvhip_set_params(vvhip_plan* p, const vvhip_params* q) {
@@ -471,7 +510,7 @@ int vvhip_set_params(vvhip_plan* p, const vvhip_params* q) {
         return fail(p, VVHIP_ERR_TOPOLOGY, "Langevin thermostat and periodic perturbation shouldn't be used together");
     p->hp.params = n;
     if (p->graph_exec) { (void) hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
-    return VVHIP_OK;
+    return upload_lane_const(p);
 }
 
 int vvhip_set_box(vvhip_plan* p, const double box[3]) {
@@ -818,6 +857,28 @@ int vvhip_time_kernel(vvhip_plan* p, int kernel, uint32_t flags, int reps, doubl
     (void) hipEventDestroy(e1);
     *ms_per_launch = (double) ms / reps;
     return VVHIP_OK;
+}
+
+// Instrumented build (-DVV_KERNEL_TIMESTAMPS): one launch of kernel B with `flags`, shader-clock stamps of block `block`:
+// out[w*16 + k] for tile waves w = 0.. (k = 0 entry, 1 loads arrived, 2 prep done, 3 scales received, 4 compute done, 5 stores
+// drained) and w = 7 for the thermostat wave (0 entry, 1 accumulators folded, 2 chain done, 3 after the barrier).
+int vvhip_debug_timestamps(vvhip_plan* p, uint32_t flags, int block, long long out[128]) {
+    NEED_BOUND(p);
+#ifndef VV_KERNEL_TIMESTAMPS
+    (void) flags; (void) block; (void) out;
+    return fail(p, VVHIP_ERR_UNSUPPORTED, "not an instrumented build");
+#else
+    if (!p->d_dbg) HIP_TRY(p, hipMalloc((void**) &p->d_dbg, 128 * sizeof(long long)));
+    HIP_TRY(p, hipMemsetAsync(p->d_dbg, 0, 128 * sizeof(long long), p->stream));
+    p->dbg_block = block;
+    const int parity = p->parity;
+    int rc = run_b(p, flags);
+    p->parity = parity;
+    if (rc != VVHIP_OK) return rc;
+    HIP_TRY(p, hipStreamSynchronize(p->stream));
+    HIP_TRY(p, hipMemcpy(out, p->d_dbg, 128 * sizeof(long long), hipMemcpyDeviceToHost));
+    return VVHIP_OK;
+#endif
 }
 
 int vvhip_comm_unique_id(void* id128) {

@@ -759,33 +759,15 @@ __device__ __forceinline__ double propagate_regs(const NHConst& c, int g, double
 // The same update on state that the caller has already loaded (kernel B issues those loads at its very top so their
 // latency overlaps the particle loads and the accumulator fold).  NC <= 4.
 struct ChainRegs { double eta[4], eta_dot[5], eta_dotdot[4]; };
-struct ChainLaneConst { double eta_mass[4], inv_eta_mass[4], nkbt, temperature; bool active; };
-// Lane g's row of the chain constants, picked with compile-time indices: a lane-indexed read of a kernel-argument
-// array would turn into dependent vector loads in the middle of the serial chain (measured: +3 us per launch).
-__device__ __forceinline__ ChainLaneConst chain_lane_const(const NHConst& c, int g) {
-    ChainLaneConst r;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        r.eta_mass[i] = g == 0 ? c.eta_mass[0][i] : g == 1 ? c.eta_mass[1][i] : c.eta_mass[2][i];
-        r.inv_eta_mass[i] = g == 0 ? c.inv_eta_mass[0][i] : g == 1 ? c.inv_eta_mass[1][i] : c.inv_eta_mass[2][i];
-    }
-    r.nkbt = g == 0 ? c.nkbt[0] : g == 1 ? c.nkbt[1] : c.nkbt[2];
-    r.temperature = g == 0 ? c.temperature[0] : g == 1 ? c.temperature[1] : c.temperature[2];
-    r.active = g < c.num_tg && r.eta_mass[0] > 0;                                // HOST:729
-    return r;
-}
 template <int NC>
-__device__ __forceinline__ double propagate_preloaded(const NHConst& c, const ChainLaneConst& lc, double ke2, ChainRegs& r) {
+__device__ __forceinline__ double propagate_preloaded(const NHConst& c, const ChainLaneBlock& lc, double ke2, ChainRegs& r) {
     // Runs in the block's thermostat wave only (lanes 0..2 = the three temperature groups), so a plain branch on
     // "group is thermostatted" is fine and the state is updated in place (fewer live registers for the whole kernel).
     double factor = 1.0;
-    if (!lc.active) return factor;                                              // HOST:729
+    if (lc.active == 0) return factor;                                          // HOST:729
     const double ke2_target = lc.nkbt;
     double expfac = 1.0;
-    const double dt2 = c.step_size / c.loops_per_step / 2;
-    const double dt4 = dt2 / 2;
-    const double dt8 = dt4 / 2;
-    const double kT = ((1.380649e-23 * 6.02214076e23) / 1000.0) * lc.temperature;
+    const double dt2 = lc.dt2, dt4 = lc.dt4, dt8 = lc.dt8, kT = lc.kT;        // computed once on the host exactly as API:343-347 does
     r.eta_dotdot[0] = (ke2 - ke2_target) * lc.inv_eta_mass[0];
     for (int iloop = 0; iloop < c.loops_per_step; iloop++) {
 #pragma unroll
@@ -816,7 +798,7 @@ __device__ __forceinline__ double propagate_preloaded(const NHConst& c, const Ch
 
 // Kernel B only inlines chain lengths up to 4 (register budget: 8 variants would cost half the occupancy);
 // longer chains take the stand-alone chain launch (vv_api.cpp decides).
-__device__ __forceinline__ double propagate_group_small(const NHConst& c, const ChainLaneConst& lc, double ke2, ChainRegs& r) {
+__device__ __forceinline__ double propagate_group_small(const NHConst& c, const ChainLaneBlock& lc, double ke2, ChainRegs& r) {
     switch (c.num_chains) {
         case 1: return propagate_preloaded<1>(c, lc, ke2, r);
         case 2: return propagate_preloaded<2>(c, lc, ke2, r);
@@ -862,6 +844,13 @@ __global__ void __launch_bounds__(64) vv_kernel_chain(const NHConst c, NHDevStat
 }
 
 // ================================================================================ kernel B
+// Instrumented build only (make -C tools/probes ts): wave `w` of block a.dbg_block records the shader clock at point k, after
+// draining its outstanding memory operations so that the stamp tells when the data had arrived.
+#ifdef VV_KERNEL_TIMESTAMPS
+#define VV_STAMP(w, k) do { if (a.dbg && (int) blockIdx.x == a.dbg_block && (threadIdx.x & 63) == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); a.dbg[(w) * 16 + (k)] = (long long) __builtin_readcyclecounter(); } } while (0)
+#else
+#define VV_STAMP(w, k) do { } while (0)
+#endif
 
 template <class real, class mixed, uint32_t SF>
 __global__ void __launch_bounds__(320) vv_kernel_b(const KArgs a) {
@@ -885,11 +874,13 @@ __global__ void __launch_bounds__(320) vv_kernel_b(const KArgs a) {
 
     // ---------------- thermostat wave: scale factors for the whole block, then done
     if (chain_wave) {
+        VV_STAMP(7, 0);
         const int cg = lane < VVHIP_NUM_TG ? lane : VVHIP_NUM_TG - 1;
         ChainRegs cr;
 #pragma unroll
         for (int i = 0; i < 4; i++) { cr.eta[i] = a.nh->s.eta[cg][i]; cr.eta_dot[i] = a.nh->s.eta_dot[cg][i]; cr.eta_dotdot[i] = a.nh->s.eta_dotdot[cg][i]; }
         cr.eta_dot[4] = a.nh->s.eta_dot[cg][4];
+        const ChainLaneBlock lc = a.lane_const[cg];
         long long tot[NUM_ACC];
 #pragma unroll
         for (int k = 0; k < NUM_ACC; k++)
@@ -898,16 +889,19 @@ __global__ void __launch_bounds__(320) vv_kernel_b(const KArgs a) {
             __shared__ unsigned int mb_words[MB_MAX_RANKS * MB_WORDS];
             mailbox_exchange(a, lane, a.nh->mb_seq + 1u, mb_words, tot);
         }
+        VV_STAMP(7, 1);
         double ke2 = 0;
 #pragma unroll
         for (int k = 0; k < VVHIP_NUM_TG; k++)
-            if (cg == k) ke2 = (double) tot[k] * a.chain.acc_inv_scale[k];
+            if (cg == k) ke2 = (double) tot[k] * lc.acc_inv_scale;
         double factor = 1.0;
-        if (!(F & B_DBG_NOMATH)) factor = propagate_group_small(a.chain, chain_lane_const(a.chain, cg), ke2, cr);
+        if (!(F & B_DBG_NOMATH)) factor = propagate_group_small(a.chain, lc, ke2, cr);
+        VV_STAMP(7, 2);
         const double bias = (F & B_UNBIAS) ? (double) tot[3] * a.chain.acc_inv_scale[3] * a.chain.inv_mass_total   // K/cosineAccelerate.cu:57-59
                                            : a.nh->scales[3];                                                 // carried over unchanged
         if (lane < VVHIP_NUM_TG) sh_scales[lane] = factor;
         if (lane == 3) sh_scales[3] = bias;
+        __syncthreads();                          // the tile waves go on; what follows is off their critical path
         if (blockIdx.x == 0) {                    // one block records the advanced thermostat and clears the idle accumulator copy
             NHDevState* out = a.nh_next;
             if (lane < VVHIP_NUM_TG) {
@@ -922,7 +916,7 @@ __global__ void __launch_bounds__(320) vv_kernel_b(const KArgs a) {
             if (lane == 4) out->mb_seq = a.nh->mb_seq + ((F & B_MAILBOX) ? 1u : 0u);
             for (int i = lane; i < NUM_ACC * ACC_SLOTS; i += 64) a.acc_next[i] = 0;
         }
-        __syncthreads();
+        VV_STAMP(7, 3);
         return;
     }
 
@@ -930,6 +924,7 @@ __global__ void __launch_bounds__(320) vv_kernel_b(const KArgs a) {
     // pays the fold + chain once and then streams many tiles; the first tile's loads overlap the thermostat wave.
     const int tile_stride = gridDim.x * tiles_per_block;
     bool need_scales = true;
+    VV_STAMP(wib, 0);
     for (int wave = blockIdx.x * tiles_per_block + wib; need_scales || wave < a.nwaves; wave += tile_stride) {
         const bool valid = wave < a.nwaves;
         int atom = -1;
@@ -982,13 +977,16 @@ __global__ void __launch_bounds__(320) vv_kernel_b(const KArgs a) {
             }
         };
         const bool prep_early = (F & B_SCALE) && !(F & (B_UNBIAS | B_BIAS_REMOVE));
+        VV_STAMP(wib, 1);
         if (prep_early) scale_prep();
+        VV_STAMP(wib, 2);
 
         if (need_scales) {
             need_scales = false;
             if (has_cw) {
                 __syncthreads();
                 sc0 = sh_scales[0]; sc1 = sh_scales[1]; sc2 = sh_scales[2]; scb = sh_scales[3];
+                VV_STAMP(wib, 3);
             } else if (F & (B_SCALE | B_UNBIAS | B_BIAS_REMOVE | B_BIAS_RESTORE)) {
                 sc0 = a.nh->scales[0]; sc1 = a.nh->scales[1]; sc2 = a.nh->scales[2]; scb = a.nh->scales[3];
             }
@@ -1168,12 +1166,14 @@ __global__ void __launch_bounds__(320) vv_kernel_b(const KArgs a) {
         }
 
         // ---------------- write back
+        VV_STAMP(wib, 4);
         if (act && vel_dirty) store_vec(velm, atom, v, (F & B_WT_STORES) != 0);
         if (act && pos_dirty) IO::store(a.posq, a.corr, atom, x, y, z, q, (F & B_WT_STORES) != 0);
         if ((F & B_VV_KICK) && massive) {
             mixed4 d = {dx, dy, dz, 0};
             if (a.pos_delta) ((mixed4*) a.pos_delta)[atom] = d;
         }
+        VV_STAMP(wib, 5);
 
         // ---------------- image charges (K/imageCharge.cu:10-26): x, y are bit copies, z is mirrored
         if ((F & B_IMAGE) && act && (meta & META_HAS_IMAGE)) {

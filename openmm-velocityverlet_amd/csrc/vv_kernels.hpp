@@ -99,6 +99,15 @@ struct NHConst {
     uint32_t flags;
 };
 
+// Chain constants of one temperature group as the thermostat wave of kernel B loads them (lane g reads row g with ordinary vector
+// loads at its very top, next to the state).  Picking lane g's row out of the kernel-argument block instead compiles to lane-indexed
+// loads from the kernarg segment issued after the fold, whose latency sat on the kernel's critical path (timeline in DESIGN.md §7).
+struct ChainLaneBlock {
+    double eta_mass[4], inv_eta_mass[4];
+    double nkbt, kT, acc_inv_scale, active;     // active != 0: the group is thermostatted (HOST:729)
+    double dt2, dt4, dt8, pad_;
+};
+
 // One argument block for kernels A and B (passed by value); pointer types are erased so that the
 // same struct serves the three precision modes.
 struct KArgs {
@@ -126,7 +135,10 @@ struct KArgs {
     const NHDevState* nh;           // thermostat state of the current parity
     NHDevState* nh_next;            // where an inline chain writes the advanced state
     NHConst chain;                  // chain constants (used by B_CHAIN)
+    const ChainLaneBlock* lane_const;   // [VVHIP_NUM_TG] the same constants, one row per group, in device memory
     Mailbox mb;                     // B_MAILBOX
+    long long* dbg;                 // timestamp buffer of the instrumented build (-DVV_KERNEL_TIMESTAMPS, tools/probes), else unused
+    int32_t dbg_block, dbg_pad_;
     int32_t padded;
     int32_t nwaves;
     uint32_t flags;
