@@ -863,6 +863,7 @@ int vvhip_time_kernel(vvhip_plan* p, int kernel, uint32_t flags, int reps, doubl
 // out[w*16 + k] for tile waves w = 0.. (k = 0 entry, 1 loads arrived, 2 prep done, 3 scales received, 4 compute done, 5 stores
 // drained) and w = 7 for the thermostat wave (0 entry, 1 accumulators folded, 2 chain done, 3 after the barrier).
 int vvhip_debug_timestamps(vvhip_plan* p, uint32_t flags, int block, long long out[128]) {
+    // bit 31 of `flags` selects kernel A (stamps: 0 entry, 1 velm arrived, 2 kicked + stored, 3 tile loop done, 4 sums added)
     NEED_BOUND(p);
 #ifndef VV_KERNEL_TIMESTAMPS
     (void) flags; (void) block; (void) out;
@@ -872,7 +873,7 @@ int vvhip_debug_timestamps(vvhip_plan* p, uint32_t flags, int block, long long o
     HIP_TRY(p, hipMemsetAsync(p->d_dbg, 0, 128 * sizeof(long long), p->stream));
     p->dbg_block = block;
     const int parity = p->parity;
-    int rc = run_b(p, flags);
+    int rc = (flags & 0x80000000u) ? run_a(p, flags & 0x7FFFFFFFu, 0) : run_b(p, flags);
     p->parity = parity;
     if (rc != VVHIP_OK) return rc;
     HIP_TRY(p, hipStreamSynchronize(p->stream));

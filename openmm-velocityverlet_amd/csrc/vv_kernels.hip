@@ -463,6 +463,14 @@ __device__ __forceinline__ void mailbox_exchange(const KArgs& a, int lane, unsig
     }
 }
 
+// Instrumented build only (make -C tools/probes ts): wave `w` of block a.dbg_block records the shader clock at point k, after
+// draining its outstanding memory operations so that the stamp tells when the data had arrived.
+#ifdef VV_KERNEL_TIMESTAMPS
+#define VV_STAMP(w, k) do { if (a.dbg && (int) blockIdx.x == a.dbg_block && (threadIdx.x & 63) == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); a.dbg[(w) * 16 + (k)] = (long long) __builtin_readcyclecounter(); } } while (0)
+#else
+#define VV_STAMP(w, k) do { } while (0)
+#endif
+
 // ================================================================================ kernel A
 template <class real, class mixed, uint32_t SF>   // SF != 0: the stage bits are a compile-time constant (hot paths)
 __global__ void __launch_bounds__(256) vv_kernel_a(const KArgs a) {
@@ -477,6 +485,7 @@ __global__ void __launch_bounds__(256) vv_kernel_a(const KArgs a) {
     // grid-stride over 64-lane tiles (the grid is capped in launch_a): per-lane partial sums run across all tiles of the
     // block, so the block reduction and its atomics are paid once per block however large the system is
     const int tile_stride = gridDim.x * (blockDim.x >> 6);
+    VV_STAMP(threadIdx.x >> 6, 0);
     for (int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); wave < a.nwaves; wave += tile_stride) {
         const int2 slot = a.slots[(size_t) wave * 64 + lane];
         const int atom = slot.x;
@@ -487,6 +496,12 @@ __global__ void __launch_bounds__(256) vv_kernel_a(const KArgs a) {
         mixed4* velm = (mixed4*) a.velm;
         mixed4 v = {0, 0, 0, 0};
         if (act) v = velm[atom];
+        // the forces are requested together with the velocity: waiting for velm.w to learn that the particle is massive would put a
+        // third dependent memory round trip in front of the kick (timeline: 0.6 us); the role word carries the same fact
+        long long fx = 0, fy = 0, fz = 0;
+        if ((F & (A_KICK_FULL | A_KICK_HALF)) && act && (meta & META_MASSIVE)) {
+            fx = a.force[atom]; fy = a.force[atom + a.padded]; fz = a.force[atom + 2 * a.padded];
+        }
         const bool massive = act && v.w != 0;
         const mixed stepSize = (mixed) a.dt;
 
@@ -554,9 +569,9 @@ __global__ void __launch_bounds__(256) vv_kernel_a(const KArgs a) {
         if ((F & A_FE_STORE) && act) ((real3*) a.fextra)[atom] = fe;
 
         // ---------------- kick
+        VV_STAMP(threadIdx.x >> 6, 1);
         if (F & (A_KICK_FULL | A_KICK_HALF)) {
             if (massive) {
-                const long long fx = a.force[atom], fy = a.force[atom + a.padded], fz = a.force[atom + 2 * a.padded];
                 if (F & A_KICK_FULL) {                                      // K/middle.cu:11-21
                     const mixed fscale = stepSize / (mixed) 0x100000000;
                     v.x += stepSize * v.w * fe.x + fscale * v.w * fx;
@@ -620,6 +635,7 @@ __global__ void __launch_bounds__(256) vv_kernel_a(const KArgs a) {
             }
         }
 
+        VV_STAMP(threadIdx.x >> 6, 2);
         // ---------------- plain kinetic energy of everything massive: sum m v^2 (OpenMM's computeKineticEnergy(0) is half of it)
         if ((F & A_KE_PLAIN) && massive) k_atom += (double) ((v.x * v.x + v.y * v.y + v.z * v.z) * P::RECIP(v.w));
 
@@ -673,11 +689,13 @@ __global__ void __launch_bounds__(256) vv_kernel_a(const KArgs a) {
                 k_com += (double) ((Vx * Vx + Vy * Vy + Vz * Vz) * Vm);
         }
     }
+    VV_STAMP(threadIdx.x >> 6, 3);
     if (F & (A_KE | A_BIAS | A_KE_PLAIN)) {
         const double vals[NUM_ACC] = {k_atom, k_com, k_drude, k_bias};
         const bool en[NUM_ACC] = {(F & (A_KE | A_KE_PLAIN)) != 0, (F & A_KE) != 0, (F & A_KE) != 0, (F & A_BIAS) != 0};
         block_accumulate<NUM_ACC>(vals, en, a.acc, a.acc_scale);
     }
+    VV_STAMP(threadIdx.x >> 6, 4);
 }
 
 // ================================================================================ NH chain
@@ -844,13 +862,6 @@ __global__ void __launch_bounds__(64) vv_kernel_chain(const NHConst c, NHDevStat
 }
 
 // ================================================================================ kernel B
-// Instrumented build only (make -C tools/probes ts): wave `w` of block a.dbg_block records the shader clock at point k, after
-// draining its outstanding memory operations so that the stamp tells when the data had arrived.
-#ifdef VV_KERNEL_TIMESTAMPS
-#define VV_STAMP(w, k) do { if (a.dbg && (int) blockIdx.x == a.dbg_block && (threadIdx.x & 63) == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); a.dbg[(w) * 16 + (k)] = (long long) __builtin_readcyclecounter(); } } while (0)
-#else
-#define VV_STAMP(w, k) do { } while (0)
-#endif
 
 template <class real, class mixed, uint32_t SF>
 __global__ void __launch_bounds__(320) vv_kernel_b(const KArgs a) {
