@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20000)
     ap.add_argument("--warmup", type=int, default=2000)
-    ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C4", "C5", "C3x8", "C3x80"])
+    ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C4", "C5", "C3x2", "C3x3", "C3x5", "C3x8", "C3x80"])
     ap.add_argument("--precision", default="mixed", choices=["single", "mixed", "double"])
     ap.add_argument("--forces", default="tether", choices=["tether", "static"])
     ap.add_argument("--steps-per-graph", type=int, default=100)

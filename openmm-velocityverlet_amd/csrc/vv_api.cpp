@@ -57,7 +57,8 @@ struct vvhip_plan {
     hipStream_t stream = nullptr;
     double box[3] = {1, 1, 1};
     double acc_scale[vv::NUM_ACC], acc_inv_scale[vv::NUM_ACC];
-    int block_threads = 256;
+    int block_threads = 256;       // 64 x tile waves per block, the same for the force provider, kernel A and kernel B
+    int grid_cap_a = 2048, grid_cap_b = 1024;   // most blocks per launch (multiples of the CU count): see pick_launch_shape
     int split_chain_waves = 12288;   // systems with at least this many waves (~0.8 M particles; measured +3 % at 0.9 M, +5 % at 8.9 M) run the chain as its own launch (VVHIP_SPLIT_CHAIN_WAVES)
     bool wt_stores = false;        // write-through stores in the fused kernels (VVHIP_WT=1; tuning experiment)
     // plan-owned device state
@@ -102,10 +103,14 @@ struct vvhip_plan {
     vv::ChainLaneBlock* d_lane_const = nullptr;   // [3] chain constants per temperature group (kernel B's thermostat wave)
     vv::ChainLaneBlock lane_const_host[VVHIP_NUM_TG] = {};
     bool lane_const_valid = false;
+    long long* d_dbg_span = nullptr;
+    int dbg_parity = 0;
     long long* d_dbg = nullptr;                   // instrumented build only (vvhip_debug_timestamps)
     int dbg_block = 0;
 };
 
+namespace vv { unsigned vv_last_grid_value = 0; }
+static unsigned vv_last_grid() { return vv::vv_last_grid_value; }
 extern "C" int vvhip_debug_read_accumulators(vvhip_plan* p, double out[4], int zero_after);
 
 namespace {
@@ -154,6 +159,32 @@ void fill_scales(vvhip_plan* p) {
     p->acc_inv_scale[3] = 1.0 / p->acc_scale[3];
 }
 
+// Launch shape.  Measured on MI355X (256 CUs): what matters at the latency-bound sizes is that every CU gets the SAME number of
+// blocks -- a CU with one block more than its neighbours finishes ~1.3 us later (its thermostat waves share the fp64 pipe), and the
+// kernel ends with its slowest CU.  C3, 1 752 tiles: 876 blocks of 2 tiles (3.4 per CU) 69.4 k steps/s; 251 blocks of 7 tiles (one
+// per CU) 74.3 k.  So: k blocks per CU, T tile waves per block (+1 thermostat wave in kernel B, whose 140 VGPRs allow 12 waves
+// per CU), chosen to maximise the fill of the last pass; fewer blocks per CU and larger blocks win ties.
+void pick_launch_shape(vvhip_plan* p) {
+    const int nw = p->hp.info.num_waves, cus = 256;
+    if (nw <= cus) { p->block_threads = 64; p->grid_cap_a = p->grid_cap_b = cus; return; }
+    // bandwidth-bound regime (the chain runs as its own launch there, kernel B fits 6 waves per SIMD): tuned at 0.9 M / 8.9 M particles
+    if (nw >= p->split_chain_waves) { p->block_threads = 256; p->grid_cap_a = 2048; p->grid_cap_b = 1024; return; }
+    double best = -1;
+    int bk = 1, bt = 1;
+    for (int k = 1; k <= 4; k++)
+        for (int t = 1; t <= 7; t++) {
+            if (k * (t + 1) > 12) continue;
+            const long cap = (long) cus * k * t;
+            const long passes = (nw + cap - 1) / cap;
+            // fill of the last pass; once several passes are needed, shapes with fewer than 8 tile waves per CU in flight are
+            // marked down (they leave memory-level parallelism unused)
+            const double fill = (double) nw / (double) (cap * passes) * (passes > 1 ? std::min(1.0, k * t / 8.0) : 1.0);
+            if (fill > best + 1e-9 || (fill > best - 1e-9 && (k < bk || (k == bk && t > bt)))) { best = fill; bk = k; bt = t; }
+        }
+    p->block_threads = 64 * bt;
+    p->grid_cap_a = p->grid_cap_b = cus * bk;
+}
+
 vv::NHConst make_chain(vvhip_plan* p, uint32_t flags);
 constexpr int kAccN = vv::NUM_ACC * vv::ACC_SLOTS;
 
@@ -193,6 +224,8 @@ vv::KArgs make_args(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
     a.mb.rank = p->mb_rank;
     a.dbg = p->d_dbg;
     a.dbg_block = p->dbg_block;
+    a.dbg_span = p->d_dbg_span;
+    a.dbg_parity = p->dbg_parity;
     a.padded = p->hp.padded_num_atoms;
     a.nwaves = p->hp.info.num_waves;
     a.flags = flags;
@@ -288,13 +321,13 @@ struct ScopedTimer {
 int run_a(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
     if (p->wt_stores && (flags & (vv::A_KICK_FULL | vv::A_KICK_HALF))) flags |= vv::A_WT_STORES;
     ScopedTimer t(p, T_A);
-    HIP_TRY(p, vv::launch_a(p->hp.precision, make_args(p, flags, random_index), p->block_threads, p->stream));
+    HIP_TRY(p, vv::launch_a(p->hp.precision, make_args(p, flags, random_index), p->block_threads, p->grid_cap_a, p->stream));
     return VVHIP_OK;
 }
 int run_b(vvhip_plan* p, uint32_t flags) {
     if (p->wt_stores) flags |= vv::B_WT_STORES;
     ScopedTimer t(p, T_B);
-    HIP_TRY(p, vv::launch_b(p->hp.precision, make_args(p, flags, 0), p->block_threads, p->stream));
+    HIP_TRY(p, vv::launch_b(p->hp.precision, make_args(p, flags, 0), p->block_threads, p->grid_cap_b, p->stream));
     if (flags & vv::B_CHAIN) p->parity ^= 1;     // the advanced thermostat state now lives in the other copy
     return VVHIP_OK;
 }
@@ -380,13 +413,12 @@ int vvhip_plan_create(const vvhip_system_desc* system, const vvhip_params* param
         vvhip_plan* p = new vvhip_plan();
         p->hp = vv::analyze(*system, *params, precision);
         fill_scales(p);
-        // small systems: one wave per block spreads the work over more CUs (256 CUs, 8 XCDs)
-        p->block_threads = p->hp.info.num_waves >= 2048 ? 256 : (p->hp.info.num_waves >= 512 ? 128 : 64);
         if (const char* e = std::getenv("VVHIP_WT")) p->wt_stores = std::atoi(e) != 0;
         if (const char* e = std::getenv("VVHIP_SPLIT_CHAIN_WAVES")) p->split_chain_waves = std::atoi(e);
+        pick_launch_shape(p);
         if (const char* e = std::getenv("VVHIP_BLOCK")) {          // tuning experiments
             const int b = std::atoi(e);
-            if (b == 64 || b == 128 || b == 192 || b == 256) p->block_threads = b;
+            if (b >= 64 && b <= 448 && b % 64 == 0) { p->block_threads = b; p->grid_cap_a = 2048; p->grid_cap_b = 1024; }
         }
         *plan_out = p;
         return VVHIP_OK;
@@ -878,6 +910,58 @@ int vvhip_debug_timestamps(vvhip_plan* p, uint32_t flags, int block, long long o
     if (rc != VVHIP_OK) return rc;
     HIP_TRY(p, hipStreamSynchronize(p->stream));
     HIP_TRY(p, hipMemcpy(out, p->d_dbg, 128 * sizeof(long long), hipMemcpyDeviceToHost));
+    return VVHIP_OK;
+#endif
+}
+
+// Instrumented build: `reps` back-to-back launches of kernel A (kernel = 0) or B (1) with `flags`; every wave stamps the 100 MHz
+// wall clock at entry and (after draining its memory operations) at exit.  out[0] = first entry -> last exit of the last launch,
+// out[1] = last exit of the launch before -> first entry of the last launch, out[2] = median wave entry - first entry,
+// out[3] = median wave lifetime (all ns).
+int vvhip_debug_span(vvhip_plan* p, int kernel, uint32_t flags, int reps, double out[8]) {
+    NEED_BOUND(p);
+#ifndef VV_KERNEL_TIMESTAMPS
+    (void) kernel; (void) flags; (void) reps; (void) out;
+    return fail(p, VVHIP_ERR_UNSUPPORTED, "not an instrumented build");
+#else
+    const size_t per = (size_t) 4096 * 8 * 2;
+    if (!p->d_dbg_span) HIP_TRY(p, hipMalloc((void**) &p->d_dbg_span, 2 * per * sizeof(long long)));
+    HIP_TRY(p, hipMemsetAsync(p->d_dbg_span, 0, 2 * per * sizeof(long long), p->stream));
+    const int parity = p->parity;
+    int rc = VVHIP_OK;
+    for (int i = 0; i < reps && rc == VVHIP_OK; i++) { p->parity = parity; p->dbg_parity = i & 1; rc = kernel == 0 ? run_a(p, flags, 0) : run_b(p, flags); }
+    p->parity = parity;
+    const int last = (reps - 1) & 1;
+    p->dbg_parity = 0;
+    long long* keep = p->d_dbg_span;
+    p->d_dbg_span = nullptr;                       // later launches run unstamped
+    if (rc != VVHIP_OK) { p->d_dbg_span = keep; return rc; }
+    HIP_TRY(p, hipStreamSynchronize(p->stream));
+    std::vector<long long> h(2 * per);
+    HIP_TRY(p, hipMemcpy(h.data(), keep, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    p->d_dbg_span = keep;
+    // the grid size is not known here: the launch of parity q used rows [q * grid, (q+1) * grid); find them by scanning non-zero pairs
+    std::vector<long long> in[2], ex[2];
+    std::vector<int> blk;
+    const int grid = (int) vv_last_grid();
+    for (int q = 0; q < 2; q++)
+        for (size_t r = 0; r < (size_t) grid * 8; r++) {
+            const long long a0 = h[(((size_t) q * grid) * 8 + r) * 2], a1 = h[(((size_t) q * grid) * 8 + r) * 2 + 1];
+            if (a0 && a1) { in[q].push_back(a0); ex[q].push_back(a1); if (q == ((reps - 1) & 1)) blk.push_back((int) (r / 8)); }
+        }
+    if (in[0].empty() || in[1].empty()) return fail(p, VVHIP_ERR_INVALID, "no stamps recorded");
+    const int L = last, P = 1 - last;
+    const long long first_in = *std::min_element(in[L].begin(), in[L].end()), last_out = *std::max_element(ex[L].begin(), ex[L].end());
+    const long long prev_out = *std::max_element(ex[P].begin(), ex[P].end());
+    std::vector<long long> rel, life;
+    for (size_t k = 0; k < in[L].size(); k++) { rel.push_back(in[L][k] - first_in); life.push_back(ex[L][k] - in[L][k]); }
+    size_t worst = 0;
+    for (size_t k = 0; k < in[L].size(); k++) if (ex[L][k] > ex[L][worst]) worst = k;
+    out[6] = (double) blk[worst]; out[7] = (double) (in[L][worst] - first_in) * 10.0;
+    std::sort(rel.begin(), rel.end()); std::sort(life.begin(), life.end());
+    out[4] = (double) life[life.size() * 9 / 10] * 10.0; out[5] = (double) life.back() * 10.0;
+    out[0] = (double) (last_out - first_in) * 10.0; out[1] = (double) (first_in - prev_out) * 10.0;
+    out[2] = (double) rel[rel.size() / 2] * 10.0; out[3] = (double) life[life.size() / 2] * 10.0;
     return VVHIP_OK;
 #endif
 }

@@ -467,13 +467,16 @@ __device__ __forceinline__ void mailbox_exchange(const KArgs& a, int lane, unsig
 // draining its outstanding memory operations so that the stamp tells when the data had arrived.
 #ifdef VV_KERNEL_TIMESTAMPS
 #define VV_STAMP(w, k) do { if (a.dbg && (int) blockIdx.x == a.dbg_block && (threadIdx.x & 63) == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); a.dbg[(w) * 16 + (k)] = (long long) __builtin_readcyclecounter(); } } while (0)
+#define VV_SPAN(k) do { if (a.dbg_span && (threadIdx.x & 63) == 0) { if (k) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+    a.dbg_span[(((size_t) a.dbg_parity * gridDim.x + blockIdx.x) * 8 + (threadIdx.x >> 6)) * 2 + (k)] = (long long) wall_clock64(); } } while (0)
 #else
 #define VV_STAMP(w, k) do { } while (0)
+#define VV_SPAN(k) do { } while (0)
 #endif
 
 // ================================================================================ kernel A
 template <class real, class mixed, uint32_t SF>   // SF != 0: the stage bits are a compile-time constant (hot paths)
-__global__ void __launch_bounds__(256) vv_kernel_a(const KArgs a) {
+__global__ void __launch_bounds__(512) vv_kernel_a(const KArgs a) {
     using real4 = typename Vec<real>::v4;
     using real3 = typename Vec<real>::v3;
     using mixed4 = typename Vec<mixed>::v4;
@@ -486,6 +489,7 @@ __global__ void __launch_bounds__(256) vv_kernel_a(const KArgs a) {
     // block, so the block reduction and its atomics are paid once per block however large the system is
     const int tile_stride = gridDim.x * (blockDim.x >> 6);
     VV_STAMP(threadIdx.x >> 6, 0);
+    VV_SPAN(0);
     for (int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); wave < a.nwaves; wave += tile_stride) {
         const int2 slot = a.slots[(size_t) wave * 64 + lane];
         const int atom = slot.x;
@@ -591,7 +595,7 @@ __global__ void __launch_bounds__(256) vv_kernel_a(const KArgs a) {
             }
         }
         if (F & A_SHAKE_V) {                   // integration.applyVelocityConstraints(tol) (HOST:151, 427), clusters solved in the wave
-            __shared__ mixed shake_page_a[4][64][7];
+            __shared__ mixed shake_page_a[8][64][7];
             const unsigned word = act ? (unsigned) a.slot_shake[(size_t) wave * 64 + lane] : 0u;
             const float4 prm = (word & 1u) ? a.slot_shake_param[(size_t) wave * 64 + lane] : make_float4(0, 0, 0, 0);
             mixed sx = 0, sy = 0, sz = 0, sq = 0;
@@ -696,6 +700,7 @@ __global__ void __launch_bounds__(256) vv_kernel_a(const KArgs a) {
         block_accumulate<NUM_ACC>(vals, en, a.acc, a.acc_scale);
     }
     VV_STAMP(threadIdx.x >> 6, 4);
+    VV_SPAN(1);
 }
 
 // ================================================================================ NH chain
@@ -864,7 +869,7 @@ __global__ void __launch_bounds__(64) vv_kernel_chain(const NHConst c, NHDevStat
 // ================================================================================ kernel B
 
 template <class real, class mixed, uint32_t SF>
-__global__ void __launch_bounds__(320) vv_kernel_b(const KArgs a) {
+__global__ void __launch_bounds__(512) vv_kernel_b(const KArgs a) {
     using real4 = typename Vec<real>::v4;
     using real3 = typename Vec<real>::v3;
     using mixed4 = typename Vec<mixed>::v4;
@@ -884,6 +889,7 @@ __global__ void __launch_bounds__(320) vv_kernel_b(const KArgs a) {
     double sc0 = 1.0, sc1 = 1.0, sc2 = 1.0, scb = 0.0;
 
     // ---------------- thermostat wave: scale factors for the whole block, then done
+    VV_SPAN(0);
     if (chain_wave) {
         VV_STAMP(7, 0);
         const int cg = lane < VVHIP_NUM_TG ? lane : VVHIP_NUM_TG - 1;
@@ -928,6 +934,7 @@ __global__ void __launch_bounds__(320) vv_kernel_b(const KArgs a) {
             for (int i = lane; i < NUM_ACC * ACC_SLOTS; i += 64) a.acc_next[i] = 0;
         }
         VV_STAMP(7, 3);
+        VV_SPAN(1);
         return;
     }
 
@@ -1064,7 +1071,7 @@ __global__ void __launch_bounds__(320) vv_kernel_b(const KArgs a) {
             ((mixed4*) a.old_delta)[atom] = od;
         }
         // per-wave LDS page and cluster word of the in-kernel SHAKE (collective over the wave: every lane walks through it)
-        __shared__ mixed shake_page_b[4][64][7];
+        __shared__ mixed shake_page_b[8][64][7];
         unsigned shake_word = 0;
         float4 shake_prm = make_float4(0, 0, 0, 0);
         if ((F & B_SHAKE) && act) {
@@ -1209,6 +1216,7 @@ __global__ void __launch_bounds__(320) vv_kernel_b(const KArgs a) {
             posq[img] = pi;
         }
     }   // tile loop
+    VV_SPAN(1);
 }
 
 // ================================================================================ stand-alone image kernel
@@ -1244,7 +1252,7 @@ __global__ void __launch_bounds__(256) vv_kernel_images(void* posq_, void* corr_
 // Mirrors oracle vvo_tether_force bit for bit: tether on massive particles, Drude-parent spring, both
 // converted to fixed point by truncation and then added as integers.
 template <class real, class mixed>
-__global__ void __launch_bounds__(256) vv_kernel_tether(const TetherArgs t) {
+__global__ void __launch_bounds__(512) vv_kernel_tether(const TetherArgs t) {
     using real4 = typename Vec<real>::v4;
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -1302,6 +1310,7 @@ __global__ void __launch_bounds__(256) vv_kernel_fill_normals(float4* out, uint3
 __global__ void vv_kernel_bump_epoch(unsigned long long* epoch) { *epoch += 1; }
 
 // ================================================================================ launchers
+extern unsigned vv_last_grid_value;      // grid of the most recent A / B launch (instrumented builds read it back)
 static inline dim3 grid_for(int nwaves, int block_threads) {
     const int wpb = block_threads / 64;
     return dim3((unsigned) ((nwaves + wpb - 1) / wpb));
@@ -1335,9 +1344,10 @@ constexpr uint32_t SF_A_MIDDLE_SHAKE = SF_A_MIDDLE | A_SHAKE_V;                 
 constexpr uint32_t SF_B_MIDDLE_HW_SHAKE = SF_B_MIDDLE_HW | B_SHAKE;
 constexpr uint32_t SF_B_MIDDLE_SHAKE = SF_B_MIDDLE | B_SHAKE;
 
-hipError_t launch_a(int precision, const KArgs& a, int block_threads, hipStream_t s) {
+hipError_t launch_a(int precision, const KArgs& a, int block_threads, int grid_cap, hipStream_t s) {
     dim3 g = grid_for(a.nwaves, block_threads);
-    if (g.x > 2048) g.x = 2048;          // 8 blocks per CU; beyond that the kernel strides over tiles
+    if ((int) g.x > grid_cap) g.x = (unsigned) grid_cap;          // beyond that the kernel strides over tiles
+    vv_last_grid_value = g.x;
     const dim3 b(block_threads);
     if (a.flags == SF_A_MIDDLE) { VV_DISPATCH_SF(vv_kernel_a, SF_A_MIDDLE, g, b, 0, s, a); }
     else if (a.flags == SF_A_MIDDLE_WT) { VV_DISPATCH_SF(vv_kernel_a, SF_A_MIDDLE_WT, g, b, 0, s, a); }
@@ -1347,11 +1357,12 @@ hipError_t launch_a(int precision, const KArgs& a, int block_threads, hipStream_
     else { VV_DISPATCH_SF(vv_kernel_a, 0u, g, b, 0, s, a); }
     return hipGetLastError();
 }
-hipError_t launch_b(int precision, const KArgs& a, int block_threads, hipStream_t s) {
-    // block_threads counts the tile waves; B_CHAIN adds the block's thermostat wave.  The grid is capped at 1024 blocks
-    // (4 per CU): beyond that the kernel strides over tiles and the per-block thermostat work is amortised.
+hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_cap, hipStream_t s) {
+    // block_threads counts the tile waves; B_CHAIN adds the block's thermostat wave.  Beyond grid_cap blocks the kernel strides
+    // over tiles and the per-block thermostat work is amortised.
     dim3 g = grid_for(a.nwaves, block_threads);
-    if (g.x > 1024) g.x = 1024;
+    if ((int) g.x > grid_cap) g.x = (unsigned) grid_cap;
+    vv_last_grid_value = g.x;
     const dim3 b(block_threads + ((a.flags & B_CHAIN) ? 64 : 0));
     if (a.flags == SF_B_MIDDLE_HW) { VV_DISPATCH_SF(vv_kernel_b, SF_B_MIDDLE_HW, g, b, 0, s, a); }
     else if (a.flags == SF_B_MIDDLE_HW_WT) { VV_DISPATCH_SF(vv_kernel_b, SF_B_MIDDLE_HW_WT, g, b, 0, s, a); }

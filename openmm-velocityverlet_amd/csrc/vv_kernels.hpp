@@ -139,6 +139,8 @@ struct KArgs {
     Mailbox mb;                     // B_MAILBOX
     long long* dbg;                 // timestamp buffer of the instrumented build (-DVV_KERNEL_TIMESTAMPS, tools/probes), else unused
     int32_t dbg_block, dbg_pad_;
+    long long* dbg_span;            // instrumented build: [2 launch parities][blocks*8 waves][2] entry / exit stamps of every wave (100 MHz wall clock)
+    int32_t dbg_parity, dbg_pad2_;
     int32_t padded;
     int32_t nwaves;
     uint32_t flags;
@@ -166,8 +168,9 @@ struct TetherArgs {
 };
 
 // launchers (precision = VVHIP_SINGLE / MIXED / DOUBLE); return hipError_t of the launch
-hipError_t launch_a(int precision, const KArgs& a, int block_threads, hipStream_t s);
-hipError_t launch_b(int precision, const KArgs& a, int block_threads, hipStream_t s);
+// block_threads = 64 x tile waves per block; grid_cap = most blocks to launch (the kernels stride over tiles beyond that)
+hipError_t launch_a(int precision, const KArgs& a, int block_threads, int grid_cap, hipStream_t s);
+hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_cap, hipStream_t s);
 hipError_t launch_chain(const NHConst& c, NHDevState* st, unsigned long long* acc, hipStream_t s);
 hipError_t launch_tether(int precision, const TetherArgs& t, int block_threads, hipStream_t s);
 // Device Gaussian generator (stand-alone hosts; inside OpenMM the random buffer is OpenMM's): Philox4x32-10 keyed by
