@@ -463,15 +463,26 @@ __device__ __forceinline__ void mailbox_exchange(const KArgs& a, int lane, unsig
     }
 }
 
-// Instrumented build only (make -C tools/probes ts): wave `w` of block a.dbg_block records the shader clock at point k, after
-// draining its outstanding memory operations so that the stamp tells when the data had arrived.
+// Instrumented build only (-DVV_KERNEL_TIMESTAMPS, tools/probes): wave `w` of block a.dbg_block records the shader clock at point k.
+// Stamps go to LDS and are copied out when the wave ends: a global store per stamp would sit in the same vmcnt queue as the loads
+// whose arrival the next stamp waits for (the first version of this did exactly that and inflated every interval by ~0.7 us).
 #ifdef VV_KERNEL_TIMESTAMPS
-#define VV_STAMP(w, k) do { if (a.dbg && (int) blockIdx.x == a.dbg_block && (threadIdx.x & 63) == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); a.dbg[(w) * 16 + (k)] = (long long) __builtin_readcyclecounter(); } } while (0)
-#define VV_SPAN(k) do { if (a.dbg_span && (threadIdx.x & 63) == 0) { if (k) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
-    a.dbg_span[(((size_t) a.dbg_parity * gridDim.x + blockIdx.x) * 8 + (threadIdx.x >> 6)) * 2 + (k)] = (long long) wall_clock64(); } } while (0)
+__shared__ long long vv_stamps[8][16];
+#define VV_STAMP_ON (a.dbg && (int) blockIdx.x == a.dbg_block && (threadIdx.x & 63) == 0)
+#define VV_STAMP(w, k) do { if (VV_STAMP_ON) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); vv_stamps[w][k] = (long long) __builtin_readcyclecounter(); } } while (0)
+#define VV_STAMP_NOWAIT(w, k) do { if (VV_STAMP_ON) { vv_stamps[w][k] = (long long) __builtin_readcyclecounter(); } } while (0)
+#define VV_STAMP_DUMP(w) do { if (VV_STAMP_ON) { for (int k_ = 0; k_ < 16; k_++) a.dbg[(w) * 16 + k_] = vv_stamps[w][k_]; } } while (0)
+// entry time stays in a register; both stamps are stored when the wave ends (after its memory operations have drained)
+#define VV_SPAN_BEGIN const long long vv_span_t0 = a.dbg_span ? (long long) wall_clock64() : 0
+#define VV_SPAN_END do { if (a.dbg_span && (threadIdx.x & 63) == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+    long long* row_ = a.dbg_span + (((size_t) a.dbg_parity * gridDim.x + blockIdx.x) * 8 + (threadIdx.x >> 6)) * 2; \
+    row_[1] = (long long) wall_clock64(); row_[0] = vv_span_t0; } } while (0)
 #else
 #define VV_STAMP(w, k) do { } while (0)
-#define VV_SPAN(k) do { } while (0)
+#define VV_STAMP_NOWAIT(w, k) do { } while (0)
+#define VV_STAMP_DUMP(w) do { } while (0)
+#define VV_SPAN_BEGIN do { } while (0)
+#define VV_SPAN_END do { } while (0)
 #endif
 
 // ================================================================================ kernel A
@@ -489,7 +500,7 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const KArgs a) {
     // block, so the block reduction and its atomics are paid once per block however large the system is
     const int tile_stride = gridDim.x * (blockDim.x >> 6);
     VV_STAMP(threadIdx.x >> 6, 0);
-    VV_SPAN(0);
+    VV_SPAN_BEGIN;
     for (int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); wave < a.nwaves; wave += tile_stride) {
         const int2 slot = a.slots[(size_t) wave * 64 + lane];
         const int atom = slot.x;
@@ -700,7 +711,8 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const KArgs a) {
         block_accumulate<NUM_ACC>(vals, en, a.acc, a.acc_scale);
     }
     VV_STAMP(threadIdx.x >> 6, 4);
-    VV_SPAN(1);
+    VV_STAMP_DUMP(threadIdx.x >> 6);
+    VV_SPAN_END;
 }
 
 // ================================================================================ NH chain
@@ -710,8 +722,8 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const KArgs a) {
 // |x| <= 2^-4 a degree-11 Taylor polynomial (Horner, 11 dependent FMAs) is exact to < 1 ulp (truncation
 // x^12/12! < 1e-23 relative); anything larger goes to the library exp.
 __device__ __forceinline__ double chain_exp(double x) {
-    // degree-11 Taylor polynomial by Estrin's scheme: the chain is one serial dependency chain executed by three lanes, so
-    // depth (5 levels) matters, not operation count.  exp(x) = sum_{k<=11} x^k/k!, |x| <= 2^-4: truncation < 1e-23 relative.
+    // degree-11 Taylor polynomial by Estrin's scheme (used by the stand-alone chain kernel and as the exact fallback of the
+    // thermostat wave).  exp(x) = sum_{k<=11} x^k/k!, |x| <= 2^-4: truncation < 1e-23 relative.
     const double x2 = x * x, x4 = x2 * x2, x8 = x4 * x4;
     const double p01 = fma(x, 1.0, 1.0), p23 = fma(x, 1.0 / 6.0, 0.5), p45 = fma(x, 1.0 / 120.0, 1.0 / 24.0);
     const double p67 = fma(x, 1.0 / 5040.0, 1.0 / 720.0), p89 = fma(x, 1.0 / 362880.0, 1.0 / 40320.0);
@@ -721,6 +733,19 @@ __device__ __forceinline__ double chain_exp(double x) {
     if (__builtin_expect(__any(fabs(x) > 0.0625), 0)) p = fabs(x) > 0.0625 ? exp(x) : p;   // wave-uniform, practically never taken
     return p;
 }
+// The thermostat wave of kernel B is one serial dependency chain of fp64 operations (three lanes of one wave doing useful work) on
+// the critical path of the whole kernel, so the DEPTH of the polynomial is what counts: degree 7 in Estrin form is three levels deep
+// (9 operations) and exact to < 1 ulp for |x| <= 2^-6 (truncation x^8/8! < 9e-20 relative).  The caller keeps the largest biased
+// exponent seen (two 32-bit operations per call) and redoes the step with chain_exp if any argument was larger.
+__device__ __forceinline__ double chain_exp_small(double x, unsigned& max_hi) {
+    const unsigned hi = (unsigned) __double2hiint(x) & 0x7FFFFFFFu;
+    max_hi = hi > max_hi ? hi : max_hi;
+    const double x2 = x * x;
+    const double p01 = x + 1.0, p23 = fma(x, 1.0 / 6.0, 0.5), p45 = fma(x, 1.0 / 120.0, 1.0 / 24.0), p67 = fma(x, 1.0 / 5040.0, 1.0 / 720.0);
+    const double x4 = x2 * x2, q0 = fma(x2, p23, p01), q1 = fma(x2, p67, p45);
+    return fma(x4, q1, q0);
+}
+constexpr unsigned CHAIN_EXP_SMALL_HI = 0x3F900000u;      // high word of 2^-6
 
 // One temperature group, chain length NC known at compile time so the chain lives in registers.
 // Differences from the host routine, both below 1 ulp per operation: chain_exp for exp, and multiplication by
@@ -782,8 +807,9 @@ __device__ __forceinline__ double propagate_regs(const NHConst& c, int g, double
 // The same update on state that the caller has already loaded (kernel B issues those loads at its very top so their
 // latency overlaps the particle loads and the accumulator fold).  NC <= 4.
 struct ChainRegs { double eta[4], eta_dot[5], eta_dotdot[4]; };
-template <int NC>
-__device__ __forceinline__ double propagate_preloaded(const NHConst& c, const ChainLaneBlock& lc, double ke2, ChainRegs& r) {
+template <int NC, bool FAST>
+__device__ __forceinline__ double propagate_preloaded(const NHConst& c, const ChainLaneBlock& lc, double ke2, ChainRegs& r, unsigned& max_hi) {
+    auto ex = [&](double x) { return FAST ? chain_exp_small(x, max_hi) : chain_exp(x); };
     // Runs in the block's thermostat wave only (lanes 0..2 = the three temperature groups), so a plain branch on
     // "group is thermostatted" is fine and the state is updated in place (fewer live registers for the whole kernel).
     double factor = 1.0;
@@ -795,12 +821,12 @@ __device__ __forceinline__ double propagate_preloaded(const NHConst& c, const Ch
     for (int iloop = 0; iloop < c.loops_per_step; iloop++) {
 #pragma unroll
         for (int ich = NC - 1; ich >= 0; ich--) {
-            expfac = chain_exp(-dt8 * r.eta_dot[ich + 1]);
+            expfac = ex(-dt8 * r.eta_dot[ich + 1]);
             r.eta_dot[ich] *= expfac;
             r.eta_dot[ich] += r.eta_dotdot[ich] * dt4;
             r.eta_dot[ich] *= expfac;
         }
-        factor *= chain_exp(-dt2 * r.eta_dot[0]);
+        factor *= ex(-dt2 * r.eta_dot[0]);
 #pragma unroll
         for (int ich = 0; ich < NC; ich++) r.eta[ich] += dt2 * r.eta_dot[ich];
         r.eta_dotdot[0] = (ke2 * factor * factor - ke2_target) * lc.inv_eta_mass[0];
@@ -809,7 +835,7 @@ __device__ __forceinline__ double propagate_preloaded(const NHConst& c, const Ch
         r.eta_dot[0] *= expfac;
 #pragma unroll
         for (int ich = 1; ich < NC; ich++) {
-            expfac = chain_exp(-dt8 * r.eta_dot[ich + 1]);
+            expfac = ex(-dt8 * r.eta_dot[ich + 1]);
             r.eta_dot[ich] *= expfac;
             r.eta_dotdot[ich] = (lc.eta_mass[ich - 1] * r.eta_dot[ich - 1] * r.eta_dot[ich - 1] - kT) * lc.inv_eta_mass[ich];
             r.eta_dot[ich] += r.eta_dotdot[ich] * dt4;
@@ -821,12 +847,23 @@ __device__ __forceinline__ double propagate_preloaded(const NHConst& c, const Ch
 
 // Kernel B only inlines chain lengths up to 4 (register budget: 8 variants would cost half the occupancy);
 // longer chains take the stand-alone chain launch (vv_api.cpp decides).
+template <int NC>
+__device__ __forceinline__ double propagate_small_nc(const NHConst& c, const ChainLaneBlock& lc, double ke2, ChainRegs& r) {
+    const ChainRegs saved = r;
+    unsigned max_hi = 0;
+    double f = propagate_preloaded<NC, true>(c, lc, ke2, r, max_hi);
+    if (__builtin_expect(__any(max_hi > CHAIN_EXP_SMALL_HI), 0)) {          // an exp argument beyond 2^-6: redo with the wide-range polynomial
+        r = saved;
+        f = propagate_preloaded<NC, false>(c, lc, ke2, r, max_hi);
+    }
+    return f;
+}
 __device__ __forceinline__ double propagate_group_small(const NHConst& c, const ChainLaneBlock& lc, double ke2, ChainRegs& r) {
     switch (c.num_chains) {
-        case 1: return propagate_preloaded<1>(c, lc, ke2, r);
-        case 2: return propagate_preloaded<2>(c, lc, ke2, r);
-        case 3: return propagate_preloaded<3>(c, lc, ke2, r);
-        default: return propagate_preloaded<4>(c, lc, ke2, r);
+        case 1: return propagate_small_nc<1>(c, lc, ke2, r);
+        case 2: return propagate_small_nc<2>(c, lc, ke2, r);
+        case 3: return propagate_small_nc<3>(c, lc, ke2, r);
+        default: return propagate_small_nc<4>(c, lc, ke2, r);
     }
 }
 __device__ __forceinline__ double propagate_group(const NHConst& c, int g, double ke2, const NHDevState* in, NHDevState* out) {
@@ -877,20 +914,23 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const KArgs a) {
     using IO = PosIO<real, mixed>;
     const int lane = threadIdx.x & 63;
     const uint32_t F = SF ? SF : a.flags;
-    // Block layout.  With B_CHAIN the LAST wave of every block is the block's thermostat wave: it folds the
+    // Block layout.  With B_CHAIN the FIRST wave of every block is the block's thermostat wave: it folds the
     // accumulators and advances the NH chain (a ~2 us serial fp64 dependency chain) while the other waves of the
     // block load their particles and do the scale-independent preparation; one barrier joins them.  Without this,
     // every tile wave pays the chain on its own critical path (measured: 9.7 -> see DESIGN.md §7).
-    const int nwb = blockDim.x >> 6, wib = threadIdx.x >> 6;
+    const int nwb = blockDim.x >> 6;
     const bool has_cw = (F & B_CHAIN) != 0;
-    const bool chain_wave = has_cw && wib == nwb - 1;
+    // the thermostat wave is wave 0: the waves of a block start in order, and the block's critical path runs through this one
+    const bool chain_wave = has_cw && (threadIdx.x >> 6) == 0;
+    const int wib = (int) (threadIdx.x >> 6) - (has_cw ? 1 : 0);      // index among the block's tile waves
     const int tiles_per_block = has_cw ? nwb - 1 : nwb;
     __shared__ double sh_scales[4];
     double sc0 = 1.0, sc1 = 1.0, sc2 = 1.0, scb = 0.0;
 
     // ---------------- thermostat wave: scale factors for the whole block, then done
-    VV_SPAN(0);
+    VV_SPAN_BEGIN;
     if (chain_wave) {
+        __builtin_amdgcn_s_setprio(3);            // the block waits for this wave: let it win the issue arbitration on its SIMD
         VV_STAMP(7, 0);
         const int cg = lane < VVHIP_NUM_TG ? lane : VVHIP_NUM_TG - 1;
         ChainRegs cr;
@@ -912,8 +952,9 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const KArgs a) {
         for (int k = 0; k < VVHIP_NUM_TG; k++)
             if (cg == k) ke2 = (double) tot[k] * lc.acc_inv_scale;
         double factor = 1.0;
+        VV_STAMP_NOWAIT(7, 4);
         if (!(F & B_DBG_NOMATH)) factor = propagate_group_small(a.chain, lc, ke2, cr);
-        VV_STAMP(7, 2);
+        VV_STAMP_NOWAIT(7, 2);
         const double bias = (F & B_UNBIAS) ? (double) tot[3] * a.chain.acc_inv_scale[3] * a.chain.inv_mass_total   // K/cosineAccelerate.cu:57-59
                                            : a.nh->scales[3];                                                 // carried over unchanged
         if (lane < VVHIP_NUM_TG) sh_scales[lane] = factor;
@@ -934,7 +975,8 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const KArgs a) {
             for (int i = lane; i < NUM_ACC * ACC_SLOTS; i += 64) a.acc_next[i] = 0;
         }
         VV_STAMP(7, 3);
-        VV_SPAN(1);
+        VV_STAMP_DUMP(7);
+        VV_SPAN_END;
         return;
     }
 
@@ -1216,7 +1258,8 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const KArgs a) {
             posq[img] = pi;
         }
     }   // tile loop
-    VV_SPAN(1);
+    VV_STAMP_DUMP(wib);
+    VV_SPAN_END;
 }
 
 // ================================================================================ stand-alone image kernel
