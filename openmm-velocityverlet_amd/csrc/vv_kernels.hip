@@ -810,6 +810,9 @@ struct ChainRegs { double eta[4], eta_dot[5], eta_dotdot[4]; };
 template <int NC, bool FAST>
 __device__ __forceinline__ double propagate_preloaded(const NHConst& c, const ChainLaneBlock& lc, double ke2, ChainRegs& r, unsigned& max_hi) {
     auto ex = [&](double x) { return FAST ? chain_exp_small(x, max_hi) : chain_exp(x); };
+    // eta_dot[NC] is the chain's closing zero (API:340-376 never writes it): exp(-dt8 * 0) is exactly 1 in both polynomials, so the
+    // two evaluations that take it as argument are skipped when the whole wave sees zeros (two of the six serial exps for NC = 3)
+    const bool tail_zero = !__any(r.eta_dot[NC] != 0);
     // Runs in the block's thermostat wave only (lanes 0..2 = the three temperature groups), so a plain branch on
     // "group is thermostatted" is fine and the state is updated in place (fewer live registers for the whole kernel).
     double factor = 1.0;
@@ -821,7 +824,7 @@ __device__ __forceinline__ double propagate_preloaded(const NHConst& c, const Ch
     for (int iloop = 0; iloop < c.loops_per_step; iloop++) {
 #pragma unroll
         for (int ich = NC - 1; ich >= 0; ich--) {
-            expfac = ex(-dt8 * r.eta_dot[ich + 1]);
+            expfac = (tail_zero && ich == NC - 1) ? 1.0 : ex(-dt8 * r.eta_dot[ich + 1]);
             r.eta_dot[ich] *= expfac;
             r.eta_dot[ich] += r.eta_dotdot[ich] * dt4;
             r.eta_dot[ich] *= expfac;
@@ -835,7 +838,7 @@ __device__ __forceinline__ double propagate_preloaded(const NHConst& c, const Ch
         r.eta_dot[0] *= expfac;
 #pragma unroll
         for (int ich = 1; ich < NC; ich++) {
-            expfac = ex(-dt8 * r.eta_dot[ich + 1]);
+            expfac = (tail_zero && ich == NC - 1) ? 1.0 : ex(-dt8 * r.eta_dot[ich + 1]);
             r.eta_dot[ich] *= expfac;
             r.eta_dotdot[ich] = (lc.eta_mass[ich - 1] * r.eta_dot[ich - 1] * r.eta_dot[ich - 1] - kT) * lc.inv_eta_mass[ich];
             r.eta_dot[ich] += r.eta_dotdot[ich] * dt4;
