@@ -327,6 +327,7 @@ __device__ __forceinline__ void shake_positions(int lane, unsigned word, float4 
             ld[k] = d2 - rijsq[k];
         }
         mixed xpi[3] = {dx, dy, dz};
+        const mixed d2tol = d2 * tol;
         bool converged = false;
         for (int iteration = 0; iteration < 15 && !converged; iteration++) {
             converged = true;
@@ -337,9 +338,11 @@ __device__ __forceinline__ void shake_positions(int lane, unsigned word, float4 
                     const mixed rpsqij = rp0 * rp0 + rp1 * rp1 + rp2 * rp2;
                     const mixed rrpr = rij[k][0] * rp0 + rij[k][1] * rp1 + rij[k][2] * rp2;
                     // both quotients are started together (the wave is latency-bound here); values as in the branchy statement
-                    const mixed diff = fabs(ld[k] - 2.0f * rrpr - rpsqij) / (d2 * tol);
-                    const mixed acor = (ld[k] - 2.0f * rrpr - rpsqij) * avgMass / (rrpr + rijsq[k]);
-                    if (diff >= 1.0f) {
+                    // OpenMM's test is fabs(..) / (d2 * tol) >= 1; the product form decides the same up to the last bit of the quotient
+                    // and saves an IEEE fp64 division per visit on this serial path (the oracle states it the same way)
+                    const mixed num = ld[k] - 2.0f * rrpr - rpsqij;
+                    const mixed acor = num * avgMass / (rrpr + rijsq[k]);
+                    if (fabs(num) >= d2tol) {
                         const mixed d0 = rij[k][0] * acor, d1 = rij[k][1] * acor, d2v = rij[k][2] * acor;
                         xpi[0] += d0 * invMassCentral; xpi[1] += d1 * invMassCentral; xpi[2] += d2v * invMassCentral;
                         xpj[k][0] -= d0 * invMassPeripheral; xpj[k][1] -= d1 * invMassPeripheral; xpj[k][2] -= d2v * invMassPeripheral;
@@ -387,6 +390,7 @@ __device__ __forceinline__ void shake_velocities(int lane, unsigned word, float4
                 rij[k][0] = rij[k][1] = rij[k][2] = 0; vj[k][0] = vj[k][1] = vj[k][2] = 0;
             }
             rijsq[k] = rij[k][0] * rij[k][0] + rij[k][1] * rij[k][1] + rij[k][2] * rij[k][2];
+            rijsq[k] = k < np ? (mixed) 1 / rijsq[k] : (mixed) 0;     // the bond does not move during the sweeps: one reciprocal, not one division per visit
         }
         mixed vi[3] = {vx, vy, vz};
         bool converged = false;
@@ -397,7 +401,7 @@ __device__ __forceinline__ void shake_velocities(int lane, unsigned word, float4
                 if (k < np) {
                     const mixed rp0 = vi[0] - vj[k][0], rp1 = vi[1] - vj[k][1], rp2 = vi[2] - vj[k][2];
                     const mixed rrpr = rp0 * rij[k][0] + rp1 * rij[k][1] + rp2 * rij[k][2];
-                    const mixed delta = -2.0f * avgMass * rrpr / rijsq[k];
+                    const mixed delta = -2.0f * avgMass * rrpr * rijsq[k];
                     const mixed d0 = rij[k][0] * delta, d1 = rij[k][1] * delta, d2v = rij[k][2] * delta;
                     vi[0] += d0 * invMassCentral; vi[1] += d1 * invMassCentral; vi[2] += d2v * invMassCentral;
                     vj[k][0] -= d0 * invMassPeripheral; vj[k][1] -= d1 * invMassPeripheral; vj[k][2] -= d2v * invMassPeripheral;

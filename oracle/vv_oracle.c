@@ -626,6 +626,7 @@ void vvo_shake_positions(int nclusters, const int* atoms, const float* params, m
             np++;
         }
         mixed xpi[3] = { pos_delta[ic].x, pos_delta[ic].y, pos_delta[ic].z };
+        const mixed d2tol = d2 * tol;
         int converged = 0;
         for (int iteration = 0; iteration < 15 && !converged; iteration++) {
             converged = 1;
@@ -633,9 +634,9 @@ void vvo_shake_positions(int nclusters, const int* atoms, const float* params, m
                 const mixed rp0 = xpi[0] - xpj[k][0], rp1 = xpi[1] - xpj[k][1], rp2 = xpi[2] - xpj[k][2];
                 const mixed rpsqij = rp0 * rp0 + rp1 * rp1 + rp2 * rp2;
                 const mixed rrpr = rij[k][0] * rp0 + rij[k][1] * rp1 + rij[k][2] * rp2;
-                const mixed diff = fabs(ld[k] - 2.0f * rrpr - rpsqij) / (d2 * tol);
-                if (diff >= 1.0f) {
-                    const mixed acor = (ld[k] - 2.0f * rrpr - rpsqij) * avgMass / (rrpr + rijsq[k]);
+                const mixed num = ld[k] - 2.0f * rrpr - rpsqij;       /* convergence test in product form: |num| >= d2*tol */
+                if (fabs(num) >= d2tol) {
+                    const mixed acor = num * avgMass / (rrpr + rijsq[k]);
                     const mixed d0 = rij[k][0] * acor, d1 = rij[k][1] * acor, d2v = rij[k][2] * acor;
                     xpi[0] += d0 * invMassCentral; xpi[1] += d1 * invMassCentral; xpi[2] += d2v * invMassCentral;
                     xpj[k][0] -= d0 * invMassPeripheral; xpj[k][1] -= d1 * invMassPeripheral; xpj[k][2] -= d2v * invMassPeripheral;
@@ -668,7 +669,7 @@ void vvo_shake_velocities(int nclusters, const int* atoms, const float* params, 
             load_pos(posq, posq_corr, j, &px, &py, &pz, &pw);
             rij[k][0] = x - px; rij[k][1] = y - py; rij[k][2] = z - pz;
             vj[k][0] = velm[j].x; vj[k][1] = velm[j].y; vj[k][2] = velm[j].z;
-            rijsq[k] = rij[k][0] * rij[k][0] + rij[k][1] * rij[k][1] + rij[k][2] * rij[k][2];
+            rijsq[k] = 1 / (rij[k][0] * rij[k][0] + rij[k][1] * rij[k][1] + rij[k][2] * rij[k][2]);   /* reciprocal once per bond */
             np++;
         }
         mixed vi[3] = { velm[ic].x, velm[ic].y, velm[ic].z };
@@ -678,7 +679,7 @@ void vvo_shake_velocities(int nclusters, const int* atoms, const float* params, 
             for (int k = 0; k < np; k++) {
                 const mixed rp0 = vi[0] - vj[k][0], rp1 = vi[1] - vj[k][1], rp2 = vi[2] - vj[k][2];
                 const mixed rrpr = rp0 * rij[k][0] + rp1 * rij[k][1] + rp2 * rij[k][2];
-                const mixed delta = -2.0f * avgMass * rrpr / rijsq[k];
+                const mixed delta = -2.0f * avgMass * rrpr * rijsq[k];
                 const mixed d0 = rij[k][0] * delta, d1 = rij[k][1] * delta, d2v = rij[k][2] * delta;
                 vi[0] += d0 * invMassCentral; vi[1] += d1 * invMassCentral; vi[2] += d2v * invMassCentral;
                 vj[k][0] -= d0 * invMassPeripheral; vj[k][1] -= d1 * invMassPeripheral; vj[k][2] -= d2v * invMassPeripheral;
