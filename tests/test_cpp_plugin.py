@@ -85,3 +85,23 @@ def test_cpp_integrator_through_plugin_matches_oracle(tmp_path, middle, cons, co
         c = cns.reshape(-1, 2)
         r = np.linalg.norm(x_g[c[:, 0]] - x_g[c[:, 1]], axis=1)
         assert np.abs(r * r - cdist ** 2).max() < 2e-5 * cdist[0] ** 2, np.abs(r - cdist).max()
+
+
+def test_cmake_build_produces_the_same_plugin(tmp_path):
+    """The CMake route (what a maintainer of an OpenMM installation would use) configures and builds the API library, the plugin and
+    the driver against the stand-in headers, reusing the in-tree libvvhip.so; the plugin exports the three registration symbols."""
+    import shutil
+    if not shutil.which("cmake") or not shutil.which("ninja"):
+        pytest.skip("cmake / ninja not available")
+    lib = os.path.join(ROOT, "openmm-velocityverlet_amd", "lib", "libvvhip.so")
+    bdir = str(tmp_path / "b")
+    r = subprocess.run(["cmake", "-S", ROOT, "-B", bdir, "-G", "Ninja", f"-DVVHIP_PREBUILT={lib}"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run(["cmake", "--build", bdir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    plug = os.path.join(bdir, "plugins", "libVelocityVerletPluginHIP.so")
+    syms = subprocess.run(["nm", "-D", plug], capture_output=True, text=True).stdout
+    for name in ("registerPlatforms", "registerKernelFactories", "registerHipVVKernelFactories"):
+        assert f" T {name}" in syms, name
+    r = subprocess.run([os.path.join(bdir, "vv_plugin_driver"), "registry"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
