@@ -60,6 +60,7 @@ struct vvhip_plan {
     int block_threads = 256;       // 64 x tile waves per block, the same for the force provider, kernel A and kernel B
     int grid_cap_a = 2048, grid_cap_b = 1024;   // most blocks per launch (multiples of the CU count): see pick_launch_shape
     int split_chain_waves = 12288;   // systems with at least this many waves (~0.8 M particles; measured +3 % at 0.9 M, +5 % at 8.9 M) run the chain as its own launch (VVHIP_SPLIT_CHAIN_WAVES)
+    bool no_moments = false;       // VVHIP_NO_MOMENTS=1: keep the three-launch cos sequence (comparison runs)
     bool wt_stores = false;        // write-through stores in the fused kernels (VVHIP_WT=1; tuning experiment)
     // plan-owned device state
     int2* d_slots = nullptr;
@@ -74,6 +75,7 @@ struct vvhip_plan {
     void* d_old_delta = nullptr;
     void* d_pos_delta = nullptr;   // used when the caller does not supply one
     void* d_comv = nullptr;        // per-segment COM velocities handed from kernel A to kernel B
+    double* d_comw = nullptr;      // per-segment mass-weighted mean of cos(kz) (moment form of the cos perturbation)
     double* d_cosz = nullptr;      // per-lane cos(2 pi z / Lz) of the current step
     unsigned long long* d_acc = nullptr;   // [2 parities][NUM_ACC][ACC_SLOTS]
     vv::NHDevState* d_nh = nullptr;         // [2 parities]
@@ -157,6 +159,14 @@ void fill_scales(vvhip_plan* p) {
     }
     p->acc_scale[3] = pick_scale(40.0 / in.inv_mass_total, 4.0);  // |sum m vx 2cos| <= 2 M |v|max, |v|max ~ 20 nm/ps
     p->acc_inv_scale[3] = 1.0 / p->acc_scale[3];
+    // moments of the cos perturbation (A_KE_MOM): Sbb = sum m b^2 <= M (|cos| <= 1, |b| <= 2), |Sab| <= sqrt(Saa Sbb)
+    const double mass = 1.0 / in.inv_mass_total;
+    for (int g = 0; g < 3; g++) {
+        p->acc_scale[4 + g] = pick_scale(std::sqrt(total * 1024.0 * 4.0 * mass), 4.0);
+        p->acc_scale[7 + g] = pick_scale(4.0 * mass, 4.0);
+        p->acc_inv_scale[4 + g] = 1.0 / p->acc_scale[4 + g];
+        p->acc_inv_scale[7 + g] = 1.0 / p->acc_scale[7 + g];
+    }
 }
 
 // Launch shape.  Measured on MI355X (256 CUs): what matters at the latency-bound sizes is that every CU gets the SAME number of
@@ -187,6 +197,8 @@ void pick_launch_shape(vvhip_plan* p) {
 
 vv::NHConst make_chain(vvhip_plan* p, uint32_t flags);
 constexpr int kAccN = vv::NUM_ACC * vv::ACC_SLOTS;
+// distance between the two parity copies: only the rows in use (4 without the cos moments)
+int acc_stride(const vvhip_plan* p) { return (p->hp.params.cos_acceleration != 0 ? vv::NUM_ACC : 4) * vv::ACC_SLOTS; }
 
 vv::KArgs make_args(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
     const vvhip_params& q = p->hp.params;
@@ -199,6 +211,7 @@ vv::KArgs make_args(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
     a.pos_delta = p->buf.pos_delta ? p->buf.pos_delta : p->d_pos_delta;
     a.old_delta = p->d_old_delta;
     a.comv = p->d_comv;
+    a.comw = p->d_comw;
     a.cosz = p->d_cosz;
     a.slots = p->d_slots;
     a.slot_image = p->d_slot_image;
@@ -211,8 +224,8 @@ vv::KArgs make_args(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
     a.big_scale = p->hp.big_scale;
     a.big_inv_scale = 1.0 / p->hp.big_scale;
     a.random = (const float4*) p->buf.random;
-    a.acc = p->d_acc + p->parity * kAccN;
-    a.acc_next = p->d_acc + (p->parity ^ 1) * kAccN;
+    a.acc = p->d_acc + p->parity * acc_stride(p);
+    a.acc_next = p->d_acc + (p->parity ^ 1) * acc_stride(p);
     a.nh = p->d_nh + p->parity;
     a.nh_next = p->d_nh + (p->parity ^ 1);
     a.chain = make_chain(p, 0);
@@ -228,6 +241,7 @@ vv::KArgs make_args(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
     a.dbg_parity = p->dbg_parity;
     a.padded = p->hp.padded_num_atoms;
     a.nwaves = p->hp.info.num_waves;
+    a.acc_rows = p->hp.params.cos_acceleration != 0 ? vv::NUM_ACC : 4;
     a.flags = flags;
     a.random_index = random_index;
     a.dt = q.step_size;
@@ -333,7 +347,7 @@ int run_b(vvhip_plan* p, uint32_t flags) {
 }
 int run_chain(vvhip_plan* p, uint32_t flags) {
     ScopedTimer t(p, T_OTHER);
-    HIP_TRY(p, vv::launch_chain(make_chain(p, flags), p->d_nh + p->parity, p->d_acc + p->parity * kAccN, p->stream));
+    HIP_TRY(p, vv::launch_chain(make_chain(p, flags), p->d_nh + p->parity, p->d_acc + p->parity * acc_stride(p), p->stream));
     return VVHIP_OK;
 }
 
@@ -382,6 +396,13 @@ uint32_t tail_flags(const vvhip_plan* p) {      // what follows every position u
     return f;
 }
 bool cos_on(const vvhip_plan* p) { return p->hp.params.cos_acceleration != 0; }
+// cos perturbation in two launches instead of three: kernel A accumulates the group sums as moments of the biased velocities next
+// to the bias moment itself, kernel B's inline chain finishes the algebra (vv_kernels.hpp: A_KE_MOM).  Not with molecules larger
+// than a wave or the stand-alone chain launch (long chains, very large systems), which keep the bias -> KE -> scale sequence.
+bool use_moments(const vvhip_plan* p) {
+    return cos_on(p) && p->hp.has_nh && p->hp.num_big == 0 && p->hp.params.num_nh_chains <= 4 && p->hp.info.num_waves < p->split_chain_waves &&
+           !p->no_moments;
+}
 bool shake_on(const vvhip_plan* p) { return !p->hp.slot_shake.empty(); }
 #define NEED_FUSABLE(p)                                                                                                   \
     do {                                                                                                                \
@@ -414,6 +435,7 @@ int vvhip_plan_create(const vvhip_system_desc* system, const vvhip_params* param
         p->hp = vv::analyze(*system, *params, precision);
         fill_scales(p);
         if (const char* e = std::getenv("VVHIP_WT")) p->wt_stores = std::atoi(e) != 0;
+        if (const char* e = std::getenv("VVHIP_NO_MOMENTS")) p->no_moments = std::atoi(e) != 0;
         if (const char* e = std::getenv("VVHIP_SPLIT_CHAIN_WAVES")) p->split_chain_waves = std::atoi(e);
         pick_launch_shape(p);
         if (const char* e = std::getenv("VVHIP_BLOCK")) {          // tuning experiments
@@ -434,7 +456,7 @@ void vvhip_plan_destroy(vvhip_plan* p) {
     if (p->bound) {
         (void) hipStreamSynchronize(p->stream);
         for (void* ptr : {(void*) p->d_slots, (void*) p->d_slot_image, (void*) p->d_slot_rand, (void*) p->d_slot_shake, (void*) p->d_slot_shake_param, (void*) p->d_slot_big, (void*) p->d_bigacc, (void*) p->d_image_pairs,
-                          p->d_fextra, p->d_old_delta, p->d_pos_delta, p->d_comv, (void*) p->d_cosz, (void*) p->d_epoch, (void*) p->d_acc, (void*) p->d_nh, (void*) p->d_lane_const, (void*) p->d_dbg})
+                          p->d_fextra, p->d_old_delta, p->d_pos_delta, p->d_comv, (void*) p->d_comw, (void*) p->d_cosz, (void*) p->d_epoch, (void*) p->d_acc, (void*) p->d_nh, (void*) p->d_lane_const, (void*) p->d_dbg})
             if (ptr) (void) hipFree(ptr);
         if (p->graph_exec) (void) hipGraphExecDestroy(p->graph_exec);
         if (p->comm) (void) rccl_api().commDestroy(p->comm);
@@ -515,6 +537,8 @@ int vvhip_bind(vvhip_plan* p, const vvhip_buffers* b) {
     HIP_TRY(p, hipMemset(p->d_cosz, 0, nslots * sizeof(double)));
     HIP_TRY(p, hipMalloc(&p->d_comv, nslots * 4 * ms));
     HIP_TRY(p, hipMemset(p->d_comv, 0, nslots * 4 * ms));
+    HIP_TRY(p, hipMalloc((void**) &p->d_comw, nslots * sizeof(double)));
+    HIP_TRY(p, hipMemset(p->d_comw, 0, nslots * sizeof(double)));
     HIP_TRY(p, hipMalloc(&p->d_pos_delta, nloc * 4 * ms));
     HIP_TRY(p, hipMemset(p->d_pos_delta, 0, nloc * 4 * ms));
     HIP_TRY(p, hipMalloc((void**) &p->d_epoch, sizeof(unsigned long long)));
@@ -540,8 +564,13 @@ int vvhip_set_params(vvhip_plan* p, const vvhip_params* q) {
     if (p->hp.params.auto_set_friction && q->auto_set_friction) n.friction = p->hp.params.friction;
     if ((q->cos_acceleration != 0) && p->hp.has_ld)
         return fail(p, VVHIP_ERR_TOPOLOGY, "Langevin thermostat and periodic perturbation shouldn't be used together");
+    const bool cos_switch = (p->hp.params.cos_acceleration != 0) != (n.cos_acceleration != 0);
     p->hp.params = n;
     if (p->graph_exec) { (void) hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
+    if (cos_switch && p->bound) {        // the accumulator copies are laid out by the rows in use: start the new layout from zeros
+        HIP_TRY(p, hipStreamSynchronize(p->stream));
+        HIP_TRY(p, hipMemset(p->d_acc, 0, 2 * kAccN * sizeof(unsigned long long)));
+    }
     return upload_lane_const(p);
 }
 
@@ -569,7 +598,7 @@ int vvhip_set_nh_state(vvhip_plan* p, const vvhip_nh_state* in) {
 int vvhip_step_middle_phases(const vvhip_plan* p) {
     if (!p) return VVHIP_ERR_INVALID;
     if (!p->hp.has_nh) return 1;
-    return cos_on(p) ? 3 : 2;
+    return (cos_on(p) && !use_moments(p)) ? 3 : 2;
 }
 
 int vvhip_step_middle_phase(vvhip_plan* p, int phase, uint32_t random_index) {
@@ -585,6 +614,9 @@ int vvhip_step_middle_phase(vvhip_plan* p, int phase, uint32_t random_index) {
     if (!cos_on(p)) {
         if (phase == 0) return run_ke(p, kick, random_index, false);
         if (phase == 1) return run_chain_and_b(p, vv::B_SCALE | drift, false);
+    } else if (use_moments(p)) {                           // bias moment and group moments in one launch
+        if (phase == 0) return run_a(p, kick | vv::A_BIAS | vv::A_CZ_STORE | vv::A_KE | vv::A_KE_MOM, random_index);
+        if (phase == 1) return run_chain_and_b(p, vv::B_SCALE | vv::B_UNBIAS | vv::B_CZ_LOAD | vv::B_KE_MOM | drift, true);
     } else {                                               // API:252-259: bias -> remove -> scale -> restore
         if (phase == 0) return run_a(p, kick | vv::A_BIAS | vv::A_CZ_STORE, random_index);
         if (phase == 1) return run_ke(p, 0, 0, true);
@@ -596,8 +628,9 @@ int vvhip_step_middle_phase(vvhip_plan* p, int phase, uint32_t random_index) {
 int vvhip_accumulators(vvhip_plan* p, int phase, void** device_ptr, int32_t* count) {
     NEED_BOUND(p);
     if (!device_ptr || !count) return VVHIP_ERR_INVALID;
-    unsigned long long* cur = p->d_acc + p->parity * kAccN;
-    if (cos_on(p) && phase == 0) { *device_ptr = cur + 3 * vv::ACC_SLOTS; *count = vv::ACC_SLOTS; }   // bias moment slots only
+    unsigned long long* cur = p->d_acc + p->parity * acc_stride(p);
+    if (use_moments(p)) { *device_ptr = cur; *count = vv::NUM_ACC * vv::ACC_SLOTS; }                  // everything kernel A produced
+    else if (cos_on(p) && phase == 0) { *device_ptr = cur + 3 * vv::ACC_SLOTS; *count = vv::ACC_SLOTS; }   // bias moment slots only
     else { *device_ptr = cur; *count = 3 * vv::ACC_SLOTS; }                                          // the three 2KE sums
     return VVHIP_OK;
 }
@@ -639,6 +672,11 @@ static int nh_half(vvhip_plan* p, uint32_t a_first, uint32_t random_index, uint3
         TRY(run_ke(p, a_first, random_index, false));
         TRY(exchange_accumulators(p, 0));
         return run_chain_and_b(p, vv::B_SCALE | b_extra, false);
+    }
+    if (use_moments(p)) {
+        TRY(run_a(p, a_first | vv::A_BIAS | vv::A_CZ_STORE | vv::A_KE | vv::A_KE_MOM, random_index));
+        TRY(exchange_accumulators(p, 0));
+        return run_chain_and_b(p, vv::B_SCALE | vv::B_UNBIAS | vv::B_CZ_LOAD | vv::B_KE_MOM | b_extra, true);
     }
     TRY(run_a(p, a_first | vv::A_BIAS | vv::A_CZ_STORE, random_index));
     TRY(exchange_accumulators(p, 0));
@@ -733,7 +771,7 @@ int vvhip_compute_kinetic_energy(vvhip_plan* p, double* kinetic_energy) {   // H
     if (!kinetic_energy) return VVHIP_ERR_INVALID;
     // uses accumulator 0 of the current copy between two steps (it is zero there) and leaves it zero again
     TRY(run_a(p, vv::A_KE_PLAIN, 0));
-    double acc[vv::NUM_ACC];
+    double acc[4];
     TRY(vvhip_debug_read_accumulators(p, acc, 1));
     *kinetic_energy = 0.5 * acc[0];
     return VVHIP_OK;
@@ -865,8 +903,9 @@ int vvhip_time_kernel(vvhip_plan* p, int kernel, uint32_t flags, int reps, doubl
     NEED_BOUND(p);
     if (reps < 1 || !ms_per_launch) return VVHIP_ERR_INVALID;
     if (flags == 0xFFFFFFFFu) {     // the stage bits vvhip_step_middle uses for this plan
-        if (kernel == 0) flags = vv::A_KICK_FULL | extra_flags(p) | (shake_on(p) ? vv::A_SHAKE_V : 0) | (p->hp.has_nh ? (cos_on(p) ? (vv::A_BIAS | vv::A_CZ_STORE) : vv::A_KE) : 0);
-        else flags = vv::B_DRIFT_MIDDLE | tail_flags(p) | (shake_on(p) ? vv::B_SHAKE : 0) | (p->hp.has_nh ? ((p->hp.params.num_nh_chains <= 4 ? vv::B_CHAIN : 0) | vv::B_SCALE | (cos_on(p) ? (vv::B_UNBIAS | vv::B_CZ_LOAD) : 0)) : 0);
+        const uint32_t mom_a = use_moments(p) ? (vv::A_KE | vv::A_KE_MOM) : 0, mom_b = use_moments(p) ? vv::B_KE_MOM : 0;
+        if (kernel == 0) flags = vv::A_KICK_FULL | extra_flags(p) | (shake_on(p) ? vv::A_SHAKE_V : 0) | (p->hp.has_nh ? (cos_on(p) ? (vv::A_BIAS | vv::A_CZ_STORE | mom_a) : vv::A_KE) : 0);
+        else flags = vv::B_DRIFT_MIDDLE | tail_flags(p) | (shake_on(p) ? vv::B_SHAKE : 0) | (p->hp.has_nh ? ((p->hp.params.num_nh_chains <= 4 ? vv::B_CHAIN : 0) | vv::B_SCALE | (cos_on(p) ? (vv::B_UNBIAS | vv::B_CZ_LOAD | mom_b) : 0)) : 0);
     }
     hipEvent_t e0, e1;
     HIP_TRY(p, hipEventCreate(&e0));
@@ -1116,13 +1155,13 @@ int vvhip_debug_read_accumulators(vvhip_plan* p, double out[4], int zero_after) 
     NEED_BOUND(p);
     static long long raw[vv::NUM_ACC * vv::ACC_SLOTS];
     HIP_TRY(p, hipStreamSynchronize(p->stream));
-    HIP_TRY(p, hipMemcpy(raw, p->d_acc + p->parity * kAccN, sizeof(raw), hipMemcpyDeviceToHost));
-    for (int i = 0; i < vv::NUM_ACC; i++) {
+    HIP_TRY(p, hipMemcpy(raw, p->d_acc + p->parity * acc_stride(p), 4 * vv::ACC_SLOTS * sizeof(long long), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 4; i++) {                 // the ABI hands out the three group sums and the bias moment
         long long s = 0;
         for (int j = 0; j < vv::ACC_SLOTS; j++) s += raw[i * vv::ACC_SLOTS + j];
         out[i] = (double) s * p->acc_inv_scale[i];
     }
-    if (zero_after) HIP_TRY(p, hipMemset(p->d_acc + p->parity * kAccN, 0, sizeof(raw)));
+    if (zero_after) HIP_TRY(p, hipMemset(p->d_acc + p->parity * acc_stride(p), 0, 4 * vv::ACC_SLOTS * sizeof(long long)));
     return VVHIP_OK;
 }
 int vvhip_debug_set_scales(vvhip_plan* p, const double scales[4]) {

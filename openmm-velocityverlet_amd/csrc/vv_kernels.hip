@@ -108,10 +108,20 @@ __device__ __forceinline__ void block_accumulate(const double (&vals)[NV], const
         if (lane == 63) red[w][k] = s;
     }
     __syncthreads();
-    if (threadIdx.x < NV && enabled[threadIdx.x]) {
+    // Thread k finishes quantity k.  Nothing here may index `enabled` or `scale` by the thread id: both live in constant / kernel
+    // argument memory, and a lane-indexed read of those turns into a global load in front of the atomic -- two dependent memory
+    // round trips at the very end of every block (seen in the ISA; ~0.5 us of kernel A's tail).  Bit mask and select chain instead.
+    unsigned mask = 0;
+#pragma unroll
+    for (int k = 0; k < NV; k++) mask |= enabled[k] ? (1u << k) : 0u;
+    if (threadIdx.x < NV && ((mask >> threadIdx.x) & 1u)) {
         double s = 0;
         for (int i = 0; i < nw; i++) s += red[i][threadIdx.x];
-        const long long q = __double2ll_rn(s * scale[threadIdx.x]);
+        double sc = 0;
+#pragma unroll
+        for (int k = 0; k < NV; k++)
+            if (enabled[k] && (int) threadIdx.x == k) sc = scale[k];
+        const long long q = __double2ll_rn(s * sc);
         if (q != 0) atomicAdd(&acc[threadIdx.x * ACC_SLOTS + (blockIdx.x & (ACC_SLOTS - 1))], (unsigned long long) q);
     }
 }
@@ -499,6 +509,7 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const KArgs a) {
     const int lane = threadIdx.x & 63;
     const uint32_t F = SF ? SF : a.flags;
     double k_atom = 0, k_com = 0, k_drude = 0, k_bias = 0;
+    double m_ab[3] = {0, 0, 0}, m_bb[3] = {0, 0, 0};      // A_KE_MOM: cross and field moments of the groups atom, com, drude
 
     // grid-stride over 64-lane tiles (the grid is capped in launch_a): per-lane partial sums run across all tiles of the
     // block, so the block reduction and its atomics are paid once per block however large the system is
@@ -685,13 +696,30 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const KArgs a) {
                 mixed4 cv = {Vx, Vy, Vz, Vw};
                 ((mixed4*) a.comv)[(size_t) wave * 64 + ((meta >> META_SEGFIRST_SHIFT) & 63)] = cv;
             }
+            // Moment form of the bias removal (K/cosineAccelerate.cu:63-73 followed by K/drudeNoseHoover.cu:33-151): the unbiased
+            // velocity is u = v - V w with w = (cos(kz), 0, 0) and V known only after the global sum, and every term of the group
+            // sums is a square of something LINEAR in the velocities, (a - V b)^2 with a from v and b from w by the same linear
+            // map.  So this launch accumulates sum a^2 (as before), sum a.b and sum b^2, and kernel B finishes the algebra.
+            mixed bx = 0, Wx = 0;
+            if (F & A_KE_MOM) {
+                const mixed wx = act ? (mixed) czl : (mixed) 0;
+                const int first = (meta >> META_SEGFIRST_SHIFT) & 63, last = (meta >> META_SEGLAST_SHIFT) & 63;
+                mixed mw = (nh && massive && use_com) ? wx * P::RECIP(v.w) : (mixed) 0;
+                mw = segment_total(mw, lane, first, last);
+                Wx = use_com ? mw * Vw : (mixed) 0;
+                if ((meta & META_COM_LEADER) && use_com) a.comw[(size_t) wave * 64 + first] = (double) Wx;
+                bx = wx;
+                if (nh) bx -= Wx;
+            }
             if (nh) { ux -= Vx; uy -= Vy; uz -= Vz; }                       // K/drudeNoseHoover.cu:45-47
             // Masses: one reciprocal per lane, the partner's comes over the shuffle network.  Where the reference divides by an
             // inverse mass this multiplies by the mass (<= 1 ulp apart, below the reduction-order noise of these sums).
             const mixed own_mass = massive ? P::RECIP(v.w) : (mixed) 0;
             const mixed px = shfl(ux, partner), py = shfl(uy, partner), pz = shfl(uz, partner), pm = shfl(own_mass, partner);
+            const mixed pbx = (F & A_KE_MOM) ? shfl(bx, partner) : (mixed) 0;
             if (role == ROLE_NH_NORMAL && massive) {                        // K/drudeNoseHoover.cu:76-83
                 k_atom += (double) ((ux * ux + uy * uy + uz * uz) * own_mass);
+                if (F & A_KE_MOM) { m_ab[0] += (double) (ux * bx * own_mass); m_bb[0] += (double) (bx * bx * own_mass); }
             } else if (role == ROLE_NH_DRUDE) {                             // K/drudeNoseHoover.cu:97-114, pair.x = Drude
                 const mixed mass1 = own_mass, mass2 = pm;
                 const mixed invTotalMass = P::RECIP(mass1 + mass2);
@@ -703,15 +731,23 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const KArgs a) {
                 const mixed rx = ux - px, ry = uy - py, rz = uz - pz;
                 k_atom += (double) ((cx * cx + cy * cy + cz * cz) * (mass1 + mass2));
                 k_drude += (double) ((rx * rx + ry * ry + rz * rz) * reducedMass);
+                if (F & A_KE_MOM) {
+                    const mixed cb = bx * mass1fract + pbx * mass2fract, rb = bx - pbx;
+                    m_ab[0] += (double) (cx * cb * (mass1 + mass2)); m_bb[0] += (double) (cb * cb * (mass1 + mass2));
+                    m_ab[2] += (double) (rx * rb * reducedMass); m_bb[2] += (double) (rb * rb * reducedMass);
+                }
             }
-            if ((meta & META_COM_LEADER) && use_com && Vw != 0 && (!(meta & META_BIGMOL) || (meta & META_BIG_FIRST)))   // K/drudeNoseHoover.cu:85-94
+            if ((meta & META_COM_LEADER) && use_com && Vw != 0 && (!(meta & META_BIGMOL) || (meta & META_BIG_FIRST))) { // K/drudeNoseHoover.cu:85-94
                 k_com += (double) ((Vx * Vx + Vy * Vy + Vz * Vz) * Vm);
+                if (F & A_KE_MOM) { m_ab[1] += (double) (Vx * Wx * Vm); m_bb[1] += (double) (Wx * Wx * Vm); }
+            }
         }
     }
     VV_STAMP(threadIdx.x >> 6, 3);
     if (F & (A_KE | A_BIAS | A_KE_PLAIN)) {
-        const double vals[NUM_ACC] = {k_atom, k_com, k_drude, k_bias};
-        const bool en[NUM_ACC] = {(F & (A_KE | A_KE_PLAIN)) != 0, (F & A_KE) != 0, (F & A_KE) != 0, (F & A_BIAS) != 0};
+        const double vals[NUM_ACC] = {k_atom, k_com, k_drude, k_bias, m_ab[0], m_ab[1], m_ab[2], m_bb[0], m_bb[1], m_bb[2]};
+        const bool mom = (F & A_KE_MOM) != 0;
+        const bool en[NUM_ACC] = {(F & (A_KE | A_KE_PLAIN)) != 0, (F & A_KE) != 0, (F & A_KE) != 0, (F & A_BIAS) != 0, mom, mom, mom, mom, mom, mom};
         block_accumulate<NUM_ACC>(vals, en, a.acc, a.acc_scale);
     }
     VV_STAMP(threadIdx.x >> 6, 4);
@@ -947,8 +983,10 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const KArgs a) {
         const ChainLaneBlock lc = a.lane_const[cg];
         long long tot[NUM_ACC];
 #pragma unroll
-        for (int k = 0; k < NUM_ACC; k++)
-            tot[k] = (F & B_DBG_NOFOLD) ? 0 : acc_total(a.acc, k, lane);
+        for (int k = 0; k < NUM_ACC; k++) {
+            const bool wanted = k < 3 || (k == 3 && (F & B_UNBIAS)) || (k > 3 && (F & B_KE_MOM));
+            tot[k] = (!wanted || (F & B_DBG_NOFOLD)) ? 0 : acc_total(a.acc, k, lane);
+        }
         if (F & B_MAILBOX) {                      // multi-GPU: block 0 publishes this rank's totals, every block collects all ranks'
             __shared__ unsigned int mb_words[MB_MAX_RANKS * MB_WORDS];
             mailbox_exchange(a, lane, a.nh->mb_seq + 1u, mb_words, tot);
@@ -958,6 +996,14 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const KArgs a) {
 #pragma unroll
         for (int k = 0; k < VVHIP_NUM_TG; k++)
             if (cg == k) ke2 = (double) tot[k] * lc.acc_inv_scale;
+        if (F & B_KE_MOM) {                       // 2KE of the bias-free velocities from the moments of the biased ones
+            const double V = (double) tot[3] * a.chain.acc_inv_scale[3] * a.chain.inv_mass_total;
+            double sab = 0, sbb = 0;
+#pragma unroll
+            for (int k = 0; k < VVHIP_NUM_TG; k++)
+                if (cg == k) { sab = (double) tot[4 + k] * a.chain.acc_inv_scale[4]; sbb = (double) tot[7 + k] * a.chain.acc_inv_scale[7]; }
+            ke2 = ke2 - 2.0 * V * sab + V * V * sbb;
+        }
         double factor = 1.0;
         VV_STAMP_NOWAIT(7, 4);
         if (!(F & B_DBG_NOMATH)) factor = propagate_group_small(a.chain, lc, ke2, cr);
@@ -979,7 +1025,7 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const KArgs a) {
             }
             if (lane == 3) { out->s.v_bias = bias; out->scales[3] = bias; }
             if (lane == 4) out->mb_seq = a.nh->mb_seq + ((F & B_MAILBOX) ? 1u : 0u);
-            for (int i = lane; i < NUM_ACC * ACC_SLOTS; i += 64) a.acc_next[i] = 0;
+            for (int i = lane; i < a.acc_rows * ACC_SLOTS; i += 64) a.acc_next[i] = 0;
         }
         VV_STAMP(7, 3);
         VV_STAMP_DUMP(7);
@@ -1014,12 +1060,13 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const KArgs a) {
 
         const bool nh = role == ROLE_NH_NORMAL || role == ROLE_NH_DRUDE || role == ROLE_NH_PARENT;
         const bool use_com = ((meta >> META_SEGFIRST_SHIFT) & 63) != ((meta >> META_SEGLAST_SHIFT) & 63) || (meta & META_COM_LEADER);
-        mixed Vx = 0, Vy = 0, Vz = 0, Vw = 0;
+        mixed Vx = 0, Vy = 0, Vz = 0, Vw = 0, com_w = 0;
         // COM velocity of this lane's molecule as kernel A's KE stage left it (of the bias-free velocities when a bias is
         // removed): one 32-byte entry per molecule, the same address for every lane of the segment
         if ((F & B_SCALE) && nh && use_com) {
             const mixed4 cv = ((const mixed4*) a.comv)[(size_t) wave * 64 + ((meta >> META_SEGFIRST_SHIFT) & 63)];
             Vx = cv.x; Vy = cv.y; Vz = cv.z; Vw = cv.w;
+            if (F & B_KE_MOM) com_w = (mixed) a.comw[(size_t) wave * 64 + ((meta >> META_SEGFIRST_SHIFT) & 63)];
         }
 
         // Factor-independent half of the scaling: velocities relative to the molecular COM, the Drude partner's over the shuffle
@@ -1067,6 +1114,7 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const KArgs a) {
             Vb = (mixed) scb;
             cz = (F & B_CZ_LOAD) ? a.cosz[(size_t) wave * 64 + lane] : cos_kz<real>(zraw, (real) a.inv_box_z);
             if ((F & (B_UNBIAS | B_BIAS_REMOVE)) && act) { v.x -= Vb * cz; vel_dirty = true; }
+            if (F & B_KE_MOM) Vx -= Vb * com_w;       // kernel A stored the COM velocity of the biased velocities: COM(u) = COM(v) - V COM(w)
         }
 
         // ---------------- NH velocity scaling (K/drudeNoseHoover.cu:157-209): the factor-independent half was prepared above
@@ -1388,6 +1436,8 @@ constexpr uint32_t SF_B_COS_HW = B_CHAIN | B_SCALE | B_UNBIAS | B_CZ_LOAD | B_DR
 constexpr uint32_t SF_B_MIDDLE_HW = B_CHAIN | B_SCALE | B_DRIFT_MIDDLE | B_HARDWALL;
 constexpr uint32_t SF_B_MIDDLE_HW_WT = SF_B_MIDDLE_HW | B_WT_STORES;
 constexpr uint32_t SF_B_MIDDLE = B_CHAIN | B_SCALE | B_DRIFT_MIDDLE;
+constexpr uint32_t SF_A_COS_MOM = A_KICK_FULL | A_COS | A_BIAS | A_CZ_STORE | A_KE | A_KE_MOM;   // cos acceleration in one launch (moments)
+constexpr uint32_t SF_B_COS_HW_MOM = SF_B_COS_HW | B_KE_MOM;
 constexpr uint32_t SF_B_MIDDLE_HW_NC = B_SCALE | B_DRIFT_MIDDLE | B_HARDWALL;                // large systems: the chain runs as its own 1-wave launch in front
 constexpr uint32_t SF_B_MIDDLE_HW_MB = SF_B_MIDDLE_HW | B_MAILBOX;
 constexpr uint32_t SF_A_MIDDLE_SHAKE = SF_A_MIDDLE | A_SHAKE_V;                         // HBonds constraints solved in-kernel
@@ -1402,6 +1452,7 @@ hipError_t launch_a(int precision, const KArgs& a, int block_threads, int grid_c
     if (a.flags == SF_A_MIDDLE) { VV_DISPATCH_SF(vv_kernel_a, SF_A_MIDDLE, g, b, 0, s, a); }
     else if (a.flags == SF_A_MIDDLE_WT) { VV_DISPATCH_SF(vv_kernel_a, SF_A_MIDDLE_WT, g, b, 0, s, a); }
     else if (a.flags == SF_A_COS1) { VV_DISPATCH_SF(vv_kernel_a, SF_A_COS1, g, b, 0, s, a); }
+    else if (a.flags == SF_A_COS_MOM) { VV_DISPATCH_SF(vv_kernel_a, SF_A_COS_MOM, g, b, 0, s, a); }
     else if (a.flags == SF_A_MIDDLE_SHAKE) { VV_DISPATCH_SF(vv_kernel_a, SF_A_MIDDLE_SHAKE, g, b, 0, s, a); }
     else if (a.flags == SF_A_COS2) { VV_DISPATCH_SF(vv_kernel_a, SF_A_COS2, g, b, 0, s, a); }
     else { VV_DISPATCH_SF(vv_kernel_a, 0u, g, b, 0, s, a); }
@@ -1418,6 +1469,7 @@ hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_c
     else if (a.flags == SF_B_MIDDLE_HW_WT) { VV_DISPATCH_SF(vv_kernel_b, SF_B_MIDDLE_HW_WT, g, b, 0, s, a); }
     else if (a.flags == SF_B_MIDDLE) { VV_DISPATCH_SF(vv_kernel_b, SF_B_MIDDLE, g, b, 0, s, a); }
     else if (a.flags == SF_B_COS_HW) { VV_DISPATCH_SF(vv_kernel_b, SF_B_COS_HW, g, b, 0, s, a); }
+    else if (a.flags == SF_B_COS_HW_MOM) { VV_DISPATCH_SF(vv_kernel_b, SF_B_COS_HW_MOM, g, b, 0, s, a); }
     else if (a.flags == SF_B_MIDDLE_HW_NC) { VV_DISPATCH_SF(vv_kernel_b, SF_B_MIDDLE_HW_NC, g, b, 0, s, a); }
     else if (a.flags == SF_B_MIDDLE_HW_MB) { VV_DISPATCH_SF(vv_kernel_b, SF_B_MIDDLE_HW_MB, g, b, 0, s, a); }
     else if (a.flags == SF_B_MIDDLE_HW_SHAKE) { VV_DISPATCH_SF(vv_kernel_b, SF_B_MIDDLE_HW_SHAKE, g, b, 0, s, a); }

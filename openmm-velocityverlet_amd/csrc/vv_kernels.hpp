@@ -27,6 +27,8 @@ enum : uint32_t {
     A_CZ_STORE = 1u << 13,   // keep cos(2 pi z / Lz) of every lane for the later kernels of this step (positions do not move in between)
     A_CZ_LOAD = 1u << 14,    // ... and take it from there instead of evaluating a double-precision cosine again
     A_SHAKE_V = 1u << 16,    // velocity constraints of the SHAKE clusters right after the kick (OpenMM applyVelocityConstraints)
+    A_KE_MOM = 1u << 17,     // with A_BIAS | A_KE in ONE launch: the group sums as moments Saa, Sab, Sbb of the still biased velocities
+                             // (accumulators 0-2, 4-6, 7-9); kernel B combines them once V is known: 2KE = Saa - 2 V Sab + V^2 Sbb
     A_WT_STORES = 1u << 27,  // write-through (sc1) store of the kicked velocities
     A_KE_PLAIN = 1u << 15,   // sum m v^2 over every massive particle into accumulator 0 (kinetic-energy query)
 };
@@ -47,6 +49,7 @@ enum : uint32_t {
     B_CZ_LOAD = 1u << 12,     // cos(2 pi z / Lz) from the per-lane cache written by kernel A (A_CZ_STORE)
     B_SHAKE = 1u << 13,       // position constraints of the SHAKE clusters on the step's displacement (OpenMM applyConstraints)
     B_MAILBOX = 1u << 14,     // multi-GPU mailbox: block 0's thermostat wave stores this rank's totals into every peer, all blocks sum all ranks' totals
+    B_KE_MOM = 1u << 15,      // the accumulators hold moments (A_KE_MOM): combine them with V, unbias the stored COM velocities with comw
     B_WT_STORES = 1u << 27,   // write-through (sc1) stores for the particle arrays: the dirty lines leave L2 during the kernel, not at its end
     B_DBG_NOFOLD = 1u << 28,  // timing experiments only: skip the accumulator fold / the chain arithmetic
     B_DBG_NOMATH = 1u << 29,
@@ -54,7 +57,8 @@ enum : uint32_t {
 // ---- chain kernel --------------------------------------------------------------------------------
 enum : uint32_t { C_CHAIN = 1u << 0, C_BIAS = 1u << 1 };
 
-constexpr int NUM_ACC = 4;     // fixed-point quantities: 2KE atom, 2KE com, 2KE drude, bias moment
+constexpr int NUM_ACC = 10;    // fixed-point quantities: 2KE atom, 2KE com, 2KE drude, bias moment; with the cos perturbation the
+                               // cross moments Sab (4-6) and the field moments Sbb (7-9) of the three groups (A_KE_MOM)
 constexpr int ACC_SLOTS = 256; // each quantity is spread over 256 int64 slots (block b adds into slot b % 256):
                                // thousands of blocks adding into ONE word serialise at ~10 ns per atomic on MI355X
                                // (measured: 17 us for kernel A at 1000 blocks); integer sums stay exact and
@@ -111,16 +115,29 @@ struct ChainLaneBlock {
 // One argument block for kernels A and B (passed by value); pointer types are erased so that the
 // same struct serves the three precision modes.
 struct KArgs {
+    // ---- first 192 bytes: what every wave needs for its first loads and kernel A for its last (three scalar-cache lines)
+    const int2* slots;
     void* velm;
     void* posq;
     void* corr;
     const long long* force;
+    void* comv;                    // mixed4 [64*nwaves]: COM velocity of the segment starting at that lane, written by A_KE, read by B_SCALE
+    unsigned long long* acc;        // accumulators of the current parity (A adds, B consumes)
+    const NHDevState* nh;           // thermostat state of the current parity
+    const ChainLaneBlock* lane_const;   // [VVHIP_NUM_TG] chain constants, one row per group, in device memory (kernel B's thermostat wave)
+    int32_t padded;
+    int32_t nwaves;
+    uint32_t flags;
+    uint32_t random_index;
+    double dt;                 // step size
+    double max_drude, hw_scale;                    // HOST:189-190
+    double acc_scale[NUM_ACC];  // fixed-point scales of the accumulated quantities (kernel A's tail)
+    // ---- the rest
     void* fextra;
     void* pos_delta;
     void* old_delta;
     double* cosz;                  // [64*nwaves] per-lane cos(2 pi z / Lz) cache of the current step
-    void* comv;                    // mixed4 [64*nwaves]: COM velocity of the segment starting at that lane, written by A_KE, read by B_SCALE
-    const int2* slots;
+    double* comw;                  // [64*nwaves] mass-weighted mean of cos(kz) over the same segment (A_KE_MOM -> B_KE_MOM)
     const int32_t* slot_image;
     const int32_t* slot_rand;
     const int32_t* slot_shake;      // packed SHAKE cluster word per lane (vv_host.hpp), NULL without in-kernel constraints
@@ -130,31 +147,23 @@ struct KArgs {
     unsigned long long* bigacc;     // int64 fixed point [num_big][4]: sum m vx, m vy, m vz, m
     double big_scale, big_inv_scale;
     const float4* random;
-    unsigned long long* acc;        // accumulators of the current parity (A adds, B consumes)
     unsigned long long* acc_next;   // other parity: zeroed by B when it runs the chain inline
-    const NHDevState* nh;           // thermostat state of the current parity
     NHDevState* nh_next;            // where an inline chain writes the advanced state
-    NHConst chain;                  // chain constants (used by B_CHAIN)
-    const ChainLaneBlock* lane_const;   // [VVHIP_NUM_TG] the same constants, one row per group, in device memory
-    Mailbox mb;                     // B_MAILBOX
-    long long* dbg;                 // timestamp buffer of the instrumented build (-DVV_KERNEL_TIMESTAMPS, tools/probes), else unused
-    int32_t dbg_block, dbg_pad_;
-    long long* dbg_span;            // instrumented build: [2 launch parities][blocks*8 waves][2] entry / exit stamps of every wave (100 MHz wall clock)
-    int32_t dbg_parity, dbg_pad2_;
-    int32_t padded;
-    int32_t nwaves;
-    uint32_t flags;
-    uint32_t random_index;
-    double dt;                 // step size
+    int32_t acc_rows, acc_rows_pad_;   // accumulator rows in use (4, or NUM_ACC with the cos moments): what kernel B has to clear
     double fscale_vv;          // 0.5*dt/2^32 computed in double on the host (HOST:306)
     double drag, randf, drag_drude, randf_drude;   // HOST:835-839
     double efscale;            // E * AVOGADRO (HOST:978)
     double cos_accel;
     double inv_box_z;
-    double max_drude, hw_scale;                    // HOST:189-190
     double mirror;
     double inv_mass_total;
-    double acc_scale[NUM_ACC], acc_inv_scale[NUM_ACC];
+    double acc_inv_scale[NUM_ACC];
+    NHConst chain;                  // chain constants (used by B_CHAIN)
+    Mailbox mb;                     // B_MAILBOX
+    long long* dbg;                 // timestamp buffer of the instrumented build (-DVV_KERNEL_TIMESTAMPS, tools/probes), else unused
+    int32_t dbg_block, dbg_pad_;
+    long long* dbg_span;            // instrumented build: [2 launch parities][blocks*8 waves][2] entry / exit stamps of every wave (100 MHz wall clock)
+    int32_t dbg_parity, dbg_pad2_;
 };
 
 struct TetherArgs {
