@@ -211,3 +211,33 @@ def test_kinetic_energy_and_group_temperatures():
         assert np.abs(ctx.getPositions() - osys.positions()).max() < 1e-11
     finally:
         ctx.close()
+
+
+def test_switching_the_cos_perturbation_on_mid_run_equals_a_fresh_start():
+    """setCosAcceleration at run time changes the accumulator layout (moment rows come into use) and the number of reductions
+    per step: continuing must give the bits of a context that starts from the same state with the perturbation already on."""
+    spec = systems.drude_il(cells=(1, 1, 1), pairs_per_cell=50, seed=21)
+
+    def make(cos):
+        it = I.VVIntegrator(333.0, 10, 1.0, 40, 0.001)
+        it.setMaxDrudeDistance(0.02)
+        it.setCosAcceleration(cos)
+        return it, I.Context(spec, it, precision="mixed", force_provider="tether")
+
+    it1, c1 = make(0.0)
+    it1.step(7)                                                  # odd: the two accumulator / thermostat copies have swapped roles
+    velm, posq, corr, nh = c1.getVelm(), c1.getPosq(), c1.getPosqCorrection(), c1.getNHState()
+    it1.setCosAcceleration(0.02)
+    it1.step(6)
+    r1 = (c1.getVelm(), c1.getPosq(), c1.getPosqCorrection(), list(c1.getNHState().ke2), it1.getViscosity())
+    c1.close()
+    it2, c2 = make(0.02)
+    c2.velm.upload(velm); c2.posq.upload(posq); c2.posq_corr.upload(corr)
+    c2.setNHState(nh)
+    c2.forces_valid = False
+    it2.step(6)
+    r2 = (c2.getVelm(), c2.getPosq(), c2.getPosqCorrection(), list(c2.getNHState().ke2), it2.getViscosity())
+    c2.close()
+    for a, b in zip(r1[:3], r2[:3]):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+    assert r1[3] == r2[3] and r1[4] == r2[4]
