@@ -342,8 +342,9 @@ def main():
         out["cpu_baseline"] = {"value": round(nsteps / cpu_elapsed, 2), "unit": "steps/s", "cores": cores, "kind": "port",
                                "sample": f"{nsteps} steps of the same {cfg} workload ({cpu_elapsed:.1f} s), oracle/vv_oracle.c with OpenMP, "
                                          f"fastest of 1..{min(ncpu, 128)} threads on a {ncpu}-CPU host"}
-    # ---- the reference's own kernel sequence on this GPU (oracle/_ref GPU build; present only if built where /root/reference exists)
-    if world == 1 and rank == 0 and not use_dist and cfg in ("C2", "C3", "C4") and args.precision == "mixed" and args.forces == "tether" and not args.hbonds:
+    # ---- still the baseline leg (the only part of this file that touches oracle/): the reference's own kernel sequence on this GPU
+    # (oracle/_ref GPU build; present only if built where /root/reference exists), reported inside the cpu_baseline object
+    if world == 1 and rank == 0 and not use_dist and not args.no_cpu_baseline and cfg in ("C2", "C3", "C4") and args.precision == "mixed" and args.forces == "tether" and not args.hbonds:
         try:
             from oracle import oracle as O
             if O.have_ref_gpu():
@@ -356,7 +357,7 @@ def main():
                 ref.step(nref); ref.sync()
                 tref = time.perf_counter() - t0
                 ref.close()
-                out["reference_kernels_on_this_gpu"] = {
+                out["cpu_baseline"]["reference_kernels_on_this_gpu"] = {
                     "value": round(nref / tref, 1), "unit": "steps/s",
                     "what": "the reference's unmodified CUDA kernels compiled for gfx950, launched in the reference's order incl. its blocking "
                             "KE download / host chain / upload per step (oracle/ref_gpu_driver.cpp); same workload and force provider"}
