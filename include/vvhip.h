@@ -267,6 +267,9 @@ int vvhip_set_random_seed(vvhip_plan* plan, uint64_t seed);
 int vvhip_fill_random(vvhip_plan* plan);
 /* The same steps enqueued one by one from C (no graph): fallback when graph capture is not wanted. */
 int vvhip_run_eager(vvhip_plan* plan, int nsteps, const void* site, double k_tether, double k_drude);
+/* ... and through the per-KernelImpl entry points in VVIntegrator::stepMiddle's order: the launches of the un-fused drop-in path
+ * (what a host with its own constraint solver between the stages pays, the solver's launches excluded). */
+int vvhip_run_eager_unfused(vvhip_plan* plan, int nsteps, const void* site, double k_tether, double k_drude);
 /* HIP-event timing of the dominant kernels on the plan's stream, for bench.py's roofline block. */
 /* Average duration of `reps` back-to-back launches of one stage kernel (0 = A, 1 = B) with the given stage bits,
  * bracketed by two HIP events on the plan's stream.  Destroys the physical state (timing only). */

@@ -60,6 +60,8 @@ struct vvhip_plan {
     int block_threads = 256;       // 64 x tile waves per block, the same for the force provider, kernel A and kernel B
     int grid_cap_a = 2048, grid_cap_b = 1024;   // most blocks per launch (multiples of the CU count): see pick_launch_shape
     int split_chain_waves = 12288;   // systems with at least this many waves (~0.8 M particles; measured +3 % at 0.9 M, +5 % at 8.9 M) run the chain as its own launch (VVHIP_SPLIT_CHAIN_WAVES)
+    bool fextra_dirty = false;     // forceExtra holds something since the last reset (split entry points)
+    bool fextra_external = false;  // the host asked for the pointer (vvhip_force_extra) and may write to it: never assume zeros
     bool no_moments = false;       // VVHIP_NO_MOMENTS=1: keep the three-launch cos sequence (comparison runs)
     bool wt_stores = false;        // write-through stores in the fused kernels (VVHIP_WT=1; tuning experiment)
     // plan-owned device state
@@ -694,7 +696,7 @@ int vvhip_step_vv_first(vvhip_plan* p) {                   // API:295-310 (force
 int vvhip_step_vv_second(vvhip_plan* p, uint32_t random_index) {   // API:316-336 (forces for the new positions)
     NEED_BOUND(p);
     uint32_t ex = extra_flags(p);
-    if (ex) ex |= vv::A_FE_STORE;                          // the first half of the NEXT step kicks with these (API:316-323)
+    if (ex) { ex |= vv::A_FE_STORE; p->fextra_dirty = true; }   // the first half of the NEXT step kicks with these (API:316-323)
     NEED_FUSABLE(p);
     return nh_half(p, vv::A_KICK_HALF | ex | (shake_on(p) ? vv::A_SHAKE_V : 0), random_index, 0);
 }
@@ -702,12 +704,14 @@ int vvhip_step_vv_second(vvhip_plan* p, uint32_t random_index) {   // API:316-33
 // ------------------------------------------------------------------------------------------ kernel-interface level
 int vvhip_reset_extra_force(vvhip_plan* p) {               // K/middle.cu:227-231
     NEED_BOUND(p);
+    if (!p->fextra_dirty && !p->fextra_external) return VVHIP_OK;   // already zero (bind zeroes it; nothing has added to it since the last reset)
+    p->fextra_dirty = false;
     ScopedTimer t(p, T_OTHER);
     const size_t nloc = (size_t) (p->hp.shard_end - p->hp.shard_begin);
     HIP_TRY(p, hipMemsetAsync(p->d_fextra, 0, nloc * 3 * sizeof_real(p->hp.precision), p->stream));
     return VVHIP_OK;
 }
-int vvhip_middle_kick(vvhip_plan* p) { NEED_BOUND(p); return run_a(p, vv::A_FE_LOAD | vv::A_KICK_FULL, 0); }
+int vvhip_middle_kick(vvhip_plan* p) { NEED_BOUND(p); return run_a(p, ((p->fextra_dirty || p->fextra_external) ? vv::A_FE_LOAD : 0) | vv::A_KICK_FULL, 0); }
 int vvhip_middle_half_drift1(vvhip_plan* p) { NEED_BOUND(p); return run_a(p, vv::A_POS1, 0); }
 int vvhip_middle_half_drift2(vvhip_plan* p) { NEED_BOUND(p); return run_b(p, vv::B_POS2); }
 int vvhip_middle_finish(vvhip_plan* p) {
@@ -718,7 +722,7 @@ int vvhip_middle_finish(vvhip_plan* p) {
 }
 int vvhip_vv_half_kick(vvhip_plan* p, int update_pos_delta) {
     NEED_BOUND(p);
-    return run_a(p, vv::A_FE_LOAD | vv::A_KICK_HALF | (update_pos_delta ? vv::A_POSDELTA_VV : 0), 0);
+    return run_a(p, ((p->fextra_dirty || p->fextra_external) ? vv::A_FE_LOAD : 0) | vv::A_KICK_HALF | (update_pos_delta ? vv::A_POSDELTA_VV : 0), 0);
 }
 int vvhip_vv_positions(vvhip_plan* p) {
     NEED_BOUND(p);
@@ -735,15 +739,18 @@ int vvhip_scale_velocity(vvhip_plan* p) {                  // HOST:670-754 witho
 int vvhip_apply_langevin_force(vvhip_plan* p, uint32_t random_index) {
     NEED_BOUND(p);
     if (!p->hp.has_ld) return VVHIP_OK;
+    p->fextra_dirty = true;
     return run_a(p, vv::A_FE_LOAD | vv::A_LD | vv::A_FE_STORE, random_index);
 }
 int vvhip_apply_electric_force(vvhip_plan* p) {
     NEED_BOUND(p);
     if (!p->hp.has_ef) return VVHIP_OK;
+    p->fextra_dirty = true;
     return run_a(p, vv::A_FE_LOAD | vv::A_EF | vv::A_FE_STORE, 0);
 }
 int vvhip_apply_cosine_force(vvhip_plan* p) {
     NEED_BOUND(p);
+    p->fextra_dirty = true;
     return run_a(p, vv::A_FE_LOAD | vv::A_COS | vv::A_FE_STORE, 0);
 }
 int vvhip_calc_velocity_bias(vvhip_plan* p) {              // HOST:1061-1082
@@ -787,6 +794,7 @@ int vvhip_update_image_positions(vvhip_plan* p) {          // HOST:904-934
 int vvhip_force_extra(vvhip_plan* p, void** device_ptr) {
     NEED_BOUND(p);
     if (!device_ptr) return VVHIP_ERR_INVALID;
+    p->fextra_external = true;
     *device_ptr = p->d_fextra;
     return VVHIP_OK;
 }
@@ -1113,6 +1121,34 @@ int vvhip_run_eager(vvhip_plan* p, int nsteps, const void* site, double k_tether
         TRY(next_random_slice(p, &ri, false));
         if (site) TRY(vvhip_synth_tether_force(p, site, k_tether, k_drude));
         TRY(vvhip_step_middle(p, ri));
+    }
+    return VVHIP_OK;
+}
+
+// The same steps through the per-KernelImpl entry points in VVIntegrator::stepMiddle's order (API:237-268) -- what the OpenMM adapter
+// issues when constraints it cannot fuse force OpenMM's solver between the stages (the solver's own launches are not included).
+int vvhip_run_eager_unfused(vvhip_plan* p, int nsteps, const void* site, double k_tether, double k_drude) {
+    NEED_BOUND(p);
+    if (nsteps < 0) return VVHIP_ERR_INVALID;
+    if (!p->hp.params.use_middle_scheme) return fail(p, VVHIP_ERR_INVALID, "plan was created for the classic scheme");
+    for (int i = 0; i < nsteps; i++) {
+        uint32_t ri = 0;
+        TRY(next_random_slice(p, &ri, false));
+        if (site) TRY(vvhip_synth_tether_force(p, site, k_tether, k_drude));
+        TRY(vvhip_reset_extra_force(p));
+        if (p->hp.has_ld) TRY(vvhip_apply_langevin_force(p, ri));
+        if (p->hp.has_ef) TRY(vvhip_apply_electric_force(p));
+        if (cos_on(p)) TRY(vvhip_apply_cosine_force(p));
+        TRY(vvhip_middle_kick(p));                  // (applyVelocityConstraints would run here)
+        TRY(vvhip_middle_half_drift1(p));
+        if (p->hp.has_nh) {
+            if (cos_on(p)) { TRY(vvhip_calc_velocity_bias(p)); TRY(vvhip_remove_velocity_bias(p)); }
+            TRY(vvhip_scale_velocity(p));
+            if (cos_on(p)) TRY(vvhip_restore_velocity_bias(p));
+        }
+        TRY(vvhip_middle_half_drift2(p));           // (applyConstraints would run here)
+        TRY(vvhip_middle_finish(p));
+        if (p->hp.has_images) TRY(vvhip_update_image_positions(p));
     }
     return VVHIP_OK;
 }

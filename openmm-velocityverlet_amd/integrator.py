@@ -372,6 +372,12 @@ class Context:
         site = self.site.ptr if self.force_provider == "tether" else None
         H.check(H.lib.vvhip_run_eager(self.plan, int(steps), site, self.k_tether, self.k_drude), self.plan)
 
+    def run_eager_unfused(self, steps: int):
+        """Middle scheme through the per-KernelImpl entry points in VVIntegrator::stepMiddle's order, enqueued from C: the launches
+        of the un-fused drop-in path (a host solver between the stages would add its own)."""
+        site = self.site.ptr if self.force_provider == "tether" else None
+        H.check(H.lib.vvhip_run_eager_unfused(self.plan, int(steps), site, self.k_tether, self.k_drude), self.plan)
+
     def comm_init(self, unique_id: bytes, nranks: int, rank: int):
         """Give the plan an RCCL communicator (vvhip_comm_init); the id comes from comm_unique_id() on rank 0."""
         buf = C.create_string_buffer(bytes(unique_id), 128)
