@@ -1,0 +1,136 @@
+"""Property tests (hypothesis) of the host analysis: random molecule inventories -- sizes from 1 to 90 particles, Drude pairs,
+massless sites, optional hydrogen constraints, both thermostat layouts, random shard cuts -- against the numpy restatement of the
+reference's initialisation (oracle.build_tables) and the invariants the kernels rely on.  No GPU."""
+import importlib
+
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, event, given, settings, strategies as st
+
+from oracle import oracle as O
+
+pkg = importlib.import_module("openmm-velocityverlet_amd")
+H, I, systems = pkg.vvhip, pkg.integrator, pkg.systems
+
+
+@st.composite
+def inventories(draw):
+    nmol = draw(st.integers(1, 12))
+    masses, mol_id, pairs, cons, cdist = [], [], [], [], []
+    for m in range(nmol):
+        size = draw(st.sampled_from([1, 2, 3, 5, 9, 17, 40, 64, 70, 90, 130]))
+        i0 = len(masses)
+        k = 0
+        while k < size:
+            kind = draw(st.sampled_from(["heavy", "heavy+drude", "hydrogen", "massless"]))
+            if kind == "heavy+drude" and k + 2 <= size:
+                masses += [12.0 - 0.4, 0.4]
+                pairs.append((len(masses) - 1, len(masses) - 2))
+                k += 2
+            elif kind == "hydrogen" and k > 0 and masses[-1] != 0:
+                masses.append(1.008)
+                k += 1
+            elif kind == "massless":
+                masses.append(0.0)
+                k += 1
+            else:
+                masses.append(12.0 + draw(st.integers(0, 3)))
+                k += 1
+        mol_id += [m] * (len(masses) - i0)
+    return masses, mol_id, pairs, draw(st.sampled_from([True, True, False])), draw(st.sampled_from([True, False])), draw(st.integers(0, 2 ** 31 - 1))
+
+
+def _spec(masses, mol_id, pairs, seed):
+    n = len(masses)
+    rng = np.random.default_rng(seed)
+    return systems.SystemSpec(name="prop", masses=np.array(masses, float), charges=np.zeros(n), positions=rng.uniform(0, 3, (n, 3)),
+                              velocities=rng.standard_normal((n, 3)), box=np.array([3.0, 3.0, 3.0]), mol_id=np.array(mol_id, np.int32),
+                              drude_pairs=np.array(pairs, np.int32).reshape(-1, 2), constraints=np.zeros((0, 2), np.int32),
+                              has_cm_motion_remover=True)
+
+
+@settings(max_examples=200, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@given(inventories())
+def test_random_inventories(inv):
+    masses, mol_id, pairs, use_com, with_constraints, seed = inv
+    spec = _spec(masses, mol_id, pairs, seed)
+    if not (spec.masses != 0).any():
+        return
+    if with_constraints:
+        spec = systems.constrain_hydrogens(spec)
+    it = I.VVIntegrator(300.0, 10, 1.0, 40, 0.001)
+    it.setUseCOMTempGroup(use_com)
+    p = O.Params(temperature=300.0, use_com_temp_group=use_com, auto_set_com_temp_group=False)
+    try:
+        t = O.build_tables(spec, p)
+    except O.OracleError:
+        event("rejected by both")
+        with pytest.raises(H.VVHipError):
+            I.plan_layout(spec, it)
+        return
+    info, slots = I.plan_layout(spec, it)
+    event(f"checked: com={bool(info.use_com_temp_group)} tg={info.num_temp_groups} big={info.max_cluster > 64} cons={with_constraints and len(spec.constraints) > 0}")
+    # ---- the reference's tables and thermostat constants
+    assert info.num_particles_nh == len(t["particles_nh"]) and info.num_normal_nh == len(t["normal_nh"]) and info.num_pairs_nh == len(t["pairs_nh"])
+    assert info.num_temp_groups == t["num_tg"] and list(info.dof) == list(t["dof"]) and list(info.nkbt) == list(t["nkbt"])
+    # ---- every particle that needs a lane has exactly one; nothing else has one
+    atoms, meta = slots[:, 0], slots[:, 1].astype(np.uint32)
+    used = atoms >= 0
+    massive = spec.masses != 0
+    in_pair = np.zeros(spec.num_atoms, bool)
+    in_pair[np.asarray(spec.drude_pairs).reshape(-1)] = True
+    assert np.array_equal(np.sort(atoms[used]), np.nonzero(massive | in_pair)[0])
+    assert info.num_slots_used == used.sum() and slots.shape[0] == 64 * info.num_waves
+    wave = np.arange(slots.shape[0]) // 64
+    lane = np.arange(slots.shape[0]) % 64
+    slot_of = -np.ones(spec.num_atoms, np.int64)
+    slot_of[atoms[used]] = np.nonzero(used)[0]
+    assert np.array_equal(((meta[used] >> 27) & 1).astype(bool), massive[atoms[used]])          # META_MASSIVE
+    # ---- Drude pairs and constraint clusters never leave their wave; partner lanes point at each other
+    for d, par in np.asarray(spec.drude_pairs).reshape(-1, 2):
+        assert wave[slot_of[d]] == wave[slot_of[par]]
+        assert ((meta[slot_of[d]] >> 4) & 63) == lane[slot_of[par]] and ((meta[slot_of[par]] >> 4) & 63) == lane[slot_of[d]]
+    if with_constraints and len(spec.constraints):
+        assert info.constraints_fused
+        for a, b in np.asarray(spec.constraints):
+            assert wave[slot_of[a]] == wave[slot_of[b]]
+    # ---- COM segments: contiguous lanes of one molecule (or of one <= 64-lane chunk of a big one), one leader each
+    if info.use_com_temp_group:
+        first, last = (meta >> 10) & 63, (meta >> 16) & 63
+        nh = np.zeros(spec.num_atoms, bool)
+        nh[t["particles_nh"]] = True
+        for s in np.nonzero(used)[0]:
+            i = atoms[s]
+            if not (nh[i] and massive[i]):
+                continue
+            seg = np.nonzero((wave == wave[s]) & (lane >= first[s]) & (lane <= last[s]) & used)[0]
+            assert (spec.mol_id[atoms[seg]] == spec.mol_id[i]).all()
+            assert ((meta[seg] >> 24) & 1).sum() == 1
+
+
+@settings(max_examples=30, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@given(inventories(), st.integers(2, 4))
+def test_shards_partition_the_lanes(inv, world):
+    masses, mol_id, pairs, use_com, _, seed = inv
+    spec = _spec(masses, mol_id, pairs, seed)
+    if not (spec.masses != 0).any():
+        return
+    D = pkg.distributed
+    it = I.VVIntegrator(300.0, 10, 1.0, 40, 0.001)
+    it.setUseCOMTempGroup(use_com)
+    try:
+        full, _ = I.plan_layout(spec, it)
+    except H.VVHipError:
+        return
+    bounds = D.shard_bounds(spec, world)
+    assert bounds[0][0] == 0 and bounds[-1][1] == spec.num_atoms and all(bounds[k][1] == bounds[k + 1][0] for k in range(world - 1))
+    total = 0
+    for b, e in bounds:
+        if e == b:
+            continue
+        info, slots = I.plan_layout(spec, it, shard=(b, e))
+        total += info.num_slots_used
+        assert list(info.dof) == list(full.dof) and list(info.nkbt) == list(full.nkbt)       # thermostat constants stay global
+        live = slots[:, 0] >= 0
+        assert (slots[live, 0] < e - b).all()                                                   # shard-relative particle indices
+    assert total == full.num_slots_used
