@@ -1,0 +1,56 @@
+"""-m gpu: randomly composed systems (molecules of 1..130 particles, Drude pairs, massless sites, hydrogen constraints) and randomly
+chosen integrator options, three steps on the GPU against the oracle.  Deterministic (derandomized hypothesis), 120 examples."""
+import importlib
+
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+from oracle import oracle as O
+from test_host_plan_properties import _spec, inventories
+
+pkg = importlib.import_module("openmm-velocityverlet_amd")
+H, I, systems = pkg.vvhip, pkg.integrator, pkg.systems
+pytestmark = pytest.mark.gpu
+
+
+@settings(max_examples=120, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.too_slow])
+@given(inventories(), st.booleans(), st.sampled_from([0.0, 0.02]), st.sampled_from([0.0, 0.02]), st.sampled_from(["mixed", "double"]))
+def test_random_systems_match_the_oracle(inv, middle, cos, maxd, prec):
+    masses, mol_id, pairs, use_com, with_constraints, seed = inv
+    spec = _spec(masses, mol_id, pairs, seed)
+    if (spec.masses != 0).sum() < 2:
+        return
+    rng = np.random.default_rng(seed + 1)
+    for d, par in np.asarray(spec.drude_pairs).reshape(-1, 2):              # Drude particles sit on their parents, cold
+        spec.positions[d] = spec.positions[par] + 2e-4 * rng.standard_normal(3)
+        spec.velocities[d] = spec.velocities[par] + 0.05 * rng.standard_normal(3)
+    molmass = np.bincount(spec.mol_id, weights=spec.masses)
+    if use_com and (molmass == 0).any():
+        return          # a molecule without mass in the COM group: the reference itself divides by zero there (K/drudeNoseHoover.cu:22-25)
+    if with_constraints:
+        spec = systems.constrain_hydrogens(spec)
+    p = O.Params(temperature=300.0, drude_temperature=1.0, max_drude_distance=maxd, cos_acceleration=cos, use_middle_scheme=middle,
+                 use_com_temp_group=use_com, auto_set_com_temp_group=False)
+    try:
+        osys = O.OracleSystem(spec, p, prec, force_mode=1)
+    except O.OracleError:
+        return
+    it = I.VVIntegrator(300.0, 10.0, 1.0, 40.0, 0.001)
+    it.setMaxDrudeDistance(maxd)
+    it.setCosAcceleration(cos)
+    it.setUseMiddleScheme(middle)
+    it.setUseCOMTempGroup(use_com)
+    ctx = I.Context(spec, it, precision=prec, force_provider="tether")
+    try:
+        osys.step(3)
+        it.step(3)
+        x_o, x_g = osys.positions(), ctx.getPositions()
+        v_o, v_g = osys.velm[:, :3].astype(np.float64), ctx.getVelocities()
+        live = osys.velm[:, 3] != 0
+        assert np.isfinite(x_g).all() and np.isfinite(v_g[live]).all()
+        ex = np.abs(x_g - x_o).max() / max(np.abs(x_o).max(), 1e-30)
+        ev = np.abs(v_g[live] - v_o[live]).max() / max(np.abs(v_o[live]).max(), 1e-30)
+        assert ex < 1e-5 and ev < 1e-5, (ex, ev, dict(middle=middle, cos=cos, maxd=maxd, prec=prec, use_com=use_com, cons=with_constraints, n=spec.num_atoms))
+    finally:
+        ctx.close()
