@@ -247,6 +247,9 @@ vv::KArgs make_args(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
     a.flags = flags;
     a.random_index = random_index;
     a.dt = q.step_size;
+    // the same IEEE quotients the kernels used to form per lane: (mixed) 1 / (mixed) dt and 1.0 / (mixed) dt
+    a.inv_dt_mixed = p->hp.precision == VVHIP_SINGLE ? (double) (1.0f / (float) q.step_size) : 1.0 / q.step_size;
+    a.inv_dt_double = p->hp.precision == VVHIP_SINGLE ? 1.0 / (double) (float) q.step_size : 1.0 / q.step_size;
     a.fscale_vv = 0.5 * q.step_size / (double) 0x100000000;                                    // HOST:306
     a.drag = q.friction;                                                                        // HOST:835-839
     a.randf = std::sqrt(2.0 * kBoltz * q.temperature * q.friction / q.step_size);

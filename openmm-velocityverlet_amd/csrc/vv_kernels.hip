@@ -32,10 +32,17 @@ template <> struct Prec<float> {
     template <class T> static __device__ __forceinline__ float SQRT(T x) { return sqrtf((float) x); }
     static __device__ __forceinline__ float RECIP(float x) { return 1.0f / x; }
     static __device__ __forceinline__ double RECIP(double x) { return 1.0f / x; }
+    // Reciprocal for quantities that only feed REDUCTIONS (kinetic-energy sums, molecular COM): hardware estimate (24 bits) + two Newton
+    // steps, within 1 ulp of the IEEE quotient (equal to it in 2^20 random samples, tools/probes/rcp_probe.cpp).  Those sums already depend on the summation order at that level, so nothing that is compared
+    // bit for bit with the oracle (kick, drift, hard wall, scaling arithmetic) goes through this; an IEEE fp64 division
+    // costs 14 instructions, this 5, on a kernel that is issue-bound at the headline size.
+    static __device__ __forceinline__ float RECIP_SUM(float x) { return __builtin_amdgcn_rcpf(x); }
+    static __device__ __forceinline__ double RECIP_SUM(double x) { double r = __builtin_amdgcn_rcp(x); r = fma(fma(-x, r, 1.0), r, r); return fma(fma(-x, r, 1.0), r, r); }
 };
 template <> struct Prec<double> {
     static __device__ __forceinline__ double SQRT(double x) { return sqrt(x); }
     static __device__ __forceinline__ double RECIP(double x) { return 1.0 / x; }
+    static __device__ __forceinline__ double RECIP_SUM(double x) { double r = __builtin_amdgcn_rcp(x); r = fma(fma(-x, r, 1.0), r, r); return fma(fma(-x, r, 1.0), r, r); }
 };
 
 // 16-byte write-through store (buffer_store_dwordx4 ... sc1): the line goes to memory now instead of staying dirty in the
@@ -160,7 +167,7 @@ __device__ __forceinline__ void com_velocity(bool contributes, mixed vx, mixed v
     const int first = (meta >> META_SEGFIRST_SHIFT) & 63, last = (meta >> META_SEGLAST_SHIFT) & 63;
     mixed mass = 0, mx = 0, my = 0, mz = 0;
     if (contributes) {
-        mass = Prec<real>::RECIP(w);
+        mass = Prec<real>::RECIP_SUM(w);
         mx = vx * mass; my = vy * mass; mz = vz * mass;
     }
     mx = segment_total(mx, lane, first, last);
@@ -168,7 +175,7 @@ __device__ __forceinline__ void com_velocity(bool contributes, mixed vx, mixed v
     mz = segment_total(mz, lane, first, last);
     mass = segment_total(mass, lane, first, last);
     Vm = mass;
-    Vw = Prec<real>::RECIP(mass);
+    Vw = Prec<real>::RECIP_SUM(mass);
     Vx = mx * Vw; Vy = my * Vw; Vz = mz * Vw;
 }
 
@@ -704,7 +711,7 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const KArgs a) {
             if (F & A_KE_MOM) {
                 const mixed wx = act ? (mixed) czl : (mixed) 0;
                 const int first = (meta >> META_SEGFIRST_SHIFT) & 63, last = (meta >> META_SEGLAST_SHIFT) & 63;
-                mixed mw = (nh && massive && use_com) ? wx * P::RECIP(v.w) : (mixed) 0;
+                mixed mw = (nh && massive && use_com) ? wx * P::RECIP_SUM(v.w) : (mixed) 0;
                 mw = segment_total(mw, lane, first, last);
                 Wx = use_com ? mw * Vw : (mixed) 0;
                 if ((meta & META_COM_LEADER) && use_com) a.comw[(size_t) wave * 64 + first] = (double) Wx;
@@ -714,7 +721,7 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const KArgs a) {
             if (nh) { ux -= Vx; uy -= Vy; uz -= Vz; }                       // K/drudeNoseHoover.cu:45-47
             // Masses: one reciprocal per lane, the partner's comes over the shuffle network.  Where the reference divides by an
             // inverse mass this multiplies by the mass (<= 1 ulp apart, below the reduction-order noise of these sums).
-            const mixed own_mass = massive ? P::RECIP(v.w) : (mixed) 0;
+            const mixed own_mass = massive ? P::RECIP_SUM(v.w) : (mixed) 0;
             const mixed px = shfl(ux, partner), py = shfl(uy, partner), pz = shfl(uz, partner), pm = shfl(own_mass, partner);
             const mixed pbx = (F & A_KE_MOM) ? shfl(bx, partner) : (mixed) 0;
             if (role == ROLE_NH_NORMAL && massive) {                        // K/drudeNoseHoover.cu:76-83
@@ -722,7 +729,7 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const KArgs a) {
                 if (F & A_KE_MOM) { m_ab[0] += (double) (ux * bx * own_mass); m_bb[0] += (double) (bx * bx * own_mass); }
             } else if (role == ROLE_NH_DRUDE) {                             // K/drudeNoseHoover.cu:97-114, pair.x = Drude
                 const mixed mass1 = own_mass, mass2 = pm;
-                const mixed invTotalMass = P::RECIP(mass1 + mass2);
+                const mixed invTotalMass = P::RECIP_SUM(mass1 + mass2);
                 const mixed reducedMass = mass1 * mass2 * invTotalMass;
                 const mixed mass1fract = invTotalMass * mass1, mass2fract = invTotalMass * mass2;
                 const mixed cx = ux * mass1fract + px * mass2fract;
@@ -1076,12 +1083,16 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const KArgs a) {
         auto scale_prep = [&]() {
             ux = v.x; uy = v.y; uz = v.z;
             if (nh) { ux -= Vx; uy -= Vy; uz -= Vz; }
-            const mixed px = shfl(ux, partner), py = shfl(uy, partner), pz = shfl(uz, partner), pw = shfl(v.w, partner);
-            if (role == ROLE_NH_DRUDE || role == ROLE_NH_PARENT) {
+            // each lane forms the reciprocal of its own inverse mass, the partner's arrives by shuffle: the same IEEE quotients as
+            // RECIP(a1w), RECIP(a2w) of K/drudeNoseHoover.cu:173-174 with one division per lane instead of two
+            const bool pair_lane = role == ROLE_NH_DRUDE || role == ROLE_NH_PARENT;
+            const mixed own_m = pair_lane ? P::RECIP(v.w) : (mixed) 0;
+            const mixed px = shfl(ux, partner), py = shfl(uy, partner), pz = shfl(uz, partner), pm = shfl(own_m, partner);
+            if (pair_lane) {
                 const bool isd = role == ROLE_NH_DRUDE;      // velAtom1 = Drude (pair.x), velAtom2 = parent
-                const mixed a1x = isd ? ux : px, a1y = isd ? uy : py, a1z = isd ? uz : pz, a1w = isd ? v.w : pw;
-                const mixed a2x = isd ? px : ux, a2y = isd ? py : uy, a2z = isd ? pz : uz, a2w = isd ? pw : v.w;
-                const mixed mass1 = P::RECIP(a1w), mass2 = P::RECIP(a2w);
+                const mixed a1x = isd ? ux : px, a1y = isd ? uy : py, a1z = isd ? uz : pz;
+                const mixed a2x = isd ? px : ux, a2y = isd ? py : uy, a2z = isd ? pz : uz;
+                const mixed mass1 = isd ? own_m : pm, mass2 = isd ? pm : own_m;
                 const mixed invTotalMass = P::RECIP(mass1 + mass2);
                 mass1fract = invTotalMass * mass1; mass2fract = invTotalMass * mass2;
                 cmx = a1x * mass1fract + a2x * mass2fract;
@@ -1189,14 +1200,14 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const KArgs a) {
             if (F & B_SHAKE)                                                       // integration.applyConstraints(tol), HOST:176
                 shake_positions<mixed>(lane, shake_word, shake_prm, (mixed) a.shake_tol, x, y, z, v.w, ddx, ddy, ddz, shake_page_b[wib]);
             if (massive) {
-                const mixed invDt = 1 / stepSize;
+                const mixed invDt = (mixed) a.inv_dt_mixed;      // = 1 / stepSize, formed once on the host
                 v.x += (ddx - odx) * invDt; v.y += (ddy - ody) * invDt; v.z += (ddz - odz) * invDt;
                 x += ddx; y += ddy; z += ddz;
                 pos_dirty = true; vel_dirty = true;
             }
         }
         if ((F & B_POS3) && massive) {                                          // K/middle.cu:70-96
-            const mixed invDt = 1 / stepSize;
+            const mixed invDt = (mixed) a.inv_dt_mixed;      // = 1 / stepSize, formed once on the host
             const mixed4 d = ((const mixed4*) a.pos_delta)[atom], od = ((const mixed4*) a.old_delta)[atom];
             v.x += (d.x - od.x) * invDt; v.y += (d.y - od.y) * invDt; v.z += (d.z - od.z) * invDt;
             x += d.x; y += d.y; z += d.z;
@@ -1210,7 +1221,7 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const KArgs a) {
             if (F & B_SHAKE)                                                       // integration.applyConstraints(tol), HOST:351
                 shake_positions<mixed>(lane, shake_word, shake_prm, (mixed) a.shake_tol, x, y, z, v.w, dx, dy, dz, shake_page_b[wib]);
             if (massive) {
-                const mixed invStepSize = 1.0 / stepSize;
+                const mixed invStepSize = (mixed) a.inv_dt_double; // = 1.0 / stepSize, formed once on the host
                 x += dx; y += dy; z += dz;
                 v.x = (mixed) (invStepSize * dx); v.y = (mixed) (invStepSize * dy); v.z = (mixed) (invStepSize * dz);
                 pos_dirty = true; vel_dirty = true;

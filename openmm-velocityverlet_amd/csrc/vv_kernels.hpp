@@ -130,6 +130,8 @@ struct KArgs {
     uint32_t flags;
     uint32_t random_index;
     double dt;                 // step size
+    double inv_dt_mixed;       // 1 / dt evaluated in the mode's `mixed` type on the host (K/middle.cu:71), widened
+    double inv_dt_double;      // 1.0 / dt in double (K/velocityVerlet.cu:43)
     double max_drude, hw_scale;                    // HOST:189-190
     double acc_scale[NUM_ACC];  // fixed-point scales of the accumulated quantities (kernel A's tail)
     // ---- the rest
