@@ -23,8 +23,10 @@ BOLTZ = (1.380649e-23 * 6.02214076e23) / 1000.0  # kJ/mol/K, as OpenMM's SimTKOp
 SEED = 20241008
 
 _M_N, _M_C, _M_H, _M_D = 14.007, 12.011, 1.008, 0.4
-# particle pattern of one c2c1im+ cation: heavy atom followed by its Drude; H are plain particles
-_CATION = "ND CD ND CD CD CD H CD H H H H H CD H H H H H".replace(" ", "")
+# particle pattern of one c2c1im+ cation (EX/models/bulk_Im21: 27 particles, 8 Drude pairs, 11 hydrogens): heavy atom followed by
+# its Drude and then by its hydrogens -- three ring C-H, N-CH3, N-CH2-CH3 -- so HBonds constraints give the 11 constraints per
+# cation (33 000 at C3) that SURVEY.md section 8 quotes
+_CATION = "ND CDH ND CDH CDH CDHHH CDHH CDHHH".replace(" ", "")
 _ANION = "NDCDNDCDND"
 
 

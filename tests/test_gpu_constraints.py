@@ -187,7 +187,7 @@ def test_full_size_c3_with_hbonds():
     it.setMaxDrudeDistance(0.02)
     ctx = I.Context(spec, it, precision="mixed", force_provider="tether")
     try:
-        assert ctx.info.constraints_fused and ctx.info.num_shake_clusters == 9000 and len(spec.constraints) == 21000
+        assert ctx.info.constraints_fused and ctx.info.num_shake_clusters == 18000 and len(spec.constraints) == 33000      # 33 000 HBond constraints at C3
         ctx.run_graph(64, steps_per_graph=8)
         _invariants(spec, ctx, "mixed", True, "C3-shake")
         st = ctx.getNHState()
