@@ -175,7 +175,7 @@ def main():
             ctx.run_eager(100)
             candidates["rccl_eager_us_per_step"] = round(timed(ctx.run_eager, 300), 2)
         have_mb = False
-        if want in ("auto", "mailbox") and cfg != "C4":          # (the bias moment of the cos perturbation goes through the collective)
+        if want in ("auto", "mailbox"):
             have_mb = setup_mailbox()
             if have_mb and want == "auto":
                 candidates["mailbox_graph_us_per_step"] = round(timed(lambda n: ctx.run_graph(n, args.steps_per_graph), 3 * args.steps_per_graph), 2)

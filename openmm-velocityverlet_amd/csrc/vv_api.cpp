@@ -356,10 +356,19 @@ int run_chain(vvhip_plan* p, uint32_t flags) {
     return VVHIP_OK;
 }
 
-// The mailbox carries the kinetic-energy totals between the ranks' kernel-B heads (inline chain); the bias moment of the cos
-// perturbation (consumed by another kernel A) and the stand-alone chain kernel still go through the collective.
+// cos perturbation in two launches instead of three: kernel A accumulates the group sums as moments of the biased velocities next
+// to the bias moment itself, kernel B's inline chain finishes the algebra (vv_kernels.hpp: A_KE_MOM).  Not with molecules larger
+// than a wave or the stand-alone chain launch (long chains, very large systems), which keep the bias -> KE -> scale sequence.
+bool use_moments(const vvhip_plan* p) {
+    return p->hp.params.cos_acceleration != 0 && p->hp.has_nh && p->hp.num_big == 0 && p->hp.params.num_nh_chains <= 4 &&
+           p->hp.info.num_waves < p->split_chain_waves && !p->no_moments;
+}
+// The mailbox carries the totals between the ranks' kernel-B heads (inline chain): the three kinetic-energy sums, and with the cos
+// perturbation in its moment form also the bias moment and the six group moments -- everything kernel A produced, one exchange per
+// thermostat application.  The three-launch cos sequence (its bias moment is consumed by another kernel A) and the stand-alone
+// chain kernel still go through the collective.
 bool use_mailbox(const vvhip_plan* p) {
-    return p->mb_on && p->hp.params.cos_acceleration == 0 && p->hp.params.num_nh_chains <= 4;
+    return p->mb_on && p->hp.params.num_nh_chains <= 4 && (p->hp.params.cos_acceleration == 0 || use_moments(p));
 }
 
 // The launch(es) that end in the per-group kinetic energies.  `first` = stage bits that must run before the KE on the
@@ -401,13 +410,6 @@ uint32_t tail_flags(const vvhip_plan* p) {      // what follows every position u
     return f;
 }
 bool cos_on(const vvhip_plan* p) { return p->hp.params.cos_acceleration != 0; }
-// cos perturbation in two launches instead of three: kernel A accumulates the group sums as moments of the biased velocities next
-// to the bias moment itself, kernel B's inline chain finishes the algebra (vv_kernels.hpp: A_KE_MOM).  Not with molecules larger
-// than a wave or the stand-alone chain launch (long chains, very large systems), which keep the bias -> KE -> scale sequence.
-bool use_moments(const vvhip_plan* p) {
-    return cos_on(p) && p->hp.has_nh && p->hp.num_big == 0 && p->hp.params.num_nh_chains <= 4 && p->hp.info.num_waves < p->split_chain_waves &&
-           !p->no_moments;
-}
 bool shake_on(const vvhip_plan* p) { return !p->hp.slot_shake.empty(); }
 #define NEED_FUSABLE(p)                                                                                                   \
     do {                                                                                                                \

@@ -81,13 +81,14 @@ def mailbox(rank, world):
     eager steps, hipGraph replay, both schemes, with and without in-kernel constraints -- against one process."""
     I = pkg.integrator
     base = S.drude_il(cells=(1, 1, 1), pairs_per_cell=60, seed=13)
-    for label, spec, middle in (("middle", base, True), ("classic", base, False),
-                                ("middle+hbonds", S.constrain_hydrogens(S.drude_il(cells=(1, 1, 1), pairs_per_cell=60, seed=13)), True)):
+    for label, spec, middle, cos in (("middle", base, True, 0.0), ("classic", base, False, 0.0), ("middle+cos", base, True, 0.02),
+                                     ("middle+hbonds", S.constrain_hydrogens(S.drude_il(cells=(1, 1, 1), pairs_per_cell=60, seed=13)), True, 0.0)):
         bounds = D.shard_bounds(spec, world)
         def make(shard):
             it = I.VVIntegrator(333.0, 10, 1.0, 40, 0.001)
             it.setMaxDrudeDistance(0.02)
             it.setUseMiddleScheme(middle)
+            it.setCosAcceleration(cos)
             return it, I.Context(spec, it, precision="mixed", force_provider="tether", shard=shard, device=0)
         it, ctx = make(bounds[rank])
         handles = [None] * world
