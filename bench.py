@@ -286,6 +286,24 @@ def main():
         out["config"]["integrator_only_steps_per_s"] = round(n2 / (time.perf_counter() - t0), 1)
         ctx.force_provider = prov
 
+    # ---- the same box with the constraints the reference's example scripts put on it (HBonds: examples/ommhelper/oplspsffile.py:952-955;
+    # rigid water for C2), solved inside the fused kernels: a secondary figure, the headline stays the workload BASELINE.json names
+    if world == 1 and rank == 0 and not use_dist and args.forces == "tether" and not args.eager and not args.hbonds and cfg in ("C2", "C3", "C4"):
+        spec_c = S.rigid_water(S.make_config(cfg)) if cfg == "C2" else S.constrain_hydrogens(S.make_config(cfg), 0.109)
+        it_c = I.VVIntegrator(it.getTemperature(), 10.0, 1.0, 40.0, dt)
+        it_c.setMaxDrudeDistance(it.getMaxDrudeDistance())
+        it_c.setCosAcceleration(it.getCosAcceleration())
+        ctx_c = I.Context(spec_c, it_c, precision=args.precision, force_provider="tether", device=local_rank)
+        nc = max(args.steps // 4, 2 * args.steps_per_graph)
+        ctx_c.run_graph(2 * args.steps_per_graph, args.steps_per_graph)
+        ctx_c.synchronize()
+        t0 = time.perf_counter()
+        ctx_c.run_graph(nc, args.steps_per_graph)
+        ctx_c.synchronize()
+        out["config"]["with_constraints"] = {"steps_per_s": round(nc / (time.perf_counter() - t0), 1), "constraints": int(len(spec_c.constraints)),
+                                             "shake_clusters": int(ctx_c.info.num_shake_clusters), "settle_molecules": int(ctx_c.info.num_settle_clusters)}
+        ctx_c.close()
+
     # ---- roofline of the dominant kernel, measured live with HIP events on the plan's stream (N = 1 only)
     if world == 1 and rank == 0 and not use_dist:
         # two HIP events around 100 back-to-back launches (x5 batches) of each stage kernel with the fused step's stage bits
