@@ -304,8 +304,9 @@ def main():
                                              "shake_clusters": int(ctx_c.info.num_shake_clusters), "settle_molecules": int(ctx_c.info.num_settle_clusters)}
         ctx_c.close()
 
-    # ---- roofline of the dominant kernel, measured live with HIP events on the plan's stream (N = 1 only)
-    if world == 1 and rank == 0 and not use_dist:
+    # ---- roofline of the dominant kernel, measured live with HIP events on the plan's stream.  At N > 1 every rank runs the same
+    # launches (the mailbox exchange inside kernel B needs its peers), rank 0 reports its own shard; PMC traffic is a N = 1 figure.
+    if (world == 1 and rank == 0 and not use_dist) or (use_dist and stepper is None):
         # two HIP events around 100 back-to-back launches (x5 batches) of each stage kernel with the fused step's stage bits
         # (per-launch events in an eager stream starve the GPU and read ~2x high; the rocprofv3 averages under
         # profiles/ are the cross-check).  Runs after the headline measurement: it scrambles the physical state.
@@ -314,22 +315,25 @@ def main():
         ms_b = statistics.median(ctx.time_kernel(1, 100) for _ in range(5))      # decide which kernel is called dominant
         dom = "B" if ms_b >= ms_a else "A"
         ms = ms_b if dom == "B" else ms_a
-        bytes_per_launch = ALGO_BYTES[args.precision][dom] * spec.num_atoms
+        n_local = bounds[rank][1] - bounds[rank][0]
+        bytes_per_launch = ALGO_BYTES[args.precision][dom] * n_local
         achieved = bytes_per_launch / (ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and world == 1:
             try:
                 rec = json.load(open(pmc))
                 if rec.get("config") == cfg and rec.get("precision") == args.precision:
                     traffic = rec.get(f"hbm_bytes_per_launch_{dom}")
             except Exception:
                 traffic = None
-        out["roofline"] = {"bound": "hbm", "kernel": f"vv_kernel_{dom.lower()}", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                           "algorithmic_bytes_per_launch": bytes_per_launch,
-                           "avg_launch_us": {"A": round(ms_a * 1e3, 3), "B": round(ms_b * 1e3, 3)},
-                           "note": "working set is Infinity-Cache resident at this size; see DESIGN.md"}
+        if rank == 0:
+            out["roofline"] = {"bound": "hbm", "kernel": f"vv_kernel_{dom.lower()}", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                               "algorithmic_bytes_per_launch": bytes_per_launch,
+                               "avg_launch_us": {"A": round(ms_a * 1e3, 3), "B": round(ms_b * 1e3, 3)},
+                               "note": "working set is Infinity-Cache resident at this size; see DESIGN.md"
+                                       + ("" if world == 1 else f"; rank 0's shard of {n_local} particles")}
 
     # ---- CPU baseline: the oracle (our C restatement of the reference path, OpenMP) on this host's cores, bounded sample
     if world == 1 and rank == 0 and not args.no_cpu_baseline and not use_dist:
