@@ -440,6 +440,7 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
             if (in_pair[i]) meta |= META_PAIR;
             if (is_drude[i]) meta |= META_IS_DRUDE;
             if (massive) meta |= META_MASSIVE;
+            if (shake_of[i] >= 0) meta |= META_SHAKE;
             if (c.big >= 0) meta |= META_BIGMOL;
             if (c.big >= 0 && c.big_first && (meta & META_COM_LEADER)) meta |= META_BIG_FIRST;
             slots[(size_t) wave * 128 + 2 * lane] = i - sb;

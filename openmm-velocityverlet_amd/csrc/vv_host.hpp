@@ -44,6 +44,8 @@ constexpr uint32_t META_IS_DRUDE = 1u << 26;   // the Drude (pair.x) of that pai
 constexpr uint32_t META_MASSIVE = 1u << 27;    // mass != 0 (velm.w != 0)
 constexpr uint32_t META_BIGMOL = 1u << 28;     // lane belongs to a molecule too large for one wave: its COM comes from bigacc
 constexpr uint32_t SHAKE_WORD_SETTLE = 1u << 30;  // slot_shake word of an apex lane: the cluster is a rigid triangle (SETTLE)
+constexpr uint32_t META_SHAKE = 1u << 30;      // member of an in-kernel constraint cluster: the kernels fetch its cluster word, parameters and
+                                               // position in the same round of loads as the velocity, not after reading the cluster word
 constexpr uint32_t META_BIG_FIRST = 1u << 29;  // leader of the FIRST chunk of such a molecule (adds M*V^2 once, clears bigacc)
 
 inline uint32_t meta_role(uint32_t m) { return m & META_ROLE_MASK; }

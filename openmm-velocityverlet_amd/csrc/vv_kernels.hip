@@ -629,11 +629,14 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const KArgs a) {
         }
         if (F & A_SHAKE_V) {                   // integration.applyVelocityConstraints(tol) (HOST:151, 427), clusters solved in the wave
             __shared__ mixed shake_page_a[8][64][7];
-            const unsigned word = act ? (unsigned) a.slot_shake[(size_t) wave * 64 + lane] : 0u;
-            const float4 prm = (word & 1u) ? a.slot_shake_param[(size_t) wave * 64 + lane] : make_float4(0, 0, 0, 0);
+            // cluster word, parameters and position are requested together, keyed by the role word's META_SHAKE bit (not one after
+            // the other, keyed by the cluster word: that put two more dependent memory round trips into this kernel)
+            const bool member = act && (meta & META_SHAKE);
+            const unsigned word = member ? (unsigned) a.slot_shake[(size_t) wave * 64 + lane] : 0u;
+            const float4 prm = member ? a.slot_shake_param[(size_t) wave * 64 + lane] : make_float4(0, 0, 0, 0);
             mixed sx = 0, sy = 0, sz = 0, sq = 0;
             real sraw = 0;
-            if (word & 3u) PosIO<real, mixed>::load(a.posq, a.corr, atom, sx, sy, sz, sq, sraw);
+            if (member) PosIO<real, mixed>::load(a.posq, a.corr, atom, sx, sy, sz, sq, sraw);
             shake_velocities<mixed>(lane, word, prm, (mixed) a.shake_tol, sx, sy, sz, v.w, v.x, v.y, v.z, shake_page_a[threadIdx.x >> 6]);
             if (massive) store_vec(velm, atom, v, (F & A_WT_STORES) != 0);
         }
@@ -1062,6 +1065,14 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const KArgs a) {
         mixed x = 0, y = 0, z = 0, q = 0;
         real zraw = 0;
         if (act && touches_pos) IO::load(a.posq, a.corr, atom, x, y, z, q, zraw);
+        // cluster word and parameters of the in-kernel SHAKE: requested here, with the particle data and in front of the thermostat
+        // barrier (they used to be read where they are needed, behind it: two exposed memory round trips per tile)
+        unsigned shake_word = 0;
+        float4 shake_prm = make_float4(0, 0, 0, 0);
+        if ((F & B_SHAKE) && act && (meta & META_SHAKE)) {
+            shake_word = (unsigned) a.slot_shake[(size_t) wave * 64 + lane];
+            shake_prm = a.slot_shake_param[(size_t) wave * 64 + lane];
+        }
         const mixed4 v_old = v;          // velocity after the kick, before the thermostat (Pos1 uses it)
         bool vel_dirty = false, pos_dirty = false;
 
@@ -1178,14 +1189,8 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const KArgs a) {
             ((mixed4*) a.pos_delta)[atom] = pd;
             ((mixed4*) a.old_delta)[atom] = od;
         }
-        // per-wave LDS page and cluster word of the in-kernel SHAKE (collective over the wave: every lane walks through it)
+        // per-wave LDS page of the in-kernel SHAKE (collective over the wave: every lane walks through it)
         __shared__ mixed shake_page_b[8][64][7];
-        unsigned shake_word = 0;
-        float4 shake_prm = make_float4(0, 0, 0, 0);
-        if ((F & B_SHAKE) && act) {
-            shake_word = (unsigned) a.slot_shake[(size_t) wave * 64 + lane];
-            if (shake_word & 1u) shake_prm = a.slot_shake_param[(size_t) wave * 64 + lane];
-        }
         if (F & B_DRIFT_MIDDLE) {
             // Pos1 (K/middle.cu:36-38) with the pre-thermostat velocity, Pos2 (:54-56) with the scaled one.  Without constraints
             // posDelta == oldDelta and Pos3's velocity correction (K/middle.cu:77-79) adds (d - d)/dt == 0 exactly; with the
