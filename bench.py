@@ -119,11 +119,20 @@ def main():
         return I.Context(spec, it, precision=args.precision, force_provider=args.forces, shard=bounds[rank], device=local_rank, stream=stream)
 
     def timed(fn, n):
-        ctx.synchronize(); dist.barrier()
-        t0 = time.perf_counter()
-        fn(n)
-        ctx.synchronize()
-        return slowest(time.perf_counter() - t0) / n * 1e6
+        """us per step of fn(n) on the slowest rank, or None if it failed on any rank (then every rank gets None)."""
+        ok, dt_ = True, 0.0
+        try:
+            ctx.synchronize(); dist.barrier()
+            t0 = time.perf_counter()
+            fn(n)
+            ctx.synchronize()
+            dt_ = time.perf_counter() - t0
+        except Exception as e:                                   # noqa: BLE001
+            sys.stderr.write(f"[rank {rank}] candidate run failed ({e})\n")
+            ok = False
+        if not agree(ok):
+            return None
+        return slowest(dt_) / n * 1e6
 
     def setup_rccl():
         try:
@@ -172,13 +181,21 @@ def main():
         ctx = fresh_context()
         have_rccl = setup_rccl() if want in ("auto", "eager", "graph") else False
         if have_rccl and want == "auto":
-            ctx.run_eager(100)
-            candidates["rccl_eager_us_per_step"] = round(timed(ctx.run_eager, 300), 2)
+            t_rccl = timed(ctx.run_eager, 100)                   # warm-up, and a first sign of life of the collective
+            t_rccl = timed(ctx.run_eager, 300) if t_rccl is not None else None
+            if t_rccl is None:
+                have_rccl = False
+            else:
+                candidates["rccl_eager_us_per_step"] = round(t_rccl, 2)
         have_mb = False
         if want in ("auto", "mailbox"):
             have_mb = setup_mailbox()
             if have_mb and want == "auto":
-                candidates["mailbox_graph_us_per_step"] = round(timed(lambda n: ctx.run_graph(n, args.steps_per_graph), 3 * args.steps_per_graph), 2)
+                t_mb = timed(lambda n: ctx.run_graph(n, args.steps_per_graph), 3 * args.steps_per_graph)
+                if t_mb is None:
+                    have_mb = False
+                else:
+                    candidates["mailbox_graph_us_per_step"] = round(t_mb, 2)
             if not have_mb:                                       # a failed trial leaves a void state behind: start over
                 if rank == 0:
                     sys.stderr.write("mailbox exchange not usable here\n")
