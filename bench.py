@@ -209,7 +209,7 @@ def main():
                         candidates.get("mailbox_graph_us_per_step", 0.0) <= candidates.get("rccl_eager_us_per_step", float("inf"))):
             dist_mode = "mailbox"
         elif have_rccl:
-            if have_mb:
+            if ctx.mailbox_status()[0]:                          # set up but not chosen: the plan must stop using it
                 ctx.mailbox_destroy()
             dist_mode = "graph" if want == "graph" else "eager"
             if dist_mode == "graph":                             # every rank must agree that capture works
