@@ -1073,6 +1073,15 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const KArgs a) {
             shake_word = (unsigned) a.slot_shake[(size_t) wave * 64 + lane];
             shake_prm = a.slot_shake_param[(size_t) wave * 64 + lane];
         }
+        // image particle of this lane's particle: its index and its present content (the charge and the correction's w survive the
+        // mirror update) are requested now, so that nothing has to be read after the position store at the end of the tile
+        int img = -1;
+        real4 img_p = {0, 0, 0, 0}, img_c = {0, 0, 0, 0};
+        if ((F & B_IMAGE) && act && (meta & META_HAS_IMAGE)) {
+            img = a.slot_image[(size_t) wave * 64 + lane];
+            img_p = ((const real4*) a.posq)[img];
+            if (IO::kMixed) img_c = ((const real4*) a.corr)[img];
+        }
         const mixed4 v_old = v;          // velocity after the kick, before the thermostat (Pos1 uses it)
         bool vel_dirty = false, pos_dirty = false;
 
@@ -1306,17 +1315,22 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const KArgs a) {
         }
         VV_STAMP(wib, 5);
 
-        // ---------------- image charges (K/imageCharge.cu:10-26): x, y are bit copies, z is mirrored
+        // ---------------- image charges (K/imageCharge.cu:10-26): x, y are bit copies of the parent's stored position, z is mirrored
         if ((F & B_IMAGE) && act && (meta & META_HAS_IMAGE)) {
-            const int img = a.slot_image[(size_t) wave * 64 + lane];
             real4* posq = (real4*) a.posq;
-            const real4 pp = posq[atom];       // re-read what was just stored: the copy must be of the stored bits
-            real4 pi = posq[img];
+            real4 pp, cp = {0, 0, 0, 0};
+            if (pos_dirty) {                   // what IO::store has just written, conversion for conversion (no re-read needed)
+                pp.x = (real) x; pp.y = (real) y; pp.z = (real) z; pp.w = (real) q;
+                if (IO::kMixed) { cp.x = (real) (x - (real) x); cp.y = (real) (y - (real) y); cp.z = (real) (z - (real) z); }
+            } else {                           // untouched parent (massless): its stored bits
+                pp = posq[atom];
+                if (IO::kMixed) cp = ((const real4*) a.corr)[atom];
+            }
+            real4 pi = img_p;
             pi.x = pp.x; pi.y = pp.y;
             if (IO::kMixed) {
                 real4* corr = (real4*) a.corr;
-                const real4 cp = corr[atom];
-                real4 ci = corr[img];
+                real4 ci = img_c;
                 ci.x = cp.x; ci.y = cp.y;
                 mixed zz = (mixed) pp.z + (mixed) cp.z;
                 zz = (mixed) a.mirror * 2 - zz;
