@@ -539,6 +539,14 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const KArgs a) {
         if ((F & (A_KICK_FULL | A_KICK_HALF)) && act && (meta & META_MASSIVE)) {
             fx = a.force[atom]; fy = a.force[atom + a.padded]; fz = a.force[atom + 2 * a.padded];
         }
+        // Langevin lanes: slot of the normal deviates and the deviates themselves, requested with the particle data (keyed by the role
+        // word) instead of after velm.w has arrived
+        float4 rnd_a = make_float4(0, 0, 0, 0), rnd_b = make_float4(0, 0, 0, 0);
+        if ((F & A_LD) && act && (role == ROLE_LD_NORMAL || role == ROLE_LD_DRUDE || role == ROLE_LD_PARENT)) {
+            const unsigned ri = a.random_index + a.slot_rand[(size_t) wave * 64 + lane];
+            rnd_a = a.random[ri];
+            if (role != ROLE_LD_NORMAL) rnd_b = a.random[ri + 1];
+        }
         const bool massive = act && v.w != 0;
         const mixed stepSize = (mixed) a.dt;
 
@@ -562,7 +570,7 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const KArgs a) {
             if (role == ROLE_LD_NORMAL && massive) {                        // K/drudeLangevin.cu:14-25
                 const mixed mass = P::RECIP(v.w);
                 const mixed sqrtMass = P::SQRT(mass);
-                const float4 rnd = a.random[a.random_index + a.slot_rand[(size_t) wave * 64 + lane]];
+                const float4 rnd = rnd_a;
                 fe.x += (-dragFactor * mass * v.x + randFactor * sqrtMass * rnd.x);
                 fe.y += (-dragFactor * mass * v.y + randFactor * sqrtMass * rnd.y);
                 fe.z += (-dragFactor * mass * v.z + randFactor * sqrtMass * rnd.z);
@@ -581,8 +589,7 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const KArgs a) {
                 const mixed cmy = v1y * mass1fract + v2y * mass2fract;
                 const mixed cmz = v1z * mass1fract + v2z * mass2fract;
                 const mixed rx = v2x - v1x, ry = v2y - v1y, rz = v2z - v1z;
-                const unsigned ri = a.random_index + a.slot_rand[(size_t) wave * 64 + lane];
-                const float4 rand1 = a.random[ri], rand2 = a.random[ri + 1];
+                const float4 rand1 = rnd_a, rand2 = rnd_b;
                 real3 cmForce, relForce;
                 cmForce.x = (-dragFactor * totMass * cmx + randFactor * sqrtTotMass * rand1.x);
                 cmForce.y = (-dragFactor * totMass * cmy + randFactor * sqrtTotMass * rand1.y);
@@ -1466,6 +1473,8 @@ constexpr uint32_t SF_B_COS_HW = B_CHAIN | B_SCALE | B_UNBIAS | B_CZ_LOAD | B_DR
 constexpr uint32_t SF_B_MIDDLE_HW = B_CHAIN | B_SCALE | B_DRIFT_MIDDLE | B_HARDWALL;
 constexpr uint32_t SF_B_MIDDLE_HW_WT = SF_B_MIDDLE_HW | B_WT_STORES;
 constexpr uint32_t SF_B_MIDDLE = B_CHAIN | B_SCALE | B_DRIFT_MIDDLE;
+constexpr uint32_t SF_A_EDL = A_KICK_FULL | A_LD | A_EF | A_KE;                                // electrode slab (BASELINE C5): Langevin subset + field
+constexpr uint32_t SF_B_EDL = SF_B_MIDDLE_HW | B_IMAGE;                                         // ... + image mirror
 constexpr uint32_t SF_A_COS_MOM = A_KICK_FULL | A_COS | A_BIAS | A_CZ_STORE | A_KE | A_KE_MOM;   // cos acceleration in one launch (moments)
 constexpr uint32_t SF_B_COS_HW_MOM = SF_B_COS_HW | B_KE_MOM;
 constexpr uint32_t SF_B_MIDDLE_HW_NC = B_SCALE | B_DRIFT_MIDDLE | B_HARDWALL;                // large systems: the chain runs as its own 1-wave launch in front
@@ -1482,6 +1491,7 @@ hipError_t launch_a(int precision, const KArgs& a, int block_threads, int grid_c
     if (a.flags == SF_A_MIDDLE) { VV_DISPATCH_SF(vv_kernel_a, SF_A_MIDDLE, g, b, 0, s, a); }
     else if (a.flags == SF_A_MIDDLE_WT) { VV_DISPATCH_SF(vv_kernel_a, SF_A_MIDDLE_WT, g, b, 0, s, a); }
     else if (a.flags == SF_A_COS1) { VV_DISPATCH_SF(vv_kernel_a, SF_A_COS1, g, b, 0, s, a); }
+    else if (a.flags == SF_A_EDL) { VV_DISPATCH_SF(vv_kernel_a, SF_A_EDL, g, b, 0, s, a); }
     else if (a.flags == SF_A_COS_MOM) { VV_DISPATCH_SF(vv_kernel_a, SF_A_COS_MOM, g, b, 0, s, a); }
     else if (a.flags == SF_A_MIDDLE_SHAKE) { VV_DISPATCH_SF(vv_kernel_a, SF_A_MIDDLE_SHAKE, g, b, 0, s, a); }
     else if (a.flags == SF_A_COS2) { VV_DISPATCH_SF(vv_kernel_a, SF_A_COS2, g, b, 0, s, a); }
@@ -1499,6 +1509,7 @@ hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_c
     else if (a.flags == SF_B_MIDDLE_HW_WT) { VV_DISPATCH_SF(vv_kernel_b, SF_B_MIDDLE_HW_WT, g, b, 0, s, a); }
     else if (a.flags == SF_B_MIDDLE) { VV_DISPATCH_SF(vv_kernel_b, SF_B_MIDDLE, g, b, 0, s, a); }
     else if (a.flags == SF_B_COS_HW) { VV_DISPATCH_SF(vv_kernel_b, SF_B_COS_HW, g, b, 0, s, a); }
+    else if (a.flags == SF_B_EDL) { VV_DISPATCH_SF(vv_kernel_b, SF_B_EDL, g, b, 0, s, a); }
     else if (a.flags == SF_B_COS_HW_MOM) { VV_DISPATCH_SF(vv_kernel_b, SF_B_COS_HW_MOM, g, b, 0, s, a); }
     else if (a.flags == SF_B_MIDDLE_HW_NC) { VV_DISPATCH_SF(vv_kernel_b, SF_B_MIDDLE_HW_NC, g, b, 0, s, a); }
     else if (a.flags == SF_B_MIDDLE_HW_MB) { VV_DISPATCH_SF(vv_kernel_b, SF_B_MIDDLE_HW_MB, g, b, 0, s, a); }
