@@ -877,16 +877,24 @@ int vvhip_run_graph(vvhip_plan* p, int nsteps, int steps_per_graph, const void* 
     NEED_BOUND(p);
     if (nsteps < 0 || steps_per_graph < 1) return VVHIP_ERR_INVALID;
     if (steps_per_graph % 2) steps_per_graph += 1;   // the thermostat double-buffers by step parity: a graph must hold an even number of steps
-    if (!p->hp.params.use_middle_scheme) return fail(p, VVHIP_ERR_UNSUPPORTED, "graph replay covers the middle scheme only");
     hipStream_t s = p->stream;
     if (!s) return fail(p, VVHIP_ERR_INVALID, "graph capture needs a non-null stream in vvhip_buffers.stream");
+    const bool middle = p->hp.params.use_middle_scheme;
+    // classic scheme (API:272-338): every step is first half -> forces -> second half, and the first half needs the forces of the
+    // current positions; they are (re)computed once per call here, outside the replayed part
+    if (!middle && site && nsteps > 0) TRY(vvhip_synth_tether_force(p, site, k_tether, k_drude));
     bool first_in_graph = false;
     auto one_step = [&]() -> int {
         uint32_t ri = 0;
         TRY(next_random_slice(p, &ri, first_in_graph));      // Langevin: a captured graph begins with a refill, so every replay draws new numbers
         first_in_graph = false;
+        if (middle) {
+            if (site) TRY(vvhip_synth_tether_force(p, site, k_tether, k_drude));
+            return vvhip_step_middle(p, ri);
+        }
+        TRY(vvhip_step_vv_first(p));
         if (site) TRY(vvhip_synth_tether_force(p, site, k_tether, k_drude));
-        return vvhip_step_middle(p, ri);
+        return vvhip_step_vv_second(p, ri);
     };
     if (!p->graph_exec || p->graph_parity != p->parity || p->graph_steps != steps_per_graph || p->graph_site != site || p->graph_kt != k_tether || p->graph_kd != k_drude) {
         if (p->graph_exec) { (void) hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
@@ -1121,11 +1129,19 @@ int vvhip_comm_destroy(vvhip_plan* p) {
 int vvhip_run_eager(vvhip_plan* p, int nsteps, const void* site, double k_tether, double k_drude) {
     NEED_BOUND(p);
     if (nsteps < 0) return VVHIP_ERR_INVALID;
+    const bool middle = p->hp.params.use_middle_scheme;
+    if (!middle && site && nsteps > 0) TRY(vvhip_synth_tether_force(p, site, k_tether, k_drude));   // see vvhip_run_graph
     for (int i = 0; i < nsteps; i++) {
         uint32_t ri = 0;
         TRY(next_random_slice(p, &ri, false));
-        if (site) TRY(vvhip_synth_tether_force(p, site, k_tether, k_drude));
-        TRY(vvhip_step_middle(p, ri));
+        if (middle) {
+            if (site) TRY(vvhip_synth_tether_force(p, site, k_tether, k_drude));
+            TRY(vvhip_step_middle(p, ri));
+        } else {
+            TRY(vvhip_step_vv_first(p));
+            if (site) TRY(vvhip_synth_tether_force(p, site, k_tether, k_drude));
+            TRY(vvhip_step_vv_second(p, ri));
+        }
     }
     return VVHIP_OK;
 }

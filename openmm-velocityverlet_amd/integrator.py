@@ -356,10 +356,12 @@ class Context:
                 H.check(L.vvhip_step_vv_second(plan, ri), plan)
 
     def run_graph(self, steps: int, steps_per_graph: int = 50):
-        """Middle scheme: replay a captured hipGraph of whole steps (force provider included).  With a Langevin subset the
+        """Replay a captured hipGraph of whole steps (force provider included; both schemes).  With a Langevin subset the
         graph starts with a refill of the random buffer by the device generator, so every replay draws fresh numbers."""
         site = self.site.ptr if self.force_provider == "tether" else None
         H.check(H.lib.vvhip_run_graph(self.plan, int(steps), int(steps_per_graph), site, self.k_tether, self.k_drude), self.plan)
+        if not self.integrator._useMiddleScheme and site is not None and steps > 0:
+            self.forces_valid = True                                # the last force evaluation was at the final positions
 
     def fill_random(self, seed=None):
         """Refill the Langevin random buffer with the device generator (Philox4x32-10 + Box-Muller)."""
@@ -368,9 +370,11 @@ class Context:
         H.check(H.lib.vvhip_fill_random(self.plan), self.plan)
 
     def run_eager(self, steps: int):
-        """Middle scheme: the same steps enqueued one by one from C (no per-step Python, no graph)."""
+        """The same steps enqueued one by one from C (no per-step Python, no graph; both schemes)."""
         site = self.site.ptr if self.force_provider == "tether" else None
         H.check(H.lib.vvhip_run_eager(self.plan, int(steps), site, self.k_tether, self.k_drude), self.plan)
+        if not self.integrator._useMiddleScheme and site is not None and steps > 0:
+            self.forces_valid = True
 
     def run_eager_unfused(self, steps: int):
         """Middle scheme through the per-KernelImpl entry points in VVIntegrator::stepMiddle's order, enqueued from C: the launches

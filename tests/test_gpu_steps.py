@@ -133,12 +133,14 @@ def test_split_entry_points_equal_fused_step():
     assert np.allclose(outs[0][0], outs[1][0], rtol=0, atol=1e-12) and np.allclose(outs[0][1], outs[1][1], rtol=1e-11, atol=1e-13)
 
 
-def test_graph_replay_equals_eager_and_is_bit_reproducible():
+@pytest.mark.parametrize("middle", [True, False])
+def test_graph_replay_equals_eager_and_is_bit_reproducible(middle):
     spec = systems.drude_il(cells=(1, 1, 1), pairs_per_cell=60, seed=4)
     res = []
     for mode in ("eager", "graph", "graph"):
         it = I.VVIntegrator(333.0, 10, 1.0, 40, 0.001)
         it.setMaxDrudeDistance(0.02)
+        it.setUseMiddleScheme(middle)
         ctx = I.Context(spec, it, precision="mixed", force_provider="tether")
         if mode == "eager":
             it.step(24)
