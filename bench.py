@@ -305,11 +305,13 @@ def main():
 
     # ---- the same box with the constraints the reference's example scripts put on it (HBonds: examples/ommhelper/oplspsffile.py:952-955;
     # rigid water for C2), solved inside the fused kernels: a secondary figure, the headline stays the workload BASELINE.json names
-    if world == 1 and rank == 0 and not use_dist and args.forces == "tether" and not args.eager and not args.hbonds and cfg in ("C2", "C3", "C4"):
+    if world == 1 and rank == 0 and not use_dist and args.forces == "tether" and not args.eager and not args.hbonds and cfg in ("C2", "C3", "C4", "C5"):
         spec_c = S.rigid_water(S.make_config(cfg)) if cfg == "C2" else S.constrain_hydrogens(S.make_config(cfg), 0.109)
         it_c = I.VVIntegrator(it.getTemperature(), 10.0, 1.0, 40.0, dt)
         it_c.setMaxDrudeDistance(it.getMaxDrudeDistance())
         it_c.setCosAcceleration(it.getCosAcceleration())
+        it_c.setMirrorLocation(it.getMirrorLocation())
+        it_c.setElectricField(it.getElectricField())
         ctx_c = I.Context(spec_c, it_c, precision=args.precision, force_provider="tether", device=local_rank)
         nc = max(args.steps // 4, 2 * args.steps_per_graph)
         ctx_c.run_graph(2 * args.steps_per_graph, args.steps_per_graph)

@@ -1498,6 +1498,15 @@ constexpr uint32_t SF_B_POS3_HW = B_POS3 | B_HARDWALL;                          
 constexpr uint32_t SF_B_POS3 = B_POS3;
 constexpr uint32_t SF_B_MIDDLE_MB = SF_B_MIDDLE | B_MAILBOX;                    // sharded runs of systems without Drude pairs
 
+// ... and the combinations the reference's example scripts actually run: HBonds constraints next to the cos perturbation
+// (run-bulk.py) and next to the electrode machinery (run-edl.py), and the sharded variants of the constrained / perturbed box
+constexpr uint32_t SF_A_COS_MOM_SHAKE = SF_A_COS_MOM | A_SHAKE_V;
+constexpr uint32_t SF_B_COS_HW_MOM_SHAKE = SF_B_COS_HW_MOM | B_SHAKE;
+constexpr uint32_t SF_A_EDL_SHAKE = SF_A_EDL | A_SHAKE_V;
+constexpr uint32_t SF_B_EDL_SHAKE = SF_B_EDL | B_SHAKE;
+constexpr uint32_t SF_B_COS_HW_MOM_MB = SF_B_COS_HW_MOM | B_MAILBOX;
+constexpr uint32_t SF_B_MIDDLE_HW_SHAKE_MB = SF_B_MIDDLE_HW_SHAKE | B_MAILBOX;
+
 #define VV_TRY_SF(KERNEL, SFV) if (a.flags == (SFV)) { VV_DISPATCH_SF(KERNEL, SFV, g, b, 0, s, a); return hipGetLastError(); }
 
 hipError_t launch_a(int precision, const KArgs& a, int block_threads, int grid_cap, hipStream_t s) {
@@ -1512,6 +1521,8 @@ hipError_t launch_a(int precision, const KArgs& a, int block_threads, int grid_c
     VV_TRY_SF(vv_kernel_a, SF_A_COS_MOM)
     VV_TRY_SF(vv_kernel_a, SF_A_EDL)
     VV_TRY_SF(vv_kernel_a, SF_A_MIDDLE_SHAKE)
+    VV_TRY_SF(vv_kernel_a, SF_A_COS_MOM_SHAKE)
+    VV_TRY_SF(vv_kernel_a, SF_A_EDL_SHAKE)
     VV_TRY_SF(vv_kernel_a, SF_A_KE)
     VV_TRY_SF(vv_kernel_a, SF_A_VV2)
     VV_TRY_SF(vv_kernel_a, SF_A_KICK)
@@ -1538,6 +1549,10 @@ hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_c
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_MB)
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_HW_SHAKE)
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_SHAKE)
+    VV_TRY_SF(vv_kernel_b, SF_B_COS_HW_MOM_SHAKE)
+    VV_TRY_SF(vv_kernel_b, SF_B_EDL_SHAKE)
+    VV_TRY_SF(vv_kernel_b, SF_B_COS_HW_MOM_MB)
+    VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_HW_SHAKE_MB)
     VV_TRY_SF(vv_kernel_b, SF_B_SCALE)
     VV_TRY_SF(vv_kernel_b, SF_B_VV1_HW)
     VV_TRY_SF(vv_kernel_b, SF_B_VV1)
