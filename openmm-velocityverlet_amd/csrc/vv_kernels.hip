@@ -13,8 +13,9 @@
 //
 // Arithmetic.  Each expression keeps the operand types and association of the reference kernel it
 // replaces (cited per stage; K/ = platforms/cuda/src/kernels/) and the library is built with
-// -ffp-contract=off, so element-wise results equal the CPU oracle bit for bit; only the order of
-// the reductions differs.  No MFMA: there is no contraction on this path (HBM/latency bound).
+// -ffp-contract=off, so element-wise results equal the CPU oracle bit for bit; only the reductions
+// differ (their order, and the reciprocals that feed nothing but sums: Prec::RECIP_SUM).  No MFMA:
+// there is no contraction on this path (HBM / latency / fp64-issue bound).
 #include "vv_kernels.hpp"
 
 #include "vv_host.hpp"
