@@ -14,9 +14,7 @@ H, I, systems = pkg.vvhip, pkg.integrator, pkg.systems
 pytestmark = pytest.mark.gpu
 
 
-@settings(max_examples=120, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.too_slow])
-@given(inventories(), st.booleans(), st.sampled_from([0.0, 0.02]), st.sampled_from([0.0, 0.02]), st.sampled_from(["mixed", "double"]))
-def test_random_systems_match_the_oracle(inv, middle, cos, maxd, prec):
+def _run(inv, middle, cos, maxd, prec):
     masses, mol_id, pairs, use_com, with_constraints, seed = inv
     spec = _spec(masses, mol_id, pairs, seed)
     if (spec.masses != 0).sum() < 2:
@@ -54,3 +52,16 @@ def test_random_systems_match_the_oracle(inv, middle, cos, maxd, prec):
         assert ex < 1e-5 and ev < 1e-5, (ex, ev, dict(middle=middle, cos=cos, maxd=maxd, prec=prec, use_com=use_com, cons=with_constraints, n=spec.num_atoms))
     finally:
         ctx.close()
+
+
+@settings(max_examples=120, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.too_slow])
+@given(inventories(), st.booleans(), st.sampled_from([0.0, 0.02]), st.sampled_from([0.0, 0.02]), st.sampled_from(["mixed", "double"]))
+def test_random_systems_match_the_oracle(inv, middle, cos, maxd, prec):
+    _run(inv, middle, cos, maxd, prec)
+
+
+@settings(max_examples=12, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large, HealthCheck.large_base_example])
+@given(inventories(max_molecules=400), st.booleans(), st.sampled_from([0.0, 0.02]), st.sampled_from([0.0, 0.02]))
+def test_random_large_systems_match_the_oracle(inv, middle, cos, maxd):
+    """Hundreds of molecules: many waves and blocks, best-fit packing across them, several launch shapes."""
+    _run(inv, middle, cos, maxd, "mixed")

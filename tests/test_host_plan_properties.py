@@ -14,8 +14,8 @@ H, I, systems = pkg.vvhip, pkg.integrator, pkg.systems
 
 
 @st.composite
-def inventories(draw):
-    nmol = draw(st.integers(1, 12))
+def inventories(draw, max_molecules=12):
+    nmol = draw(st.integers(1, max_molecules))
     masses, mol_id, pairs, cons, cdist = [], [], [], [], []
     for m in range(nmol):
         size = draw(st.sampled_from([1, 2, 3, 5, 9, 17, 40, 64, 70, 90, 130]))
