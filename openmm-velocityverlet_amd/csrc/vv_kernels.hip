@@ -48,10 +48,13 @@ template <> struct Prec<double> {
 
 // 16-byte write-through store (buffer_store_dwordx4 ... sc1): the line goes to memory now instead of staying dirty in the
 // XCD's L2 until the end-of-kernel write-back (MI355X_MICROARCH.md "publish-large").  `base` must be wave-uniform.
+#ifndef VV_WT_AUX
+#define VV_WT_AUX 16      // cache-policy bits of the experiment: 16 = sc1 (write-through), 2 = nt (streaming)
+#endif
 typedef unsigned int vv_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store16_wt(void* base, unsigned byte_offset, const void* src) {
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0xFFFFFFFF, 0x00020000);
-    __builtin_amdgcn_raw_buffer_store_b128(*(const vv_u4*) src, rsrc, (int) byte_offset, 0, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(*(const vv_u4*) src, rsrc, (int) byte_offset, 0, VV_WT_AUX);
 }
 template <class V>
 __device__ __forceinline__ void store_vec(V* base, int index, const V& val, bool write_through) {
