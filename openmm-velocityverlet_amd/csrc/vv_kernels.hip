@@ -1508,6 +1508,10 @@ constexpr uint32_t SF_A_COS_MOM_SHAKE = SF_A_COS_MOM | A_SHAKE_V;
 constexpr uint32_t SF_B_COS_HW_MOM_SHAKE = SF_B_COS_HW_MOM | B_SHAKE;
 constexpr uint32_t SF_A_EDL_SHAKE = SF_A_EDL | A_SHAKE_V;
 constexpr uint32_t SF_B_EDL_SHAKE = SF_B_EDL | B_SHAKE;
+constexpr uint32_t SF_A_LD = A_KICK_FULL | A_LD | A_KE;                     // a Langevin subset without the field (thermostatted wall)
+constexpr uint32_t SF_A_EF = A_KICK_FULL | A_EF | A_KE;                     // a field on the bulk without Langevin particles
+constexpr uint32_t SF_A_LD_SHAKE = SF_A_LD | A_SHAKE_V;
+constexpr uint32_t SF_A_EF_SHAKE = SF_A_EF | A_SHAKE_V;
 constexpr uint32_t SF_B_COS_HW_MOM_MB = SF_B_COS_HW_MOM | B_MAILBOX;
 constexpr uint32_t SF_B_MIDDLE_HW_SHAKE_MB = SF_B_MIDDLE_HW_SHAKE | B_MAILBOX;
 
@@ -1527,6 +1531,10 @@ hipError_t launch_a(int precision, const KArgs& a, int block_threads, int grid_c
     VV_TRY_SF(vv_kernel_a, SF_A_MIDDLE_SHAKE)
     VV_TRY_SF(vv_kernel_a, SF_A_COS_MOM_SHAKE)
     VV_TRY_SF(vv_kernel_a, SF_A_EDL_SHAKE)
+    VV_TRY_SF(vv_kernel_a, SF_A_LD)
+    VV_TRY_SF(vv_kernel_a, SF_A_EF)
+    VV_TRY_SF(vv_kernel_a, SF_A_LD_SHAKE)
+    VV_TRY_SF(vv_kernel_a, SF_A_EF_SHAKE)
     VV_TRY_SF(vv_kernel_a, SF_A_KE)
     VV_TRY_SF(vv_kernel_a, SF_A_VV2)
     VV_TRY_SF(vv_kernel_a, SF_A_KICK)
