@@ -77,6 +77,7 @@ struct vvhip_plan {
     void* d_old_delta = nullptr;
     void* d_pos_delta = nullptr;   // used when the caller does not supply one
     void* d_comv = nullptr;        // per-segment COM velocities handed from kernel A to kernel B
+    double* d_seg_mass = nullptr;  // static (mass, 1/mass) per COM segment
     double* d_comw = nullptr;      // per-segment mass-weighted mean of cos(kz) (moment form of the cos perturbation)
     double* d_cosz = nullptr;      // per-lane cos(2 pi z / Lz) of the current step
     unsigned long long* d_acc = nullptr;   // [2 parities][NUM_ACC][ACC_SLOTS]
@@ -214,6 +215,7 @@ vv::KArgs make_args(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
     a.old_delta = p->d_old_delta;
     a.comv = p->d_comv;
     a.comw = p->d_comw;
+    a.seg_mass = p->d_seg_mass;
     a.cosz = p->d_cosz;
     a.slots = p->d_slots;
     a.slot_image = p->d_slot_image;
@@ -463,7 +465,7 @@ void vvhip_plan_destroy(vvhip_plan* p) {
     if (p->bound) {
         (void) hipStreamSynchronize(p->stream);
         for (void* ptr : {(void*) p->d_slots, (void*) p->d_slot_image, (void*) p->d_slot_rand, (void*) p->d_slot_shake, (void*) p->d_slot_shake_param, (void*) p->d_slot_big, (void*) p->d_bigacc, (void*) p->d_image_pairs,
-                          p->d_fextra, p->d_old_delta, p->d_pos_delta, p->d_comv, (void*) p->d_comw, (void*) p->d_cosz, (void*) p->d_epoch, (void*) p->d_acc, (void*) p->d_nh, (void*) p->d_lane_const, (void*) p->d_dbg, (void*) p->d_dbg_span})
+                          p->d_fextra, p->d_old_delta, p->d_pos_delta, p->d_comv, (void*) p->d_comw, (void*) p->d_seg_mass, (void*) p->d_cosz, (void*) p->d_epoch, (void*) p->d_acc, (void*) p->d_nh, (void*) p->d_lane_const, (void*) p->d_dbg, (void*) p->d_dbg_span})
             if (ptr) (void) hipFree(ptr);
         if (p->graph_exec) (void) hipGraphExecDestroy(p->graph_exec);
         if (p->comm) (void) rccl_api().commDestroy(p->comm);
@@ -544,6 +546,8 @@ int vvhip_bind(vvhip_plan* p, const vvhip_buffers* b) {
     HIP_TRY(p, hipMemset(p->d_cosz, 0, nslots * sizeof(double)));
     HIP_TRY(p, hipMalloc(&p->d_comv, nslots * 4 * ms));
     HIP_TRY(p, hipMemset(p->d_comv, 0, nslots * 4 * ms));
+    HIP_TRY(p, hipMalloc((void**) &p->d_seg_mass, hp.seg_mass.size() * sizeof(double)));
+    HIP_TRY(p, hipMemcpy(p->d_seg_mass, hp.seg_mass.data(), hp.seg_mass.size() * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(p, hipMalloc((void**) &p->d_comw, nslots * sizeof(double)));
     HIP_TRY(p, hipMemset(p->d_comw, 0, nslots * sizeof(double)));
     HIP_TRY(p, hipMalloc(&p->d_pos_delta, nloc * 4 * ms));

@@ -417,6 +417,13 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
         if (best_fit && fill[wave] < 64) open_by_free[64 - fill[wave]].push_back(wave);
         const int first_lane = lane, last_lane = lane + sz - 1;
         for (int k = 0; k < sz; k++) { lane_of[c.members[k]] = lane + k; wave_of[c.members[k]] = wave; }
+        if (c.com_segment) {
+            double m = 0;
+            for (int k = 0; k < sz; k++) { const int i = c.members[k]; if (is_nh[i] && sys.masses[i] != 0.0) m += sys.masses[i]; }
+            if (hp.seg_mass.size() < (size_t) (wave + 1) * 128) hp.seg_mass.resize((size_t) (wave + 1) * 128, 0.0);
+            hp.seg_mass[((size_t) wave * 64 + first_lane) * 2] = m;
+            hp.seg_mass[((size_t) wave * 64 + first_lane) * 2 + 1] = m != 0 ? 1.0 / m : 0.0;
+        }
         bool leader_set = false;
         for (int k = 0; k < sz; k++, lane++) {
             const int i = c.members[k];
@@ -467,6 +474,7 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
         }
     info.num_waves = nwaves;
     info.num_slots_used = used;
+    hp.seg_mass.resize((size_t) nwaves * 128, 0.0);
 
     if (hp.has_images) {
         hp.slot_image.assign((size_t) nwaves * 64, -1);

@@ -62,6 +62,9 @@ struct HostPlan {
     // work-item layout: 64 lanes per wave; slots[2*i] = shard-relative particle index or -1, slots[2*i+1] = meta
     std::vector<int32_t> slots;
     std::vector<int32_t> slot_image;   // [64*waves] shard-relative image particle of this lane's particle, or -1
+    // [2*64*waves] at the slot of a COM segment's first lane: mass of the segment's thermostatted particles, summed in particle order as
+    // the reference does (K/drudeNoseHoover.cu:15-25), and its reciprocal -- static, so kernel A need not scan the masses every step
+    std::vector<double> seg_mass;
     std::vector<int32_t> slot_rand;    // [64*waves] offset into the Langevin slice of the random buffer, or -1
     // in-kernel SHAKE (hydrogen-type clusters): per lane a packed word and, for central lanes, OpenMM-style cluster parameters
     //   word: bit0 central, bit1 peripheral, bits2-3 = #peripherals (central) or own index (peripheral),

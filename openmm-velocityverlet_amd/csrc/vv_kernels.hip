@@ -167,19 +167,18 @@ __device__ __forceinline__ double cos_kz(real z, real inv_box_z) {
 // V = (sum m v) * RECIP(sum m), with comVelm.w = RECIP(sum m).
 template <class real, class mixed>
 __device__ __forceinline__ void com_velocity(bool contributes, mixed vx, mixed vy, mixed vz, mixed w, int lane,
-                                             unsigned meta, mixed& Vx, mixed& Vy, mixed& Vz, mixed& Vw, mixed& Vm) {
+                                             unsigned meta, mixed seg_m, mixed seg_w, mixed& Vx, mixed& Vy, mixed& Vz, mixed& Vw, mixed& Vm) {
     const int first = (meta >> META_SEGFIRST_SHIFT) & 63, last = (meta >> META_SEGLAST_SHIFT) & 63;
-    mixed mass = 0, mx = 0, my = 0, mz = 0;
+    mixed mx = 0, my = 0, mz = 0;
     if (contributes) {
-        mass = Prec<real>::RECIP_SUM(w);
+        const mixed mass = Prec<real>::RECIP_SUM(w);
         mx = vx * mass; my = vy * mass; mz = vz * mass;
     }
     mx = segment_total(mx, lane, first, last);
     my = segment_total(my, lane, first, last);
     mz = segment_total(mz, lane, first, last);
-    mass = segment_total(mass, lane, first, last);
-    Vm = mass;
-    Vw = Prec<real>::RECIP_SUM(mass);
+    Vm = seg_m;                 // the segment's mass is static: summed once on the host (vv_host.hpp: seg_mass), not scanned every step
+    Vw = seg_w;
     Vx = mx * Vw; Vy = my * Vw; Vz = mz * Vw;
 }
 
@@ -551,6 +550,8 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const KArgs a) {
             rnd_a = a.random[ri];
             if (role != ROLE_LD_NORMAL) rnd_b = a.random[ri + 1];
         }
+        double2 seg_mw = {0, 0};                 // (mass, 1/mass) of this lane's COM segment, one 16-byte entry per segment
+        if ((F & A_KE) && act) seg_mw = ((const double2*) a.seg_mass)[(size_t) wave * 64 + ((meta >> META_SEGFIRST_SHIFT) & 63)];
         const bool massive = act && v.w != 0;
         const mixed stepSize = (mixed) a.dt;
 
@@ -703,7 +704,7 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const KArgs a) {
             const bool use_com = ((meta >> META_SEGFIRST_SHIFT) & 63) != ((meta >> META_SEGLAST_SHIFT) & 63) ||
                                  (meta & META_COM_LEADER);
             // the COM stage is wave-uniform on purpose: lanes outside a COM segment scan a 1-lane segment
-            com_velocity<real, mixed>(nh && massive && use_com, ux, uy, uz, v.w, lane, meta, Vx, Vy, Vz, Vw, Vm);
+            com_velocity<real, mixed>(nh && massive && use_com, ux, uy, uz, v.w, lane, meta, (mixed) seg_mw.x, (mixed) seg_mw.y, Vx, Vy, Vz, Vw, Vm);
             if (!use_com) { Vx = 0; Vy = 0; Vz = 0; Vw = 0; }
             if (a.slot_big && (meta & META_BIGMOL) && nh) {     // molecule spread over several waves: totals from the accumulator
                 const unsigned long long* src = a.bigacc + 4 * (size_t) a.slot_big[(size_t) wave * 64 + lane];

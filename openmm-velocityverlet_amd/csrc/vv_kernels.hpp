@@ -139,6 +139,7 @@ struct KArgs {
     void* pos_delta;
     void* old_delta;
     double* cosz;                  // [64*nwaves] per-lane cos(2 pi z / Lz) cache of the current step
+    const double* seg_mass;        // [2*64*nwaves] (mass, 1/mass) of the COM segment starting at that lane (static; vv_host.hpp)
     double* comw;                  // [64*nwaves] mass-weighted mean of cos(kz) over the same segment (A_KE_MOM -> B_KE_MOM)
     const int32_t* slot_image;
     const int32_t* slot_rand;
