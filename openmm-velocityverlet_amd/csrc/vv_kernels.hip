@@ -1272,7 +1272,7 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const KArgs a) {
                 const mixed deltax = p1x - p2x, deltay = p1y - p2y, deltaz = p1z - p2z;
                 const mixed r = P::SQRT(deltax * deltax + deltay * deltay + deltaz * deltaz);
                 const mixed rInv = P::RECIP(r);
-                if (rInv * maxDrudeDistance < 1) {
+                if (__builtin_expect(rInv * maxDrudeDistance < 1, 0)) {      // rare: keep the hit path out of the fall-through code
                     // both lanes of a pair see the same r, so both are in here: the partner's velocity is fetched only now
                     const mixed ovx = shfl(v.x, partner), ovy = shfl(v.y, partner), ovz = shfl(v.z, partner);
                     mixed vel1x = isd ? v.x : ovx, vel1y = isd ? v.y : ovy, vel1z = isd ? v.z : ovz;
