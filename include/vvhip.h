@@ -274,6 +274,10 @@ int vvhip_run_eager_unfused(vvhip_plan* plan, int nsteps, const void* site, doub
 /* Average duration of `reps` back-to-back launches of one stage kernel (0 = A, 1 = B) with the given stage bits,
  * bracketed by two HIP events on the plan's stream.  Destroys the physical state (timing only). */
 int vvhip_time_kernel(vvhip_plan* plan, int kernel, uint32_t flags, int reps, double* ms_per_launch);
+/* Tracing: roctx ranges around every launch group (visible with rocprofv3 --marker-trace); the OpenMM adapter switches it on with
+ * VVIntegrator::setDebugEnabled and prints the reference's per-call lines itself (VVIntegrator.h:417-419, CudaVVKernels.cpp:57,120,...).
+ * Also VVHIP_ROCTX=1 in the environment.  libroctx64 is resolved at run time. */
+int vvhip_set_trace(vvhip_plan* plan, int enable);
 int vvhip_timing_enable(vvhip_plan* plan, int enable);
 int vvhip_timing_read(vvhip_plan* plan, double* ms_pass_a, double* ms_pass_b, double* ms_other, int32_t launches[3]);
 

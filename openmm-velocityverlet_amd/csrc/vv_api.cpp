@@ -49,6 +49,27 @@ constexpr double kBoltz = (1.380649e-23 * kAvogadro) / 1000.0;
 enum TimerClass { T_A = 0, T_B = 1, T_OTHER = 2 };
 }  // namespace
 
+// roctx ranges around every launch group (rocprofv3 --marker-trace): resolved lazily, only if VVHIP_ROCTX=1 or vvhip_set_trace(plan, 1)
+struct RoctxApi {
+    bool tried = false;
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+};
+RoctxApi& roctx_api() {
+    static RoctxApi r;
+    if (r.tried) return r;
+    r.tried = true;
+    for (const char* name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+        void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (!h) continue;
+        r.push = (int (*)(const char*)) dlsym(h, "roctxRangePushA");
+        r.pop = (int (*)()) dlsym(h, "roctxRangePop");
+        if (r.push && r.pop) break;
+        r.push = nullptr; r.pop = nullptr;
+    }
+    return r;
+}
+
 struct vvhip_plan {
     vv::HostPlan hp;
     std::string err;
@@ -60,6 +81,7 @@ struct vvhip_plan {
     int block_threads = 256;       // 64 x tile waves per block, the same for the force provider, kernel A and kernel B
     int grid_cap_a = 2048, grid_cap_b = 1024;   // most blocks per launch (multiples of the CU count): see pick_launch_shape
     int split_chain_waves = 12288;   // systems with at least this many waves (~0.8 M particles; measured +3 % at 0.9 M, +5 % at 8.9 M) run the chain as its own launch (VVHIP_SPLIT_CHAIN_WAVES)
+    bool trace = false;            // roctx range + one stderr line per launch group (the reference's setDebugEnabled, VVIntegrator.h:417-419)
     bool fextra_dirty = false;     // forceExtra holds something since the last reset (split entry points)
     bool fextra_external = false;  // the host asked for the pointer (vvhip_force_extra) and may write to it: never assume zeros
     bool no_moments = false;       // VVHIP_NO_MOMENTS=1: keep the three-launch cos sequence (comparison runs)
@@ -323,8 +345,12 @@ struct ScopedTimer {
     vvhip_plan* p;
     int cls;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    bool on;
+    bool on, ranged = false;
     ScopedTimer(vvhip_plan* p_, int cls_) : p(p_), cls(cls_), on(p_->timing && !p_->capturing) {
+        if (p->trace && !p->capturing) {
+            static const char* names[3] = {"vvhip kernel A (kick / extra forces / sums)", "vvhip kernel B (thermostat / drift / hard wall)", "vvhip other"};
+            if (roctx_api().push) { roctx_api().push(names[cls]); ranged = true; }
+        }
         if (on) {
             (void) hipEventCreate(&e0);
             (void) hipEventCreate(&e1);
@@ -332,6 +358,7 @@ struct ScopedTimer {
         }
     }
     ~ScopedTimer() {
+        if (ranged) roctx_api().pop();
         if (on) {
             (void) hipEventRecord(e1, p->stream);
             p->events[cls].emplace_back(e0, e1);
@@ -445,6 +472,7 @@ int vvhip_plan_create(const vvhip_system_desc* system, const vvhip_params* param
         fill_scales(p);
         if (const char* e = std::getenv("VVHIP_WT")) p->wt_stores = std::atoi(e) != 0;
         if (const char* e = std::getenv("VVHIP_NO_MOMENTS")) p->no_moments = std::atoi(e) != 0;
+        if (const char* e = std::getenv("VVHIP_ROCTX")) p->trace = std::atoi(e) != 0;
         if (const char* e = std::getenv("VVHIP_SPLIT_CHAIN_WAVES")) p->split_chain_waves = std::atoi(e);
         pick_launch_shape(p);
         if (const char* e = std::getenv("VVHIP_BLOCK")) {          // tuning experiments
@@ -1178,6 +1206,11 @@ int vvhip_run_eager_unfused(vvhip_plan* p, int nsteps, const void* site, double 
     return VVHIP_OK;
 }
 
+int vvhip_set_trace(vvhip_plan* p, int enable) {
+    if (!p) return VVHIP_ERR_INVALID;
+    p->trace = enable != 0;
+    return VVHIP_OK;
+}
 int vvhip_timing_enable(vvhip_plan* p, int enable) {
     if (!p) return VVHIP_ERR_INVALID;
     p->timing = enable != 0;

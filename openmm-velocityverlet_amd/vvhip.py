@@ -128,6 +128,7 @@ def _load():
         "vvhip_debug_read_accumulators": [vp, P(dbl * 4), C.c_int],
         "vvhip_debug_set_scales": [vp, P(dbl * 4)],
         "vvhip_debug_old_delta": [vp, P(vp)],
+        "vvhip_set_trace": [vp, C.c_int],
         "vvhip_debug_span": [vp, C.c_int, C.c_uint32, C.c_int, P(C.c_double * 8)],
         "vvhip_debug_timestamps": [vp, C.c_uint32, C.c_int, P(C.c_longlong * 128)],
     }

@@ -31,6 +31,7 @@ private:
     vvhip_params last;
     int ldRandoms;
     bool noConstraints;
+    bool debug = false;      // last VVIntegrator::getDebugEnabled() handed to vvhip_set_trace
 };
 
 class HipVVStepCommon {          // code shared by the two step kernels

@@ -102,6 +102,10 @@ HipVVPlan::HipVVPlan(HipContext& cu, const System& system, const VVIntegrator& i
 HipVVPlan::~HipVVPlan() { vvhip_plan_destroy(plan); }
 void HipVVPlan::check(int rc) const { if (rc != VVHIP_OK) throw OpenMMException(vvhip_last_error(plan)); }
 void HipVVPlan::syncParameters(const VVIntegrator& it) {
+    if (it.getDebugEnabled() != debug) {              // VVIntegrator.h:417-419: one line per kernel call on stdout, here plus roctx ranges
+        debug = it.getDebugEnabled();
+        check(vvhip_set_trace(plan, debug ? 1 : 0));
+    }
     vvhip_params now = paramsOf(it);
     if (!sameParams(now, last)) { check(vvhip_set_params(plan, &now)); last = now; }
     check(vvhip_set_box(plan, cu.getPeriodicBoxSize()));
@@ -135,12 +139,14 @@ void HipIntegrateMiddleStepKernel::resetExtraForce(ContextImpl&, const VVIntegra
 void HipIntegrateMiddleStepKernel::firstIntegrate(ContextImpl&, const VVIntegrator& it) {              // HOST:129-159
     cu.setAsCurrent();
     plan->syncParameters(it);
+    if (it.getDebugEnabled()) std::cout << "HipIntegrateMiddleStepKernel firstIntegrate" << std::endl;
     plan->check(vvhip_middle_kick(plan->get()));
     cu.getIntegrationUtilities().applyVelocityConstraints(it.getConstraintTolerance());
     plan->check(vvhip_middle_half_drift1(plan->get()));
 }
 void HipIntegrateMiddleStepKernel::secondIntegrate(ContextImpl&, const VVIntegrator& it) {             // HOST:161-231
     cu.setAsCurrent();
+    if (it.getDebugEnabled()) std::cout << "HipIntegrateMiddleStepKernel secondIntegrate" << std::endl;
     plan->check(vvhip_middle_half_drift2(plan->get()));
     cu.getIntegrationUtilities().applyConstraints(it.getConstraintTolerance());
     plan->check(vvhip_middle_finish(plan->get()));
@@ -155,6 +161,7 @@ bool HipIntegrateMiddleStepKernel::canFuse(ContextImpl&, const VVIntegrator&) co
 void HipIntegrateMiddleStepKernel::fusedMiddleStep(ContextImpl&, const VVIntegrator& it) {
     cu.setAsCurrent();
     plan->syncParameters(it);
+    if (it.getDebugEnabled()) std::cout << "HipIntegrateMiddleStepKernel fusedMiddleStep" << std::endl;
     plan->check(vvhip_step_middle(plan->get(), it.getParticlesLD().empty() ? 0 : nextRandomIndex()));
     cu.reorderAtoms();
     advanceClock(it);

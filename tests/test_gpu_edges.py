@@ -241,3 +241,18 @@ def test_switching_the_cos_perturbation_on_mid_run_equals_a_fresh_start():
     for a, b in zip(r1[:3], r2[:3]):
         assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
     assert r1[3] == r2[3] and r1[4] == r2[4]
+
+
+def test_trace_switch_does_not_change_results():
+    """vvhip_set_trace (roctx ranges around the launch groups; the adapter ties it to VVIntegrator::setDebugEnabled) is observational."""
+    spec = systems.drude_il(cells=(1, 1, 1), pairs_per_cell=20, seed=5)
+    res = []
+    for trace in (0, 1):
+        it = I.VVIntegrator(333.0, 10, 1.0, 40, 0.001)
+        it.setMaxDrudeDistance(0.02)
+        ctx = I.Context(spec, it, precision="mixed", force_provider="tether")
+        H.check(H.lib.vvhip_set_trace(ctx.plan, trace), ctx.plan)
+        it.step(5)
+        res.append(ctx.getVelm())
+        ctx.close()
+    assert np.array_equal(res[0].view(np.uint8), res[1].view(np.uint8))
