@@ -14,9 +14,11 @@ I, systems = pkg.integrator, pkg.systems
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not O.have_ref_gpu(), reason="oracle/_ref GPU build absent (needs /root/reference at build time)")]
 
 
-@pytest.mark.parametrize("case,cos", [("bulk", 0.0), ("bulk", 0.02), ("water", 0.0)])
+@pytest.mark.parametrize("case,cos", [("bulk", 0.0), ("bulk", 0.02), ("water", 0.0), ("C3-full-size", 0.0), ("C3-full-size", 0.02)])
 def test_reference_kernels_on_gpu_vs_oracle_vs_product(case, cos):
-    if case == "bulk":
+    if case == "C3-full-size":              # BASELINE.json's headline box: 111 000 particles through the reference's own kernels
+        spec, T, maxd = systems.make_config("C3"), 333.0, 0.02
+    elif case == "bulk":
         spec, T, maxd = systems.drude_il(cells=(1, 1, 1), pairs_per_cell=60, seed=41), 333.0, 0.02
     else:
         spec, T, maxd = systems.spce_water(400, seed=42), 300.0, 0.0
