@@ -182,18 +182,23 @@ def test_full_size_c3_properties():
 
 
 @pytest.mark.parametrize("prec", ["mixed", "double"])      # single: see the module docstring -- at 1e5 particles the reference's serial float
-@pytest.mark.parametrize("cfg,cos,hbonds", [("C3", 0.0, False), ("C3", 0.02, False), ("C3", 0.0, True), ("C5", 0.0, False)])   # sums carry ~1e-4 noise
+@pytest.mark.parametrize("cfg,cos,hbonds", [("C3", 0.0, False), ("C3", 0.02, False), ("C3", 0.0, True), ("C5", 0.0, False),   # sums carry ~1e-4 noise
+                                            ("C3-classic", 0.0, False), ("C3-classic", 0.02, True), ("C2", 0.0, True), ("C1", 0.0, False)])
 def test_full_size_configs_against_the_oracle(cfg, cos, hbonds, prec):
     """BASELINE.json's configurations at their FULL size against the oracle (the C restatement needs ~0.1 s for these 10 steps at
     111 000 particles): positions and velocities within 1e-5 relative (measured ~1e-15), the group sums within 1e-10."""
+    middle = "classic" not in cfg
+    cfg = cfg.split("-")[0]
     spec = systems.make_config(cfg)
     if hbonds:
-        spec = systems.constrain_hydrogens(spec)
+        spec = systems.rigid_water(spec) if cfg == "C2" else systems.constrain_hydrogens(spec)
     kw = {}
+    if cfg in ("C1", "C2"):
+        kw = dict(maxd=0.0, T=300.0 if cfg == "C2" else 333.0, dt=0.002 if cfg == "C2" else 0.001)
     if cfg == "C5":
         lz = float(spec.box[2])
         kw = dict(mirror=lz / 2, efield=2.0 / lz * 2 * 1.602176634e-22)
-    osys, ctx, it = _pair(spec, prec, True, nsteps=10, cos=cos, **kw)
+    osys, ctx, it = _pair(spec, prec, middle, nsteps=10, cos=cos, **kw)
     try:
         ex, ev = _check(osys, ctx, prec, label=f"full {cfg} cos={cos} hbonds={hbonds} {prec}")
         print(f"full-size {cfg} cos={cos} hbonds={hbonds} {prec}: {spec.num_atoms} particles, rel err pos {ex:.2e} vel {ev:.2e}")
