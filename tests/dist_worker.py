@@ -82,6 +82,7 @@ def mailbox(rank, world):
     I = pkg.integrator
     base = S.drude_il(cells=(1, 1, 1), pairs_per_cell=60, seed=13)
     for label, spec, middle, cos in (("middle", base, True, 0.0), ("classic", base, False, 0.0), ("middle+cos", base, True, 0.02),
+                                     ("full-size C3", S.make_config("C3"), True, 0.0),
                                      ("middle+hbonds", S.constrain_hydrogens(S.drude_il(cells=(1, 1, 1), pairs_per_cell=60, seed=13)), True, 0.0)):
         bounds = D.shard_bounds(spec, world)
         def make(shard):
