@@ -39,7 +39,9 @@ enum {
     VVHIP_ERR_TOPOLOGY = -2,      /* the reference's OpenMMException cases (API:149,155; HOST:519,537,787,801) */
     VVHIP_ERR_UNSUPPORTED = -3,   /* valid for the reference, not implemented here (message says what) */
     VVHIP_ERR_HIP = -4,           /* a HIP runtime call failed */
-    VVHIP_ERR_NO_DEVICE = -5      /* no usable GPU: the product has no CPU path */
+    VVHIP_ERR_NO_DEVICE = -5,     /* no usable GPU: the product has no CPU path */
+    VVHIP_ERR_EXCHANGE = -6,      /* multi-GPU: a mailbox wait on the peers timed out; the ranks have diverged, the run is void (sticky) */
+    VVHIP_ERR_OVERFLOW = -7       /* a fixed-point accumulator left its range (2KE > 1024 x the thermostat target); sticky */
 };
 
 /* OpenMM's CudaPrecision / HipPrecision property (examples/run-bulk.py:78) */
@@ -253,13 +255,23 @@ int vvhip_free(void* ptr);
 int vvhip_memcpy_h2d(void* dst, const void* src, size_t bytes);
 int vvhip_memcpy_d2h(void* dst, const void* src, size_t bytes);
 int vvhip_memset(void* dst, int value, size_t bytes);
-int vvhip_synchronize(vvhip_plan* plan);
+int vvhip_synchronize(vvhip_plan* plan);         /* hipStreamSynchronize + the sticky health check below */
+/* Sticky health flags the kernels raise in pinned host memory (read without synchronising): a mailbox wait on the peers ran out
+ * (VVHIP_ERR_EXCHANGE), a fixed-point accumulator left its range (VVHIP_ERR_OVERFLOW).  vvhip_run_graph / vvhip_run_eager refuse
+ * to start and vvhip_synchronize returns the error once a flag is up; vvhip_status_clear resets them (after the host has
+ * restored a valid state). */
+int vvhip_status(vvhip_plan* plan, int32_t* mailbox_timed_out, int32_t* accumulator_overflow);
+int vvhip_status_clear(vvhip_plan* plan);
 int vvhip_stream_create(void** stream);          /* hipStreamCreateWithFlags(non-blocking) */
 int vvhip_stream_destroy(void* stream);
 int vvhip_synth_tether_force(vvhip_plan* plan, const void* site /* real4[n] */, double k_tether, double k_drude);
 /* Captures `steps_per_graph` steps (optionally with the synthetic force kernel in front of each) into a
  * hipGraph once and replays it; returns after enqueueing.  Middle scheme only. */
 int vvhip_run_graph(vvhip_plan* plan, int nsteps, int steps_per_graph, const void* site, double k_tether, double k_drude);
+/* Captures, instantiates and uploads that graph for BOTH thermostat parities WITHOUT launching anything (no-op for a parity
+ * whose executable is already there).  The plan keeps one executable per parity, so a host that calls this after its warm-up
+ * never pays a capture inside a timed region, whatever mix of replays and odd tails follows; vvhip_run_graph replays floor(nsteps / steps_per_graph) times and enqueues the remainder step by step. */
+int vvhip_graph_prepare(vvhip_plan* plan, int steps_per_graph, const void* site, double k_tether, double k_drude);
 /* Device Gaussian generator for stand-alone hosts (inside OpenMM the buffer and its refills are OpenMM's): Philox4x32-10 +
  * Box-Muller.  vvhip_fill_random refills the bound random buffer; the vvhip_run_* loops refill it themselves whenever a step's
  * slice (max(normalLD,1) + 2 max(pairsLD,1) float4, HOST:806-807,863) no longer fits, and at the start of every captured graph. */

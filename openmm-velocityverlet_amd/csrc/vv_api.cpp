@@ -112,10 +112,17 @@ struct vvhip_plan {
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events[3];
     // captured graph for vvhip_run_graph
-    hipGraphExec_t graph_exec = nullptr;
-    int graph_steps = 0, graph_parity = 0;
-    const void* graph_site = nullptr;
-    double graph_kt = 0, graph_kd = 0;
+    // One executable per thermostat parity (the state is double-buffered by step parity, so a graph captured at parity q only
+    // replays correctly when the plan is at parity q again).  Captured by vvhip_graph_prepare / the first vvhip_run_graph that
+    // needs it, never re-captured while the key (steps, force provider) is unchanged: a run that alternates eager tails and
+    // replays keeps both.
+    struct GraphSlot {
+        hipGraphExec_t exec = nullptr;
+        int steps = 0;
+        const void* site = nullptr;
+        double kt = 0, kd = 0;
+        uint32_t random_end = 0;               // prepareRandomNumbers cursor after the graph's last step
+    } graph[2];
     bool capturing = false;
     // particle sharding over GPUs: RCCL communicator for the accumulator exchange (null = single GPU)
     ncclComm_t comm = nullptr;
@@ -127,6 +134,14 @@ struct vvhip_plan {
     std::vector<void*> mb_opened;                 // hipIpcOpenMemHandle mappings to close
     int mb_ranks = 0, mb_rank = 0;
     bool mb_on = false;
+    // Sticky health word in pinned host memory, written by the kernels with system-scope stores when something goes wrong and
+    // read by the host without synchronising: [0] a mailbox wait on the peers ran out (the ranks have diverged), [1] a fixed-point
+    // accumulator left its range (|sum| x scale >= 2^62: the thermostat would see garbage).  Checked at the entry of the run loops
+    // and in vvhip_synchronize / vvhip_status.
+    unsigned int* h_status = nullptr;
+    unsigned int* d_status = nullptr;             // the same words as the device sees them
+    bool launch_shape_forced = false;             // VVHIP_BLOCK given: keep it at bind
+    int num_cus = 256;                            // hipDeviceProp_t::multiProcessorCount of the bound device
     vv::ChainLaneBlock* d_lane_const = nullptr;   // [3] chain constants per temperature group (kernel B's thermostat wave)
     vv::ChainLaneBlock lane_const_host[VVHIP_NUM_TG] = {};
     bool lane_const_valid = false;
@@ -135,6 +150,11 @@ struct vvhip_plan {
     long long* d_dbg = nullptr;                   // instrumented build only (vvhip_debug_timestamps)
     int dbg_block = 0;
 };
+
+static void drop_graphs(vvhip_plan* p) {
+    for (auto& g : p->graph)
+        if (g.exec) { (void) hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+}
 
 namespace vv { unsigned vv_last_grid_value = 0; }
 static unsigned vv_last_grid() { return vv::vv_last_grid_value; }
@@ -145,6 +165,14 @@ namespace {
 int fail(vvhip_plan* p, int code, const std::string& msg) {
     if (p) p->err = msg;
     return code;
+}
+// Sticky failures the kernels reported through the pinned status word (no synchronisation: the word lives in host memory).
+int check_exchange_health(vvhip_plan* p) {
+    if (!p->h_status) return VVHIP_OK;
+    const unsigned int mb = __atomic_load_n(&p->h_status[0], __ATOMIC_RELAXED), ov = __atomic_load_n(&p->h_status[1], __ATOMIC_RELAXED);
+    if (mb) return fail(p, VVHIP_ERR_EXCHANGE, "multi-GPU mailbox: a wait on the peers' thermostat totals timed out; this rank went on with incomplete sums, the run is void");
+    if (ov) return fail(p, VVHIP_ERR_OVERFLOW, "a fixed-point accumulator overflowed (kinetic energy beyond 1024 x the thermostat target): the thermostat input is invalid");
+    return VVHIP_OK;
 }
 int hip_fail(vvhip_plan* p, hipError_t e, const char* what) {
     return fail(p, e == hipErrorNoDevice || e == hipErrorInvalidDevice ? VVHIP_ERR_NO_DEVICE : VVHIP_ERR_HIP,
@@ -200,10 +228,12 @@ void fill_scales(vvhip_plan* p) {
 // per CU) 74.3 k.  So: k blocks per CU, T tile waves per block (+1 thermostat wave in kernel B, whose 140 VGPRs allow 12 waves
 // per CU), chosen to maximise the fill of the last pass; fewer blocks per CU and larger blocks win ties.
 void pick_launch_shape(vvhip_plan* p) {
-    const int nw = p->hp.info.num_waves, cus = 256;
+    // cus = what the bound device reports (256 on an MI355X in SPX mode; 32 per XCD partition in CPX mode); before vvhip_bind the
+    // plan assumes a whole MI355X.
+    const int nw = p->hp.info.num_waves, cus = p->num_cus;
     if (nw <= cus) { p->block_threads = 64; p->grid_cap_a = p->grid_cap_b = cus; return; }
     // bandwidth-bound regime (the chain runs as its own launch there, kernel B fits 6 waves per SIMD): tuned at 0.9 M / 8.9 M particles
-    if (nw >= p->split_chain_waves) { p->block_threads = 256; p->grid_cap_a = 2048; p->grid_cap_b = 1024; return; }
+    if (nw >= p->split_chain_waves) { p->block_threads = 256; p->grid_cap_a = 8 * cus; p->grid_cap_b = 4 * cus; return; }
     double best = -1;
     int bk = 1, bt = 1;
     for (int k = 1; k <= 4; k++)
@@ -261,6 +291,7 @@ vv::KArgs make_args(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
     a.mb.ctl = p->d_mb_ctl;
     a.mb.ranks = p->mb_ranks;
     a.mb.rank = p->mb_rank;
+    a.status = p->d_status;
     a.dbg = p->d_dbg;
     a.dbg_block = p->dbg_block;
     a.dbg_span = p->d_dbg_span;
@@ -477,7 +508,7 @@ int vvhip_plan_create(const vvhip_system_desc* system, const vvhip_params* param
         pick_launch_shape(p);
         if (const char* e = std::getenv("VVHIP_BLOCK")) {          // tuning experiments
             const int b = std::atoi(e);
-            if (b >= 64 && b <= 448 && b % 64 == 0) { p->block_threads = b; p->grid_cap_a = 2048; p->grid_cap_b = 1024; }
+            if (b >= 64 && b <= 448 && b % 64 == 0) { p->block_threads = b; p->grid_cap_a = 2048; p->grid_cap_b = 1024; p->launch_shape_forced = true; }
         }
         *plan_out = p;
         return VVHIP_OK;
@@ -495,9 +526,10 @@ void vvhip_plan_destroy(vvhip_plan* p) {
         for (void* ptr : {(void*) p->d_slots, (void*) p->d_slot_image, (void*) p->d_slot_rand, (void*) p->d_slot_shake, (void*) p->d_slot_shake_param, (void*) p->d_slot_big, (void*) p->d_bigacc, (void*) p->d_image_pairs,
                           p->d_fextra, p->d_old_delta, p->d_pos_delta, p->d_comv, (void*) p->d_comw, (void*) p->d_seg_mass, (void*) p->d_cosz, (void*) p->d_epoch, (void*) p->d_acc, (void*) p->d_nh, (void*) p->d_lane_const, (void*) p->d_dbg, (void*) p->d_dbg_span})
             if (ptr) (void) hipFree(ptr);
-        if (p->graph_exec) (void) hipGraphExecDestroy(p->graph_exec);
+        drop_graphs(p);
         if (p->comm) (void) rccl_api().commDestroy(p->comm);
         mailbox_release(p);
+        if (p->h_status) (void) hipHostFree(p->h_status);
         for (auto& v : p->events)
             for (auto& e : v) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
     }
@@ -590,6 +622,18 @@ int vvhip_bind(vvhip_plan* p, const vvhip_buffers* b) {
         for (int g = 0; g < 3; g++) { init[c].s.vscale[g] = 1.0; init[c].scales[g] = 1.0; }
     HIP_TRY(p, hipMemcpy(p->d_nh, init, sizeof(init), hipMemcpyHostToDevice));
     HIP_TRY(p, hipMalloc((void**) &p->d_lane_const, VVHIP_NUM_TG * sizeof(vv::ChainLaneBlock)));
+    HIP_TRY(p, hipHostMalloc((void**) &p->h_status, 4 * sizeof(unsigned int), hipHostMallocMapped));
+    std::memset(p->h_status, 0, 4 * sizeof(unsigned int));
+    HIP_TRY(p, hipHostGetDevicePointer((void**) &p->d_status, p->h_status, 0));
+    {   // launch shape for the device this plan is bound to (one block per CU balancing needs the real CU count)
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 &&
+            prop.multiProcessorCount != p->num_cus) {
+            p->num_cus = prop.multiProcessorCount;
+            if (!p->launch_shape_forced) pick_launch_shape(p);
+        }
+    }
     p->bound = true;
     return upload_lane_const(p);
 }
@@ -605,7 +649,7 @@ int vvhip_set_params(vvhip_plan* p, const vvhip_params* q) {
         return fail(p, VVHIP_ERR_TOPOLOGY, "Langevin thermostat and periodic perturbation shouldn't be used together");
     const bool cos_switch = (p->hp.params.cos_acceleration != 0) != (n.cos_acceleration != 0);
     p->hp.params = n;
-    if (p->graph_exec) { (void) hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
+    drop_graphs(p);
     if (cos_switch && p->bound) {        // the accumulator copies are laid out by the rows in use: start the new layout from zeros
         HIP_TRY(p, hipStreamSynchronize(p->stream));
         HIP_TRY(p, hipMemset(p->d_acc, 0, 2 * kAccN * sizeof(unsigned long long)));
@@ -616,7 +660,7 @@ int vvhip_set_params(vvhip_plan* p, const vvhip_params* q) {
 int vvhip_set_box(vvhip_plan* p, const double box[3]) {
     if (!p || !box) return VVHIP_ERR_INVALID;
     for (int i = 0; i < 3; i++) p->box[i] = box[i];
-    if (p->graph_exec) { (void) hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
+    drop_graphs(p);
     return VVHIP_OK;
 }
 
@@ -853,6 +897,19 @@ int vvhip_memset(void* dst, int value, size_t bytes) { return hipMemset(dst, val
 int vvhip_synchronize(vvhip_plan* p) {
     NEED_BOUND(p);
     HIP_TRY(p, hipStreamSynchronize(p->stream));
+    return check_exchange_health(p);      // a mailbox time-out / accumulator overflow of the work just finished surfaces here
+}
+int vvhip_status(vvhip_plan* p, int32_t* mailbox_timed_out, int32_t* accumulator_overflow) {
+    NEED_BOUND(p);
+    if (mailbox_timed_out) *mailbox_timed_out = (int32_t) __atomic_load_n(&p->h_status[0], __ATOMIC_RELAXED);
+    if (accumulator_overflow) *accumulator_overflow = (int32_t) __atomic_load_n(&p->h_status[1], __ATOMIC_RELAXED);
+    return VVHIP_OK;
+}
+int vvhip_status_clear(vvhip_plan* p) {
+    NEED_BOUND(p);
+    HIP_TRY(p, hipStreamSynchronize(p->stream));
+    std::memset(p->h_status, 0, 4 * sizeof(unsigned int));
+    if (p->d_mb_ctl) HIP_TRY(p, hipMemset(p->d_mb_ctl, 0, 4 * sizeof(unsigned int)));
     return VVHIP_OK;
 }
 
@@ -905,50 +962,84 @@ int vvhip_fill_random(vvhip_plan* p) {
     return VVHIP_OK;
 }
 
+// One step of the plan-driven loops (vvhip_run_graph / vvhip_run_eager): force provider + fused step, in the scheme's order.
+static int plan_step(vvhip_plan* p, const void* site, double k_tether, double k_drude, bool refill) {
+    uint32_t ri = 0;
+    TRY(next_random_slice(p, &ri, refill));
+    if (p->hp.params.use_middle_scheme) {
+        if (site) TRY(vvhip_synth_tether_force(p, site, k_tether, k_drude));
+        return vvhip_step_middle(p, ri);
+    }
+    TRY(vvhip_step_vv_first(p));
+    if (site) TRY(vvhip_synth_tether_force(p, site, k_tether, k_drude));
+    return vvhip_step_vv_second(p, ri);
+}
+
+// Capture + instantiate + upload the graph of `steps_per_graph` steps for thermostat parity `q`, unless that slot already holds it.
+// Nothing is launched: the physical state is untouched.
+static int prepare_slot(vvhip_plan* p, int q, int steps_per_graph, const void* site, double k_tether, double k_drude) {
+    hipStream_t s = p->stream;
+    vvhip_plan::GraphSlot& g = p->graph[q & 1];
+    if (g.exec && g.steps == steps_per_graph && g.site == site && g.kt == k_tether && g.kd == k_drude) return VVHIP_OK;
+    if (g.exec) { (void) hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+    // The capture walks the host-side cursors (parity, Langevin random slice) through the graph's steps; they are put back
+    // afterwards, because nothing has run yet.  A replay moves them to the graph's end (vvhip_run_graph).
+    const int parity0 = p->parity;
+    const uint32_t random0 = p->random_pos;
+    const bool fextra_dirty0 = p->fextra_dirty;
+    p->parity = q & 1;
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) { p->parity = parity0; return hip_fail(p, e, "hipStreamBeginCapture"); }
+    p->capturing = true;
+    int rc = VVHIP_OK;
+    // Langevin: a captured graph begins with a refill of the random buffer (the device generator's epoch advances per refill), so every replay draws new numbers
+    for (int i = 0; i < steps_per_graph && rc == VVHIP_OK; i++) rc = plan_step(p, site, k_tether, k_drude, i == 0 && p->hp.has_ld);
+    p->capturing = false;
+    e = hipStreamEndCapture(s, &graph);
+    g.random_end = p->random_pos;
+    p->parity = parity0; p->random_pos = random0; p->fextra_dirty = fextra_dirty0;
+    if (rc != VVHIP_OK) { if (graph) (void) hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) return hip_fail(p, e, "hipStreamEndCapture");
+    e = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+    (void) hipGraphDestroy(graph);
+    if (e != hipSuccess) { g.exec = nullptr; return hip_fail(p, e, "hipGraphInstantiate"); }
+    (void) hipGraphUpload(g.exec, s);                // pay the first launch's set-up here, not in the caller's timed region
+    g.steps = steps_per_graph; g.site = site; g.kt = k_tether; g.kd = k_drude;
+    return VVHIP_OK;
+}
+
+// Both parities' executables, ready to launch.  Hosts call this outside any timed region (bench.py does, after its warm-up);
+// vvhip_run_graph prepares the slot of the current parity itself when it is missing.
+int vvhip_graph_prepare(vvhip_plan* p, int steps_per_graph, const void* site, double k_tether, double k_drude) {
+    NEED_BOUND(p);
+    if (steps_per_graph < 1) return VVHIP_ERR_INVALID;
+    if (steps_per_graph % 2) steps_per_graph += 1;   // the thermostat double-buffers by step parity: a graph must hold an even number of steps
+    if (!p->stream) return fail(p, VVHIP_ERR_INVALID, "graph capture needs a non-null stream in vvhip_buffers.stream");
+    TRY(prepare_slot(p, p->parity, steps_per_graph, site, k_tether, k_drude));
+    return prepare_slot(p, p->parity ^ 1, steps_per_graph, site, k_tether, k_drude);
+}
+
 int vvhip_run_graph(vvhip_plan* p, int nsteps, int steps_per_graph, const void* site, double k_tether, double k_drude) {
     NEED_BOUND(p);
     if (nsteps < 0 || steps_per_graph < 1) return VVHIP_ERR_INVALID;
-    if (steps_per_graph % 2) steps_per_graph += 1;   // the thermostat double-buffers by step parity: a graph must hold an even number of steps
+    if (steps_per_graph % 2) steps_per_graph += 1;
+    TRY(check_exchange_health(p));
     hipStream_t s = p->stream;
     if (!s) return fail(p, VVHIP_ERR_INVALID, "graph capture needs a non-null stream in vvhip_buffers.stream");
     const bool middle = p->hp.params.use_middle_scheme;
     // classic scheme (API:272-338): every step is first half -> forces -> second half, and the first half needs the forces of the
     // current positions; they are (re)computed once per call here, outside the replayed part
     if (!middle && site && nsteps > 0) TRY(vvhip_synth_tether_force(p, site, k_tether, k_drude));
-    bool first_in_graph = false;
-    auto one_step = [&]() -> int {
-        uint32_t ri = 0;
-        TRY(next_random_slice(p, &ri, first_in_graph));      // Langevin: a captured graph begins with a refill, so every replay draws new numbers
-        first_in_graph = false;
-        if (middle) {
-            if (site) TRY(vvhip_synth_tether_force(p, site, k_tether, k_drude));
-            return vvhip_step_middle(p, ri);
-        }
-        TRY(vvhip_step_vv_first(p));
-        if (site) TRY(vvhip_synth_tether_force(p, site, k_tether, k_drude));
-        return vvhip_step_vv_second(p, ri);
-    };
-    if (!p->graph_exec || p->graph_parity != p->parity || p->graph_steps != steps_per_graph || p->graph_site != site || p->graph_kt != k_tether || p->graph_kd != k_drude) {
-        if (p->graph_exec) { (void) hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
-        hipGraph_t g = nullptr;
-        HIP_TRY(p, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        p->capturing = true;
-        p->graph_parity = p->parity;
-        int rc = VVHIP_OK;
-        first_in_graph = p->hp.has_ld;
-        for (int i = 0; i < steps_per_graph && rc == VVHIP_OK; i++) rc = one_step();
-        p->capturing = false;
-        hipError_t e = hipStreamEndCapture(s, &g);
-        if (rc != VVHIP_OK) { if (g) (void) hipGraphDestroy(g); return rc; }
-        if (e != hipSuccess) return hip_fail(p, e, "hipStreamEndCapture");
-        e = hipGraphInstantiate(&p->graph_exec, g, nullptr, nullptr, 0);
-        (void) hipGraphDestroy(g);
-        if (e != hipSuccess) return hip_fail(p, e, "hipGraphInstantiate");
-        p->graph_steps = steps_per_graph; p->graph_site = site; p->graph_kt = k_tether; p->graph_kd = k_drude;
-    }
     int done = 0;
-    for (; done + steps_per_graph <= nsteps; done += steps_per_graph) HIP_TRY(p, hipGraphLaunch(p->graph_exec, s));
-    for (; done < nsteps; done++) TRY(one_step());
+    if (nsteps >= steps_per_graph) {
+        TRY(prepare_slot(p, p->parity, steps_per_graph, site, k_tether, k_drude));     // no-op when the slot of this parity is ready
+        const vvhip_plan::GraphSlot& g = p->graph[p->parity & 1];
+        for (; done + steps_per_graph <= nsteps; done += steps_per_graph) HIP_TRY(p, hipGraphLaunch(g.exec, s));
+        p->random_pos = g.random_end;                // an even number of steps: the parity is where it was
+        if (!middle && extra_flags(p)) p->fextra_dirty = true;
+    }
+    for (; done < nsteps; done++) TRY(plan_step(p, site, k_tether, k_drude, false));
     return VVHIP_OK;
 }
 
@@ -958,7 +1049,8 @@ int vvhip_time_kernel(vvhip_plan* p, int kernel, uint32_t flags, int reps, doubl
     if (flags == 0xFFFFFFFFu) {     // the stage bits vvhip_step_middle uses for this plan
         const uint32_t mom_a = use_moments(p) ? (vv::A_KE | vv::A_KE_MOM) : 0, mom_b = use_moments(p) ? vv::B_KE_MOM : 0;
         if (kernel == 0) flags = vv::A_KICK_FULL | extra_flags(p) | (shake_on(p) ? vv::A_SHAKE_V : 0) | (p->hp.has_nh ? (cos_on(p) ? (vv::A_BIAS | vv::A_CZ_STORE | mom_a) : vv::A_KE) : 0);
-        else flags = vv::B_DRIFT_MIDDLE | tail_flags(p) | (shake_on(p) ? vv::B_SHAKE : 0) | (p->hp.has_nh ? ((p->hp.params.num_nh_chains <= 4 ? vv::B_CHAIN : 0) | vv::B_SCALE | (cos_on(p) ? (vv::B_UNBIAS | vv::B_CZ_LOAD | mom_b) : 0)) : 0);
+        const bool split = p->hp.info.num_waves >= p->split_chain_waves && !use_mailbox(p);    // as run_chain_and_b decides
+        if (kernel != 0) flags = vv::B_DRIFT_MIDDLE | tail_flags(p) | (shake_on(p) ? vv::B_SHAKE : 0) | (p->hp.has_nh ? (((p->hp.params.num_nh_chains <= 4 && !split) ? vv::B_CHAIN : 0) | vv::B_SCALE | (cos_on(p) ? (vv::B_UNBIAS | vv::B_CZ_LOAD | mom_b) : 0)) : 0);
     }
     hipEvent_t e0, e1;
     HIP_TRY(p, hipEventCreate(&e0));
@@ -1078,7 +1170,7 @@ int vvhip_comm_init(vvhip_plan* p, const void* id128, int nranks, int rank) {
     ncclResult_t e = r.commInitRank(&p->comm, nranks, id, rank);
     if (e != ncclSuccess) { p->comm = nullptr; return fail(p, VVHIP_ERR_HIP, std::string("ncclCommInitRank: ") + (r.getErrorString ? r.getErrorString(e) : "error")); }
     p->comm_ranks = nranks;
-    if (p->graph_exec) { (void) hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
+    drop_graphs(p);
     return VVHIP_OK;
 }
 // ---- xGMI mailbox (include/vvhip.h): create -> exchange the 64-byte handles by any means -> connect
@@ -1098,7 +1190,7 @@ int vvhip_mailbox_create(vvhip_plan* p, int nranks, int rank, void* handle64) {
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "the C ABI hands the IPC handle over as 64 bytes");
     HIP_TRY(p, hipStreamSynchronize(p->stream));
     mailbox_release(p);
-    if (p->graph_exec) { (void) hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
+    drop_graphs(p);
     const size_t bytes = (size_t) 2 * nranks * vv::MB_WORDS * sizeof(unsigned long long);
     // uncached: peers' stores land in this GPU's memory over xGMI and must be seen by loads that would otherwise hit in L2
     HIP_TRY(p, hipExtMallocWithFlags((void**) &p->mb_local, std::max(bytes, (size_t) 4096), hipDeviceMallocUncached));
@@ -1148,7 +1240,7 @@ int vvhip_mailbox_status(vvhip_plan* p, int32_t* active, int32_t* timed_out) {
 int vvhip_mailbox_destroy(vvhip_plan* p) {
     NEED_BOUND(p);
     HIP_TRY(p, hipStreamSynchronize(p->stream));
-    if (p->graph_exec) { (void) hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
+    drop_graphs(p);
     mailbox_release(p);
     return VVHIP_OK;
 }
@@ -1161,20 +1253,9 @@ int vvhip_comm_destroy(vvhip_plan* p) {
 int vvhip_run_eager(vvhip_plan* p, int nsteps, const void* site, double k_tether, double k_drude) {
     NEED_BOUND(p);
     if (nsteps < 0) return VVHIP_ERR_INVALID;
-    const bool middle = p->hp.params.use_middle_scheme;
-    if (!middle && site && nsteps > 0) TRY(vvhip_synth_tether_force(p, site, k_tether, k_drude));   // see vvhip_run_graph
-    for (int i = 0; i < nsteps; i++) {
-        uint32_t ri = 0;
-        TRY(next_random_slice(p, &ri, false));
-        if (middle) {
-            if (site) TRY(vvhip_synth_tether_force(p, site, k_tether, k_drude));
-            TRY(vvhip_step_middle(p, ri));
-        } else {
-            TRY(vvhip_step_vv_first(p));
-            if (site) TRY(vvhip_synth_tether_force(p, site, k_tether, k_drude));
-            TRY(vvhip_step_vv_second(p, ri));
-        }
-    }
+    TRY(check_exchange_health(p));
+    if (!p->hp.params.use_middle_scheme && site && nsteps > 0) TRY(vvhip_synth_tether_force(p, site, k_tether, k_drude));   // see vvhip_run_graph
+    for (int i = 0; i < nsteps; i++) TRY(plan_step(p, site, k_tether, k_drude, false));
     return VVHIP_OK;
 }
 

@@ -108,7 +108,7 @@ __device__ __forceinline__ T segment_total(T x, int lane, int first, int last) {
 // Block partials -> fixed-point atomics.  vals[k] is the calling thread's contribution.
 template <int NV>
 __device__ __forceinline__ void block_accumulate(const double (&vals)[NV], const bool (&enabled)[NV],
-                                                 unsigned long long* acc, const double* scale) {
+                                                 unsigned long long* acc, const double* scale, unsigned int* status) {
     __shared__ double red[16][NV];
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -132,7 +132,13 @@ __device__ __forceinline__ void block_accumulate(const double (&vals)[NV], const
 #pragma unroll
         for (int k = 0; k < NV; k++)
             if (enabled[k] && (int) threadIdx.x == k) sc = scale[k];
-        const long long q = __double2ll_rn(s * sc);
+        const double scaled = s * sc;
+        // every block stays below 2^62 / blocks, so the int64 total over all blocks (and ranks <= 16 with 1024x headroom in the scale)
+        // cannot wrap unnoticed; a block beyond that (or a NaN) raises the sticky flag in host memory instead of feeding the
+        // thermostat garbage (vvhip_synchronize / the run loops return VVHIP_ERR_OVERFLOW)
+        if (__builtin_expect(!(fabs(scaled) * (double) gridDim.x < 4611686018427387904.0), 0) && status)
+            __hip_atomic_store(&status[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const long long q = __double2ll_rn(scaled);
         if (q != 0) atomicAdd(&acc[threadIdx.x * ACC_SLOTS + (blockIdx.x & (ACC_SLOTS - 1))], (unsigned long long) q);
     }
 }
@@ -470,7 +476,11 @@ __device__ __forceinline__ void mailbox_exchange(const KArgs& a, int lane, unsig
         for (;;) {
             v = __hip_atomic_load(&box[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if ((unsigned int) (v >> 32) == seq) break;
-            if (dead || wall_clock64() - t0 > 500000000LL) { a.mb.ctl[0] = 1u; break; }      // 100 MHz counter
+            if (dead || wall_clock64() - t0 > 500000000LL) {                                 // 100 MHz counter
+                a.mb.ctl[0] = 1u;
+                if (a.status) __hip_atomic_store(&a.status[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // the host sees it without a sync
+                break;
+            }
             __builtin_amdgcn_s_sleep(1);
         }
         words[i] = (unsigned int) v;
@@ -770,7 +780,7 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const KArgs a) {
         const double vals[NUM_ACC] = {k_atom, k_com, k_drude, k_bias, m_ab[0], m_ab[1], m_ab[2], m_bb[0], m_bb[1], m_bb[2]};
         const bool mom = (F & A_KE_MOM) != 0;
         const bool en[NUM_ACC] = {(F & (A_KE | A_KE_PLAIN)) != 0, (F & A_KE) != 0, (F & A_KE) != 0, (F & A_BIAS) != 0, mom, mom, mom, mom, mom, mom};
-        block_accumulate<NUM_ACC>(vals, en, a.acc, a.acc_scale);
+        block_accumulate<NUM_ACC>(vals, en, a.acc, a.acc_scale, a.status);
     }
     VV_STAMP(threadIdx.x >> 6, 4);
     VV_STAMP_DUMP(threadIdx.x >> 6);

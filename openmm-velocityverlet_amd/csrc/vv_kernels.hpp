@@ -163,6 +163,7 @@ struct KArgs {
     double acc_inv_scale[NUM_ACC];
     NHConst chain;                  // chain constants (used by B_CHAIN)
     Mailbox mb;                     // B_MAILBOX
+    unsigned int* status;           // pinned host words, system-scope stores: [0] mailbox wait timed out, [1] accumulator overflow (sticky)
     long long* dbg;                 // timestamp buffer of the instrumented build (-DVV_KERNEL_TIMESTAMPS, tools/probes), else unused
     int32_t dbg_block, dbg_pad_;
     long long* dbg_span;            // instrumented build: [2 launch parities][blocks*8 waves][2] entry / exit stamps of every wave (100 MHz wall clock)

@@ -334,6 +334,8 @@ class Context:
             old = self.random_index
             self.random_index += cnt
             return old
+        # exhausted: OpenMM's prepareRandomNumbers refills the buffer here; so does this host, with the device generator
+        self.fill_random()
         self.random_index = cnt
         return 0
 
@@ -362,6 +364,21 @@ class Context:
         H.check(H.lib.vvhip_run_graph(self.plan, int(steps), int(steps_per_graph), site, self.k_tether, self.k_drude), self.plan)
         if not self.integrator._useMiddleScheme and site is not None and steps > 0:
             self.forces_valid = True                                # the last force evaluation was at the final positions
+
+    def graph_prepare(self, steps_per_graph: int = 50):
+        """Capture + instantiate + upload the graph for the current thermostat parity without launching it (vvhip_graph_prepare):
+        hosts call it after their warm-up so that no capture ever falls into a timed region."""
+        site = self.site.ptr if self.force_provider == "tether" else None
+        H.check(H.lib.vvhip_graph_prepare(self.plan, int(steps_per_graph), site, self.k_tether, self.k_drude), self.plan)
+
+    def status(self):
+        """(mailbox_timed_out, accumulator_overflow): the sticky health flags, read without synchronising."""
+        a, b = C.c_int32(0), C.c_int32(0)
+        H.check(H.lib.vvhip_status(self.plan, C.byref(a), C.byref(b)), self.plan)
+        return bool(a.value), bool(b.value)
+
+    def status_clear(self):
+        H.check(H.lib.vvhip_status_clear(self.plan), self.plan)
 
     def fill_random(self, seed=None):
         """Refill the Langevin random buffer with the device generator (Philox4x32-10 + Box-Muller)."""

@@ -19,7 +19,7 @@ SINGLE, MIXED, DOUBLE = 0, 1, 2
 PRECISION = {"single": SINGLE, "mixed": MIXED, "double": DOUBLE}
 REAL = {"single": np.float32, "mixed": np.float32, "double": np.float64}
 MIXED_T = {"single": np.float32, "mixed": np.float64, "double": np.float64}
-OK, ERR_INVALID, ERR_TOPOLOGY, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5
+OK, ERR_INVALID, ERR_TOPOLOGY, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE, ERR_EXCHANGE, ERR_OVERFLOW = 0, -1, -2, -3, -4, -5, -6, -7
 
 # stage bits of csrc/vv_kernels.hpp (only the test hooks need them)
 A_FE_LOAD, A_FE_STORE, A_LD, A_EF, A_COS, A_KICK_FULL, A_KICK_HALF, A_POSDELTA_VV, A_POS1, A_BIAS, A_KE, A_UNBIAS_ACC, A_COMPART, A_CZ_STORE, A_CZ_LOAD = \
@@ -116,6 +116,8 @@ def _load():
         "vvhip_stream_create": [P(vp)], "vvhip_stream_destroy": [vp],
         "vvhip_synth_tether_force": [vp, vp, dbl, dbl],
         "vvhip_run_graph": [vp, C.c_int, C.c_int, vp, dbl, dbl],
+        "vvhip_graph_prepare": [vp, C.c_int, vp, dbl, dbl],
+        "vvhip_status": [vp, P(i32), P(i32)], "vvhip_status_clear": [vp],
         "vvhip_run_eager": [vp, C.c_int, vp, dbl, dbl],
         "vvhip_run_eager_unfused": [vp, C.c_int, vp, dbl, dbl],
         "vvhip_set_random_seed": [vp, C.c_uint64], "vvhip_fill_random": [vp],

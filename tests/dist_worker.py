@@ -135,10 +135,22 @@ def mailbox(rank, world):
     if rank == 0:
         t0 = time.perf_counter()
         it.step(3)
-        ctx.synchronize()
+        try:                                         # the failure surfaces as an error code on the next host call that looks
+            ctx.synchronize()
+            raise AssertionError("vvhip_synchronize did not report the timed-out exchange")
+        except pkg.vvhip.VVHipError as e:
+            assert e.code == pkg.vvhip.ERR_EXCHANGE, e
         waited = time.perf_counter() - t0
-        assert ctx.mailbox_status() == (True, True)
+        assert ctx.status() == (True, False)
         assert 3.0 < waited < 12.0, waited          # one ~5 s wait, the following steps do not wait again
+        for call in (lambda: ctx.run_eager(1), lambda: ctx.run_graph(8, 8)):     # the run loops refuse to continue a void run
+            try:
+                call()
+                raise AssertionError("a run loop started on a plan whose exchange had timed out")
+            except pkg.vvhip.VVHipError as e:
+                assert e.code == pkg.vvhip.ERR_EXCHANGE, e
+        ctx.status_clear()
+        assert ctx.status() == (False, False)
         print(f"absent peer: reported after {waited:.1f} s", flush=True)
     dist.barrier()
     ctx.mailbox_destroy()
