@@ -157,6 +157,11 @@ int vvhip_plan_get_slots(const vvhip_plan* plan, int32_t* slots, int32_t capacit
 int vvhip_bind(vvhip_plan* plan, const vvhip_buffers* buffers);
 int vvhip_set_params(vvhip_plan* plan, const vvhip_params* params);
 int vvhip_set_box(vvhip_plan* plan, const double box[3]);      /* cu.getPeriodicBoxSize() (HOST:1057,1129) */
+/* The plan caches, per work-item, the mass RECIP(velm.w) and the Drude-pair mass fractions (filled on the device from velm.w in
+ * front of the first launch that needs them; the reference recomputes them in every kernel, K/drudeNoseHoover.cu:173-180).  A host
+ * that rewrites the inverse masses in velm.w (OpenMM does so only in Context::reinitialize, which rebuilds the kernels anyway)
+ * calls this; binding a different velm array does it implicitly. */
+int vvhip_masses_changed(vvhip_plan* plan);
 /* Blocking copies of the thermostat state (checkpoint / tests). */
 int vvhip_get_nh_state(vvhip_plan* plan, vvhip_nh_state* out);
 int vvhip_set_nh_state(vvhip_plan* plan, const vvhip_nh_state* in);

@@ -99,6 +99,10 @@ struct vvhip_plan {
     void* d_old_delta = nullptr;
     void* d_pos_delta = nullptr;   // used when the caller does not supply one
     void* d_comv = nullptr;        // per-segment COM velocities handed from kernel A to kernel B
+    double* d_slot_m = nullptr;    // static per-lane RECIP(velm.w) (vv_kernels.hpp: A_MTAB), filled on the device from velm.w
+    double* d_slot_f = nullptr;    // static per-lane Drude-pair mass fraction (A_MTAB / B_MTAB)
+    bool mass_tab_a = false, mass_tab_b = true;   // kernel A / B launches read the tables (defaults follow the build; VVHIP_MTAB_A / VVHIP_MTAB_B override: comparison runs)
+    bool mass_tab_valid = false;   // tables match the bound velm.w (vvhip_bind / vvhip_masses_changed reset it)
     double* d_seg_mass = nullptr;  // static (mass, 1/mass) per COM segment
     double* d_comw = nullptr;      // per-segment mass-weighted mean of cos(kz) (moment form of the cos perturbation)
     double* d_cosz = nullptr;      // per-lane cos(2 pi z / Lz) of the current step
@@ -182,6 +186,11 @@ int hip_fail(vvhip_plan* p, hipError_t e, const char* what) {
     do {                                                         \
         hipError_t e_ = (call);                                  \
         if (e_ != hipSuccess) return hip_fail(p, e_, #call);     \
+    } while (0)
+#define TRY(x)                       \
+    do {                             \
+        int rc_ = (x);               \
+        if (rc_ != VVHIP_OK) return rc_; \
     } while (0)
 #define NEED_BOUND(p)                                                                  \
     do {                                                                               \
@@ -270,6 +279,8 @@ vv::KArgs make_args(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
     a.seg_mass = p->d_seg_mass;
     a.cosz = p->d_cosz;
     a.slots = p->d_slots;
+    a.slot_m = p->d_slot_m;
+    a.slot_f = p->d_slot_f;
     a.slot_image = p->d_slot_image;
     a.slot_rand = p->d_slot_rand;
     a.slot_shake = p->d_slot_shake;
@@ -397,13 +408,24 @@ struct ScopedTimer {
     }
 };
 
+// The static mass tables are filled lazily, right in front of the first stage launch that reads them (by then velm.w is what the
+// host integrates with); inside a graph capture that would record the fill into every replay, so the capture entry points call this first.
+int ensure_mass_table(vvhip_plan* p) {
+    if (!(p->mass_tab_a || p->mass_tab_b) || p->mass_tab_valid) return VVHIP_OK;
+    if (p->capturing) return fail(p, VVHIP_ERR_INVALID, "internal: mass tables must be filled before a graph capture starts");
+    HIP_TRY(p, vv::launch_mass_table(p->hp.precision, p->buf.velm, p->d_slots, p->hp.info.num_waves, p->d_slot_m, p->d_slot_f, p->stream));
+    p->mass_tab_valid = true;
+    return VVHIP_OK;
+}
 int run_a(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
+    if (p->mass_tab_a) { flags |= vv::A_MTAB; TRY(ensure_mass_table(p)); }
     if (p->wt_stores && (flags & (vv::A_KICK_FULL | vv::A_KICK_HALF))) flags |= vv::A_WT_STORES;
     ScopedTimer t(p, T_A);
     HIP_TRY(p, vv::launch_a(p->hp.precision, make_args(p, flags, random_index), p->block_threads, p->grid_cap_a, p->stream));
     return VVHIP_OK;
 }
 int run_b(vvhip_plan* p, uint32_t flags) {
+    if (p->mass_tab_b) { flags |= vv::B_MTAB; TRY(ensure_mass_table(p)); }
     if (p->wt_stores) flags |= vv::B_WT_STORES;
     ScopedTimer t(p, T_B);
     HIP_TRY(p, vv::launch_b(p->hp.precision, make_args(p, flags, 0), p->block_threads, p->grid_cap_b, p->stream));
@@ -477,12 +499,6 @@ bool shake_on(const vvhip_plan* p) { return !p->hp.slot_shake.empty(); }
             return fail(p, VVHIP_ERR_UNSUPPORTED, "the System has constraints this backend cannot solve in-kernel: use the split entry points around the host's constraint solver"); \
     } while (0)
 
-#define TRY(x)                       \
-    do {                             \
-        int rc_ = (x);               \
-        if (rc_ != VVHIP_OK) return rc_; \
-    } while (0)
-
 }  // namespace
 
 extern "C" {
@@ -503,6 +519,10 @@ int vvhip_plan_create(const vvhip_system_desc* system, const vvhip_params* param
         fill_scales(p);
         if (const char* e = std::getenv("VVHIP_WT")) p->wt_stores = std::atoi(e) != 0;
         if (const char* e = std::getenv("VVHIP_NO_MOMENTS")) p->no_moments = std::atoi(e) != 0;
+        p->mass_tab_a = vv::sf_kernels_use_mass_table(0);
+        p->mass_tab_b = vv::sf_kernels_use_mass_table(1);
+        if (const char* e = std::getenv("VVHIP_MTAB_A")) p->mass_tab_a = std::atoi(e) != 0;
+        if (const char* e = std::getenv("VVHIP_MTAB_B")) p->mass_tab_b = std::atoi(e) != 0;
         if (const char* e = std::getenv("VVHIP_ROCTX")) p->trace = std::atoi(e) != 0;
         if (const char* e = std::getenv("VVHIP_SPLIT_CHAIN_WAVES")) p->split_chain_waves = std::atoi(e);
         pick_launch_shape(p);
@@ -524,7 +544,7 @@ void vvhip_plan_destroy(vvhip_plan* p) {
     if (p->bound) {
         (void) hipStreamSynchronize(p->stream);
         for (void* ptr : {(void*) p->d_slots, (void*) p->d_slot_image, (void*) p->d_slot_rand, (void*) p->d_slot_shake, (void*) p->d_slot_shake_param, (void*) p->d_slot_big, (void*) p->d_bigacc, (void*) p->d_image_pairs,
-                          p->d_fextra, p->d_old_delta, p->d_pos_delta, p->d_comv, (void*) p->d_comw, (void*) p->d_seg_mass, (void*) p->d_cosz, (void*) p->d_epoch, (void*) p->d_acc, (void*) p->d_nh, (void*) p->d_lane_const, (void*) p->d_dbg, (void*) p->d_dbg_span})
+                          p->d_fextra, p->d_old_delta, p->d_pos_delta, p->d_comv, (void*) p->d_comw, (void*) p->d_seg_mass, (void*) p->d_slot_m, (void*) p->d_slot_f, (void*) p->d_cosz, (void*) p->d_epoch, (void*) p->d_acc, (void*) p->d_nh, (void*) p->d_lane_const, (void*) p->d_dbg, (void*) p->d_dbg_span})
             if (ptr) (void) hipFree(ptr);
         drop_graphs(p);
         if (p->comm) (void) rccl_api().commDestroy(p->comm);
@@ -565,6 +585,7 @@ int vvhip_bind(vvhip_plan* p, const vvhip_buffers* b) {
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0)
         return fail(p, VVHIP_ERR_NO_DEVICE, "no HIP device: libvvhip has no CPU path");
+    if (p->bound && b->velm != p->buf.velm) { p->mass_tab_valid = false; drop_graphs(p); }   // another velm array: its inverse masses are re-read
     p->buf = *b;
     p->stream = (hipStream_t) b->stream;
     if (p->bound) return VVHIP_OK;      // re-binding only swaps the caller-owned pointers
@@ -608,6 +629,8 @@ int vvhip_bind(vvhip_plan* p, const vvhip_buffers* b) {
     HIP_TRY(p, hipMemset(p->d_comv, 0, nslots * 4 * ms));
     HIP_TRY(p, hipMalloc((void**) &p->d_seg_mass, hp.seg_mass.size() * sizeof(double)));
     HIP_TRY(p, hipMemcpy(p->d_seg_mass, hp.seg_mass.data(), hp.seg_mass.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(p, hipMalloc((void**) &p->d_slot_m, nslots * sizeof(double)));
+    HIP_TRY(p, hipMalloc((void**) &p->d_slot_f, nslots * sizeof(double)));
     HIP_TRY(p, hipMalloc((void**) &p->d_comw, nslots * sizeof(double)));
     HIP_TRY(p, hipMemset(p->d_comw, 0, nslots * sizeof(double)));
     HIP_TRY(p, hipMalloc(&p->d_pos_delta, nloc * 4 * ms));
@@ -664,6 +687,13 @@ int vvhip_set_box(vvhip_plan* p, const double box[3]) {
     return VVHIP_OK;
 }
 
+int vvhip_masses_changed(vvhip_plan* p) {
+    if (!p) return VVHIP_ERR_INVALID;
+    p->mass_tab_valid = false;                       // refilled from velm.w in front of the next stage launch
+    drop_graphs(p);
+    return VVHIP_OK;
+}
+
 int vvhip_get_nh_state(vvhip_plan* p, vvhip_nh_state* out) {
     NEED_BOUND(p);
     HIP_TRY(p, hipStreamSynchronize(p->stream));
@@ -673,7 +703,10 @@ int vvhip_get_nh_state(vvhip_plan* p, vvhip_nh_state* out) {
 int vvhip_set_nh_state(vvhip_plan* p, const vvhip_nh_state* in) {
     NEED_BOUND(p);
     HIP_TRY(p, hipStreamSynchronize(p->stream));
-    HIP_TRY(p, hipMemcpy(&p->d_nh[p->parity].s, in, sizeof(*in), hipMemcpyHostToDevice));
+    vvhip_nh_state st = *in;
+    for (int g = 0; g < VVHIP_NUM_TG; g++)            // the chain's closing element is 0 by construction (API:340-376 never writes it)
+        for (int i = std::max(0, std::min(p->hp.params.num_nh_chains, VVHIP_MAX_CHAINS)); i <= VVHIP_MAX_CHAINS; i++) st.eta_dot[g][i] = 0.0;
+    HIP_TRY(p, hipMemcpy(&p->d_nh[p->parity].s, &st, sizeof(st), hipMemcpyHostToDevice));
     return VVHIP_OK;
 }
 
@@ -979,6 +1012,7 @@ static int plan_step(vvhip_plan* p, const void* site, double k_tether, double k_
 // Nothing is launched: the physical state is untouched.
 static int prepare_slot(vvhip_plan* p, int q, int steps_per_graph, const void* site, double k_tether, double k_drude) {
     hipStream_t s = p->stream;
+    TRY(ensure_mass_table(p));                       // a one-off fill must not be recorded into the replayed graph
     vvhip_plan::GraphSlot& g = p->graph[q & 1];
     if (g.exec && g.steps == steps_per_graph && g.site == site && g.kt == k_tether && g.kd == k_drude) return VVHIP_OK;
     if (g.exec) { (void) hipGraphExecDestroy(g.exec); g.exec = nullptr; }

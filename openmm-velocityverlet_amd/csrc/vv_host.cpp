@@ -424,7 +424,6 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
             hp.seg_mass[((size_t) wave * 64 + first_lane) * 2] = m;
             hp.seg_mass[((size_t) wave * 64 + first_lane) * 2 + 1] = m != 0 ? 1.0 / m : 0.0;
         }
-        bool leader_set = false;
         for (int k = 0; k < sz; k++, lane++) {
             const int i = c.members[k];
             uint32_t role;
@@ -443,7 +442,7 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
             meta |= (uint32_t) sl << META_SEGLAST_SHIFT;
             if (is_el[i]) meta |= META_EFIELD;
             if (image_of[i] >= 0) meta |= META_HAS_IMAGE;
-            if (c.com_segment && !leader_set) { meta |= META_COM_LEADER; leader_set = true; }
+            if (c.com_segment && k == sz - 1) meta |= META_COM_LEADER;      // the LAST lane: its wave-prefix value already ends the segment (kernel A's KE stage)
             if (in_pair[i]) meta |= META_PAIR;
             if (is_drude[i]) meta |= META_IS_DRUDE;
             if (massive) meta |= META_MASSIVE;

@@ -72,15 +72,24 @@ __device__ __forceinline__ double shfl(double x, int src) { return __shfl(x, src
 // ---- wave-wide inclusive prefix sum on the DPP network (no LDS round trips): Hillis-Steele inside each 16-lane
 // row (row_shr 1,2,4,8; lanes without a source add 0), then row 0 -> row 1 / row 2 -> row 3 (row_bcast:15) and
 // rows 0+1 -> rows 2,3 (row_bcast:31).  Lane 63 ends up with the wave total.
+// ROW_MASK 0xF with bound_ctrl writes EVERY lane (lanes without a source read 0), so the destination needs no initial value:
+// __builtin_amdgcn_mov_dpp.  The two row_bcast steps write only some rows; there the unwritten lanes must read 0, which costs a
+// zeroing move per 32-bit half (update_dpp with old = 0).  Using update_dpp everywhere, as round 1 did, put those moves into all
+// 6 steps of every scan (24 instructions per 64-bit scan instead of 20).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_fetch32(int v) {
+    if (ROW_MASK == 0xF) return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true);
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, true);
+}
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_fetch(double x) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROW_MASK, 0xF, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, 0xF, true);
+    const int lo = dpp_fetch32<CTRL, ROW_MASK>(__double2loint(x));
+    const int hi = dpp_fetch32<CTRL, ROW_MASK>(__double2hiint(x));
     return __hiloint2double(hi, lo);
 }
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_fetch(float x) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xF, true));
+    return __int_as_float(dpp_fetch32<CTRL, ROW_MASK>(__float_as_int(x)));
 }
 template <class T>
 __device__ __forceinline__ T wave_scan(T x) {
@@ -91,6 +100,15 @@ __device__ __forceinline__ T wave_scan(T x) {
     x += dpp_fetch<0x142, 0xA>(x);   // row_bcast:15 into rows 1 and 3
     x += dpp_fetch<0x143, 0xC>(x);   // row_bcast:31 into rows 2 and 3
     return x;
+}
+// Three independent scans, step by step side by side: the compiler keeps the order of the source, and a DPP read needs two wait
+// states after the VALU write of its source -- alone, every step of a scan is followed by an s_nop and a dependent add; three
+// interleaved scans fill each other's gaps.
+template <class T>
+__device__ __forceinline__ void wave_scan3(T& x, T& y, T& z) {
+#define VV_SCAN_STEP(CTRL, MASK) { const T dx_ = dpp_fetch<CTRL, MASK>(x), dy_ = dpp_fetch<CTRL, MASK>(y), dz_ = dpp_fetch<CTRL, MASK>(z); x += dx_; y += dy_; z += dz_; }
+    VV_SCAN_STEP(0x111, 0xF) VV_SCAN_STEP(0x112, 0xF) VV_SCAN_STEP(0x114, 0xF) VV_SCAN_STEP(0x118, 0xF) VV_SCAN_STEP(0x142, 0xA) VV_SCAN_STEP(0x143, 0xC)
+#undef VV_SCAN_STEP
 }
 // total of a wave in lane 63
 __device__ __forceinline__ double wave_sum(double x) { return wave_scan(x); }
@@ -112,9 +130,15 @@ __device__ __forceinline__ void block_accumulate(const double (&vals)[NV], const
     __shared__ double red[16][NV];
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    // the three kinetic-energy sums side by side (wave_scan3), the rest one by one
+    if (NV >= 3 && enabled[0] && enabled[1] && enabled[2]) {
+        double s0 = vals[0], s1 = vals[1], s2 = vals[2];
+        wave_scan3(s0, s1, s2);
+        if (lane == 63) { red[w][0] = s0; red[w][1] = s1; red[w][2] = s2; }
+    }
 #pragma unroll
     for (int k = 0; k < NV; k++) {
-        if (!enabled[k]) continue;           // compile-time in the specialised kernels
+        if (!enabled[k] || (k < 3 && enabled[0] && enabled[1] && enabled[2])) continue;           // compile-time in the specialised kernels
         double s = wave_sum(vals[k]);
         if (lane == 63) red[w][k] = s;
     }
@@ -147,8 +171,8 @@ __device__ __forceinline__ void block_accumulate(const double (&vals)[NV], const
 // total taken from lane 63).
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ long long dpp_fetch_i64(long long x) {
-    const int lo = __builtin_amdgcn_update_dpp(0, (int) (x & 0xFFFFFFFFll), CTRL, ROW_MASK, 0xF, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int) (x >> 32), CTRL, ROW_MASK, 0xF, true);
+    const int lo = dpp_fetch32<CTRL, ROW_MASK>((int) (x & 0xFFFFFFFFll));
+    const int hi = dpp_fetch32<CTRL, ROW_MASK>((int) (x >> 32));
     return ((long long) hi << 32) | (unsigned int) lo;
 }
 __device__ __forceinline__ long long acc_total(const unsigned long long* acc, int k, int lane) {
@@ -167,25 +191,6 @@ __device__ __forceinline__ long long acc_total(const unsigned long long* acc, in
 template <class real>
 __device__ __forceinline__ double cos_kz(real z, real inv_box_z) {
     return cos(2 * 3.1415926 * z * inv_box_z);   // literal pi and double cosine in every mode (quirk Q2)
-}
-
-// Molecular centre-of-mass velocity of this lane's segment (K/drudeNoseHoover.cu:5-31):
-// V = (sum m v) * RECIP(sum m), with comVelm.w = RECIP(sum m).
-template <class real, class mixed>
-__device__ __forceinline__ void com_velocity(bool contributes, mixed vx, mixed vy, mixed vz, mixed w, int lane,
-                                             unsigned meta, mixed seg_m, mixed seg_w, mixed& Vx, mixed& Vy, mixed& Vz, mixed& Vw, mixed& Vm) {
-    const int first = (meta >> META_SEGFIRST_SHIFT) & 63, last = (meta >> META_SEGLAST_SHIFT) & 63;
-    mixed mx = 0, my = 0, mz = 0;
-    if (contributes) {
-        const mixed mass = Prec<real>::RECIP_SUM(w);
-        mx = vx * mass; my = vy * mass; mz = vz * mass;
-    }
-    mx = segment_total(mx, lane, first, last);
-    my = segment_total(my, lane, first, last);
-    mz = segment_total(mz, lane, first, last);
-    Vm = seg_m;                 // the segment's mass is static: summed once on the host (vv_host.hpp: seg_mass), not scanned every step
-    Vw = seg_w;
-    Vx = mx * Vw; Vy = my * Vw; Vz = mz * Vw;
 }
 
 // positions are posq (+ posqCorrection in mixed mode): K/middle.cu:81-96
@@ -505,6 +510,8 @@ __shared__ long long vv_stamps[8][16];
 #define VV_STAMP_ON (a.dbg && (int) blockIdx.x == a.dbg_block && (threadIdx.x & 63) == 0)
 #define VV_STAMP(w, k) do { if (VV_STAMP_ON) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); vv_stamps[w][k] = (long long) __builtin_readcyclecounter(); } } while (0)
 #define VV_STAMP_NOWAIT(w, k) do { if (VV_STAMP_ON) { vv_stamps[w][k] = (long long) __builtin_readcyclecounter(); } } while (0)
+// stamp that cannot be taken before `val` has been computed (pure arithmetic is free to move across the other forms)
+#define VV_STAMP_AFTER(w, k, val) do { asm volatile("" :: "v"(val) : "memory"); if (VV_STAMP_ON) { vv_stamps[w][k] = (long long) __builtin_readcyclecounter(); } asm volatile("" ::: "memory"); } while (0)
 #define VV_STAMP_DUMP(w) do { if (VV_STAMP_ON) { for (int k_ = 0; k_ < 16; k_++) a.dbg[(w) * 16 + k_] = vv_stamps[w][k_]; } } while (0)
 // entry time stays in a register; both stamps are stored when the wave ends (after its memory operations have drained)
 #define VV_SPAN_BEGIN const long long vv_span_t0 = a.dbg_span ? (long long) wall_clock64() : 0
@@ -514,6 +521,7 @@ __shared__ long long vv_stamps[8][16];
 #else
 #define VV_STAMP(w, k) do { } while (0)
 #define VV_STAMP_NOWAIT(w, k) do { } while (0)
+#define VV_STAMP_AFTER(w, k, val) do { } while (0)
 #define VV_STAMP_DUMP(w) do { } while (0)
 #define VV_SPAN_BEGIN do { } while (0)
 #define VV_SPAN_END do { } while (0)
@@ -561,9 +569,20 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const KArgs a) {
             if (role != ROLE_LD_NORMAL) rnd_b = a.random[ri + 1];
         }
         double2 seg_mw = {0, 0};                 // (mass, 1/mass) of this lane's COM segment, one 16-byte entry per segment
-        if ((F & A_KE) && act) seg_mw = ((const double2*) a.seg_mass)[(size_t) wave * 64 + ((meta >> META_SEGFIRST_SHIFT) & 63)];
+        if ((F & A_KE) && act && (meta & META_COM_LEADER)) seg_mw = ((const double2*) a.seg_mass)[(size_t) wave * 64 + ((meta >> META_SEGFIRST_SHIFT) & 63)];
+        // Static per-lane masses (A_MTAB): m = RECIP(velm.w) and, for the members of a Drude pair, the mass fraction m / (m1 + m2), both
+        // formed ONCE by vv_kernel_mass_table with the very operations the stages below used to repeat every step (IEEE quotients of the
+        // mode's `mixed` type), so every value is bit-identical to the per-step one; velm.w never changes during a run.
+        mixed tab_m = 0, tab_f = 0;
+        if ((F & A_MTAB) && (F & (A_KE | A_BIAS | A_COS | A_LD | A_KE_PLAIN | A_COMPART)) && act && (meta & META_MASSIVE)) {
+            tab_m = (mixed) a.slot_m[(size_t) wave * 64 + lane];
+            if ((F & A_KE) && (meta & META_PAIR)) tab_f = (mixed) a.slot_f[(size_t) wave * 64 + lane];
+        }
         const bool massive = act && v.w != 0;
         const mixed stepSize = (mixed) a.dt;
+        // own mass: bit-exact form (feeds element-wise results) and the form for quantities that only feed reductions
+        auto mass_exact = [&]() -> mixed { return (F & A_MTAB) ? tab_m : P::RECIP(v.w); };
+        auto mass_sum = [&]() -> mixed { return (F & A_MTAB) ? tab_m : P::RECIP_SUM(v.w); };
 
         real4 pq = {0, 0, 0, 0};
         const bool need_pos = ((F & (A_COS | A_BIAS | A_UNBIAS_ACC)) && !(F & A_CZ_LOAD)) || ((F & A_EF) && (meta & META_EFIELD));
@@ -583,7 +602,7 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const KArgs a) {
             const mixed dragFactor = (mixed) a.drag, randFactor = (mixed) a.randf;
             const mixed dragFactorDrude = (mixed) a.drag_drude, randFactorDrude = (mixed) a.randf_drude;
             if (role == ROLE_LD_NORMAL && massive) {                        // K/drudeLangevin.cu:14-25
-                const mixed mass = P::RECIP(v.w);
+                const mixed mass = mass_exact();
                 const mixed sqrtMass = P::SQRT(mass);
                 const float4 rnd = rnd_a;
                 fe.x += (-dragFactor * mass * v.x + randFactor * sqrtMass * rnd.x);
@@ -624,7 +643,7 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const KArgs a) {
         if ((F & A_EF) && act && (meta & META_EFIELD))                      // K/electricField.cu:8-10
             fe.z += (real) a.efscale * pq.w;
         if ((F & A_COS) && massive)                                         // K/cosineAccelerate.cu:9
-            fe.x += (real) a.cos_accel * czl * P::RECIP(v.w);
+            fe.x += (real) a.cos_accel * czl * mass_exact();
         if ((F & A_FE_STORE) && act) ((real3*) a.fextra)[atom] = fe;
 
         // ---------------- kick
@@ -671,7 +690,7 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const KArgs a) {
 
         // ---------------- periodic bias moment (K/cosineAccelerate.cu:24-27; massless -> 0)
         if ((F & A_BIAS) && massive) {
-            const mixed t = P::RECIP(v.w) * v.x * 2 * czl;
+            const mixed t = mass_exact() * v.x * 2 * czl;
             k_bias += (double) t;
         }
 
@@ -685,7 +704,7 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const KArgs a) {
             }
             const int first = (meta >> META_SEGFIRST_SHIFT) & 63, last = (meta >> META_SEGLAST_SHIFT) & 63;
             mixed mass = 0, mx = 0, my = 0, mz = 0;
-            if (nhb && massive) { mass = P::RECIP(v.w); mx = bx * mass; my = v.y * mass; mz = v.z * mass; }
+            if (nhb && massive) { mass = mass_exact(); mx = bx * mass; my = v.y * mass; mz = v.z * mass; }
             mx = segment_total(mx, lane, first, last); my = segment_total(my, lane, first, last);
             mz = segment_total(mz, lane, first, last); mass = segment_total(mass, lane, first, last);
             if (nhb && (meta & META_COM_LEADER)) {
@@ -699,85 +718,93 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const KArgs a) {
 
         VV_STAMP(threadIdx.x >> 6, 2);
         // ---------------- plain kinetic energy of everything massive: sum m v^2 (OpenMM's computeKineticEnergy(0) is half of it)
-        if ((F & A_KE_PLAIN) && massive) k_atom += (double) ((v.x * v.x + v.y * v.y + v.z * v.z) * P::RECIP(v.w));
+        if ((F & A_KE_PLAIN) && massive) k_atom += (double) ((v.x * v.x + v.y * v.y + v.z * v.z) * mass_exact());
 
-        // ---------------- kinetic energies of the thermostat groups
+        // ---------------- kinetic energies of the thermostat groups (K/drudeNoseHoover.cu:33-151)
+        // The reference forms, per particle, the velocity relative to the molecular centre of mass, splits every Drude pair into its
+        // centre-of-mass and relative motion and squares those.  All three group sums are quadratic forms, and Koenig's theorem turns
+        // them into sums that need far less per-lane work (this stage was 85 % of kernel A's instructions, and at the headline size
+        // the kernel is VALU-issue bound):
+        //     sum_bodies M_b (c_b - V)^2 = sum_lanes m u^2 - sum_pairs mu r^2 - sum_molecules M V^2          (2KE of group "atom")
+        // with r = u_parent - u_drude (the molecular V cancels), mu the pair's reduced mass and V = P / M the molecular COM velocity
+        // from the segment's momentum P.  So every thermostatted lane adds m u^2, the Drude lane of a pair adds mu r^2 to the Drude
+        // group, and the LAST lane of a molecule's segment (the COM leader, vv_host.cpp) takes P = S[last] - S[first-1] from the wave
+        // prefix sum of the momenta, stores V for kernel B and adds M V^2 to the COM group; the three differences are formed per lane
+        // before the block reduction.  Nothing is broadcast back to the lanes and no pair COM is built.  Reductions only: the sums
+        // agree with the reference's to rounding (~1e-15 relative), like every other summation order.
         if (F & A_KE) {
             const bool nh = role == ROLE_NH_NORMAL || role == ROLE_NH_DRUDE || role == ROLE_NH_PARENT;
-            mixed ux = v.x, uy = v.y, uz = v.z;
+            mixed ux = v.x;
             if (F & A_UNBIAS_ACC) {                                         // K/cosineAccelerate.cu:53-58, 69-71
                 // same expression as the chain kernel writes to scales[3], so kernel B removes exactly this V
                 const mixed V = (mixed) ((double) acc_total(a.acc, 3, lane) * a.acc_inv_scale[3] * a.inv_mass_total);
                 if (act) ux -= V * czl;
             }
-            mixed Vx = 0, Vy = 0, Vz = 0, Vw = 0, Vm = 0;
-            const bool use_com = ((meta >> META_SEGFIRST_SHIFT) & 63) != ((meta >> META_SEGLAST_SHIFT) & 63) ||
-                                 (meta & META_COM_LEADER);
-            // the COM stage is wave-uniform on purpose: lanes outside a COM segment scan a 1-lane segment
-            com_velocity<real, mixed>(nh && massive && use_com, ux, uy, uz, v.w, lane, meta, (mixed) seg_mw.x, (mixed) seg_mw.y, Vx, Vy, Vz, Vw, Vm);
-            if (!use_com) { Vx = 0; Vy = 0; Vz = 0; Vw = 0; }
-            if (a.slot_big && (meta & META_BIGMOL) && nh) {     // molecule spread over several waves: totals from the accumulator
-                const unsigned long long* src = a.bigacc + 4 * (size_t) a.slot_big[(size_t) wave * 64 + lane];
-                const mixed sx = (mixed) ((double) (long long) src[0] * a.big_inv_scale), sy = (mixed) ((double) (long long) src[1] * a.big_inv_scale);
-                const mixed sz = (mixed) ((double) (long long) src[2] * a.big_inv_scale), sm = (mixed) ((double) (long long) src[3] * a.big_inv_scale);
-                Vm = sm;
-                Vw = P::RECIP(sm);
-                Vx = sx * Vw; Vy = sy * Vw; Vz = sz * Vw;
+            const int first = (meta >> META_SEGFIRST_SHIFT) & 63, last = (meta >> META_SEGLAST_SHIFT) & 63;
+            const bool use_com = first != last || (meta & META_COM_LEADER);
+            const bool leader = use_com && (meta & META_COM_LEADER);       // the last lane of its segment
+            const bool contrib = nh && massive;
+            const mixed own_mass = massive ? mass_sum() : (mixed) 0;
+            const mixed wx = ((F & A_KE_MOM) && act) ? (mixed) czl : (mixed) 0;      // the field of the cos perturbation, (cos kz, 0, 0)
+            mixed px = 0, py = 0, pz = 0, pw = 0;
+            if (contrib) {
+                px = ux * own_mass; py = v.y * own_mass; pz = v.z * own_mass;
+                k_atom += (double) (px * ux + py * v.y + pz * v.z);
+                if (F & A_KE_MOM) { pw = wx * own_mass; m_ab[0] += (double) (px * wx); m_bb[0] += (double) (pw * wx); }
             }
-            if ((meta & META_COM_LEADER) && use_com) {      // hand the COM velocity to the scaling kernel (the reference's comVelm[id_mol])
-                mixed4 cv = {Vx, Vy, Vz, Vw};
-                ((mixed4*) a.comv)[(size_t) wave * 64 + ((meta >> META_SEGFIRST_SHIFT) & 63)] = cv;
-            }
-            // Moment form of the bias removal (K/cosineAccelerate.cu:63-73 followed by K/drudeNoseHoover.cu:33-151): the unbiased
-            // velocity is u = v - V w with w = (cos(kz), 0, 0) and V known only after the global sum, and every term of the group
-            // sums is a square of something LINEAR in the velocities, (a - V b)^2 with a from v and b from w by the same linear
-            // map.  So this launch accumulates sum a^2 (as before), sum a.b and sum b^2, and kernel B finishes the algebra.
-            mixed bx = 0, Wx = 0;
-            if (F & A_KE_MOM) {
-                const mixed wx = act ? (mixed) czl : (mixed) 0;
-                const int first = (meta >> META_SEGFIRST_SHIFT) & 63, last = (meta >> META_SEGLAST_SHIFT) & 63;
-                mixed mw = (nh && massive && use_com) ? wx * P::RECIP_SUM(v.w) : (mixed) 0;
-                mw = segment_total(mw, lane, first, last);
-                Wx = use_com ? mw * Vw : (mixed) 0;
-                if ((meta & META_COM_LEADER) && use_com) a.comw[(size_t) wave * 64 + first] = (double) Wx;
-                bx = wx;
-                if (nh) bx -= Wx;
-            }
-            if (nh) { ux -= Vx; uy -= Vy; uz -= Vz; }                       // K/drudeNoseHoover.cu:45-47
-            // Masses: one reciprocal per lane, the partner's comes over the shuffle network.  Where the reference divides by an
-            // inverse mass this multiplies by the mass (<= 1 ulp apart, below the reduction-order noise of these sums).
-            const mixed own_mass = massive ? P::RECIP_SUM(v.w) : (mixed) 0;
-            const mixed px = shfl(ux, partner), py = shfl(uy, partner), pz = shfl(uz, partner), pm = shfl(own_mass, partner);
-            const mixed pbx = (F & A_KE_MOM) ? shfl(bx, partner) : (mixed) 0;
-            if (role == ROLE_NH_NORMAL && massive) {                        // K/drudeNoseHoover.cu:76-83
-                k_atom += (double) ((ux * ux + uy * uy + uz * uz) * own_mass);
-                if (F & A_KE_MOM) { m_ab[0] += (double) (ux * bx * own_mass); m_bb[0] += (double) (bx * bx * own_mass); }
-            } else if (role == ROLE_NH_DRUDE) {                             // K/drudeNoseHoover.cu:97-114, pair.x = Drude
-                const mixed mass1 = own_mass, mass2 = pm;
-                const mixed invTotalMass = P::RECIP_SUM(mass1 + mass2);
-                const mixed reducedMass = mass1 * mass2 * invTotalMass;
-                const mixed mass1fract = invTotalMass * mass1, mass2fract = invTotalMass * mass2;
-                const mixed cx = ux * mass1fract + px * mass2fract;
-                const mixed cy = uy * mass1fract + py * mass2fract;
-                const mixed cz = uz * mass1fract + pz * mass2fract;
-                const mixed rx = ux - px, ry = uy - py, rz = uz - pz;
-                k_atom += (double) ((cx * cx + cy * cy + cz * cz) * (mass1 + mass2));
-                k_drude += (double) ((rx * rx + ry * ry + rz * rz) * reducedMass);
-                if (F & A_KE_MOM) {
-                    const mixed cb = bx * mass1fract + pbx * mass2fract, rb = bx - pbx;
-                    m_ab[0] += (double) (cx * cb * (mass1 + mass2)); m_bb[0] += (double) (cb * cb * (mass1 + mass2));
-                    m_ab[2] += (double) (rx * rb * reducedMass); m_bb[2] += (double) (rb * rb * reducedMass);
+            // ---- Drude pairs: relative motion (K/drudeNoseHoover.cu:97-114, pair.x = Drude); the Drude lane adds for the pair
+            if (__any(role == ROLE_NH_DRUDE)) {
+                const mixed ox = shfl(ux, partner), oy = shfl(v.y, partner), oz = shfl(v.z, partner);
+                const mixed om = (F & A_MTAB) ? shfl(tab_f, partner) : shfl(own_mass, partner);     // partner's mass fraction / mass
+                const mixed ow = (F & A_KE_MOM) ? shfl(wx, partner) : (mixed) 0;
+                if (role == ROLE_NH_DRUDE) {
+                    const mixed reducedMass = (F & A_MTAB) ? own_mass * om : own_mass * om * P::RECIP_SUM(own_mass + om);
+                    const mixed rx = ox - ux, ry = oy - v.y, rz = oz - v.z;
+                    k_drude += (double) ((rx * rx + ry * ry + rz * rz) * reducedMass);
+                    if (F & A_KE_MOM) { const mixed rb = ow - wx; m_ab[2] += (double) (rx * rb * reducedMass); m_bb[2] += (double) (rb * rb * reducedMass); }
                 }
             }
-            if ((meta & META_COM_LEADER) && use_com && Vw != 0 && (!(meta & META_BIGMOL) || (meta & META_BIG_FIRST))) { // K/drudeNoseHoover.cu:85-94
-                k_com += (double) ((Vx * Vx + Vy * Vy + Vz * Vz) * Vm);
-                if (F & A_KE_MOM) { m_ab[1] += (double) (Vx * Wx * Vm); m_bb[1] += (double) (Wx * Wx * Vm); }
+            // ---- molecular centre of mass (K/drudeNoseHoover.cu:5-31, 85-94): only where a wave holds COM segments at all
+            if (__any(use_com)) {
+                const bool in_seg = contrib && use_com;
+                mixed Sx = in_seg ? px : (mixed) 0, Sy = in_seg ? py : (mixed) 0, Sz = in_seg ? pz : (mixed) 0;
+                wave_scan3(Sx, Sy, Sz);
+                const int prev = first > 0 ? first - 1 : 0;
+                mixed Tx = Sx - shfl(Sx, prev), Ty = Sy - shfl(Sy, prev), Tz = Sz - shfl(Sz, prev);
+                if (first == 0) { Tx = Sx; Ty = Sy; Tz = Sz; }
+                mixed Tw = 0;
+                if (F & A_KE_MOM) {      // the shuffle must run in ALL lanes: a lane reads its left neighbour segment's last lane
+                    const mixed Sw = wave_scan(in_seg ? pw : (mixed) 0);
+                    const mixed Lw = shfl(Sw, prev);
+                    Tw = first > 0 ? Sw - Lw : Sw;
+                }
+                if (leader) {
+                    mixed Vm = (mixed) seg_mw.x, Vw = (mixed) seg_mw.y;      // static: summed once on the host in particle order (vv_host.hpp: seg_mass)
+                    if (a.slot_big && (meta & META_BIGMOL)) {     // molecule spread over several waves: totals from the accumulator
+                        const unsigned long long* src = a.bigacc + 4 * (size_t) a.slot_big[(size_t) wave * 64 + lane];
+                        Tx = (mixed) ((double) (long long) src[0] * a.big_inv_scale); Ty = (mixed) ((double) (long long) src[1] * a.big_inv_scale);
+                        Tz = (mixed) ((double) (long long) src[2] * a.big_inv_scale); Vm = (mixed) ((double) (long long) src[3] * a.big_inv_scale);
+                        Vw = P::RECIP(Vm);
+                    }
+                    const mixed Vx = Tx * Vw, Vy = Ty * Vw, Vz = Tz * Vw;        // V = P * RECIP(M), comVelm.w = RECIP(M)
+                    const mixed4 cv = {Vx, Vy, Vz, Vw};
+                    ((mixed4*) a.comv)[(size_t) wave * 64 + first] = cv;         // the reference's comVelm[id_mol], handed to kernel B
+                    const bool counts = Vw != 0 && (!(meta & META_BIGMOL) || (meta & META_BIG_FIRST));
+                    if (counts) k_com += (double) ((Vx * Vx + Vy * Vy + Vz * Vz) * Vm);
+                    if (F & A_KE_MOM) {
+                        const mixed Wx = Tw * Vw;                                // mass-weighted mean of cos(kz) over the molecule
+                        a.comw[(size_t) wave * 64 + first] = (double) Wx;
+                        if (counts) { m_ab[1] += (double) (Vx * Wx * Vm); m_bb[1] += (double) (Wx * Wx * Vm); }
+                    }
+                }
             }
         }
     }
     VV_STAMP(threadIdx.x >> 6, 3);
     if (F & (A_KE | A_BIAS | A_KE_PLAIN)) {
-        const double vals[NUM_ACC] = {k_atom, k_com, k_drude, k_bias, m_ab[0], m_ab[1], m_ab[2], m_bb[0], m_bb[1], m_bb[2]};
+        // group "atom" by difference (see the KE stage); with A_KE_PLAIN k_com and k_drude are zero
+        const double vals[NUM_ACC] = {k_atom - k_drude - k_com, k_com, k_drude, k_bias, m_ab[0] - m_ab[2] - m_ab[1], m_ab[1], m_ab[2],
+                                      m_bb[0] - m_bb[2] - m_bb[1], m_bb[1], m_bb[2]};
         const bool mom = (F & A_KE_MOM) != 0;
         const bool en[NUM_ACC] = {(F & (A_KE | A_KE_PLAIN)) != 0, (F & A_KE) != 0, (F & A_KE) != 0, (F & A_BIAS) != 0, mom, mom, mom, mom, mom, mom};
         block_accumulate<NUM_ACC>(vals, en, a.acc, a.acc_scale, a.status);
@@ -806,18 +833,25 @@ __device__ __forceinline__ double chain_exp(double x) {
     return p;
 }
 // The thermostat wave of kernel B is one serial dependency chain of fp64 operations (three lanes of one wave doing useful work) on
-// the critical path of the whole kernel, so the DEPTH of the polynomial is what counts: degree 7 in Estrin form is three levels deep
-// (9 operations) and exact to < 1 ulp for |x| <= 2^-6 (truncation x^8/8! < 9e-20 relative).  The caller keeps the largest biased
-// exponent seen (two 32-bit operations per call) and redoes the step with chain_exp if any argument was larger.
+// the critical path of the whole kernel: ~700 cycles for a three-link chain when every exp is ONE polynomial evaluation
+// (tools/probes/dpchain3_probe.cpp).  The arguments are -dt/8 eta_dot and -dt/2 eta_dot; with the Drude thermostat's 40/ps and
+// dt = 1 fs the latter reaches 0.02-0.05 in ordinary runs.  Round 1 used a degree-7 polynomial (|x| <= 2^-6) with a complete re-run
+// of the chain on the degree-11 one whenever an argument was larger -- which in the headline workload was EVERY step: the chain
+// took 2 640 cycles (stamps, tools/probes/b_timeline.py).  Now: degree 11 in Estrin form (one level deeper than degree 7, five
+// more operations), exact to < 1 ulp for |x| <= 2^-3 (truncation x^12/12! < 3e-20 relative); the caller keeps the largest biased
+// exponent seen (two 32-bit operations per call) and redoes the step with the library exp only beyond that.
 __device__ __forceinline__ double chain_exp_small(double x, unsigned& max_hi) {
     const unsigned hi = (unsigned) __double2hiint(x) & 0x7FFFFFFFu;
     max_hi = hi > max_hi ? hi : max_hi;
     const double x2 = x * x;
     const double p01 = x + 1.0, p23 = fma(x, 1.0 / 6.0, 0.5), p45 = fma(x, 1.0 / 120.0, 1.0 / 24.0), p67 = fma(x, 1.0 / 5040.0, 1.0 / 720.0);
-    const double x4 = x2 * x2, q0 = fma(x2, p23, p01), q1 = fma(x2, p67, p45);
-    return fma(x4, q1, q0);
+    const double p89 = fma(x, 1.0 / 362880.0, 1.0 / 40320.0), pab = fma(x, 1.0 / 39916800.0, 1.0 / 3628800.0);
+    const double x4 = x2 * x2, q0 = fma(x2, p23, p01), q1 = fma(x2, p67, p45), q2 = fma(x2, pab, p89);
+    const double x8 = x4 * x4;
+    return fma(x8, q2, fma(x4, q1, q0));
 }
-constexpr unsigned CHAIN_EXP_SMALL_HI = 0x3F900000u;      // high word of 2^-6
+constexpr unsigned CHAIN_EXP_SMALL_HI = 0x3FC00000u;      // high word of 2^-3
+__device__ __forceinline__ double chain_exp_wide(double x) { return exp(x); }
 
 // One temperature group, chain length NC known at compile time so the chain lives in registers.
 // Differences from the host routine, both below 1 ulp per operation: chain_exp for exp, and multiplication by
@@ -881,10 +915,11 @@ __device__ __forceinline__ double propagate_regs(const NHConst& c, int g, double
 struct ChainRegs { double eta[4], eta_dot[5], eta_dotdot[4]; };
 template <int NC, bool FAST>
 __device__ __forceinline__ double propagate_preloaded(const NHConst& c, const ChainLaneBlock& lc, double ke2, ChainRegs& r, unsigned& max_hi) {
-    auto ex = [&](double x) { return FAST ? chain_exp_small(x, max_hi) : chain_exp(x); };
-    // eta_dot[NC] is the chain's closing zero (API:340-376 never writes it): exp(-dt8 * 0) is exactly 1 in both polynomials, so the
-    // two evaluations that take it as argument are skipped when the whole wave sees zeros (two of the six serial exps for NC = 3)
-    const bool tail_zero = !__any(r.eta_dot[NC] != 0);
+    auto ex = [&](double x) { return FAST ? chain_exp_small(x, max_hi) : chain_exp_wide(x); };
+    // eta_dot[NC] is the chain's closing zero: the reference sizes etaDot numChains + 1, initialises it to 0 and never writes the last
+    // element (API:340-376), and vvhip_set_nh_state keeps it 0 here.  exp(-dt8 * 0) is exactly 1, so the two evaluations that take
+    // it as argument are dropped at compile time (two of the six serial exps for NC = 3).
+    constexpr bool tail_zero = true;
     // Runs in the block's thermostat wave only (lanes 0..2 = the three temperature groups), so a plain branch on
     // "group is thermostatted" is fine and the state is updated in place (fewer live registers for the whole kernel).
     double factor = 1.0;
@@ -927,7 +962,7 @@ __device__ __forceinline__ double propagate_small_nc(const NHConst& c, const Cha
     const ChainRegs saved = r;
     unsigned max_hi = 0;
     double f = propagate_preloaded<NC, true>(c, lc, ke2, r, max_hi);
-    if (__builtin_expect(__any(max_hi > CHAIN_EXP_SMALL_HI), 0)) {          // an exp argument beyond 2^-6: redo with the wide-range polynomial
+    if (__builtin_expect(__any(max_hi > CHAIN_EXP_SMALL_HI), 0)) {          // an exp argument beyond 2^-3: redo with the library exp
         r = saved;
         f = propagate_preloaded<NC, false>(c, lc, ke2, r, max_hi);
     }
@@ -1042,9 +1077,17 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const KArgs a) {
             ke2 = ke2 - 2.0 * V * sab + V * V * sbb;
         }
         double factor = 1.0;
-        VV_STAMP_NOWAIT(7, 4);
+        VV_STAMP_AFTER(7, 4, ke2);
+#ifdef VV_CHAIN_TWICE      // probe (instrumented builds): the same chain code once more on perturbed input, to tell cold instruction fetch from arithmetic latency
+        {
+            ChainRegs tmp = cr;
+            const double f0 = propagate_group_small<(SF != 0 ? 3 : 0)>(a.chain, lc, ke2 * 1.0000001, tmp);
+            if (f0 == 123.456) cr.eta[0] += 1e-300;      // keeps the first evaluation alive
+            VV_STAMP_AFTER(7, 5, f0);
+        }
+#endif
         if (!(F & B_DBG_NOMATH)) factor = propagate_group_small<(SF != 0 ? 3 : 0)>(a.chain, lc, ke2, cr);
-        VV_STAMP_NOWAIT(7, 2);
+        VV_STAMP_AFTER(7, 2, factor);
         const double bias = (F & B_UNBIAS) ? (double) tot[3] * a.chain.acc_inv_scale[3] * a.chain.inv_mass_total   // K/cosineAccelerate.cu:57-59
                                            : a.nh->scales[3];                                                 // carried over unchanged
         if (lane < VVHIP_NUM_TG) sh_scales[lane] = factor;
@@ -1127,21 +1170,30 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const KArgs a) {
         // network, mass fractions, COM / relative split of the pair.  Without a bias to remove first it runs here, i.e. while
         // the tile waves of the first iteration wait for the thermostat wave.
         mixed ux = 0, uy = 0, uz = 0, cmx = 0, cmy = 0, cmz = 0, rx = 0, ry = 0, rz = 0, mass1fract = 0, mass2fract = 0;
+        // B_MTAB: the pair's mass fractions are static (vv_kernel_mass_table formed them with the operations of K/drudeNoseHoover.cu:173-180
+        // on the same inverse masses, so they are the per-step values bit for bit): one 8-byte load per pair lane, requested with the
+        // particle data, instead of two IEEE fp64 divisions per lane and step
+        mixed tab_f = 0;
+        if ((F & B_MTAB) && (F & B_SCALE) && act && (role == ROLE_NH_DRUDE || role == ROLE_NH_PARENT)) tab_f = (mixed) a.slot_f[(size_t) wave * 64 + lane];
         auto scale_prep = [&]() {
             ux = v.x; uy = v.y; uz = v.z;
             if (nh) { ux -= Vx; uy -= Vy; uz -= Vz; }
             // each lane forms the reciprocal of its own inverse mass, the partner's arrives by shuffle: the same IEEE quotients as
             // RECIP(a1w), RECIP(a2w) of K/drudeNoseHoover.cu:173-174 with one division per lane instead of two
             const bool pair_lane = role == ROLE_NH_DRUDE || role == ROLE_NH_PARENT;
-            const mixed own_m = pair_lane ? P::RECIP(v.w) : (mixed) 0;
+            const mixed own_m = (F & B_MTAB) ? tab_f : (pair_lane ? P::RECIP(v.w) : (mixed) 0);     // with the table: the own FRACTION travels
             const mixed px = shfl(ux, partner), py = shfl(uy, partner), pz = shfl(uz, partner), pm = shfl(own_m, partner);
             if (pair_lane) {
                 const bool isd = role == ROLE_NH_DRUDE;      // velAtom1 = Drude (pair.x), velAtom2 = parent
                 const mixed a1x = isd ? ux : px, a1y = isd ? uy : py, a1z = isd ? uz : pz;
                 const mixed a2x = isd ? px : ux, a2y = isd ? py : uy, a2z = isd ? pz : uz;
-                const mixed mass1 = isd ? own_m : pm, mass2 = isd ? pm : own_m;
-                const mixed invTotalMass = P::RECIP(mass1 + mass2);
-                mass1fract = invTotalMass * mass1; mass2fract = invTotalMass * mass2;
+                if (F & B_MTAB) {
+                    mass1fract = isd ? own_m : pm; mass2fract = isd ? pm : own_m;
+                } else {
+                    const mixed mass1 = isd ? own_m : pm, mass2 = isd ? pm : own_m;
+                    const mixed invTotalMass = P::RECIP(mass1 + mass2);
+                    mass1fract = invTotalMass * mass1; mass2fract = invTotalMass * mass2;
+                }
                 cmx = a1x * mass1fract + a2x * mass2fract;
                 cmy = a1y * mass1fract + a2y * mass2fract;
                 cmz = a1z * mass1fract + a2z * mass2fract;
@@ -1281,8 +1333,13 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const KArgs a) {
                 const mixed vel1w = isd ? v.w : ovw, vel2w = isd ? ovw : v.w;
                 const mixed deltax = p1x - p2x, deltay = p1y - p2y, deltaz = p1z - p2z;
                 const mixed r = P::SQRT(deltax * deltax + deltay * deltay + deltaz * deltaz);
-                const mixed rInv = P::RECIP(r);
-                if (__builtin_expect(rInv * maxDrudeDistance < 1, 0)) {      // rare: keep the hit path out of the fall-through code
+                // The reference decides on rInv * maxDrudeDistance < 1 with rInv = RECIP(r) (K/middle.cu:128-131), an IEEE division per
+                // pair and step.  r <= 0.99999 max implies rInv * max >= 1.00001 (1 - 2^-23)^2 > 1 in every mode, i.e. "no hit" without
+                // forming the quotient; only pairs within 1e-5 of the wall or beyond it take the exact test.  Same decisions, same bits.
+                mixed rInv = 0;
+                bool hit = false;
+                if (__builtin_expect(r > maxDrudeDistance * (mixed) 0.99999, 0)) { rInv = P::RECIP(r); hit = rInv * maxDrudeDistance < 1; }
+                if (__builtin_expect(hit, 0)) {      // rare: keep the hit path out of the fall-through code
                     // both lanes of a pair see the same r, so both are in here: the partner's velocity is fetched only now
                     const mixed ovx = shfl(v.x, partner), ovy = shfl(v.y, partner), ovz = shfl(v.z, partner);
                     mixed vel1x = isd ? v.x : ovx, vel1y = isd ? v.y : ovy, vel1z = isd ? v.z : ovz;
@@ -1372,6 +1429,35 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const KArgs a) {
     }   // tile loop
     VV_STAMP_DUMP(wib);
     VV_SPAN_END;
+}
+
+// ================================================================================ static mass tables
+// One launch per binding: slot_m = RECIP(velm.w) and, for the two lanes of a Drude pair, slot_f = invTotalMass * own mass with
+// invTotalMass = RECIP(mass1 + mass2) -- the operations of K/drudeNoseHoover.cu:173-180 / K/drudeLangevin.cu:16,36-44 in the mode's
+// `mixed` type, so that the stages reading the tables get the very bits they used to recompute in every step.
+template <class real, class mixed>
+__global__ void __launch_bounds__(256) vv_kernel_mass_table(const void* velm_, const int2* slots, int nwaves, double* slot_m, double* slot_f) {
+    using mixed4 = typename Vec<mixed>::v4;
+    using P = Prec<real>;
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wave >= nwaves) return;
+    const int2 slot = slots[(size_t) wave * 64 + lane];
+    const unsigned meta = (unsigned) slot.y;
+    const int partner = (meta >> META_PARTNER_SHIFT) & 63;
+    mixed w = 0;
+    if (slot.x >= 0) w = ((const mixed4*) velm_)[slot.x].w;
+    const mixed m = w != 0 ? P::RECIP(w) : (mixed) 0;
+    const mixed pm = shfl(m, partner);
+    mixed f = 0;
+    if (slot.x >= 0 && (meta & META_PAIR)) {
+        const bool isd = (meta & META_IS_DRUDE) != 0;
+        const mixed mass1 = isd ? m : pm, mass2 = isd ? pm : m;        // 1 = Drude, 2 = parent: the reference's operand order
+        const mixed invTotalMass = P::RECIP(mass1 + mass2);
+        f = invTotalMass * m;
+    }
+    slot_m[(size_t) wave * 64 + lane] = (double) m;
+    slot_f[(size_t) wave * 64 + lane] = (double) f;
 }
 
 // ================================================================================ stand-alone image kernel
@@ -1531,13 +1617,27 @@ constexpr uint32_t SF_A_EF_SHAKE = SF_A_EF | A_SHAKE_V;
 constexpr uint32_t SF_B_COS_HW_MOM_MB = SF_B_COS_HW_MOM | B_MAILBOX;
 constexpr uint32_t SF_B_MIDDLE_HW_SHAKE_MB = SF_B_MIDDLE_HW_SHAKE | B_MAILBOX;
 
-#define VV_TRY_SF(KERNEL, SFV) if (a.flags == (SFV)) { VV_DISPATCH_SF(KERNEL, SFV, g, b, 0, s, a); return hipGetLastError(); }
+// Which specialised kernels are compiled with the static mass tables; a launch whose flags disagree with the build falls through to
+// the generic kernel.  Measured on MI355X (gpurun_out/r02c-e): kernel B gains at every size (two IEEE fp64 divisions per pair lane
+// gone, 140 -> 101 VGPRs; C3 5.74 -> 5.29 us with the chain fix, 8.9 M particles unchanged), kernel A does not -- with the Koenig
+// form of its KE stage it needs one cheap reciprocal per lane, and the 16 bytes per lane of table traffic cost it 13 % at
+// 8.9 M particles (217 -> 247 us) for nothing at 111 k.  So: B with the table (VV_SF_MTAB_B=1), A without (VV_SF_MTAB_A=0).
+#ifndef VV_SF_MTAB_A
+#define VV_SF_MTAB_A 0
+#endif
+#ifndef VV_SF_MTAB_B
+#define VV_SF_MTAB_B 1
+#endif
+constexpr uint32_t SF_AM = VV_SF_MTAB_A ? A_MTAB : 0u, SF_BM = VV_SF_MTAB_B ? B_MTAB : 0u;
+bool sf_kernels_use_mass_table(int kernel) { return kernel == 0 ? VV_SF_MTAB_A != 0 : VV_SF_MTAB_B != 0; }
+#define VV_TRY_SF(KERNEL, SFV) if (a.flags == ((SFV) | XM)) { VV_DISPATCH_SF(KERNEL, ((SFV) | XM), g, b, 0, s, a); return hipGetLastError(); }
 
 hipError_t launch_a(int precision, const KArgs& a, int block_threads, int grid_cap, hipStream_t s) {
     dim3 g = grid_for(a.nwaves, block_threads);
     if ((int) g.x > grid_cap) g.x = (unsigned) grid_cap;          // beyond that the kernel strides over tiles
     vv_last_grid_value = g.x;
     const dim3 b(block_threads);
+    constexpr uint32_t XM = SF_AM;
     VV_TRY_SF(vv_kernel_a, SF_A_MIDDLE)
     VV_TRY_SF(vv_kernel_a, SF_A_MIDDLE_WT)
     VV_TRY_SF(vv_kernel_a, SF_A_COS1)
@@ -1566,6 +1666,7 @@ hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_c
     if ((int) g.x > grid_cap) g.x = (unsigned) grid_cap;
     vv_last_grid_value = g.x;
     const dim3 b(block_threads + ((a.flags & B_CHAIN) ? 64 : 0));
+    constexpr uint32_t XM = SF_BM;
     if ((a.flags & B_CHAIN) && a.chain.num_chains != 3) {       // the specialised kernels carry the three-link chain only
         VV_DISPATCH_SF(vv_kernel_b, 0u, g, b, 0, s, a);
         return hipGetLastError();
@@ -1600,6 +1701,11 @@ hipError_t launch_chain(const NHConst& c, NHDevState* st, unsigned long long* ac
 }
 hipError_t launch_tether(int precision, const TetherArgs& t, int block_threads, hipStream_t s) {
     VV_DISPATCH(vv_kernel_tether, grid_for(t.nwaves, block_threads), dim3(block_threads), 0, s, t);
+    return hipGetLastError();
+}
+hipError_t launch_mass_table(int precision, const void* velm, const int2* slots, int nwaves, double* slot_m, double* slot_f, hipStream_t s) {
+    if (nwaves <= 0) return hipSuccess;
+    VV_DISPATCH(vv_kernel_mass_table, dim3((unsigned) ((nwaves + 3) / 4)), dim3(256), 0, s, velm, slots, nwaves, slot_m, slot_f);
     return hipGetLastError();
 }
 hipError_t launch_fill_normals(float4* out, uint32_t count, uint64_t seed, unsigned long long* epoch, hipStream_t s) {

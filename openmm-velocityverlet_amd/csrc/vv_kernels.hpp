@@ -29,6 +29,8 @@ enum : uint32_t {
     A_SHAKE_V = 1u << 16,    // velocity constraints of the SHAKE clusters right after the kick (OpenMM applyVelocityConstraints)
     A_KE_MOM = 1u << 17,     // with A_BIAS | A_KE in ONE launch: the group sums as moments Saa, Sab, Sbb of the still biased velocities
                              // (accumulators 0-2, 4-6, 7-9); kernel B combines them once V is known: 2KE = Saa - 2 V Sab + V^2 Sbb
+    A_MTAB = 1u << 18,       // own mass and Drude-pair mass fraction from the static per-lane tables (slot_m, slot_f) instead of
+                             // reciprocals / IEEE divisions of velm.w in every step
     A_WT_STORES = 1u << 27,  // write-through (sc1) store of the kicked velocities
     A_KE_PLAIN = 1u << 15,   // sum m v^2 over every massive particle into accumulator 0 (kinetic-energy query)
 };
@@ -50,6 +52,7 @@ enum : uint32_t {
     B_SHAKE = 1u << 13,       // position constraints of the SHAKE clusters on the step's displacement (OpenMM applyConstraints)
     B_MAILBOX = 1u << 14,     // multi-GPU mailbox: block 0's thermostat wave stores this rank's totals into every peer, all blocks sum all ranks' totals
     B_KE_MOM = 1u << 15,      // the accumulators hold moments (A_KE_MOM): combine them with V, unbias the stored COM velocities with comw
+    B_MTAB = 1u << 16,        // Drude-pair mass fractions from the static per-lane table (slot_f) instead of two IEEE divisions per lane
     B_WT_STORES = 1u << 27,   // write-through (sc1) stores for the particle arrays: the dirty lines leave L2 during the kernel, not at its end
     B_DBG_NOFOLD = 1u << 28,  // timing experiments only: skip the accumulator fold / the chain arithmetic
     B_DBG_NOMATH = 1u << 29,
@@ -141,6 +144,8 @@ struct KArgs {
     double* cosz;                  // [64*nwaves] per-lane cos(2 pi z / Lz) cache of the current step
     const double* seg_mass;        // [2*64*nwaves] (mass, 1/mass) of the COM segment starting at that lane (static; vv_host.hpp)
     double* comw;                  // [64*nwaves] mass-weighted mean of cos(kz) over the same segment (A_KE_MOM -> B_KE_MOM)
+    const double* slot_m;           // [64*nwaves] RECIP(velm.w) of the lane's particle in the mode's `mixed` type, widened (0 = massless / idle)
+    const double* slot_f;           // [64*nwaves] Drude-pair lanes: invTotalMass * own mass (K/drudeNoseHoover.cu:173-180), else 0
     const int32_t* slot_image;
     const int32_t* slot_rand;
     const int32_t* slot_shake;      // packed SHAKE cluster word per lane (vv_host.hpp), NULL without in-kernel constraints
@@ -186,6 +191,11 @@ hipError_t launch_a(int precision, const KArgs& a, int block_threads, int grid_c
 hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_cap, hipStream_t s);
 hipError_t launch_chain(const NHConst& c, NHDevState* st, unsigned long long* acc, hipStream_t s);
 hipError_t launch_tether(int precision, const TetherArgs& t, int block_threads, hipStream_t s);
+// Fills the static per-lane mass tables from the inverse masses in velm.w (once per binding; see A_MTAB / B_MTAB).
+hipError_t launch_mass_table(int precision, const void* velm, const int2* slots, int nwaves, double* slot_m, double* slot_f, hipStream_t s);
+// whether the specialised kernels A (kernel = 0) / B (1) of this build were compiled with the mass tables (they then carry A_MTAB /
+// B_MTAB in their stage sets)
+bool sf_kernels_use_mass_table(int kernel);
 // Device Gaussian generator (stand-alone hosts; inside OpenMM the random buffer is OpenMM's): Philox4x32-10 keyed by
 // `seed`, counter = (*epoch, element index); a second 1-thread launch bumps *epoch so that graph replays draw fresh numbers.
 hipError_t launch_fill_normals(float4* out, uint32_t count, uint64_t seed, unsigned long long* epoch, hipStream_t s);

@@ -249,6 +249,7 @@ class Context:
         self.site = H.DeviceArray.from_host(posq)
         self.force = H.DeviceArray.from_host(np.zeros(3 * self.padded, dtype=np.int64))
         self.pos_delta = H.DeviceArray.from_host(np.zeros((nloc, 4), dtype=M))
+        self._random_injected = random is not None
         if random is None and self.info.num_normal_ld + self.info.num_pairs_ld > 0:
             random = np.random.default_rng(1).standard_normal((1 << 16, 4)).astype(np.float32)   # seed 1
         self.random_host = None if random is None else np.ascontiguousarray(random, dtype=np.float32)
@@ -334,8 +335,10 @@ class Context:
             old = self.random_index
             self.random_index += cnt
             return old
-        # exhausted: OpenMM's prepareRandomNumbers refills the buffer here; so does this host, with the device generator
-        self.fill_random()
+        # exhausted: OpenMM's prepareRandomNumbers refills the buffer here; so does this host, with the device generator -- unless the
+        # caller injected the normals (parity runs against the oracle, which has no generator and starts over at index 0)
+        if not self._random_injected:
+            self.fill_random()
         self.random_index = cnt
         return 0
 

@@ -26,6 +26,7 @@ A_FE_LOAD, A_FE_STORE, A_LD, A_EF, A_COS, A_KICK_FULL, A_KICK_HALF, A_POSDELTA_V
     [1 << i for i in range(15)]
 B_SCALE, B_UNBIAS, B_BIAS_REMOVE, B_BIAS_RESTORE, B_DRIFT_MIDDLE, B_POS2, B_POS3, B_VV_KICK, B_VV_POS, B_HARDWALL, B_IMAGE, B_CHAIN, B_CZ_LOAD = \
     [1 << i for i in range(13)]
+A_MTAB, B_MTAB = 1 << 18, 1 << 16        # static mass tables: added by the library itself (vv_api.cpp run_a / run_b)
 C_CHAIN, C_BIAS = 1, 2
 
 
@@ -117,7 +118,7 @@ def _load():
         "vvhip_synth_tether_force": [vp, vp, dbl, dbl],
         "vvhip_run_graph": [vp, C.c_int, C.c_int, vp, dbl, dbl],
         "vvhip_graph_prepare": [vp, C.c_int, vp, dbl, dbl],
-        "vvhip_status": [vp, P(i32), P(i32)], "vvhip_status_clear": [vp],
+        "vvhip_status": [vp, P(i32), P(i32)], "vvhip_status_clear": [vp], "vvhip_masses_changed": [vp],
         "vvhip_run_eager": [vp, C.c_int, vp, dbl, dbl],
         "vvhip_run_eager_unfused": [vp, C.c_int, vp, dbl, dbl],
         "vvhip_set_random_seed": [vp, C.c_uint64], "vvhip_fill_random": [vp],

@@ -6,7 +6,9 @@ import numpy as np
 sys.path.insert(0, "/root/repo")
 pkg = importlib.import_module("openmm-velocityverlet_amd")
 I, S, H = pkg.integrator, pkg.systems, pkg.vvhip
-spec = S.make_config("C3")
+import os
+SMALL = int(os.environ.get("SMALL", "0"))          # SMALL=n: n ion pairs only (12 -> one block), to tell chip-wide effects from block-local ones
+spec = S.drude_il(cells=(1, 1, 1), pairs_per_cell=SMALL, seed=3) if SMALL else S.make_config("C3")
 it = I.VVIntegrator(333.0, 10, 1.0, 40, 0.001); it.setMaxDrudeDistance(0.02)
 ctx = I.Context(spec, it, precision="mixed", force_provider="tether")
 ctx.run_graph(200, 100); ctx.synchronize()
@@ -16,7 +18,7 @@ names_c = ["entry", "acc folded", "chain done", "after barrier"]
 GHZ = 2.4      # shader clock assumed for the conversion (MI355X boost); relative numbers are what matter
 for flags, label in ((FULL, "B full"), (1 | 16 | 512, "B without chain wave")):
     print(label)
-    for block in (0, 1, 125, 250):
+    for block in ((0,) if SMALL else (0, 1, 125, 250)):
         acc = []
         for rep in range(5):
             it.step(1)
@@ -31,10 +33,10 @@ for flags, label in ((FULL, "B full"), (1 | 16 | 512, "B without chain wave")):
         line = f"  block {block:4d}: "
         for w in (0, 1):
             line += f"tile{w} " + " ".join(f"{(t[w, k] - t0) / GHZ:6.0f}" if 0 < t[w, k] - t0 < 10**7 else "     -" for k in range(6)) + " | "
-        line += "thermo " + " ".join(f"{(t[7, k] - t0) / GHZ:6.0f}" if 0 <= t[7, k] - t0 < 10**7 else "     -" for k in (0, 1, 4, 2, 3))
+        line += "thermo " + " ".join(f"{(t[7, k] - t0) / GHZ:6.0f}" if 0 <= t[7, k] - t0 < 10**7 else "     -" for k in (0, 1, 4, 5, 2, 3))
         print(line)
 print("A full (kick + KE): entry, velm arrived, kicked + stored, tile loop done, sums added  [ns]")
-for block in (0, 1, 125, 250):
+for block in ((0,) if SMALL else (0, 1, 125, 250)):
     ctx.calcForces()
     out = (C.c_longlong * 128)()
     H.check(H.lib.vvhip_debug_timestamps(ctx.plan, 0x80000000 | 32 | 1024, block, C.byref(out)), ctx.plan)
