@@ -11,10 +11,16 @@
  * (oracle/_ref/libvvref_*.so; see ref_prelude.h for how and under which stated
  * assumptions), by tests/test_oracle_vs_ref.py in this container, and against the
  * golden vectors those runs produced (tests/golden/*.npz) everywhere else.
- * NOT pinned by reference code: vvo_propagate_nh_chain (the reference routine,
- * openmmapi/src/VVIntegrator.cpp:340-376, needs OpenMM headers that are absent;
- * it is pinned only by an independent pure-Python restatement and analytic
- * identities) and vvo_tether_force (our own synthetic force provider).
+ * vvo_propagate_nh_chain is checked bit-for-bit against the reference's own
+ * VVIntegrator::propagateNHChain (openmmapi/src/VVIntegrator.cpp:340-376, compiled in
+ * place by `make refapi` against the stand-in OpenMM headers of compat/:
+ * oracle/_ref/libvvref_api.so) through tests/golden/refapi_chain.npz and live in this
+ * container (tests/test_ref_api.py).  Both reference builds need a stand-in for
+ * something OpenMM supplies (the JIT prelude; the headers), so by the tier's rule the
+ * oracle stays "parity unpinned" formally -- see DESIGN.md section 2 for what executed
+ * reference code stands behind which statement.  vvo_tether_force is our own
+ * synthetic force provider; the SHAKE / SETTLE statements follow OpenMM's published
+ * algorithm (its source is not under /root/reference).
  *
  * Build once per precision mode (oracle/Makefile):
  *   VVO_SINGLE real=float  mixed=float
