@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--large-n", default="C3x80", choices=["C3x8", "C3x80", "none"],
                     help="secondary block (N = 1, config C3): the same kernels on the tiled box, where HBM bandwidth is the bound")
+    ap.add_argument("--synthetic", action="store_true", help="procedural look-alike systems instead of the reference's example models (C3 / C4 / C5)")
     ap.add_argument("--hbonds", action="store_true", help="constraints solved in-kernel: HBonds (SHAKE) for the ionic liquids, rigid water (SETTLE) for C2; not the headline workload")
     args = ap.parse_args()
 
@@ -76,14 +77,13 @@ def main():
 
     # ---- workload (BASELINE.json configs[2] / [3]; C3xK = the same cell tiled K times along z)
     cfg = args.config
+    # C3 / C4 / C5 come from the reference's own example models (tests/golden/topo_*.npz <- examples/models/{bulk_Im21,edl_Im21});
+    # --synthetic selects the procedural look-alikes of round 1.  --hbonds: the constraints the example scripts put on the System
+    # (HBonds -> in-kernel SHAKE; rigidWater for C2 -> SETTLE)
     if cfg.startswith("C3x"):
-        spec = S.make_config("C3", float(cfg[3:]))
+        spec = S.make_config("C3", float(cfg[3:]), hbonds=args.hbonds, synthetic=args.synthetic)
     else:
-        spec = S.make_config(cfg)
-    if args.hbonds and cfg == "C2":
-        spec = S.rigid_water(spec)                    # rigidWater=True: O-H, O-H, H-H (SETTLE)
-    elif args.hbonds:
-        spec = S.constrain_hydrogens(spec, 0.109)
+        spec = S.make_config(cfg, hbonds=args.hbonds, synthetic=args.synthetic)
     dt = 0.002 if cfg == "C2" else 0.001
     it = I.VVIntegrator(300.0 if cfg == "C2" else 333.0, 10.0, 1.0, 40.0, dt)
     if cfg not in ("C1", "C2"):
@@ -369,7 +369,7 @@ def main():
     # ---- the same box with the constraints the reference's example scripts put on it (HBonds: examples/ommhelper/oplspsffile.py:952-955;
     # rigid water for C2), solved inside the fused kernels: a secondary figure, the headline stays the workload BASELINE.json names
     if world == 1 and rank == 0 and not use_dist and args.forces == "tether" and not args.eager and not args.hbonds and cfg in ("C2", "C3", "C4", "C5"):
-        spec_c = S.rigid_water(S.make_config(cfg)) if cfg == "C2" else S.constrain_hydrogens(S.make_config(cfg), 0.109)
+        spec_c = S.make_config(cfg, hbonds=True, synthetic=args.synthetic)
         it_c = I.VVIntegrator(it.getTemperature(), 10.0, 1.0, 40.0, dt)
         it_c.setMaxDrudeDistance(it.getMaxDrudeDistance())
         it_c.setCosAcceleration(it.getCosAcceleration())
@@ -417,7 +417,7 @@ def main():
     # the HBM roofline is the real bound.  Secondary block (config.large_n); the headline stays the workload BASELINE.json names.
     if world == 1 and rank == 0 and not use_dist and cfg == "C3" and args.large_n != "none" and not args.eager and not args.hbonds:
         try:
-            spec_l = S.make_config("C3", float(args.large_n[3:]))
+            spec_l = S.make_config("C3", float(args.large_n[3:]), synthetic=args.synthetic)
             it_l = I.VVIntegrator(333.0, 10.0, 1.0, 40.0, dt)
             it_l.setMaxDrudeDistance(0.02)
             ctx_l = I.Context(spec_l, it_l, precision=args.precision, force_provider="tether", device=local_rank)

@@ -14,6 +14,7 @@ Everything is deterministic: ``numpy.random.default_rng(20241008)`` (BASELINE.md
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 from typing import List, Tuple
 
@@ -226,6 +227,8 @@ def constrain_hydrogens(spec: SystemSpec, distance: float = 0.109) -> SystemSpec
     """HBonds constraints as examples/ommhelper/oplspsffile.py:952-955 asks of OpenMM: every H (mass 1.008 here) is constrained to
     the heavy particle in front of it in its molecule (the generator lists a heavy atom, its Drude, then its hydrogens), and the
     hydrogens are put at exactly `distance` from it so the initial state satisfies the constraints."""
+    if spec.name.startswith(("bulk_Im21", "edl_Im21")):
+        raise ValueError("the reference-derived systems carry their own HBonds constraints: make_config(..., hbonds=True)")
     m = spec.masses
     cons = []
     heavy = -1
@@ -277,17 +280,118 @@ def rigid_water(spec: SystemSpec, d_oh: float = 0.1, d_hh: float = 0.1633) -> Sy
     return spec
 
 
-def make_config(name: str, scale: float = 1.0) -> SystemSpec:
-    """BASELINE.json configs by id.  `scale` < 1 gives a reduced copy for fast parity tests."""
+# ---------------------------------------------------------------------------------------------------------------------------
+# The reference's own example models: tests/golden/topo_{bulk_Im21,edl_Im21}.npz hold masses, charges,
+# molecule ids, Drude pairs, HBonds constraints, positions and the Langevin / image / electrolyte sets parsed from
+# examples/models/{bulk_Im21,edl_Im21} by tests/golden/make_topologies.py (index and number data, no file text).  The particle order
+# inside the real ions differs from the procedural look-alike above (the hydrogens of c2c1im+ come after the ring, not next to their
+# carbon), which is what decides the wave packing and the SHAKE cluster shapes.
+_TOPO_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def have_reference_topologies() -> bool:
+    return all(os.path.exists(os.path.join(_TOPO_DIR, f)) for f in ("topo_bulk_Im21.npz", "topo_edl_Im21.npz"))
+
+
+def _on_constraint_manifold(pos, vel, cons, dist):
+    """Hydrogens moved along their bond to the constraint length (conf.gro has three decimals) and the bond-parallel relative velocity
+    removed, so that the start satisfies position and velocity constraints."""
+    if len(cons) == 0:
+        return
+    h, x = cons[:, 0], cons[:, 1]
+    u = pos[h] - pos[x]
+    u /= np.linalg.norm(u, axis=1)[:, None]
+    pos[h] = pos[x] + dist[:, None] * u
+    rel = vel[h] - vel[x]
+    vel[h] -= (rel * u).sum(1)[:, None] * u
+
+
+def bulk_Im21(cells=(2, 2, 3), pairs_per_cell=250, hbonds=False, T=333.0, T_drude=1.0, seed=SEED) -> SystemSpec:
+    """C3 / C4 as SURVEY.md section 8 defines them: examples/models/bulk_Im21 (250 c2c1im+ + 250 dca-, 9 250 particles, box 3.1 x 3.1 x
+    6.1 nm) tiled `cells` times -> 111 000 particles, 6 000 molecules, 39 000 Drude pairs for 2 x 2 x 3.  `pairs_per_cell` < 250 keeps the
+    first ion pairs of the cell only (reduced copies for fast tests).  hbonds: the 11 X-H constraints per cation that constraints=HBonds
+    puts on the System (examples/run-bulk.py), solved by the fused kernels."""
+    z = np.load(os.path.join(_TOPO_DIR, "topo_bulk_Im21.npz"))
+    mol0 = z["mol_id"]
+    k = int(pairs_per_cell)
+    assert 1 <= k <= 250
+    keep = np.nonzero((mol0 < k) | ((mol0 >= 250) & (mol0 < 250 + k)))[0]        # conf.gro lists the 250 cations, then the 250 anions
+    renum = -np.ones(mol0.size, dtype=np.int64)
+    renum[keep] = np.arange(keep.size)
+    n1 = keep.size
+    masses1, charges1, pos1 = z["masses"][keep], z["charges"][keep], z["positions"][keep].astype(np.float64)
+    _, mol1 = np.unique(mol0[keep], return_inverse=True)
+    pairs1 = renum[z["drude_pairs"][np.isin(z["drude_pairs"][:, 0], keep)]]
+    sel = np.isin(z["constraints"][:, 0], keep)
+    cons1, dist1 = renum[z["constraints"][sel]], z["constraint_distances"][sel]
+    box1 = z["box"].astype(np.float64)
+    cx, cy, cz = cells
+    ncell = cx * cy * cz
+    nmol1 = int(mol1.max()) + 1
+    shifts = np.array([[i, j, l] for i in range(cx) for j in range(cy) for l in range(cz)], dtype=np.float64) * box1
+    masses = np.tile(masses1, ncell)
+    charges = np.tile(charges1, ncell)
+    pos = (pos1[None, :, :] + shifts[:, None, :]).reshape(-1, 3)
+    off = (np.arange(ncell) * n1)[:, None, None]
+    pairs = (pairs1[None, :, :] + off).reshape(-1, 2).astype(np.int32)
+    cons = (cons1[None, :, :] + off).reshape(-1, 2).astype(np.int32)
+    dist = np.tile(dist1, ncell)
+    mol = (mol1[None, :] + (np.arange(ncell) * nmol1)[:, None]).reshape(-1).astype(np.int32)
+    isd = np.zeros(masses.size, dtype=bool)
+    isd[pairs[:, 0]] = True
+    parent_of = np.arange(masses.size) - 1
+    rng = np.random.default_rng(seed)
+    vel = _maxwell_boltzmann(rng, masses, isd, parent_of, T, T_drude)
+    spec = SystemSpec(name=f"bulk_Im21_{cx}x{cy}x{cz}" + ("" if k == 250 else f"x{k}"), masses=masses, charges=charges, positions=pos, velocities=vel,
+                      box=box1 * np.array(cells, dtype=np.float64), mol_id=mol, drude_pairs=pairs, constraints=np.zeros((0, 2), np.int32))
+    if hbonds:
+        _on_constraint_manifold(spec.positions, spec.velocities, cons, dist)
+        spec.constraints, spec.constraint_distances = cons, dist
+    return spec
+
+
+def edl_Im21(hbonds=False, T=333.0, T_drude=1.0, seed=SEED) -> SystemSpec:
+    """C5 as SURVEY.md section 8 defines it: examples/models/edl_Im21/conf.gro -- 2 496 MoS2 atoms (Langevin subset), 511 ion pairs =
+    18 907 ionic-liquid particles (Nose-Hoover, electrolyte for the field), 18 907 massless images; mirror at Lz / 2 = 8 nm."""
+    z = np.load(os.path.join(_TOPO_DIR, "topo_edl_Im21.npz"))
+    masses, pairs = z["masses"].astype(np.float64), z["drude_pairs"].astype(np.int32)
+    isd = np.zeros(masses.size, dtype=bool)
+    isd[pairs[:, 0]] = True
+    rng = np.random.default_rng(seed)
+    vel = _maxwell_boltzmann(rng, masses, isd, np.arange(masses.size) - 1, T, T_drude)
+    spec = SystemSpec(name="edl_Im21", masses=masses, charges=z["charges"].astype(np.float64), positions=z["positions"].astype(np.float64),
+                      velocities=vel, box=z["box"].astype(np.float64), mol_id=z["mol_id"].astype(np.int32), drude_pairs=pairs,
+                      constraints=np.zeros((0, 2), np.int32), has_cm_motion_remover=False)
+    spec.particles_ld = [int(i) for i in z["particles_ld"]]
+    spec.image_pairs = [(int(a), int(b)) for a, b in z["image_pairs"]]
+    spec.particles_electrolyte = [int(i) for i in z["particles_electrolyte"]]
+    if hbonds:
+        cons, dist = z["constraints"].astype(np.int32), z["constraint_distances"].astype(np.float64)
+        _on_constraint_manifold(spec.positions, spec.velocities, cons, dist)
+        spec.constraints, spec.constraint_distances = cons, dist
+    return spec
+
+
+def make_config(name: str, scale: float = 1.0, hbonds: bool = False, synthetic: bool = False) -> SystemSpec:
+    """BASELINE.json configs by id.  C3 / C4 / C5 are built from the reference's own example models (bulk_Im21 tiled 2 x 2 x 3; edl_Im21);
+    `synthetic=True` (or missing fixtures) gives the procedural look-alikes instead.  `scale` > 1 tiles C3 further along z, `scale` < 1
+    gives a reduced copy for fast parity tests.  hbonds: with the HBonds constraints of the example scripts (rigid water for C2)."""
+    real = have_reference_topologies() and not synthetic
     if name == "C1":
         return nondrude_il(max(2, int(round(83 * scale))))
     if name == "C2":
-        return spce_water(max(4, int(round(3333 * scale))))
+        spec = spce_water(max(4, int(round(3333 * scale))))
+        return rigid_water(spec) if hbonds else spec
     if name in ("C3", "C4"):
-        if scale >= 1.0:
-            k = int(round(scale))
-            return drude_il(cells=(2, 2, 3 * k))
-        return drude_il(cells=(1, 1, 1), pairs_per_cell=max(2, int(round(3000 * scale))))
+        if real:
+            if scale >= 1.0:
+                return bulk_Im21(cells=(2, 2, 3 * int(round(scale))), hbonds=hbonds)
+            return bulk_Im21(cells=(1, 1, 1), pairs_per_cell=max(2, min(250, int(round(3000 * scale)))), hbonds=hbonds)
+        spec = drude_il(cells=(2, 2, 3 * int(round(scale)))) if scale >= 1.0 else drude_il(cells=(1, 1, 1), pairs_per_cell=max(2, int(round(3000 * scale))))
+        return constrain_hydrogens(spec) if hbonds else spec
     if name == "C5":
-        return edl_slab(max(2, int(round(511 * scale))), max(3, int(round(2496 * scale))))
+        if real and scale >= 1.0:
+            return edl_Im21(hbonds=hbonds)
+        spec = edl_slab(max(2, int(round(511 * scale))), max(3, int(round(2496 * scale))))
+        return constrain_hydrogens(spec) if hbonds else spec
     raise ValueError(f"unknown config {name!r}")

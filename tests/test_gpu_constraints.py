@@ -182,7 +182,7 @@ def test_unfusable_topology_is_left_to_the_host_solver():
 
 def test_full_size_c3_with_hbonds():
     """BASELINE.json C3 (111 000 particles) with HBonds constraints, size-independent properties only."""
-    spec = systems.constrain_hydrogens(systems.make_config("C3"))
+    spec = systems.make_config("C3", hbonds=True)
     it = I.VVIntegrator(333.0, 10, 1.0, 40, 0.001)
     it.setMaxDrudeDistance(0.02)
     ctx = I.Context(spec, it, precision="mixed", force_provider="tether")

@@ -182,16 +182,14 @@ def test_full_size_c3_properties():
 
 
 @pytest.mark.parametrize("prec", ["mixed", "double"])      # single: see the module docstring -- at 1e5 particles the reference's serial float
-@pytest.mark.parametrize("cfg,cos,hbonds", [("C3", 0.0, False), ("C3", 0.02, False), ("C3", 0.0, True), ("C5", 0.0, False),   # sums carry ~1e-4 noise
+@pytest.mark.parametrize("cfg,cos,hbonds", [("C3", 0.0, False), ("C3", 0.02, False), ("C3", 0.0, True), ("C5", 0.0, False), ("C5", 0.0, True),   # sums carry ~1e-4 noise
                                             ("C3-classic", 0.0, False), ("C3-classic", 0.02, True), ("C2", 0.0, True), ("C1", 0.0, False)])
 def test_full_size_configs_against_the_oracle(cfg, cos, hbonds, prec):
     """BASELINE.json's configurations at their FULL size against the oracle (the C restatement needs ~0.1 s for these 10 steps at
     111 000 particles): positions and velocities within 1e-5 relative (measured ~1e-15), the group sums within 1e-10."""
     middle = "classic" not in cfg
     cfg = cfg.split("-")[0]
-    spec = systems.make_config(cfg)
-    if hbonds:
-        spec = systems.rigid_water(spec) if cfg == "C2" else systems.constrain_hydrogens(spec)
+    spec = systems.make_config(cfg, hbonds=hbonds)          # C3 / C5: the reference's example models (tests/golden/topo_*.npz)
     kw = {}
     if cfg in ("C1", "C2"):
         kw = dict(maxd=0.0, T=300.0 if cfg == "C2" else 333.0, dt=0.002 if cfg == "C2" else 0.001)

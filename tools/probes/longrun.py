@@ -5,8 +5,7 @@ sys.path.insert(0, "/root/repo")
 pkg = importlib.import_module("openmm-velocityverlet_amd")
 I, S = pkg.integrator, pkg.systems
 for hb in (False, True):
-    spec = S.make_config("C3")
-    if hb: spec = S.constrain_hydrogens(spec)
+    spec = S.make_config("C3", hbonds=hb)
     it = I.VVIntegrator(333.0, 10, 1.0, 40, 0.001); it.setMaxDrudeDistance(0.02)
     ctx = I.Context(spec, it, precision="mixed", force_provider="tether")
     t0 = time.perf_counter()
