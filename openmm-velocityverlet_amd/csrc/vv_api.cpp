@@ -682,8 +682,9 @@ int vvhip_set_params(vvhip_plan* p, const vvhip_params* q) {
 
 int vvhip_set_box(vvhip_plan* p, const double box[3]) {
     if (!p || !box) return VVHIP_ERR_INVALID;
+    if (p->box[0] == box[0] && p->box[1] == box[1] && p->box[2] == box[2]) return VVHIP_OK;      // hosts re-send it every step
     for (int i = 0; i < 3; i++) p->box[i] = box[i];
-    drop_graphs(p);
+    drop_graphs(p);                                  // the box is baked into the captured kernel arguments
     return VVHIP_OK;
 }
 

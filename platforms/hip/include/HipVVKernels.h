@@ -29,6 +29,7 @@ private:
     HipContext& cu;
     vvhip_plan* plan;
     vvhip_params last;
+    double lastBox[3] = {0, 0, 0};
     int ldRandoms;
     bool noConstraints;
     bool debug = false;      // last VVIntegrator::getDebugEnabled() handed to vvhip_set_trace
@@ -39,7 +40,9 @@ protected:
     explicit HipVVStepCommon(HipContext& cu) : cu(cu) {}
     void create(const System& system, const VVIntegrator& integrator, const DrudeForce* force);
     void advanceClock(const VVIntegrator& integrator);
+    void announceStepSize(const VVIntegrator& integrator, bool classic);     // setNextStepSize / (0, dt) upload on a change (HOST:136-141, 307-319)
     uint32_t nextRandomIndex();
+    double prevStepSize = -1.0;
     HipContext& cu;
     std::shared_ptr<HipVVPlan> plan;
 };

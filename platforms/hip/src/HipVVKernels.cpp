@@ -38,7 +38,12 @@ bool sameParams(const vvhip_params& a, const vvhip_params& b) {
     return a.temperature == b.temperature && a.frequency == b.frequency && a.drude_temperature == b.drude_temperature &&
            a.drude_frequency == b.drude_frequency && a.step_size == b.step_size && a.loops_per_step == b.loops_per_step &&
            a.max_drude_distance == b.max_drude_distance && a.friction == b.friction && a.drude_friction == b.drude_friction &&
-           a.mirror_location == b.mirror_location && a.electric_field == b.electric_field && a.cos_acceleration == b.cos_acceleration;
+           a.mirror_location == b.mirror_location && a.electric_field == b.electric_field && a.cos_acceleration == b.cos_acceleration &&
+           a.constraint_tolerance == b.constraint_tolerance;      // the reference hands getConstraintTolerance() to the solver at every call (HOST:151,176)
+}
+void boxOf(HipContext& cu, double out[3]) {      // cu.getPeriodicBoxSize() is a double4 by value (HOST:1129-1130)
+    const double4 box = cu.getPeriodicBoxSize();
+    out[0] = box.x; out[1] = box.y; out[2] = box.z;
 }
 }  // namespace
 
@@ -85,13 +90,17 @@ HipVVPlan::HipVVPlan(HipContext& cu, const System& system, const VVIntegrator& i
     noConstraints = info.constraints_fused != 0;      // no constraints at all, or all of them solved inside the kernels
     HipIntegrationUtilities& integration = cu.getIntegrationUtilities();
     vvhip_buffers b = {};
-    b.velm = cu.getVelm().getDevicePointer(); b.posq = cu.getPosq().getDevicePointer();
-    b.posq_correction = cu.getUseMixedPrecision() ? cu.getPosqCorrection().getDevicePointer() : NULL;
-    b.force = cu.getForce().getDevicePointer(); b.pos_delta = integration.getPosDelta().getDevicePointer();
-    b.random = integration.getRandom().getDevicePointer(); b.random_size = (uint32_t) integration.getRandom().getSize();
+    // getDevicePointer() is an lvalue device-pointer handle in OpenMM (the reference passes its address as a kernel argument,
+    // HOST:144-147); its value is what the C ABI takes
+    b.velm = (void*) cu.getVelm().getDevicePointer(); b.posq = (void*) cu.getPosq().getDevicePointer();
+    b.posq_correction = cu.getUseMixedPrecision() ? (void*) cu.getPosqCorrection().getDevicePointer() : NULL;
+    b.force = (void*) cu.getForce().getDevicePointer(); b.pos_delta = (void*) integration.getPosDelta().getDevicePointer();
+    b.random = (const void*) integration.getRandom().getDevicePointer(); b.random_size = (uint32_t) integration.getRandom().getSize();
     b.stream = (void*) cu.getCurrentStream();
     check(vvhip_bind(plan, &b));
-    check(vvhip_set_box(plan, cu.getPeriodicBoxSize()));
+    double box[3];
+    boxOf(cu, box);
+    check(vvhip_set_box(plan, box));
     std::cerr << "HIP velocity-Verlet plan: " << n << " particles in " << info.num_waves << " waves (" << info.num_slots_used
               << " lanes used), " << info.num_temp_groups << " temperature group(s), NH pairs " << info.num_pairs_nh
               << ", Langevin particles " << ld.size() << ", image pairs " << info.num_images << "\n";
@@ -108,7 +117,12 @@ void HipVVPlan::syncParameters(const VVIntegrator& it) {
     }
     vvhip_params now = paramsOf(it);
     if (!sameParams(now, last)) { check(vvhip_set_params(plan, &now)); last = now; }
-    check(vvhip_set_box(plan, cu.getPeriodicBoxSize()));
+    double box[3];
+    boxOf(cu, box);
+    if (box[0] != lastBox[0] || box[1] != lastBox[1] || box[2] != lastBox[2]) {      // a barostat move: the box is read live (HOST:1057, 1129)
+        check(vvhip_set_box(plan, box));
+        lastBox[0] = box[0]; lastBox[1] = box[1]; lastBox[2] = box[2];
+    }
 }
 std::shared_ptr<HipVVPlan> HipVVPlan::create(HipContext& cu, const System& s, const VVIntegrator& it, const DrudeForce* f) {
     std::shared_ptr<HipVVPlan> p(new HipVVPlan(cu, s, it, f));
@@ -125,8 +139,22 @@ std::shared_ptr<HipVVPlan> HipVVPlan::find(HipContext& cu) {
 
 // ------------------------------------------------------------------------------------------ step kernels
 void HipVVStepCommon::create(const System& system, const VVIntegrator& it, const DrudeForce* force) {
+    ContextSelector selector(cu);                                                                       // HOST:60, 246
+    cu.getPlatformData().initializeContexts(system);                                                    // HOST:61, 247
     cu.getIntegrationUtilities().initRandomNumberGenerator((unsigned int) it.getRandomNumberSeed());   // HOST:63
     plan = HipVVPlan::create(cu, system, it, force);
+    prevStepSize = -1.0;                                                                                // HOST:115
+}
+// OpenMM's own kernels (constraint solvers, virtual sites) read the step size from integration.getStepSize(): the middle kernel
+// announces a change with setNextStepSize (HOST:136-141), the classic kernel uploads (0, dt) itself (HOST:307-319).
+void HipVVStepCommon::announceStepSize(const VVIntegrator& it, bool classic) {
+    const double stepSize = it.getStepSize();
+    if (stepSize == prevStepSize) return;
+    HipIntegrationUtilities& integration = cu.getIntegrationUtilities();
+    if (!classic) integration.setNextStepSize(stepSize);
+    else if (cu.getUseDoublePrecision() || cu.getUseMixedPrecision()) { double ss[2] = {0.0, stepSize}; integration.getStepSize().upload(ss); }
+    else { float ss[2] = {0.0f, (float) stepSize}; integration.getStepSize().upload(ss); }
+    prevStepSize = stepSize;
 }
 void HipVVStepCommon::advanceClock(const VVIntegrator& it) {      // HOST:219-220, 430-431
     cu.setTime(cu.getTime() + it.getStepSize());
@@ -135,10 +163,11 @@ void HipVVStepCommon::advanceClock(const VVIntegrator& it) {      // HOST:219-22
 uint32_t HipVVStepCommon::nextRandomIndex() { return (uint32_t) cu.getIntegrationUtilities().prepareRandomNumbers(plan->numLangevinRandoms()); }
 
 void HipIntegrateMiddleStepKernel::initialize(const System& s, const VVIntegrator& it, const DrudeForce* f) { create(s, it, f); }
-void HipIntegrateMiddleStepKernel::resetExtraForce(ContextImpl&, const VVIntegrator&) { plan->check(vvhip_reset_extra_force(plan->get())); }
+void HipIntegrateMiddleStepKernel::resetExtraForce(ContextImpl&, const VVIntegrator&) { cu.setAsCurrent(); plan->check(vvhip_reset_extra_force(plan->get())); }
 void HipIntegrateMiddleStepKernel::firstIntegrate(ContextImpl&, const VVIntegrator& it) {              // HOST:129-159
     cu.setAsCurrent();
     plan->syncParameters(it);
+    announceStepSize(it, false);
     if (it.getDebugEnabled()) std::cout << "HipIntegrateMiddleStepKernel firstIntegrate" << std::endl;
     plan->check(vvhip_middle_kick(plan->get()));
     cu.getIntegrationUtilities().applyVelocityConstraints(it.getConstraintTolerance());
@@ -161,8 +190,10 @@ bool HipIntegrateMiddleStepKernel::canFuse(ContextImpl&, const VVIntegrator&) co
 void HipIntegrateMiddleStepKernel::fusedMiddleStep(ContextImpl&, const VVIntegrator& it) {
     cu.setAsCurrent();
     plan->syncParameters(it);
+    announceStepSize(it, false);
     if (it.getDebugEnabled()) std::cout << "HipIntegrateMiddleStepKernel fusedMiddleStep" << std::endl;
     plan->check(vvhip_step_middle(plan->get(), it.getParticlesLD().empty() ? 0 : nextRandomIndex()));
+    cu.getIntegrationUtilities().computeVirtualSites();      // as the un-fused path and the reference after every position update (HOST:214)
     cu.reorderAtoms();
     advanceClock(it);
 }
@@ -170,10 +201,11 @@ void HipIntegrateMiddleStepKernel::fusedVVFirstHalf(ContextImpl&, const VVIntegr
 void HipIntegrateMiddleStepKernel::fusedVVSecondHalf(ContextImpl&, const VVIntegrator&) { throw OpenMMException("middle-scheme kernel asked for a classic step"); }
 
 void HipIntegrateVVStepKernel::initialize(const System& s, const VVIntegrator& it, const DrudeForce* f) { create(s, it, f); }
-void HipIntegrateVVStepKernel::resetExtraForce(ContextImpl&, const VVIntegrator&) { plan->check(vvhip_reset_extra_force(plan->get())); }
+void HipIntegrateVVStepKernel::resetExtraForce(ContextImpl&, const VVIntegrator&) { cu.setAsCurrent(); plan->check(vvhip_reset_extra_force(plan->get())); }
 void HipIntegrateVVStepKernel::firstIntegrate(ContextImpl&, const VVIntegrator& it) {                   // HOST:296-382
     cu.setAsCurrent();
     plan->syncParameters(it);
+    announceStepSize(it, true);
     plan->check(vvhip_vv_half_kick(plan->get(), 1));
     cu.getIntegrationUtilities().applyConstraints(it.getConstraintTolerance());
     plan->check(vvhip_vv_positions(plan->get()));
@@ -192,46 +224,54 @@ void HipIntegrateVVStepKernel::fusedMiddleStep(ContextImpl&, const VVIntegrator&
 void HipIntegrateVVStepKernel::fusedVVFirstHalf(ContextImpl&, const VVIntegrator& it) {
     cu.setAsCurrent();
     plan->syncParameters(it);
+    announceStepSize(it, true);
     plan->check(vvhip_step_vv_first(plan->get()));
+    cu.getIntegrationUtilities().computeVirtualSites();      // HOST:374
     cu.reorderAtoms();
 }
 void HipIntegrateVVStepKernel::fusedVVSecondHalf(ContextImpl&, const VVIntegrator& it) {
+    cu.setAsCurrent();
     plan->check(vvhip_step_vv_second(plan->get(), it.getParticlesLD().empty() ? 0 : nextRandomIndex()));
     advanceClock(it);
 }
 
 // ------------------------------------------------------------------------------------------ modifier kernels
-void HipModifyDrudeNoseKernel::initialize(const System&, const VVIntegrator&, const DrudeForce*) { plan = HipVVPlan::find(cu); }
+void HipModifyDrudeNoseKernel::initialize(const System&, const VVIntegrator&, const DrudeForce*) { ContextSelector selector(cu); plan = HipVVPlan::find(cu); }
 void HipModifyDrudeNoseKernel::scaleVelocity(ContextImpl&, const VVIntegrator& it) {                    // HOST:670-754
+    cu.setAsCurrent();
     plan->syncParameters(it);
     plan->check(vvhip_scale_velocity(plan->get()));
 }
 
-void HipModifyDrudeLangevinKernel::initialize(const System&, const VVIntegrator&, const DrudeForce*, Kernel&) { plan = HipVVPlan::find(cu); }
+void HipModifyDrudeLangevinKernel::initialize(const System&, const VVIntegrator&, const DrudeForce*, Kernel&) { ContextSelector selector(cu); plan = HipVVPlan::find(cu); }
 void HipModifyDrudeLangevinKernel::applyLangevinForce(ContextImpl&, const VVIntegrator& it) {            // HOST:826-872
+    cu.setAsCurrent();
     plan->syncParameters(it);
     const int randomIndex = cu.getIntegrationUtilities().prepareRandomNumbers(plan->numLangevinRandoms());
     plan->check(vvhip_apply_langevin_force(plan->get(), (uint32_t) randomIndex));
 }
 
-void HipModifyImageChargeKernel::initialize(const System&, const VVIntegrator&) { plan = HipVVPlan::find(cu); }
+void HipModifyImageChargeKernel::initialize(const System&, const VVIntegrator&) { ContextSelector selector(cu); plan = HipVVPlan::find(cu); }
 void HipModifyImageChargeKernel::updateImagePositions(ContextImpl&, const VVIntegrator& it) {            // HOST:904-934
+    cu.setAsCurrent();
     plan->syncParameters(it);
     plan->check(vvhip_update_image_positions(plan->get()));
 }
 
-void HipModifyElectricFieldKernel::initialize(const System&, const VVIntegrator&, Kernel&) { plan = HipVVPlan::find(cu); }
+void HipModifyElectricFieldKernel::initialize(const System&, const VVIntegrator&, Kernel&) { ContextSelector selector(cu); plan = HipVVPlan::find(cu); }
 void HipModifyElectricFieldKernel::applyElectricForce(ContextImpl&, const VVIntegrator& it) {            // HOST:971-992
+    cu.setAsCurrent();
     plan->syncParameters(it);
     plan->check(vvhip_apply_electric_force(plan->get()));
 }
 
-void HipModifyCosineAccelerateKernel::initialize(const System&, const VVIntegrator&, Kernel&) { plan = HipVVPlan::find(cu); }
-void HipModifyCosineAccelerateKernel::applyCosineForce(ContextImpl&, const VVIntegrator& it) { plan->syncParameters(it); plan->check(vvhip_apply_cosine_force(plan->get())); }
-void HipModifyCosineAccelerateKernel::calcVelocityBias(ContextImpl&, const VVIntegrator&) { plan->check(vvhip_calc_velocity_bias(plan->get())); }
-void HipModifyCosineAccelerateKernel::removeVelocityBias(ContextImpl&, const VVIntegrator&) { plan->check(vvhip_remove_velocity_bias(plan->get())); }
-void HipModifyCosineAccelerateKernel::restoreVelocityBias(ContextImpl&, const VVIntegrator&) { plan->check(vvhip_restore_velocity_bias(plan->get())); }
+void HipModifyCosineAccelerateKernel::initialize(const System&, const VVIntegrator&, Kernel&) { ContextSelector selector(cu); plan = HipVVPlan::find(cu); }
+void HipModifyCosineAccelerateKernel::applyCosineForce(ContextImpl&, const VVIntegrator& it) { cu.setAsCurrent(); plan->syncParameters(it); plan->check(vvhip_apply_cosine_force(plan->get())); }
+void HipModifyCosineAccelerateKernel::calcVelocityBias(ContextImpl&, const VVIntegrator&) { cu.setAsCurrent(); plan->check(vvhip_calc_velocity_bias(plan->get())); }
+void HipModifyCosineAccelerateKernel::removeVelocityBias(ContextImpl&, const VVIntegrator&) { cu.setAsCurrent(); plan->check(vvhip_remove_velocity_bias(plan->get())); }
+void HipModifyCosineAccelerateKernel::restoreVelocityBias(ContextImpl&, const VVIntegrator&) { cu.setAsCurrent(); plan->check(vvhip_restore_velocity_bias(plan->get())); }
 void HipModifyCosineAccelerateKernel::calcViscosity(ContextImpl&, const VVIntegrator& it, double& vMax, double& invVis) {   // HOST:1112-1134
+    cu.setAsCurrent();
     plan->syncParameters(it);
     plan->check(vvhip_calc_viscosity(plan->get(), &vMax, &invVis));
 }

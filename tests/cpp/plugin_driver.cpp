@@ -149,6 +149,7 @@ static int run(const char* out, bool middle, int consMode, double cosacc, int ns
     cu.getVelm().upload(velm.data()); cu.getPosq().upload(posq.data()); cu.getPosqCorrection().upload(corr.data());
     HipArray site; site.initialize(n, 16); site.upload(posq.data());
     HipPlatform::PlatformData pd; pd.contexts.push_back(&cu);
+    cu.setPlatformData(&pd);
     ctx.getImpl().setPlatformData(&pd);
     ctx.getImpl().setMolecules(molecules);
     ForceUser fu = {&cu, &site};
@@ -162,6 +163,14 @@ static int run(const char* out, bool middle, int consMode, double cosacc, int ns
     put(f, masses); put(f, charges); put(f, molId); put(f, pairs); put(f, cons); put(f, pos); put(f, vel);
     put(f, velm); put(f, posq); put(f, corr); put(f, vis); put(f, consDist);
     std::printf("RUN OK steps=%d time=%.6f stepCount=%lld vMax=%.9g\n", nsteps, cu.getTime(), cu.getStepCount(), vis[0]);
+    // how the adapters used the context services (the reference's pattern: HOST:60-63, 136-141, 214-216, 307-319)
+    double ss[2] = {-1, -1};
+    cu.getIntegrationUtilities().getStepSize().download(ss);
+    const HipIntegrationUtilities::Calls& c = cu.getIntegrationUtilities().calls;
+    std::printf("SERVICES selector=%d depth=%d initializeContexts=%d initRandom=%d setNextStepSize=%d stepSize=(%.6g,%.6g) virtualSites=%d reorder=%d "
+                "applyConstraints=%d applyVelocityConstraints=%d setAsCurrent=%d\n", cu.selectorUses, cu.selectorDepth, pd.initializeContextsCalls,
+                c.initRandom, c.setNextStepSize, ss[0], ss[1], c.computeVirtualSites, cu.reorderCalls, c.applyConstraints, c.applyVelocityConstraints,
+                cu.setAsCurrentCalls);
     return 0;
 }
 

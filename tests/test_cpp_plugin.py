@@ -64,6 +64,22 @@ def test_cpp_integrator_through_plugin_matches_oracle(tmp_path, middle, cons, co
     r = subprocess.run([DRIVER, "run", dump, str(middle), str(cons), str(cos), str(nsteps)], capture_output=True, text=True)
     assert r.returncode == 0 and "RUN OK" in r.stdout, r.stdout + r.stderr
     assert f"stepCount={nsteps}" in r.stdout
+    # the adapters use the context services the way the reference's CUDA kernels do (platforms/cuda/src/CudaVVKernels.cpp):
+    # ContextSelector in every initialize() (:60, 246, 468, ...), initializeContexts + initRandomNumberGenerator once (:61-63), the step
+    # size announced once (setNextStepSize, :136-141; the classic kernel uploads (0, dt) itself, :307-319), virtual sites recomputed
+    # and atoms reordered after every position update, also on the fused path (:214-216, 374-381)
+    import re
+    sv = dict(re.findall(r"(\w+)=(\([^)]*\)|\S+)", next(ln for ln in r.stdout.splitlines() if ln.startswith("SERVICES"))))
+    nkern = 2 + (1 if cos else 0)                        # step kernel + Nose-Hoover (+ cos) initialize() calls
+    assert int(sv["selector"]) == nkern and int(sv["depth"]) == 0 and int(sv["initializeContexts"]) == 1 and int(sv["initRandom"]) == 1
+    assert int(sv["setNextStepSize"]) == (1 if middle else 0)
+    assert sv["stepSize"] == "(0,0.001)"
+    assert int(sv["virtualSites"]) == nsteps and int(sv["reorder"]) == nsteps
+    assert int(sv["setAsCurrent"]) >= nsteps
+    if cons == 1:                                        # constraints the kernels cannot fuse: OpenMM's solver runs between the stages
+        assert int(sv["applyConstraints"]) == nsteps and int(sv["applyVelocityConstraints"]) == nsteps
+    else:
+        assert int(sv["applyConstraints"]) == 0 and int(sv["applyVelocityConstraints"]) == 0
     masses, charges, mol, pairs, cns, pos, vel, velm, posq, corr, vis, cdist = _read(dump)
     n = masses.shape[0]
     spec = systems.SystemSpec(name="cpp", masses=masses, charges=charges, positions=pos.reshape(n, 3), velocities=vel.reshape(n, 3),

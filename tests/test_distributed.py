@@ -64,3 +64,60 @@ def test_bench_two_ranks_share_one_gpu_mailbox():
     line = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["value"] > 100
     assert "mailbox" in line["config"]["parallelism"], line["config"]["parallelism"] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("cfg", ["C3", "C4"])
+def test_shard_plans_for_the_scaling_run_host_only(cfg, world):
+    """What `bench.py --gpus N` builds on every rank, without a GPU: molecule-aligned shards of the headline box, one plan per
+    rank with GLOBAL thermostat constants (DOF, chain masses, total mass), every particle in exactly one shard, and the exchange
+    payload the mailbox carries (3 totals; 10 with the cos perturbation in its moment form = 20 words)."""
+    import importlib
+    import numpy as np
+    pkg = importlib.import_module("openmm-velocityverlet_amd")
+    I, S, D = pkg.integrator, pkg.systems, pkg.distributed
+    spec = S.make_config(cfg)
+    bounds = D.shard_bounds(spec, world)
+    assert bounds[0][0] == 0 and bounds[-1][1] == spec.num_atoms and all(b[1] == c[0] for b, c in zip(bounds, bounds[1:]))
+    sizes = np.array([e - b for b, e in bounds])
+    assert sizes.min() > 0 and (sizes.max() - sizes.min()) <= 2 * 27 + 10          # balanced to within a couple of ions
+    mol = np.asarray(spec.mol_id)
+    for b, e in bounds[:-1]:
+        assert mol[e - 1] != mol[e]                                               # never inside a molecule (nor a Drude pair / COM group)
+    infos, used = [], 0
+    for r in range(world):
+        it = I.VVIntegrator(333.0, 10.0, 1.0, 40.0, 0.001)
+        it.setMaxDrudeDistance(0.02)
+        if cfg == "C4":
+            it.setCosAcceleration(0.02)
+        plan, info, _ = I.create_plan(spec, it, shard=bounds[r])
+        infos.append((list(info.dof), list(info.nkbt), [list(info.eta_mass[g])[:3] for g in range(3)], info.inv_mass_total, info.num_temp_groups))
+        used += info.num_slots_used
+        assert pkg.vvhip.lib.vvhip_step_middle_phases(plan) == 2                   # kick+sums | exchange | chain+scale+drift, also with cos
+        pkg.vvhip.lib.vvhip_plan_destroy(plan)
+    assert used == spec.num_atoms
+    assert all(i == infos[0] for i in infos)
+    assert np.allclose(infos[0][0], [198000.0, 17997.0, 117000.0], atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,cfg", [(4, "C3"), (8, "C3"), (4, "C4"), (8, "C4")])
+def test_bench_rank_counts_of_the_scaling_run_on_one_gpu(world, cfg):
+    """bench.py's N = 4 and N = 8 logic (shard bounds, handle gather, mailbox trial, agreement, replayed graphs; with C4 the
+    20-word payload of the cos moments) with all ranks on GPU 0 -- a dry run of the driver's scaling command for rank-count bugs.
+    gloo carries the set-up traffic because RCCL refuses several ranks on one device; the exchange itself is the mailbox (hipIpc)."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(29550 + world + (1 if cfg == "C4" else 0)), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--backend", "gloo",
+           "--share-device", "--config", cfg, "--steps", "200", "--warmup", "40", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    # speed means nothing here (N processes time-slice one GPU and wait for each other's kernels: tens of steps/s); the run must
+    # complete with every rank's thermostat bits equal -- bench.py exits non-zero otherwise
+    assert line["n_gpus"] == world and line["value"] > 1 and line["steps"] == 200, line
+    assert f"x{world}" in line["config"]["parallelism"]
+    # several processes time-slicing one GPU may lose the mailbox trial (its waits are bounded); then the run falls back to the
+    # per-step collective -- either way every rank finished with identical thermostat bits (bench.py checks that itself)
+    assert any(k in line["config"]["parallelism"] for k in ("mailbox", "python", "eager"))
