@@ -7,7 +7,7 @@
 // assumes a different signature:
 //   * getDevicePointer() is an LVALUE device-pointer handle (the reference takes its address: HOST:144-147, 179-184);
 //   * getPeriodicBoxSize() returns a double4 BY VALUE (HOST:1129-1130), getInvPeriodicBoxSizePointer() a host pointer (HOST:1057);
-//   * ContextSelector guards every initialize() (HOST:60, 246, 468, ...), setAsCurrent() every call (HOST:123, 133, 165, ...);
+//   * ContextSelector guards every initialize() (HOST:60, 246, 466, ...), setAsCurrent() every call (HOST:123, 133, 165, ...);
 //   * integration.setNextStepSize() / getStepSize() carry the step size to OpenMM's own kernels (HOST:138-141, 309-319);
 //   * constraint / virtual-site / reorder / kinetic-energy hooks are OpenMM's: here they only count calls.
 // Nothing here is OpenMM source; INTEGRATION.md section 2 lists the same signatures.
@@ -132,7 +132,7 @@ inline void HipIntegrationUtilities::setNextStepSize(double size) {             
     lastStepSize = size;
 }
 
-class ContextSelector {                  // RAII guard of the reference's initialize() methods (HOST:60, 246, 468, 766, 883, 945, 1003)
+class ContextSelector {                  // RAII guard of the reference's initialize() methods (HOST:60, 246, 466, 765, 882, 944, 1002)
 public:
     explicit ContextSelector(HipContext& cu) : cu(cu) { cu.pushAsCurrent(); }
     ~ContextSelector() { cu.popAsCurrent(); }

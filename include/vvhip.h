@@ -171,11 +171,13 @@ int vvhip_set_nh_state(vvhip_plan* plan, const vvhip_nh_state* in);
  * virtual sites (those solvers are OpenMM's).  Forces for the step must already be in `force`.
  *
  * Middle scheme (API:232-270 after calcForcesAndEnergy): 2 launches
- *   pass A: extra forces (Langevin, E-field, cos) + full kick + molecular COM + per-group 2KE
- *           (+ cos bias moments) -> fixed-point accumulators
- *   pass B: NH chain (device) + velocity scaling + bias remove/restore + both half drifts +
- *           hard wall + image mirror
- * With cos acceleration a third launch sits between them (bias must be known before the KE).
+ *   pass A: extra forces (Langevin, E-field, cos) + full kick (+ velocity constraints) + molecular COM + per-group
+ *           2KE -> fixed-point accumulators; with cos acceleration also the bias moment and the group sums as
+ *           moments of the still biased velocities, so that no launch is needed between bias and 2KE
+ *   pass B: NH chain (device) + velocity scaling + bias remove/restore + both half drifts (+ position
+ *           constraints) + hard wall + image mirror
+ * Only molecules larger than one 64-lane wave, chains longer than 4 and systems beyond ~0.8 M particles take more
+ * launches (per-molecule COM accumulation, stand-alone chain kernel, the three-launch cos sequence).
  * Classic scheme: vvhip_step_vv_first() = API:295-310, vvhip_step_vv_second() = API:316-336.
  * `random_index` = integration.prepareRandomNumbers(...) for this step (HOST:863), ignored unless
  * Langevin particles exist. */
@@ -183,8 +185,8 @@ int vvhip_step_middle(vvhip_plan* plan, uint32_t random_index);
 int vvhip_step_vv_first(vvhip_plan* plan);
 int vvhip_step_vv_second(vvhip_plan* plan, uint32_t random_index);
 /* vvhip_step_middle cut at its global reductions, for hosts that shard particles over GPUs and run a
- * collective in between.  A step has vvhip_step_middle_phases() phases (2, or 3 with cos acceleration:
- * the bias must be known before the kinetic energies).  After every phase but the last, the host sums
+ * collective in between.  A step has vvhip_step_middle_phases() phases (1 without NH particles, else 2; 3 only
+ * where the cos perturbation cannot use its moment form, see above).  After every phase but the last, the host sums
  * the accumulator range reported by vvhip_accumulators(phase) element-wise over ranks (ncclSum on
  * int64; fixed point makes the result independent of rank order) on the plan's stream:
  *     for (ph = 0; ph < P; ph++) { vvhip_step_middle_phase(plan, ph, ri); if (ph < P-1) all_reduce(acc(ph)); }
@@ -205,12 +207,15 @@ int vvhip_comm_destroy(vvhip_plan* plan);
 
 /* Exchange without a collective launch, for the ranks of ONE node ("mailbox" over xGMI peer mappings).  Every rank calls
  * vvhip_mailbox_create (allocates its uncached box, returns a 64-byte hipIpc handle), the host gathers all handles in rank
- * order (ranks * 64 bytes, any transport) and every rank calls vvhip_mailbox_connect.  From then on kernel A's last block stores
- * the rank's int64 totals into every peer's box and kernel B's thermostat wave sums them in rank order: a sharded step stays two
- * launches, replayable from a hipGraph, and all ranks continue with identical bits.  Used for the kinetic-energy reduction of
- * steps without cos acceleration and chain length <= 4 (vvhip_mailbox_status: active); everything else keeps using the RCCL
- * communicator if one is set.  A rank that does not hear from its peers within ~5 s raises `timed_out` and carries on with
- * wrong sums instead of hanging the GPU: hosts check vvhip_mailbox_status after a trial run and fall back to vvhip_comm_*.
+ * order (ranks * 64 bytes, any transport) and every rank calls vvhip_mailbox_connect.  From then on the thermostat wave of block 0
+ * of kernel B -- which has just folded the rank's accumulators, complete since kernel A ended -- stores the rank's int64 totals into
+ * every peer's box (one 8-byte {sequence, payload} word each) and the thermostat wave of every block polls the rank's own box and
+ * adds the peers' words: a sharded step stays two launches, replayable from a hipGraph, and all ranks continue with identical
+ * bits.  Carries the three kinetic-energy totals, and with the cos perturbation in its moment form also the bias moment and the
+ * six group moments (10 totals = 20 words); chain lengths <= 4 (vvhip_mailbox_status: active); everything else keeps using the
+ * RCCL communicator if one is set.  A rank that does not hear from its peers within ~5 s raises a sticky flag and carries on
+ * with incomplete sums instead of hanging the GPU; the flag surfaces as VVHIP_ERR_EXCHANGE from vvhip_synchronize and from the
+ * next vvhip_run_graph / vvhip_run_eager (see vvhip_status), so a host can never take a figure from a diverged run.
  * No reference counterpart (the reference is single-GPU: CudaVVKernelFactory.cpp:68). */
 int vvhip_mailbox_create(vvhip_plan* plan, int nranks, int rank, void* handle64);
 int vvhip_mailbox_connect(vvhip_plan* plan, const void* handles);
@@ -228,7 +233,7 @@ int vvhip_middle_finish(vvhip_plan* plan);                     /* secondIntegrat
 /* IntegrateVVStepKernel (VVKernels.h:94-130; HOST:296-442) */
 int vvhip_vv_half_kick(vvhip_plan* plan, int update_pos_delta);/* HOST:341-348 / 417-424 */
 int vvhip_vv_positions(vvhip_plan* plan);                      /* HOST:355-372: positions + hard wall */
-/* ModifyDrudeNoseKernel (VVKernels.h:138-157; HOST:670-754): 2 launches, no host round trip */
+/* ModifyDrudeNoseKernel (VVKernels.h:138-157; HOST:670-754): 2 launches (sums | chain + scaling), no host round trip */
 int vvhip_scale_velocity(vvhip_plan* plan);
 /* ModifyDrudeLangevinKernel (VVKernels.h:165-184; HOST:826-872) */
 int vvhip_apply_langevin_force(vvhip_plan* plan, uint32_t random_index);
@@ -270,8 +275,9 @@ int vvhip_status_clear(vvhip_plan* plan);
 int vvhip_stream_create(void** stream);          /* hipStreamCreateWithFlags(non-blocking) */
 int vvhip_stream_destroy(void* stream);
 int vvhip_synth_tether_force(vvhip_plan* plan, const void* site /* real4[n] */, double k_tether, double k_drude);
-/* Captures `steps_per_graph` steps (optionally with the synthetic force kernel in front of each) into a
- * hipGraph once and replays it; returns after enqueueing.  Middle scheme only. */
+/* Replays hipGraphs of `steps_per_graph` whole steps (optionally with the synthetic force kernel in front of each; both
+ * schemes): floor(nsteps / steps_per_graph) replays, the remainder enqueued step by step; returns after enqueueing.  The
+ * graph of the current thermostat parity is captured on first use (see vvhip_graph_prepare to do that up front). */
 int vvhip_run_graph(vvhip_plan* plan, int nsteps, int steps_per_graph, const void* site, double k_tether, double k_drude);
 /* Captures, instantiates and uploads that graph for BOTH thermostat parities WITHOUT launching anything (no-op for a parity
  * whose executable is already there).  The plan keeps one executable per parity, so a host that calls this after its warm-up
