@@ -4,6 +4,8 @@ in KB; FETCH_SIZE reads exactly half of a wide coalesced streaming read -> doubl
 import csv, glob, json, os, sys
 
 out_dir, tag = sys.argv[1], sys.argv[2]
+cfg = sys.argv[3] if len(sys.argv) > 3 else "C3"
+natoms = {"C3": 111000, "C4": 111000, "C5": 40310, "C3x8": 888000, "C3x80": 8880000}.get(cfg, 111000)
 names = {"vv_kernel_a": "A", "vv_kernel_b": "B", "vv_kernel_tether": "tether"}
 raw = {}
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -16,8 +18,8 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
                 if key in row["Kernel_Name"]:
                     rec = raw.setdefault(short, {}).setdefault(counter, [0.0, 0])
                     rec[0] += float(row["Counter_Value"]); rec[1] += 1
-res = {"config": "C3", "precision": "mixed", "round": tag,
-       "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 400 --warmup 100 --no-cpu-baseline (two separate passes; tools/profile_round.sh)",
+res = {"config": cfg, "precision": "mixed", "round": tag,
+       "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --config %s --large-n none --no-cpu-baseline (two separate passes; tools/profile_round.sh)" % cfg,
        "correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE (KB) reads exactly half of a wide coalesced streaming read on gfx950 -> doubled; WRITE_SIZE (KB) as is; x1024 for bytes",
        "raw_kb": {}}
 for short, d in raw.items():
@@ -25,5 +27,8 @@ for short, d in raw.items():
     res["raw_kb"][short]["dispatches"] = max(v[1] for v in d.values())
     f = d.get("FETCH_SIZE", [0, 1]); w = d.get("WRITE_SIZE", [0, 1])
     res[f"hbm_bytes_per_launch_{short}"] = int(round((2 * f[0] / max(f[1], 1) + w[0] / max(w[1], 1)) * 1024))
-res["algorithmic_bytes_per_launch"] = {"A": 94 * 111000, "B": 134 * 111000}
+res["algorithmic_bytes_per_launch"] = {"A": 94 * natoms, "B": 134 * natoms}
+for k in ("A", "B"):
+    if f"hbm_bytes_per_launch_{k}" in res:
+        res[f"traffic_over_algorithmic_{k}"] = round(res[f"hbm_bytes_per_launch_{k}"] / res["algorithmic_bytes_per_launch"][k], 3)
 print(json.dumps(res, indent=1))

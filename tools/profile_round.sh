@@ -1,21 +1,29 @@
 #!/bin/bash
-# Collects the evidence bench.py's numbers rest on, on the GPU box:  tools/profile_round.sh <tag>   (e.g. r01d)
-#   gpurun_out/<tag>/bench_C3_mixed.json            the default bench line
-#   gpurun_out/<tag>/kernel_stats.csv               rocprofv3 --kernel-trace --stats of the same command (shorter run)
-#   gpurun_out/<tag>/pmc.json                       HBM bytes per launch from FETCH_SIZE / WRITE_SIZE (separate passes, guide's corrections)
-# Copy what should be judged into profiles/ afterwards.
+# Collects the evidence bench.py's numbers rest on, on the GPU box:  tools/profile_round.sh <tag> [config]   (e.g. r02a C3x80)
+#   gpurun_out/<tag>/bench_<config>_mixed.json                 the bench line (config C3: the default command AND the driver's --steps 20 --warmup 5)
+#   gpurun_out/<tag>/kernel_stats_<config>.csv                 rocprofv3 --kernel-trace --stats of the same command (shorter run, no secondary blocks)
+#   gpurun_out/<tag>/pmc_<config>.json                         HBM bytes per launch from FETCH_SIZE / WRITE_SIZE (separate passes, guide's corrections)
+# Copy what should be judged into profiles/ afterwards (profiles/pmc_latest[_<config>].json is what bench.py reads for roofline.traffic).
 set -u
-TAG=${1:-r01x}
+TAG=${1:-r02x}
+CFG=${2:-C3}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-python3 "$ROOT/bench.py" 2>"$OUT/bench.stderr" | tail -1 > "$OUT/bench_C3_mixed.json"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- python3 "$ROOT/bench.py" --steps 4000 --warmup 400 --no-cpu-baseline > "$OUT/stats.log" 2>&1
-cp "$OUT"/stats/run_kernel_stats.csv "$OUT/kernel_stats.csv" 2>/dev/null || find "$OUT/stats" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
+if [ "$CFG" = "C3" ]; then
+    python3 "$ROOT/bench.py" 2>"$OUT/bench_$CFG.stderr" | tail -1 > "$OUT/bench_${CFG}_mixed.json"
+    python3 "$ROOT/bench.py" --gpus 1 --steps 20 --warmup 5 2>>"$OUT/bench_$CFG.stderr" | tail -1 > "$OUT/bench_${CFG}_mixed_driver_flags.json"
+    STEPS="--steps 4000 --warmup 400"; PSTEPS="--steps 400 --warmup 100"
+else
+    python3 "$ROOT/bench.py" --config "$CFG" --large-n none --steps 200 --warmup 40 --no-cpu-baseline 2>"$OUT/bench_$CFG.stderr" | tail -1 > "$OUT/bench_${CFG}_mixed.json"
+    STEPS="--steps 100 --warmup 20"; PSTEPS="--steps 40 --warmup 10"
+fi
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$CFG" -o run -- python3 "$ROOT/bench.py" --config "$CFG" --large-n none $STEPS --no-cpu-baseline > "$OUT/stats_$CFG.log" 2>&1
+cp "$OUT/stats_$CFG"/run_kernel_stats.csv "$OUT/kernel_stats_$CFG.csv" 2>/dev/null || find "$OUT/stats_$CFG" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_$CFG.csv" \;
 for C in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_$C" -o run -- python3 "$ROOT/bench.py" --steps 400 --warmup 100 --no-cpu-baseline > "$OUT/pmc_$C.log" 2>&1
+    rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_$C" -o run -- python3 "$ROOT/bench.py" --config "$CFG" --large-n none $PSTEPS --no-cpu-baseline > "$OUT/pmc_${CFG}_$C.log" 2>&1
 done
-python3 "$ROOT/tools/pmc_summary.py" "$OUT" "$TAG" > "$OUT/pmc.json"
-rm -rf "$OUT/stats" "$OUT"/pmc_FETCH_SIZE "$OUT"/pmc_WRITE_SIZE
-cat "$OUT/bench_C3_mixed.json"; head -5 "$OUT/kernel_stats.csv"; cat "$OUT/pmc.json"
+python3 "$ROOT/tools/pmc_summary.py" "$OUT" "$TAG" "$CFG" > "$OUT/pmc_$CFG.json"
+rm -rf "$OUT/stats_$CFG" "$OUT"/pmc_FETCH_SIZE "$OUT"/pmc_WRITE_SIZE
+cat "$OUT/bench_${CFG}_mixed.json"; head -6 "$OUT/kernel_stats_$CFG.csv"; cat "$OUT/pmc_$CFG.json"
