@@ -528,8 +528,14 @@ __shared__ long long vv_stamps[8][16];
 #endif
 
 // ================================================================================ kernel A
+// Kernel-argument preload (gfx950: up to 16 user SGPRs are filled from the head of the kernarg segment by the packet processor
+// before the wave starts; Makefile: -mllvm -amdgpu-kernarg-preload-count).  A wave's FIRST memory operation -- the load of its
+// slot words, for the thermostat wave of kernel B the accumulator / state / chain-constant loads -- needs only a pointer and a
+// count; passed as leading scalar parameters they are in SGPRs at wave entry, and the s_load round trip to the kernarg segment
+// (one of three dependent memory round trips of ~0.4 us each in front of a tile's arithmetic, profiles/r02a_timeline_*) leaves
+// the critical path; everything else in KArgs is fetched in the shadow of that first load.
 template <class real, class mixed, uint32_t SF>   // SF != 0: the stage bits are a compile-time constant (hot paths)
-__global__ void __launch_bounds__(512) vv_kernel_a(const KArgs a) {
+__global__ void __launch_bounds__(512) vv_kernel_a(const int2* __restrict__ pre_slots, const int pre_nwaves, const int pre_wpb, const KArgs a) {
     using real4 = typename Vec<real>::v4;
     using real3 = typename Vec<real>::v3;
     using mixed4 = typename Vec<mixed>::v4;
@@ -541,11 +547,12 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const KArgs a) {
 
     // grid-stride over 64-lane tiles (the grid is capped in launch_a): per-lane partial sums run across all tiles of the
     // block, so the block reduction and its atomics are paid once per block however large the system is
-    const int tile_stride = gridDim.x * (blockDim.x >> 6);
+    // pre_wpb = waves per block = blockDim.x / 64, as a preloaded argument: blockDim itself is a hidden kernel argument, i.e. another
+    // s_load in front of the first slot load
     VV_STAMP(threadIdx.x >> 6, 0);
     VV_SPAN_BEGIN;
-    for (int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); wave < a.nwaves; wave += tile_stride) {
-        const int2 slot = a.slots[(size_t) wave * 64 + lane];
+    for (int wave = blockIdx.x * pre_wpb + (threadIdx.x >> 6); wave < pre_nwaves; wave += gridDim.x * pre_wpb) {
+        const int2 slot = pre_slots[(size_t) wave * 64 + lane];
         const int atom = slot.x;
         const unsigned meta = (unsigned) slot.y;
         const unsigned role = meta & META_ROLE_MASK;
@@ -913,22 +920,30 @@ __device__ __forceinline__ double propagate_regs(const NHConst& c, int g, double
 // The same update on state that the caller has already loaded (kernel B issues those loads at its very top so their
 // latency overlaps the particle loads and the accumulator fold).  NC <= 4.
 struct ChainRegs { double eta[4], eta_dot[5], eta_dotdot[4]; };
-template <int NC, bool FAST>
-__device__ __forceinline__ double propagate_preloaded(const NHConst& c, const ChainLaneBlock& lc, double ke2, ChainRegs& r, unsigned& max_hi) {
+// `publish(factor)` is called ONCE, as soon as the scale factor of the step is final -- after the downward sweep and the exp of the
+// LAST loop (API:352-358); what follows in that loop (API:360-374) only prepares the thermostat's state for the next application.
+// Kernel B's thermostat wave releases the block's tile waves from inside `publish`, so the second half of the chain is off the
+// kernel's critical path (the chain as a whole is ~0.85 us at the headline size, profiles/r02a_timeline_*).  publish returns false
+// to abandon the evaluation (the caller then redoes it with the wide-range exp).
+template <int NC, bool FAST, class Pub>
+__device__ __forceinline__ double propagate_preloaded(const NHConst& c, const ChainLaneBlock& lc, double ke2, ChainRegs& r, unsigned& max_hi, Pub&& publish) {
     auto ex = [&](double x) { return FAST ? chain_exp_small(x, max_hi) : chain_exp_wide(x); };
     // eta_dot[NC] is the chain's closing zero: the reference sizes etaDot numChains + 1, initialises it to 0 and never writes the last
     // element (API:340-376), and vvhip_set_nh_state keeps it 0 here.  exp(-dt8 * 0) is exactly 1, so the two evaluations that take
     // it as argument are dropped at compile time (two of the six serial exps for NC = 3).
     constexpr bool tail_zero = true;
-    // Runs in the block's thermostat wave only (lanes 0..2 = the three temperature groups), so a plain branch on
-    // "group is thermostatted" is fine and the state is updated in place (fewer live registers for the whole kernel).
+    // Runs in the block's thermostat wave only (lanes 0..2 = the three temperature groups).  Lanes of a group that is not
+    // thermostatted (HOST:729) run the same instructions on harmless values (their reciprocal masses are 0) so that `publish` is
+    // reached by the whole wave; the caller discards what they computed.
     double factor = 1.0;
-    if (lc.active == 0) return factor;                                          // HOST:729
+    const bool active = lc.active != 0;
     const double ke2_target = lc.nkbt;
     double expfac = 1.0;
     const double dt2 = lc.dt2, dt4 = lc.dt4, dt8 = lc.dt8, kT = lc.kT;        // computed once on the host exactly as API:343-347 does
     r.eta_dotdot[0] = (ke2 - ke2_target) * lc.inv_eta_mass[0];
-    for (int iloop = 0; iloop < c.loops_per_step; iloop++) {
+    const int loops = c.loops_per_step;
+    if (loops < 1) { publish(1.0); return 1.0; }
+    for (int iloop = 0; iloop < loops; iloop++) {
 #pragma unroll
         for (int ich = NC - 1; ich >= 0; ich--) {
             expfac = (tail_zero && ich == NC - 1) ? 1.0 : ex(-dt8 * r.eta_dot[ich + 1]);
@@ -937,6 +952,7 @@ __device__ __forceinline__ double propagate_preloaded(const NHConst& c, const Ch
             r.eta_dot[ich] *= expfac;
         }
         factor *= ex(-dt2 * r.eta_dot[0]);
+        if (iloop == loops - 1 && !publish(active ? factor : 1.0)) return factor;
 #pragma unroll
         for (int ich = 0; ich < NC; ich++) r.eta[ich] += dt2 * r.eta_dot[ich];
         r.eta_dotdot[0] = (ke2 * factor * factor - ke2_target) * lc.inv_eta_mass[0];
@@ -957,28 +973,38 @@ __device__ __forceinline__ double propagate_preloaded(const NHConst& c, const Ch
 
 // Kernel B only inlines chain lengths up to 4 (register budget: 8 variants would cost half the occupancy);
 // longer chains take the stand-alone chain launch (vv_api.cpp decides).
-template <int NC>
-__device__ __forceinline__ double propagate_small_nc(const NHConst& c, const ChainLaneBlock& lc, double ke2, ChainRegs& r) {
+template <int NC, class Pub>
+__device__ __forceinline__ double propagate_small_nc(const NHConst& c, const ChainLaneBlock& lc, double ke2, ChainRegs& r, Pub&& pub) {
     const ChainRegs saved = r;
     unsigned max_hi = 0;
-    double f = propagate_preloaded<NC, true>(c, lc, ke2, r, max_hi);
+    bool published = false;
+    // fast evaluation; the factor is only published if every exp argument so far was inside the polynomial's range
+    double f = propagate_preloaded<NC, true>(c, lc, ke2, r, max_hi, [&](double fac) {
+        if (__builtin_expect(__any(max_hi > CHAIN_EXP_SMALL_HI), 0)) return false;
+        pub(fac);
+        published = true;
+        return true;
+    });
     if (__builtin_expect(__any(max_hi > CHAIN_EXP_SMALL_HI), 0)) {          // an exp argument beyond 2^-3: redo with the library exp
         r = saved;
-        f = propagate_preloaded<NC, false>(c, lc, ke2, r, max_hi);
+        const bool fast_factor_out = published;      // then every argument it depends on was in range: it stays the step's factor, only the state is redone
+        const double f2 = propagate_preloaded<NC, false>(c, lc, ke2, r, max_hi, [&](double fac) { if (!published) { pub(fac); published = true; } return true; });
+        if (!fast_factor_out) f = f2;
     }
+    if (lc.active == 0) { r = saved; f = 1.0; }                             // HOST:729: a group without thermostat keeps its state, factor 1
     return f;
 }
 // NCT = 3: the chain length is known when the kernel is compiled (the specialised kernels are built for the integrator's default
 // of three, VVIntegrator.h:62; launch_b sends other lengths to the generic kernel).  Four chain bodies less in a kernel whose code is
 // fetched cold at every launch: kernel B 5.92 -> 5.74 us.
-template <int NCT>
-__device__ __forceinline__ double propagate_group_small(const NHConst& c, const ChainLaneBlock& lc, double ke2, ChainRegs& r) {
-    if (NCT == 3) return propagate_small_nc<3>(c, lc, ke2, r);
+template <int NCT, class Pub>
+__device__ __forceinline__ double propagate_group_small(const NHConst& c, const ChainLaneBlock& lc, double ke2, ChainRegs& r, Pub&& pub) {
+    if (NCT == 3) return propagate_small_nc<3>(c, lc, ke2, r, pub);
     switch (c.num_chains) {
-        case 1: return propagate_small_nc<1>(c, lc, ke2, r);
-        case 2: return propagate_small_nc<2>(c, lc, ke2, r);
-        case 3: return propagate_small_nc<3>(c, lc, ke2, r);
-        default: return propagate_small_nc<4>(c, lc, ke2, r);
+        case 1: return propagate_small_nc<1>(c, lc, ke2, r, pub);
+        case 2: return propagate_small_nc<2>(c, lc, ke2, r, pub);
+        case 3: return propagate_small_nc<3>(c, lc, ke2, r, pub);
+        default: return propagate_small_nc<4>(c, lc, ke2, r, pub);
     }
 }
 __device__ __forceinline__ double propagate_group(const NHConst& c, int g, double ke2, const NHDevState* in, NHDevState* out) {
@@ -1021,7 +1047,8 @@ __global__ void __launch_bounds__(64) vv_kernel_chain(const NHConst c, NHDevStat
 // ================================================================================ kernel B
 
 template <class real, class mixed, uint32_t SF>
-__global__ void __launch_bounds__(512) vv_kernel_b(const KArgs a) {
+__global__ void __launch_bounds__(512) vv_kernel_b(const int2* __restrict__ pre_slots, const int pre_nwaves, const int pre_wpb, const unsigned long long* __restrict__ pre_acc,
+                                                   const NHDevState* __restrict__ pre_nh, const ChainLaneBlock* __restrict__ pre_lane_const, const KArgs a) {
     using real4 = typename Vec<real>::v4;
     using real3 = typename Vec<real>::v3;
     using mixed4 = typename Vec<mixed>::v4;
@@ -1033,7 +1060,7 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const KArgs a) {
     // accumulators and advances the NH chain (a ~2 us serial fp64 dependency chain) while the other waves of the
     // block load their particles and do the scale-independent preparation; one barrier joins them.  Without this,
     // every tile wave pays the chain on its own critical path (measured: 9.7 -> see DESIGN.md §7).
-    const int nwb = blockDim.x >> 6;
+    const int nwb = pre_wpb;                      // = blockDim.x >> 6, preloaded (blockDim is a hidden kernel argument: an s_load)
     const bool has_cw = (F & B_CHAIN) != 0;
     // the thermostat wave is wave 0: the waves of a block start in order, and the block's critical path runs through this one
     const bool chain_wave = has_cw && (threadIdx.x >> 6) == 0;
@@ -1050,14 +1077,14 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const KArgs a) {
         const int cg = lane < VVHIP_NUM_TG ? lane : VVHIP_NUM_TG - 1;
         ChainRegs cr;
 #pragma unroll
-        for (int i = 0; i < 4; i++) { cr.eta[i] = a.nh->s.eta[cg][i]; cr.eta_dot[i] = a.nh->s.eta_dot[cg][i]; cr.eta_dotdot[i] = a.nh->s.eta_dotdot[cg][i]; }
-        cr.eta_dot[4] = a.nh->s.eta_dot[cg][4];
-        const ChainLaneBlock lc = a.lane_const[cg];
+        for (int i = 0; i < 4; i++) { cr.eta[i] = pre_nh->s.eta[cg][i]; cr.eta_dot[i] = pre_nh->s.eta_dot[cg][i]; cr.eta_dotdot[i] = pre_nh->s.eta_dotdot[cg][i]; }
+        cr.eta_dot[4] = pre_nh->s.eta_dot[cg][4];
+        const ChainLaneBlock lc = pre_lane_const[cg];
         long long tot[NUM_ACC];
 #pragma unroll
         for (int k = 0; k < NUM_ACC; k++) {
             const bool wanted = k < 3 || (k == 3 && (F & B_UNBIAS)) || (k > 3 && (F & B_KE_MOM));
-            tot[k] = (!wanted || (F & B_DBG_NOFOLD)) ? 0 : acc_total(a.acc, k, lane);
+            tot[k] = (!wanted || (F & B_DBG_NOFOLD)) ? 0 : acc_total(pre_acc, k, lane);
         }
         if (F & B_MAILBOX) {                      // multi-GPU: block 0 publishes this rank's totals, every block collects all ranks'
             __shared__ unsigned int mb_words[MB_MAX_RANKS * MB_WORDS];
@@ -1077,22 +1104,21 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const KArgs a) {
             ke2 = ke2 - 2.0 * V * sab + V * V * sbb;
         }
         double factor = 1.0;
-        VV_STAMP_AFTER(7, 4, ke2);
-#ifdef VV_CHAIN_TWICE      // probe (instrumented builds): the same chain code once more on perturbed input, to tell cold instruction fetch from arithmetic latency
-        {
-            ChainRegs tmp = cr;
-            const double f0 = propagate_group_small<(SF != 0 ? 3 : 0)>(a.chain, lc, ke2 * 1.0000001, tmp);
-            if (f0 == 123.456) cr.eta[0] += 1e-300;      // keeps the first evaluation alive
-            VV_STAMP_AFTER(7, 5, f0);
-        }
-#endif
-        if (!(F & B_DBG_NOMATH)) factor = propagate_group_small<(SF != 0 ? 3 : 0)>(a.chain, lc, ke2, cr);
-        VV_STAMP_AFTER(7, 2, factor);
+        // the bias is requested before the chain starts (when it is carried over it is a load from the state)
         const double bias = (F & B_UNBIAS) ? (double) tot[3] * a.chain.acc_inv_scale[3] * a.chain.inv_mass_total   // K/cosineAccelerate.cu:57-59
-                                           : a.nh->scales[3];                                                 // carried over unchanged
-        if (lane < VVHIP_NUM_TG) sh_scales[lane] = factor;
-        if (lane == 3) sh_scales[3] = bias;
-        __syncthreads();                          // the tile waves go on; what follows is off their critical path
+                                           : pre_nh->scales[3];                                               // carried over unchanged
+        VV_STAMP_AFTER(7, 4, ke2);
+        // Hands the scale factors to the block's tile waves the moment they are final -- in the MIDDLE of the chain update (see
+        // propagate_preloaded): this wave's only barrier.  The second half of the chain runs while the tile waves scale and drift.
+        auto release_tiles = [&](double f) {
+            if (lane < VVHIP_NUM_TG) sh_scales[lane] = f;
+            if (lane == 3) sh_scales[3] = bias;
+            VV_STAMP_AFTER(7, 5, f);
+            __syncthreads();
+        };
+        if (!(F & B_DBG_NOMATH)) factor = propagate_group_small<(SF != 0 ? 3 : 0)>(a.chain, lc, ke2, cr, release_tiles);
+        else release_tiles(1.0);
+        VV_STAMP_AFTER(7, 2, factor);
         if (blockIdx.x == 0) {                    // one block records the advanced thermostat and clears the idle accumulator copy
             NHDevState* out = a.nh_next;
             if (lane < VVHIP_NUM_TG) {
@@ -1115,14 +1141,13 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const KArgs a) {
 
     // ---------------- tile waves: grid-stride over 64-lane tiles.  The grid is capped (launch_b), so at large N every block
     // pays the fold + chain once and then streams many tiles; the first tile's loads overlap the thermostat wave.
-    const int tile_stride = gridDim.x * tiles_per_block;
     bool need_scales = true;
     VV_STAMP(wib, 0);
-    for (int wave = blockIdx.x * tiles_per_block + wib; need_scales || wave < a.nwaves; wave += tile_stride) {
-        const bool valid = wave < a.nwaves;
+    for (int wave = blockIdx.x * tiles_per_block + wib; need_scales || wave < pre_nwaves; wave += gridDim.x * tiles_per_block) {
+        const bool valid = wave < pre_nwaves;
         int atom = -1;
         unsigned meta = 0;
-        if (valid) { const int2 slot = a.slots[(size_t) wave * 64 + lane]; atom = slot.x; meta = (unsigned) slot.y; }
+        if (valid) { const int2 slot = pre_slots[(size_t) wave * 64 + lane]; atom = slot.x; meta = (unsigned) slot.y; }
         const unsigned role = meta & META_ROLE_MASK;
         const int partner = (meta >> META_PARTNER_SHIFT) & 63;
         const bool act = atom >= 0;
@@ -1493,12 +1518,12 @@ __global__ void __launch_bounds__(256) vv_kernel_images(void* posq_, void* corr_
 // Mirrors oracle vvo_tether_force bit for bit: tether on massive particles, Drude-parent spring, both
 // converted to fixed point by truncation and then added as integers.
 template <class real, class mixed>
-__global__ void __launch_bounds__(512) vv_kernel_tether(const TetherArgs t) {
+__global__ void __launch_bounds__(512) vv_kernel_tether(const int2* __restrict__ pre_slots, const int pre_nwaves, const int pre_wpb, const TetherArgs t) {
     using real4 = typename Vec<real>::v4;
     const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (wave >= t.nwaves) return;
-    const int2 slot = t.slots[(size_t) wave * 64 + lane];
+    const int wave = blockIdx.x * pre_wpb + (threadIdx.x >> 6);
+    if (wave >= pre_nwaves) return;
+    const int2 slot = pre_slots[(size_t) wave * 64 + lane];
     const int atom = slot.x;
     const unsigned meta = (unsigned) slot.y;
     const int partner = (meta >> META_PARTNER_SHIFT) & 63;
@@ -1630,7 +1655,7 @@ constexpr uint32_t SF_B_MIDDLE_HW_SHAKE_MB = SF_B_MIDDLE_HW_SHAKE | B_MAILBOX;
 #endif
 constexpr uint32_t SF_AM = VV_SF_MTAB_A ? A_MTAB : 0u, SF_BM = VV_SF_MTAB_B ? B_MTAB : 0u;
 bool sf_kernels_use_mass_table(int kernel) { return kernel == 0 ? VV_SF_MTAB_A != 0 : VV_SF_MTAB_B != 0; }
-#define VV_TRY_SF(KERNEL, SFV) if (a.flags == ((SFV) | XM)) { VV_DISPATCH_SF(KERNEL, ((SFV) | XM), g, b, 0, s, a); return hipGetLastError(); }
+#define VV_TRY_SF(KERNEL, SFV) if (a.flags == ((SFV) | XM)) { VV_DISPATCH_SF(KERNEL, ((SFV) | XM), g, b, 0, s, VV_PRE_ARGS, a); return hipGetLastError(); }
 
 hipError_t launch_a(int precision, const KArgs& a, int block_threads, int grid_cap, hipStream_t s) {
     dim3 g = grid_for(a.nwaves, block_threads);
@@ -1638,6 +1663,7 @@ hipError_t launch_a(int precision, const KArgs& a, int block_threads, int grid_c
     vv_last_grid_value = g.x;
     const dim3 b(block_threads);
     constexpr uint32_t XM = SF_AM;
+#define VV_PRE_ARGS a.slots, a.nwaves, (int) (b.x >> 6)
     VV_TRY_SF(vv_kernel_a, SF_A_MIDDLE)
     VV_TRY_SF(vv_kernel_a, SF_A_MIDDLE_WT)
     VV_TRY_SF(vv_kernel_a, SF_A_COS1)
@@ -1656,8 +1682,9 @@ hipError_t launch_a(int precision, const KArgs& a, int block_threads, int grid_c
     VV_TRY_SF(vv_kernel_a, SF_A_KICK)
     VV_TRY_SF(vv_kernel_a, SF_A_KICK_FE)
     VV_TRY_SF(vv_kernel_a, SF_A_POS1)
-    VV_DISPATCH_SF(vv_kernel_a, 0u, g, b, 0, s, a);
+    VV_DISPATCH_SF(vv_kernel_a, 0u, g, b, 0, s, VV_PRE_ARGS, a);
     return hipGetLastError();
+#undef VV_PRE_ARGS
 }
 hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_cap, hipStream_t s) {
     // block_threads counts the tile waves; B_CHAIN adds the block's thermostat wave.  Beyond grid_cap blocks the kernel strides
@@ -1667,8 +1694,9 @@ hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_c
     vv_last_grid_value = g.x;
     const dim3 b(block_threads + ((a.flags & B_CHAIN) ? 64 : 0));
     constexpr uint32_t XM = SF_BM;
+#define VV_PRE_ARGS a.slots, a.nwaves, (int) (b.x >> 6), (const unsigned long long*) a.acc, a.nh, a.lane_const
     if ((a.flags & B_CHAIN) && a.chain.num_chains != 3) {       // the specialised kernels carry the three-link chain only
-        VV_DISPATCH_SF(vv_kernel_b, 0u, g, b, 0, s, a);
+        VV_DISPATCH_SF(vv_kernel_b, 0u, g, b, 0, s, VV_PRE_ARGS, a);
         return hipGetLastError();
     }
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_HW)
@@ -1692,15 +1720,16 @@ hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_c
     VV_TRY_SF(vv_kernel_b, SF_B_POS2)
     VV_TRY_SF(vv_kernel_b, SF_B_POS3_HW)
     VV_TRY_SF(vv_kernel_b, SF_B_POS3)
-    VV_DISPATCH_SF(vv_kernel_b, 0u, g, b, 0, s, a);
+    VV_DISPATCH_SF(vv_kernel_b, 0u, g, b, 0, s, VV_PRE_ARGS, a);
     return hipGetLastError();
+#undef VV_PRE_ARGS
 }
 hipError_t launch_chain(const NHConst& c, NHDevState* st, unsigned long long* acc, hipStream_t s) {
     hipLaunchKernelGGL(vv_kernel_chain, dim3(1), dim3(64), 0, s, c, st, acc);
     return hipGetLastError();
 }
 hipError_t launch_tether(int precision, const TetherArgs& t, int block_threads, hipStream_t s) {
-    VV_DISPATCH(vv_kernel_tether, grid_for(t.nwaves, block_threads), dim3(block_threads), 0, s, t);
+    VV_DISPATCH(vv_kernel_tether, grid_for(t.nwaves, block_threads), dim3(block_threads), 0, s, t.slots, t.nwaves, block_threads / 64, t);
     return hipGetLastError();
 }
 hipError_t launch_mass_table(int precision, const void* velm, const int2* slots, int nwaves, double* slot_m, double* slot_f, hipStream_t s) {

@@ -223,24 +223,38 @@ def test_full_size_configs_against_the_oracle(cfg, cos, hbonds, prec):
 
 
 def test_full_size_c3_single_precision():
-    """Single precision at the FULL C3 size, GPU against the one-thread oracle in the same mode.  What differs between the two is
-    only the order of the float sums behind the thermostat (111 000 terms: serial on the CPU, waves and blocks on the GPU; ~1e-4
-    relative in 2KE either way) -- and a 1e-4 error in 2KE moves the scale factor by ~1e-9 per step (d(factor) = dt/2 * dt/4 *
-    d(2KE) / Q with Q = dof kT / omega^2), so the trajectories must agree far inside north_star's 1e-5; measured ~1e-7.  For scale:
-    the single-precision trajectory as a whole lies 4e-4 (velocities, 4 steps) from the mixed-precision one, in the oracle and on the
-    GPU alike -- float positions under the 209 200 kJ/mol/nm^2 Drude spring -- which is why the reference's examples run mixed."""
+    """Single precision at the FULL C3 size, GPU against the one-thread oracle in the same mode.  The element-wise stages are
+    bit-identical; what differs is the order of the float sums behind the thermostat (111 000 terms: serial on the CPU, waves and
+    blocks on the GPU), i.e. scale factors that differ in their last float bits.  That is enough to flip the rounding of a float
+    POSITION now and then -- one ulp at x = 18 nm is 1.9e-6 nm -- and the Drude spring (209 200 kJ/mol/nm^2 on a 0.4 u particle)
+    turns a one-ulp position difference into dv = k dx dt / m ~ 1e-3 nm/ps on that Drude particle within a step: 1e-4 of the
+    largest velocity (measured: 1.1e-4 after 4 steps), in the oracle-vs-oracle comparison of two summation orders just the same.
+    That noise is INTERNAL to a Drude pair (the spring force cancels in the pair's momentum), so the check is: positions to
+    1e-6, velocities of all particles outside Drude pairs and the centre-of-mass velocity of every pair to 1e-5 (north_star), the
+    group sums to 1e-4.  It is also why the reference's examples run mixed precision (examples/run-bulk.py:78)."""
     spec = systems.make_config("C3")
     nsteps = 4
     o_single, ctx, it = _pair(spec, "single", True, nsteps=nsteps)
     try:
         v_o, v_g = o_single.velm[:, :3].astype(np.float64), ctx.getVelocities()
         x_o, x_g = o_single.positions(), ctx.getPositions()
-        ev = np.abs(v_g - v_o).max() / np.abs(v_o).max()
+        scale = np.abs(v_o).max()
         ex = np.abs(x_g - x_o).max() / np.abs(x_o).max()
+        d, p = spec.drude_pairs[:, 0], spec.drude_pairs[:, 1]
+        free = np.ones(spec.num_atoms, dtype=bool)
+        free[d] = False
+        free[p] = False
+        ev_free = np.abs(v_g[free] - v_o[free]).max() / scale
+        m = spec.masses
+        com = lambda v: (m[d, None] * v[d] + m[p, None] * v[p]) / (m[d] + m[p])[:, None]
+        ev_com = np.abs(com(v_g) - com(v_o)).max() / scale
+        ev_raw = np.abs(v_g - v_o).max() / scale
         ke_o, ke_g = o_single.ke2(), np.array(list(ctx.getNHState().ke2))
-        print(f"single precision, full C3, {nsteps} steps: GPU vs oracle rel err pos {ex:.2e} vel {ev:.2e}; 2KE {ke_g} vs {ke_o}")
-        assert ex < 1e-5 and ev < 1e-5
-        assert np.allclose(ke_g, ke_o, rtol=1e-3)
+        print(f"single precision, full C3, {nsteps} steps: GPU vs oracle rel err pos {ex:.2e}; vel outside pairs {ev_free:.2e}, pair COM {ev_com:.2e}, "
+              f"raw incl. Drude relative motion {ev_raw:.2e}; 2KE {ke_g} vs {ke_o}")
+        assert ex < 1e-6 and ev_free < 1e-5 and ev_com < 1e-5
+        assert ev_raw < 1e-3
+        assert np.allclose(ke_g, ke_o, rtol=1e-4)
     finally:
         ctx.close()
 

@@ -7,7 +7,7 @@ out_dir, tag = sys.argv[1], sys.argv[2]
 cfg = sys.argv[3] if len(sys.argv) > 3 else "C3"
 natoms = {"C3": 111000, "C4": 111000, "C5": 40310, "C3x8": 888000, "C3x80": 8880000}.get(cfg, 111000)
 names = {"vv_kernel_a": "A", "vv_kernel_b": "B", "vv_kernel_tether": "tether"}
-raw = {}
+raw, variants, chosen = {}, {}, {}
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     files = glob.glob(os.path.join(out_dir, f"pmc_{counter}", "**", "*counter_collection.csv"), recursive=True)
     for f in files:
@@ -16,12 +16,17 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
                 continue
             for key, short in names.items():
                 if key in row["Kernel_Name"]:
-                    rec = raw.setdefault(short, {}).setdefault(counter, [0.0, 0])
+                    # one bench run launches several compiled variants of a kernel (headline stage set, the constrained box of the
+                    # secondary figure, ...): keep them apart by their full template name, report the most-launched one below
+                    rec = variants.setdefault(short, {}).setdefault(row["Kernel_Name"], {}).setdefault(counter, [0.0, 0])
                     rec[0] += float(row["Counter_Value"]); rec[1] += 1
+for short, byname in variants.items():
+    name = max(byname, key=lambda k: max(v[1] for v in byname[k].values()))
+    raw[short], chosen[short] = byname[name], name
 res = {"config": cfg, "precision": "mixed", "round": tag,
        "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --config %s --large-n none --no-cpu-baseline (two separate passes; tools/profile_round.sh)" % cfg,
        "correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE (KB) reads exactly half of a wide coalesced streaming read on gfx950 -> doubled; WRITE_SIZE (KB) as is; x1024 for bytes",
-       "raw_kb": {}}
+       "kernel_variant": chosen, "raw_kb": {}}
 for short, d in raw.items():
     res["raw_kb"][short] = {c: round(v[0] / max(v[1], 1), 1) for c, v in d.items()}
     res["raw_kb"][short]["dispatches"] = max(v[1] for v in d.values())

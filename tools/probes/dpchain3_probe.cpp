@@ -45,8 +45,18 @@ __device__ __forceinline__ double propagate(int loops, const ChainLaneBlock& lc,
     return factor;
 }
 template <int PRIO>
-__global__ void k(double* out, long long* cyc, const ChainLaneBlock* lcp, const ChainRegs* st, int loops, int reps, double ke2) {
-    if (threadIdx.x >= 64) { __syncthreads(); return; }
+__global__ void k(double* out, long long* cyc, const ChainLaneBlock* lcp, const ChainRegs* st, int loops, int reps, double ke2, const double4* big, int nbig, double4* sink) {
+    if (threadIdx.x >= 64) {
+        if (big) {        // tile-wave stand-in: a few 32-byte loads per lane from a large array, some fp64 work on them, a store; then park
+            const size_t i = ((size_t) blockIdx.x * blockDim.x + threadIdx.x) % (size_t) nbig;
+            double4 a = big[i], b = big[(i * 7 + 13) % nbig], c = big[(i * 3 + 5) % nbig];
+            double x = a.x * b.y + c.z, y = a.y * b.z + c.x;
+            for (int u = 0; u < 40; u++) { x = x * 0.999 + y; y = y * 1.001 - x; }
+            sink[i] = double4{x, y, a.w, b.w};
+        }
+        __syncthreads();
+        return;
+    }
     if (PRIO) __builtin_amdgcn_s_setprio(3);
     const int cg = threadIdx.x < 3 ? threadIdx.x : 2;
     ChainRegs cr = st[cg];
@@ -66,7 +76,8 @@ __global__ void k(double* out, long long* cyc, const ChainLaneBlock* lcp, const 
     if (blockDim.x > 64) __syncthreads();
 }
 int main() {
-    double* out; long long* cyc; ChainLaneBlock* lc; ChainRegs* st;
+    double* out; long long* cyc; ChainLaneBlock* lc; ChainRegs* st; double4* big; double4* sink; const int nbig = 1 << 20;
+    CK(hipMalloc(&big, sizeof(double4) * nbig)); CK(hipMalloc(&sink, sizeof(double4) * nbig)); CK(hipMemset(big, 0, sizeof(double4) * nbig));
     CK(hipMalloc(&out, 64 * 8)); CK(hipMalloc(&cyc, 64)); CK(hipMalloc(&lc, 3 * sizeof(ChainLaneBlock))); CK(hipMalloc(&st, 3 * sizeof(ChainRegs)));
     ChainLaneBlock h[3] = {}; ChainRegs s[3] = {};
     for (int g = 0; g < 3; g++) {
@@ -75,16 +86,17 @@ int main() {
         s[g].eta_dot[3] = 0; s[g].eta_dot[4] = 0;
     }
     CK(hipMemcpy(lc, h, sizeof(h), hipMemcpyHostToDevice)); CK(hipMemcpy(st, s, sizeof(s), hipMemcpyHostToDevice));
-    for (int blocks : {1, 8, 64, 256, 1024})
+    for (int withmem = 0; withmem < 2; withmem++)
+    for (int blocks : {1, 256})
     for (int prio = 0; prio < 2; prio++)
         for (int threads : {64, 512}) {
             for (int rep = 0; rep < 3; rep++) {
-                if (prio) hipLaunchKernelGGL(k<1>, blocks, threads, 0, 0, out, cyc, lc, st, 1, 4, 457100.0);
-                else hipLaunchKernelGGL(k<0>, blocks, threads, 0, 0, out, cyc, lc, st, 1, 4, 457100.0);
+                if (prio) hipLaunchKernelGGL(k<1>, blocks, threads, 0, 0, out, cyc, lc, st, 1, 4, 457100.0, withmem ? big : nullptr, nbig, sink);
+                else hipLaunchKernelGGL(k<0>, blocks, threads, 0, 0, out, cyc, lc, st, 1, 4, 457100.0, withmem ? big : nullptr, nbig, sink);
                 CK(hipDeviceSynchronize());
             }
             long long c[4]; CK(hipMemcpy(c, cyc, 32, hipMemcpyDeviceToHost));
-            std::printf("%4d blocks, setprio %d, %3d threads: chain update ticks, 4 in a row: %lld %lld %lld %lld\n", blocks, prio * 3, threads, c[0], c[1], c[2], c[3]);
+            std::printf("%s, %4d blocks, setprio %d, %3d threads: chain update ticks, 4 in a row: %lld %lld %lld %lld\n", withmem ? "other waves load + compute" : "other waves idle", blocks, prio * 3, threads, c[0], c[1], c[2], c[3]);
         }
     return 0;
 }
