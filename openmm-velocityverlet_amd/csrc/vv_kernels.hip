@@ -1118,8 +1118,23 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const int2* __restrict__ pre_
             VV_STAMP_AFTER(7, 5, f);
             __syncthreads();
         };
+#ifdef VV_CHAIN_LOOP       // probe (instrumented builds): the SAME chain code executed twice in a real loop (first pass on a scratch copy,
+        {                      // no publish) to tell cold instruction fetch from arithmetic latency; stamp 6 = end of the first pass
+            const ChainRegs keep = cr;
+            const int passes = a.dbg ? 2 : 1;
+#pragma nounroll
+            for (int pass = 0; pass < passes; pass++) {
+                const bool last = pass == passes - 1;
+                if (!last) cr = keep;
+                auto maybe = [&](double f) { if (last) release_tiles(f); };
+                factor = propagate_group_small<(SF != 0 ? 3 : 0)>(a.chain, lc, ke2, cr, maybe);
+                if (!last) { VV_STAMP_AFTER(7, 6, factor); cr = keep; }
+            }
+        }
+#else
         if (!(F & B_DBG_NOMATH)) factor = propagate_group_small<(SF != 0 ? 3 : 0)>(a.chain, lc, ke2, cr, release_tiles);
         else release_tiles(1.0);
+#endif
         VV_STAMP_AFTER(7, 2, factor);
         if (blockIdx.x == 0) {                    // one block records the advanced thermostat and clears the idle accumulator copy
             NHDevState* out = a.nh_next;

@@ -33,7 +33,7 @@ for flags, label in ((FULL, "B full"), (1 | 16 | 512, "B without chain wave")):
         line = f"  block {block:4d}: "
         for w in (0, 1):
             line += f"tile{w} " + " ".join(f"{(t[w, k] - t0) / GHZ:6.0f}" if 0 < t[w, k] - t0 < 10**7 else "     -" for k in range(6)) + " | "
-        line += "thermo " + " ".join(f"{(t[7, k] - t0) / GHZ:6.0f}" if 0 <= t[7, k] - t0 < 10**7 else "     -" for k in (0, 1, 4, 5, 2, 3))
+        line += "thermo " + " ".join(f"{(t[7, k] - t0) / GHZ:6.0f}" if 0 <= t[7, k] - t0 < 10**7 else "     -" for k in (0, 1, 4, 6, 5, 2, 3))
         print(line)
 print("A full (kick + KE): entry, velm arrived, kicked + stored, tile loop done, sums added  [ns]")
 for block in ((0,) if SMALL else (0, 1, 125, 250)):
