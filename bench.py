@@ -18,10 +18,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# algorithmic bytes per particle per launch, mixed precision (228 B/atom/step = A + B)
-ALGO_BYTES = {"mixed": {"A": 32 + 24 + 32 + 6, "B": 32 + 32 + 32 + 32 + 6},
-              "single": {"A": 16 + 24 + 16 + 6, "B": 16 + 16 + 16 + 16 + 6},
-              "double": {"A": 32 + 24 + 32 + 6, "B": 32 + 32 + 32 + 32 + 6}}
+# Algorithmic bytes per particle per launch come from the plan (vvhip_algorithmic_bytes; SURVEY.md §8d's accounting).  Mixed precision:
+# 94 (A) + 134 (B) = 228 B/atom/step where kernel A writes the kicked velocities back; 62 + 158 = 220 where it keeps them in registers
+# and kernel B repeats the kick from velm + force (the headline path: no extra forces, no in-kernel constraints).
 HBM_PEAK_GBS = 8000.0      # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured float4 copy)
 
 
@@ -392,7 +391,8 @@ def main():
         dom = "B" if ms_b >= ms_a else "A"
         ms = ms_b if dom == "B" else ms_a
         n_local = bounds[rank][1] - bounds[rank][0]
-        bytes_per_launch = ALGO_BYTES[args.precision][dom] * n_local
+        algo = dict(zip("AB", ctx.algorithmic_bytes()))
+        bytes_per_launch = algo[dom] * n_local
         achieved = bytes_per_launch / (ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
@@ -406,7 +406,7 @@ def main():
         if rank == 0:
             out["roofline"] = {"bound": "hbm", "kernel": f"vv_kernel_{dom.lower()}", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                               "algorithmic_bytes_per_launch": bytes_per_launch,
+                               "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_bytes_per_particle": algo,
                                "avg_launch_us": {"A": round(ms_a * 1e3, 3), "B": round(ms_b * 1e3, 3)},
                                "note": (("working set (%.0f MB) is L2 / Infinity-Cache resident at this size: the launch is latency bound, "
                                          "see config.large_n for the bandwidth-bound regime" % (228e-6 * n_local)) if n_local < 2_000_000 else
@@ -427,8 +427,9 @@ def main():
             nl = spec_l.num_atoms
             blk = {"workload": f"{args.large_n}: {nl} particles, {spec_l.num_molecules} molecules (the C3 cell tiled along z)",
                    "steps_per_s": round(sps_l, 1), "atom_steps_per_s": round(sps_l * nl, 1), "roofline": {}}
+            algo_l = dict(zip("AB", ctx_l.algorithmic_bytes()))
             for k, ms in (("A", la), ("B", lb)):
-                by = ALGO_BYTES[args.precision][k] * nl
+                by = algo_l[k] * nl
                 ach = by / (ms * 1e-3) / 1e9
                 tr = None
                 pmc_l = os.path.join(ROOT, "profiles", f"pmc_latest_{args.large_n}.json")

@@ -193,6 +193,10 @@ int vvhip_step_vv_second(vvhip_plan* plan, uint32_t random_index);
  * That all-reduce (64 int64 slots per reduced quantity, <= 1.5 KB, latency-bound) is the only cross-GPU
  * exchange per thermostat application. */
 int vvhip_step_middle_phases(const vvhip_plan* plan);
+/* Algorithmic bytes per particle moved by kernel A / kernel B of this plan's fused middle step (particle arrays + 6 bytes of index per
+ * pass, SURVEY section 8d's accounting).  Plans without extra forces and in-kernel constraints keep the kicked velocities in registers in
+ * kernel A and repeat the kick in kernel B: 62 + 158 bytes in mixed precision instead of 94 + 134. */
+int vvhip_algorithmic_bytes(const vvhip_plan* plan, int32_t* bytes_a, int32_t* bytes_b);
 int vvhip_step_middle_phase(vvhip_plan* plan, int phase, uint32_t random_index);
 int vvhip_accumulators(vvhip_plan* plan, int phase, void** device_ptr, int32_t* count);
 

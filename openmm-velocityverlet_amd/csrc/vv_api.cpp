@@ -86,6 +86,7 @@ struct vvhip_plan {
     bool fextra_external = false;  // the host asked for the pointer (vvhip_force_extra) and may write to it: never assume zeros
     bool no_moments = false;       // VVHIP_NO_MOMENTS=1: keep the three-launch cos sequence (comparison runs)
     bool wt_stores = false;        // write-through stores in the fused kernels (VVHIP_WT=1; tuning experiment)
+    bool rekick = true;            // fused middle step: kick repeated in kernel B instead of a velm store in kernel A (use_rekick)
     // plan-owned device state
     int2* d_slots = nullptr;
     int32_t* d_slot_image = nullptr;
@@ -519,6 +520,7 @@ int vvhip_plan_create(const vvhip_system_desc* system, const vvhip_params* param
         fill_scales(p);
         if (const char* e = std::getenv("VVHIP_WT")) p->wt_stores = std::atoi(e) != 0;
         if (const char* e = std::getenv("VVHIP_NO_MOMENTS")) p->no_moments = std::atoi(e) != 0;
+        if (const char* e = std::getenv("VVHIP_REKICK")) p->rekick = std::atoi(e) != 0;
         p->mass_tab_a = vv::sf_kernels_use_mass_table(0);
         p->mass_tab_b = vv::sf_kernels_use_mass_table(1);
         if (const char* e = std::getenv("VVHIP_MTAB_A")) p->mass_tab_a = std::atoi(e) != 0;
@@ -718,11 +720,34 @@ int vvhip_step_middle_phases(const vvhip_plan* p) {
     return (cos_on(p) && !use_moments(p)) ? 3 : 2;
 }
 
+// The fused middle step without a velm round trip between its kernels: kernel A keeps the kicked velocities in registers, kernel B
+// repeats the kick from velm + force (vv_kernels.hpp: A_NOSTORE / B_KICK).  Needs what A adds to the velocities beyond the plain
+// kick to be absent or cheap to repeat: no Langevin subset and no field (kernel B repeats the cos force from the cached cos(kz), in
+// the two-launch moment form only), no in-kernel velocity constraints; and a thermostat, i.e. the A -> B pair of one step
+// (VVHIP_REKICK=0 switches it off: comparison runs).
+static bool use_rekick(const vvhip_plan* p) {
+    const uint32_t ex = extra_flags(p);
+    const bool extra_ok = ex == 0 || (ex == vv::A_COS && use_moments(p));
+    return p->rekick && p->hp.has_nh && extra_ok && !shake_on(p) && p->hp.num_big == 0 && !p->wt_stores;
+}
+
+// Algorithmic bytes per particle that kernel A / kernel B of the fused middle step must move (SURVEY section 8d's accounting: particle
+// arrays + 6 bytes of index per pass): what bench.py prices the launches with.
+int vvhip_algorithmic_bytes(const vvhip_plan* p, int32_t* bytes_a, int32_t* bytes_b) {
+    if (!p || !bytes_a || !bytes_b) return VVHIP_ERR_INVALID;
+    const int v = p->hp.precision == VVHIP_SINGLE ? 16 : 32;                       // velm: mixed4
+    const int x = p->hp.precision == VVHIP_SINGLE ? 16 : 32;                       // posq (+ posqCorrection in mixed mode; double4 in double mode)
+    if (use_rekick(p)) { *bytes_a = v + 24 + 6; *bytes_b = v + 24 + x + v + x + 6; }    // A: R velm, R force;  B: R velm, R force, R pos, W velm, W pos
+    else { *bytes_a = v + 24 + v + 6; *bytes_b = v + x + v + x + 6; }                   // A: R velm, R force, W velm;  B: R velm, R pos, W velm, W pos
+    return VVHIP_OK;
+}
+
 int vvhip_step_middle_phase(vvhip_plan* p, int phase, uint32_t random_index) {
     NEED_BOUND(p);
     NEED_FUSABLE(p);
-    const uint32_t kick = vv::A_KICK_FULL | extra_flags(p) | (shake_on(p) ? vv::A_SHAKE_V : 0);
-    const uint32_t drift = vv::B_DRIFT_MIDDLE | tail_flags(p) | (shake_on(p) ? vv::B_SHAKE : 0);
+    const bool rk = use_rekick(p);
+    const uint32_t kick = vv::A_KICK_FULL | extra_flags(p) | (shake_on(p) ? vv::A_SHAKE_V : 0) | (rk ? vv::A_NOSTORE : 0);
+    const uint32_t drift = vv::B_DRIFT_MIDDLE | tail_flags(p) | (shake_on(p) ? vv::B_SHAKE : 0) | (rk ? vv::B_KICK : 0);
     if (!p->hp.has_nh) {                                   // API:251: no NH particles, nothing to reduce
         if (phase != 0) return fail(p, VVHIP_ERR_INVALID, "phase out of range");
         TRY(run_a(p, kick, random_index));
@@ -1083,9 +1108,10 @@ int vvhip_time_kernel(vvhip_plan* p, int kernel, uint32_t flags, int reps, doubl
     if (reps < 1 || !ms_per_launch) return VVHIP_ERR_INVALID;
     if (flags == 0xFFFFFFFFu) {     // the stage bits vvhip_step_middle uses for this plan
         const uint32_t mom_a = use_moments(p) ? (vv::A_KE | vv::A_KE_MOM) : 0, mom_b = use_moments(p) ? vv::B_KE_MOM : 0;
-        if (kernel == 0) flags = vv::A_KICK_FULL | extra_flags(p) | (shake_on(p) ? vv::A_SHAKE_V : 0) | (p->hp.has_nh ? (cos_on(p) ? (vv::A_BIAS | vv::A_CZ_STORE | mom_a) : vv::A_KE) : 0);
+        const bool rk = use_rekick(p);
+        if (kernel == 0) flags = vv::A_KICK_FULL | (rk ? vv::A_NOSTORE : 0) | extra_flags(p) | (shake_on(p) ? vv::A_SHAKE_V : 0) | (p->hp.has_nh ? (cos_on(p) ? (vv::A_BIAS | vv::A_CZ_STORE | mom_a) : vv::A_KE) : 0);
         const bool split = p->hp.info.num_waves >= p->split_chain_waves && !use_mailbox(p);    // as run_chain_and_b decides
-        if (kernel != 0) flags = vv::B_DRIFT_MIDDLE | tail_flags(p) | (shake_on(p) ? vv::B_SHAKE : 0) | (p->hp.has_nh ? (((p->hp.params.num_nh_chains <= 4 && !split) ? vv::B_CHAIN : 0) | vv::B_SCALE | (cos_on(p) ? (vv::B_UNBIAS | vv::B_CZ_LOAD | mom_b) : 0)) : 0);
+        if (kernel != 0) flags = vv::B_DRIFT_MIDDLE | (rk ? vv::B_KICK : 0) | tail_flags(p) | (shake_on(p) ? vv::B_SHAKE : 0) | (p->hp.has_nh ? (((p->hp.params.num_nh_chains <= 4 && !split) ? vv::B_CHAIN : 0) | vv::B_SCALE | (cos_on(p) ? (vv::B_UNBIAS | vv::B_CZ_LOAD | mom_b) : 0)) : 0);
     }
     hipEvent_t e0, e1;
     HIP_TRY(p, hipEventCreate(&e0));

@@ -670,7 +670,7 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const int2* __restrict__ pre_
                     v.y += 0.5 * stepSize * v.w * fe.y + fscale * v.w * fy;
                     v.z += 0.5 * stepSize * v.w * fe.z + fscale * v.w * fz;
                 }
-                if (!(F & A_SHAKE_V)) store_vec(velm, atom, v, (F & A_WT_STORES) != 0);
+                if (!(F & (A_SHAKE_V | A_NOSTORE))) store_vec(velm, atom, v, (F & A_WT_STORES) != 0);
                 if (F & A_POSDELTA_VV) {                                    // K/velocityVerlet.cu:24-26
                     mixed4 d = {stepSize * v.x, stepSize * v.y, stepSize * v.z, 0};
                     ((mixed4*) a.pos_delta)[atom] = d;
@@ -1194,8 +1194,22 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const int2* __restrict__ pre_
             img_p = ((const real4*) a.posq)[img];
             if (IO::kMixed) img_c = ((const real4*) a.corr)[img];
         }
+        // B_KICK: kernel A kept its kicked velocities in registers (A_NOSTORE); the same kick again here, from the same velm and force
+        // bits with the same expression (K/middle.cu:11-21; forceExtra is zero on this path), gives the same velocities bit for bit.
+        // cos(2 pi z / Lz) of this lane, cached by kernel A (A_CZ_STORE): requested with the particle data
+        double cz_early = 0;
+        if ((F & B_CZ_LOAD) && valid) cz_early = a.cosz[(size_t) wave * 64 + lane];
+        if ((F & B_KICK) && act && (meta & META_MASSIVE)) {
+            const long long fx = a.force[atom], fy = a.force[atom + a.padded], fz = a.force[atom + 2 * a.padded];
+            real3 fe = {0, 0, 0};
+            if (F & B_UNBIAS) fe.x += (real) a.cos_accel * cz_early * P::RECIP(v.w);      // K/cosineAccelerate.cu:9, kernel A's A_COS term to the bit
+            const mixed fscale = stepSize / (mixed) 0x100000000;
+            v.x += stepSize * v.w * fe.x + fscale * v.w * fx;
+            v.y += stepSize * v.w * fe.y + fscale * v.w * fy;
+            v.z += stepSize * v.w * fe.z + fscale * v.w * fz;
+        }
         const mixed4 v_old = v;          // velocity after the kick, before the thermostat (Pos1 uses it)
-        bool vel_dirty = false, pos_dirty = false;
+        bool vel_dirty = (F & B_KICK) != 0, pos_dirty = false;
 
         const bool nh = role == ROLE_NH_NORMAL || role == ROLE_NH_DRUDE || role == ROLE_NH_PARENT;
         const bool use_com = ((meta >> META_SEGFIRST_SHIFT) & 63) != ((meta >> META_SEGLAST_SHIFT) & 63) || (meta & META_COM_LEADER);
@@ -1264,7 +1278,7 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const int2* __restrict__ pre_
         mixed Vb = 0;
         if (F & (B_UNBIAS | B_BIAS_REMOVE | B_BIAS_RESTORE)) {
             Vb = (mixed) scb;
-            cz = (F & B_CZ_LOAD) ? a.cosz[(size_t) wave * 64 + lane] : cos_kz<real>(zraw, (real) a.inv_box_z);
+            cz = (F & B_CZ_LOAD) ? cz_early : cos_kz<real>(zraw, (real) a.inv_box_z);
             if ((F & (B_UNBIAS | B_BIAS_REMOVE)) && act) { v.x -= Vb * cz; vel_dirty = true; }
             if (F & B_KE_MOM) Vx -= Vb * com_w;       // kernel A stored the COM velocity of the biased velocities: COM(u) = COM(v) - V COM(w)
         }
@@ -1658,6 +1672,16 @@ constexpr uint32_t SF_A_LD_SHAKE = SF_A_LD | A_SHAKE_V;
 constexpr uint32_t SF_A_EF_SHAKE = SF_A_EF | A_SHAKE_V;
 constexpr uint32_t SF_B_COS_HW_MOM_MB = SF_B_COS_HW_MOM | B_MAILBOX;
 constexpr uint32_t SF_B_MIDDLE_HW_SHAKE_MB = SF_B_MIDDLE_HW_SHAKE | B_MAILBOX;
+// the headline path without a velm round trip between the kernels (A_NOSTORE / B_KICK): plain, sharded, very large, without hard wall
+constexpr uint32_t SF_A_MIDDLE_NS = SF_A_MIDDLE | A_NOSTORE;
+constexpr uint32_t SF_B_MIDDLE_HW_K = SF_B_MIDDLE_HW | B_KICK;
+constexpr uint32_t SF_B_MIDDLE_K = SF_B_MIDDLE | B_KICK;
+constexpr uint32_t SF_B_MIDDLE_HW_NC_K = SF_B_MIDDLE_HW_NC | B_KICK;
+constexpr uint32_t SF_B_MIDDLE_HW_MB_K = SF_B_MIDDLE_HW_MB | B_KICK;
+constexpr uint32_t SF_B_MIDDLE_MB_K = SF_B_MIDDLE_MB | B_KICK;
+constexpr uint32_t SF_A_COS_MOM_NS = SF_A_COS_MOM | A_NOSTORE;                         // ... and with the cos perturbation (BASELINE C4)
+constexpr uint32_t SF_B_COS_HW_MOM_K = SF_B_COS_HW_MOM | B_KICK;
+constexpr uint32_t SF_B_COS_HW_MOM_MB_K = SF_B_COS_HW_MOM_MB | B_KICK;
 
 // Which specialised kernels are compiled with the static mass tables; a launch whose flags disagree with the build falls through to
 // the generic kernel.  Measured on MI355X (gpurun_out/r02c-e): kernel B gains at every size (two IEEE fp64 divisions per pair lane
@@ -1681,6 +1705,8 @@ hipError_t launch_a(int precision, const KArgs& a, int block_threads, int grid_c
     const dim3 b(block_threads);
     constexpr uint32_t XM = SF_AM;
 #define VV_PRE_ARGS a.slots, a.nwaves, (int) (b.x >> 6)
+    VV_TRY_SF(vv_kernel_a, SF_A_MIDDLE_NS)
+    VV_TRY_SF(vv_kernel_a, SF_A_COS_MOM_NS)
     VV_TRY_SF(vv_kernel_a, SF_A_MIDDLE)
     VV_TRY_SF(vv_kernel_a, SF_A_MIDDLE_WT)
     VV_TRY_SF(vv_kernel_a, SF_A_COS1)
@@ -1716,6 +1742,13 @@ hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_c
         VV_DISPATCH_SF(vv_kernel_b, 0u, g, b, 0, s, VV_PRE_ARGS, a);
         return hipGetLastError();
     }
+    VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_HW_K)
+    VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_K)
+    VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_HW_NC_K)
+    VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_HW_MB_K)
+    VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_MB_K)
+    VV_TRY_SF(vv_kernel_b, SF_B_COS_HW_MOM_K)
+    VV_TRY_SF(vv_kernel_b, SF_B_COS_HW_MOM_MB_K)
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_HW)
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_HW_WT)
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE)

@@ -31,6 +31,9 @@ enum : uint32_t {
                              // (accumulators 0-2, 4-6, 7-9); kernel B combines them once V is known: 2KE = Saa - 2 V Sab + V^2 Sbb
     A_MTAB = 1u << 18,       // own mass and Drude-pair mass fraction from the static per-lane tables (slot_m, slot_f) instead of
                              // reciprocals / IEEE divisions of velm.w in every step
+    A_NOSTORE = 1u << 19,    // the kicked velocities stay in registers (KE stage) and are NOT written back: kernel B repeats the kick
+                             // itself (B_KICK) from velm + force -- 24 bytes of force read there instead of 32 bytes written here and
+                             // 3.5 MB less dirty data behind this launch at the headline size (the kernel boundary waits for it)
     A_WT_STORES = 1u << 27,  // write-through (sc1) store of the kicked velocities
     A_KE_PLAIN = 1u << 15,   // sum m v^2 over every massive particle into accumulator 0 (kinetic-energy query)
 };
@@ -52,6 +55,8 @@ enum : uint32_t {
     B_SHAKE = 1u << 13,       // position constraints of the SHAKE clusters on the step's displacement (OpenMM applyConstraints)
     B_MAILBOX = 1u << 14,     // multi-GPU mailbox: block 0's thermostat wave stores this rank's totals into every peer, all blocks sum all ranks' totals
     B_KE_MOM = 1u << 15,      // the accumulators hold moments (A_KE_MOM): combine them with V, unbias the stored COM velocities with comw
+    B_KICK = 1u << 17,        // v += dt*invM*Fe + dt/2^32*invM*F (K/middle.cu:6-23) on the freshly loaded velocities: partner of A_NOSTORE, the
+                              // very expression kernel A evaluated (same operands, same order: same bits); Fe = the cos force with B_UNBIAS
     B_MTAB = 1u << 16,        // Drude-pair mass fractions from the static per-lane table (slot_f) instead of two IEEE divisions per lane
     B_WT_STORES = 1u << 27,   // write-through (sc1) stores for the particle arrays: the dirty lines leave L2 during the kernel, not at its end
     B_DBG_NOFOLD = 1u << 28,  // timing experiments only: skip the accumulator fold / the chain arithmetic

@@ -447,6 +447,12 @@ class Context:
         H.check(H.lib.vvhip_timing_read(self.plan, C.byref(a), C.byref(b), C.byref(o), C.byref(n)), self.plan)
         return dict(ms_a=a.value, ms_b=b.value, ms_other=o.value, launches=list(n))
 
+    def algorithmic_bytes(self):
+        """(bytes_A, bytes_B) per particle of the fused middle step's two kernels (vvhip_algorithmic_bytes)."""
+        a, b = C.c_int32(0), C.c_int32(0)
+        H.check(H.lib.vvhip_algorithmic_bytes(self.plan, C.byref(a), C.byref(b)), self.plan)
+        return a.value, b.value
+
     def time_kernel(self, kernel: int, reps: int = 200) -> float:
         """Average ms of `reps` back-to-back launches of stage kernel 0 (A) / 1 (B) with the fused step's stage bits.
         Timing only: the physical state is not meaningful afterwards."""

@@ -101,6 +101,7 @@ def _load():
         "vvhip_step_vv_first": [vp],
         "vvhip_step_vv_second": [vp, u32],
         "vvhip_step_middle_phases": [vp],
+        "vvhip_algorithmic_bytes": [vp, P(i32), P(i32)],
         "vvhip_step_middle_phase": [vp, C.c_int, u32],
         "vvhip_accumulators": [vp, C.c_int, P(vp), P(i32)],
         "vvhip_reset_extra_force": [vp], "vvhip_middle_kick": [vp], "vvhip_middle_half_drift1": [vp],

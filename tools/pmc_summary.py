@@ -32,7 +32,10 @@ for short, d in raw.items():
     res["raw_kb"][short]["dispatches"] = max(v[1] for v in d.values())
     f = d.get("FETCH_SIZE", [0, 1]); w = d.get("WRITE_SIZE", [0, 1])
     res[f"hbm_bytes_per_launch_{short}"] = int(round((2 * f[0] / max(f[1], 1) + w[0] / max(w[1], 1)) * 1024))
-res["algorithmic_bytes_per_launch"] = {"A": 94 * natoms, "B": 134 * natoms}
+# mixed precision; C3 / C3xK run the register-kick path (kernel A keeps the kicked velocities, kernel B repeats the kick: 62 + 158 B),
+# configurations with extra forces the store path (94 + 134 B): vvhip_algorithmic_bytes
+per = {"A": 62, "B": 158} if cfg.startswith("C3") or cfg in ("C1", "C2") else {"A": 94, "B": 134}
+res["algorithmic_bytes_per_launch"] = {k: v * natoms for k, v in per.items()}
 for k in ("A", "B"):
     if f"hbm_bytes_per_launch_{k}" in res:
         res[f"traffic_over_algorithmic_{k}"] = round(res[f"hbm_bytes_per_launch_{k}"] / res["algorithmic_bytes_per_launch"][k], 3)
