@@ -1388,13 +1388,19 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const int2* __restrict__ pre_
                 mixed p2x = isd ? ox : x, p2y = isd ? oy : y, p2z = isd ? oz : z;
                 const mixed vel1w = isd ? v.w : ovw, vel2w = isd ? ovw : v.w;
                 const mixed deltax = p1x - p2x, deltay = p1y - p2y, deltaz = p1z - p2z;
-                const mixed r = P::SQRT(deltax * deltax + deltay * deltay + deltaz * deltaz);
-                // The reference decides on rInv * maxDrudeDistance < 1 with rInv = RECIP(r) (K/middle.cu:128-131), an IEEE division per
-                // pair and step.  r <= 0.99999 max implies rInv * max >= 1.00001 (1 - 2^-23)^2 > 1 in every mode, i.e. "no hit" without
-                // forming the quotient; only pairs within 1e-5 of the wall or beyond it take the exact test.  Same decisions, same bits.
-                mixed rInv = 0;
+                const mixed r2 = deltax * deltax + deltay * deltay + deltaz * deltaz;
+                // The reference decides on rInv * maxDrudeDistance < 1 with r = SQRT(r2), rInv = RECIP(r) (K/middle.cu:126-131): a square
+                // root and an IEEE division per pair and step.  r2 <= (0.9999 max)^2 implies r <= 0.99999 max (SQRT is a float sqrt in
+                // mixed mode: relative error 1.2e-7), which implies rInv * max >= 1.00001 (1 - 2^-23)^2 > 1 in every mode, i.e. "no hit"
+                // without forming either; only pairs within 1e-4 of the wall or beyond it take the exact test.  Same decisions, same bits.
+                mixed r = 0, rInv = 0;
                 bool hit = false;
-                if (__builtin_expect(r > maxDrudeDistance * (mixed) 0.99999, 0)) { rInv = P::RECIP(r); hit = rInv * maxDrudeDistance < 1; }
+                const mixed nearWall = maxDrudeDistance * (mixed) 0.9999;
+                if (__builtin_expect(r2 > nearWall * nearWall, 0)) {
+                    r = P::SQRT(r2);
+                    rInv = P::RECIP(r);
+                    hit = rInv * maxDrudeDistance < 1;
+                }
                 if (__builtin_expect(hit, 0)) {      // rare: keep the hit path out of the fall-through code
                     // both lanes of a pair see the same r, so both are in here: the partner's velocity is fetched only now
                     const mixed ovx = shfl(v.x, partner), ovy = shfl(v.y, partner), ovz = shfl(v.z, partner);

@@ -1,0 +1,3 @@
+// oracle/refhost stand-in: everything lives in CudaContext.h
+#pragma once
+#include "CudaContext.h"

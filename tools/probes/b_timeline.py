@@ -16,7 +16,7 @@ FULL = 2048 | 1 | 16 | 512
 names_t = ["entry", "loads arrived", "prep done", "scales received", "compute done", "stores drained"]
 names_c = ["entry", "acc folded", "chain done", "after barrier"]
 GHZ = 2.4      # shader clock assumed for the conversion (MI355X boost); relative numbers are what matter
-for flags, label in ((FULL, "B full"), (1 | 16 | 512, "B without chain wave")):
+for flags, label in ((FULL, "B full"), (1 | 16 | 512 | (1 << 17), "B without chain wave")):
     print(label)
     for block in ((0,) if SMALL else (0, 1, 125, 250)):
         acc = []
@@ -39,7 +39,7 @@ print("A full (kick + KE): entry, velm arrived, kicked + stored, tile loop done,
 for block in ((0,) if SMALL else (0, 1, 125, 250)):
     ctx.calcForces()
     out = (C.c_longlong * 128)()
-    H.check(H.lib.vvhip_debug_timestamps(ctx.plan, 0x80000000 | 32 | 1024, block, C.byref(out)), ctx.plan)
+    H.check(H.lib.vvhip_debug_timestamps(ctx.plan, 0x80000000 | 32 | 1024 | (1 << 19), block, C.byref(out)), ctx.plan)      # A_KICK_FULL | A_KE | A_NOSTORE
     H.check(H.lib.vvhip_step_middle_phase(ctx.plan, 1, 0), ctx.plan)
     t = np.array(out, dtype=np.int64).reshape(8, 16)
     t0 = min(t[0, 0], t[1, 0])

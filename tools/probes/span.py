@@ -11,7 +11,7 @@ for cfg in ("C3", "C2"):
     ctx = I.Context(spec, it, precision="mixed", force_provider="tether")
     ctx.run_graph(200, 100); ctx.synchronize()
     hw = 512 if cfg == "C3" else 0
-    for name, k, f in (("A kick+KE", 0, 32 | 1024), ("B full", 1, 2048 | 1 | 16 | hw), ("B no chain wave", 1, 1 | 16 | hw)):
+    for name, k, f in (("A kick+KE (no store)", 0, 32 | 1024 | (1 << 19)), ("B full + kick", 1, 2048 | 1 | 16 | hw | (1 << 17)), ("B no chain wave", 1, 1 | 16 | hw | (1 << 17))):
         out = (C.c_double * 8)()
         H.check(H.lib.vvhip_debug_span(ctx.plan, k, f, 40, C.byref(out)), ctx.plan)
         ms = C.c_double(0)
