@@ -1,0 +1,121 @@
+"""oracle/make_golden_refhost.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Records, from the REFERENCE's whole step compiled for the CPU (oracle/_ref/libvvref_host_*.so: its VVIntegrator.cpp, CudaVVKernels.cpp,
+CudaVVKernelFactory.cpp and kernels/*.cu in place; `make -C oracle refhost`, build container only), for each configuration below:
+  tests/golden/refhost_<name>.npz   velm / posq after `steps` steps in the three precisions (static forces, injected normals), and the
+                                    thermostat constants of CudaModifyDrudeNoseKernel::initialize (dof, nkbt, eta_mass, num_tg)
+  tests/golden/refhost_launches.json the reference's kernel launch order of one step per configuration
+Inputs are regenerated from seeds by `make_spec` / `inputs_for`, so the fixtures hold outputs only.
+
+    python -m oracle.make_golden_refhost
+"""
+from __future__ import annotations
+
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import oracle as O  # noqa: E402
+
+systems = importlib.import_module("openmm-velocityverlet_amd.systems")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+LAUNCHES = os.path.join(GOLDEN, "refhost_launches.json")
+STEPS = 6
+
+
+def _bulk(**kw):
+    spec = systems.drude_il(cells=(1, 1, 1), pairs_per_cell=6, seed=5)
+    rng = np.random.default_rng(6)
+    d = spec.drude_pairs[:, 0]
+    far = rng.choice(d, size=max(2, len(d) // 6), replace=False)       # some Drudes beyond the hard wall from the first step on
+    spec.positions[far] = spec.positions[far - 1] + rng.normal(0, 0.02, size=(len(far), 3))
+    return spec, O.Params(temperature=333.0, max_drude_distance=0.02, **kw)
+
+
+def _edl(**kw):
+    spec = systems.edl_slab(num_ion_pairs=3, num_electrode=10, seed=23)
+    mol0 = spec.mol_id[10]                                              # first IL molecule -> Langevin set, so the pair branch runs
+    members = [int(i) for i in np.nonzero(spec.mol_id == mol0)[0] if spec.masses[i] != 0]
+    spec.particles_ld = list(spec.particles_ld) + members
+    return spec, O.Params(temperature=333.0, max_drude_distance=0.02, mirror_location=float(spec.box[2]) / 2,
+                          electric_field=2.0 / float(spec.box[2]) * 1.602176634e-22, **kw)     # (the host multiplies by 6.24e21: SURVEY quirk Q12)
+
+
+def _langevin_only():
+    spec = systems.nondrude_il(num_pairs=3, seed=9)
+    spec.particles_ld = list(range(spec.num_atoms))
+    return spec, O.Params(temperature=333.0)
+
+
+CONFIGS = {
+    "bulk_middle": lambda: _bulk(),
+    "bulk_middle_cos": lambda: _bulk(cos_acceleration=0.01),
+    "bulk_classic": lambda: _bulk(use_middle_scheme=False),
+    "bulk_classic_cos": lambda: _bulk(use_middle_scheme=False, cos_acceleration=0.01),
+    "bulk_nocom": lambda: _bulk(use_com_temp_group=False, auto_set_com_temp_group=False),
+    "bulk_chain5_loops3": lambda: _bulk(num_chains=5, loops_per_step=3),
+    "edl": lambda: _edl(),
+    "edl_classic": lambda: _edl(use_middle_scheme=False),
+    "nondrude": lambda: (systems.nondrude_il(num_pairs=4, seed=8), O.Params(temperature=333.0)),
+    "nondrude_com": lambda: (systems.nondrude_il(num_pairs=4, seed=8), O.Params(temperature=333.0, use_com_temp_group=True, auto_set_com_temp_group=False)),
+    "water": lambda: (systems.spce_water(20, seed=31), O.Params(temperature=300.0, step_size=0.002)),
+    "langevin_only": _langevin_only,
+}
+
+
+def precisions_of(name):
+    """The reference passes posqCorrection = 0 to updateImagePositions outside mixed mode (CudaVVKernels.cpp:928) and the kernel
+    dereferences it unconditionally (kernels/imageCharge.cu:15-16): with image pairs only mixed precision can run (here: a segfault)."""
+    return ("mixed",) if name.startswith("edl") else O.PRECISIONS
+
+
+def make_spec(name):
+    return CONFIGS[name]()
+
+
+def inputs_for(spec, params, steps, seed=3):
+    """(random float4 buffer, static int64 forces) for a run of `steps` steps: regenerated from the seed wherever they are needed."""
+    rng = np.random.default_rng(seed)
+    t = O.build_tables(spec, params)
+    force = rng.integers(-(1 << 40), 1 << 40, size=3 * O.padded(spec.num_atoms)).astype(np.int64)
+    nrand = (max(len(t["normal_ld"]), 1) + 2 * max(len(t["pairs_ld"]), 1)) * steps + 5
+    return rng.standard_normal((nrand, 4)).astype(np.float32), force
+
+
+def main():
+    from oracle import refhost as RH
+    launches = {}
+    for name in sorted(CONFIGS):
+        out = dict(steps=np.int32(STEPS))
+        for prec in precisions_of(name):
+            spec, params = make_spec(name)
+            rnd, force = inputs_for(spec, params, STEPS)
+            r = RH.RefHost(spec, params, prec, random=rnd, force=force)
+            assert r.h, r.error
+            r.launches()
+            r.step(1)
+            if prec == "mixed":
+                launches[name] = r.launches()
+            r.step(STEPS - 1)
+            out[f"velm_{prec}"], out[f"posq_{prec}"] = r.velm.copy(), r.posq.copy()
+            th = r.thermostat()
+            out["num_tg"] = np.int32(th["num_tg"] if th else 0)
+            if th:
+                out["dof"], out["nkbt"], out["eta_mass"] = th["dof"], th["nkbt"], th["eta_mass"]
+            r.close()
+        np.savez_compressed(os.path.join(GOLDEN, f"refhost_{name}.npz"), **out)
+        print(name, "ok", launches[name])
+    with open(LAUNCHES, "w") as f:
+        json.dump(launches, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -182,7 +182,7 @@ def build_tables(spec, params: Params) -> Dict:
         num_particles_ld=int(is_ld.sum()),
         image_pairs=np.array(spec.image_pairs, dtype=np.int32).reshape(-1, 2),
         particles_electrolyte=np.array(spec.particles_electrolyte, dtype=np.int32),
-        inv_mass_total=1.0 / float(np.sum(spec.masses)),            # HOST:1028-1031
+        inv_mass_total=1.0 / float(np.cumsum(np.asarray(spec.masses, dtype=np.float64))[-1]),   # HOST:1028-1031: summed in particle order (np.sum adds pairwise: 1 ulp off)
         mol_inv_mass=mol_inv_mass,
     )
 

@@ -22,17 +22,8 @@
 #include "openmm/Platform.h"
 #include "openmm/System.h"
 
-// ---- CUDA vector types as the host code uses them (layout = the kernels' own, oracle/ref_prelude.h)
-struct int2 { int x, y; };
-struct float2 { float x, y; };   struct float3 { float x, y, z; };   struct float4 { float x, y, z, w; };
-struct double2 { double x, y; }; struct double3 { double x, y, z; }; struct double4 { double x, y, z, w; };
-static inline int2 make_int2(int x, int y) { int2 r = {x, y}; return r; }
-static inline float2 make_float2(float x, float y) { float2 r = {x, y}; return r; }
-static inline float3 make_float3(float x, float y, float z) { float3 r = {x, y, z}; return r; }
-static inline float4 make_float4(float x, float y, float z, float w) { float4 r = {x, y, z, w}; return r; }
-static inline double2 make_double2(double x, double y) { double2 r = {x, y}; return r; }
-static inline double3 make_double3(double x, double y, double z) { double3 r = {x, y, z}; return r; }
-static inline double4 make_double4(double x, double y, double z, double w) { double4 r = {x, y, z, w}; return r; }
+// ---- CUDA vector types (int2, float4, double4, make_*): the HIP host headers compat/OpenMMCompat.h already includes define them with
+//      the same layout as the kernels' own (oracle/ref_prelude.h)
 
 // ---- driver handles
 typedef unsigned long long CUdeviceptr;                  // holds a host address here

@@ -1,0 +1,188 @@
+"""The REFERENCE's whole step -- VVIntegrator.cpp + CudaVVKernels.cpp + CudaVVKernelFactory.cpp + kernels/*.cu, compiled in place for the CPU
+(oracle/_ref/libvvref_host_*.so, `make -C oracle refhost`; build container only, the .so files travel to the GPU box) -- against the oracle:
+
+* trajectories bit for bit (static forces, injected normals) for every scheme / modifier combination of SURVEY.md section 8;
+* the host constants CudaModifyDrudeNoseKernel::initialize derives (degrees of freedom, N kB T, thermostat masses:
+  CudaVVKernels.cpp:505-594) against oracle.build_tables and against the product's plan (vv::analyze through the C-ABI);
+* the reference's launch order per step against the stage list DESIGN.md section 2 says the two fused kernels cover.
+
+Where the reference build is absent the committed goldens (tests/golden/refhost_*.npz, oracle/make_golden_refhost.py) stand in.
+"""
+import importlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O, refhost as RH
+from oracle.make_golden_refhost import CONFIGS, GOLDEN, LAUNCHES, inputs_for, make_spec, precisions_of
+
+systems = importlib.import_module("openmm-velocityverlet_amd.systems")
+have = pytest.mark.skipif(not all(RH.available(p) for p in O.PRECISIONS), reason="oracle/_ref/libvvref_host_* not built (reference sources absent)")
+
+
+def _pair(name, prec, steps):
+    spec, params = make_spec(name)
+    rnd, force = inputs_for(spec, params, steps)
+    r = RH.RefHost(spec, params, prec, random=rnd, force=force)
+    assert r.h, r.error
+    o = O.OracleSystem(spec, params, prec, random=rnd, force_mode=0)
+    o.state["force"][:] = force
+    return spec, params, r, o
+
+
+@have
+@pytest.mark.parametrize("prec", O.PRECISIONS)
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_reference_pipeline_equals_oracle_bit_for_bit(name, prec):
+    if prec not in precisions_of(name):
+        pytest.skip("the reference dereferences a null posqCorrection for image pairs outside mixed precision")
+    steps = 6
+    spec, params, r, o = _pair(name, prec, steps)
+    for s in range(steps):
+        r.step(1)
+        o.step(1)
+        assert np.array_equal(r.velm.view(np.uint8), o.velm.view(np.uint8)), f"{name}/{prec}: velocities differ at step {s}"
+        assert np.array_equal(r.posq.view(np.uint8), o.posq.view(np.uint8)), f"{name}/{prec}: positions differ at step {s}"
+        if prec == "mixed":
+            assert np.array_equal(r.state["posq_corr"].view(np.uint8), o.posq_corr.view(np.uint8)), f"{name}/{prec}: corrections, step {s}"
+    th = r.thermostat()
+    if th is not None:
+        cs = o.chain_state()
+        nc = params.num_chains
+        for g in range(th["num_tg"]):
+            assert np.array_equal(th["eta"][g, :nc], cs["eta"][g]), (name, g)
+            assert np.array_equal(th["eta_dot"][g, :nc], cs["eta_dot"][g][:nc]), (name, g)
+        assert np.array_equal(th["ke2"][:th["num_tg"]], o.ke2()[:th["num_tg"]])
+        assert np.array_equal(th["vscale"][:th["num_tg"]], o.vscale()[:th["num_tg"]])
+    if params.cos_acceleration != 0:
+        assert r.viscosity() == o.viscosity()
+    assert abs(r.time() - steps * params.step_size) < 1e-12
+    r.close()
+
+
+@have
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_reference_host_constants_equal_oracle_tables(name):
+    spec, params = make_spec(name)
+    r = RH.RefHost(spec, params, "mixed")
+    assert r.h, r.error
+    t = O.build_tables(spec, params)
+    th = r.thermostat()
+    if th is None:
+        assert len(t["particles_nh"]) == 0
+        return
+    assert th["num_tg"] == t["num_tg"]
+    assert np.array_equal(th["dof"], t["dof"])
+    assert np.array_equal(th["nkbt"][:t["num_tg"]], t["nkbt"][:t["num_tg"]])
+    assert np.array_equal(th["eta_mass"][:t["num_tg"], :params.num_chains], t["eta_mass"][:t["num_tg"], :params.num_chains])
+    assert (th["num_particles_nh"], th["num_molecules_nh"], th["num_normal_nh"], th["num_pairs_nh"]) == (
+        len(t["particles_nh"]), len(t["molecules_nh"]), len(t["normal_nh"]), len(t["pairs_nh"]))
+    r.close()
+
+
+@have
+@pytest.mark.parametrize("which", ["C3", "C3_hbonds", "C5", "C2_rigid", "C1"])
+def test_reference_host_constants_at_baseline_sizes(which):
+    """The full-size BASELINE configurations: DOF / N kB T / thermostat masses of the reference's own initialize()."""
+    spec = {"C3": lambda: systems.make_config("C3"), "C3_hbonds": lambda: systems.make_config("C3", hbonds=True), "C5": lambda: systems.make_config("C5"),
+            "C2_rigid": lambda: systems.rigid_water(systems.make_config("C2")), "C1": lambda: systems.make_config("C1")}[which]()
+    params = O.Params(temperature=333.0, max_drude_distance=0.02 if len(spec.drude_pairs) else 0.0,
+                      mirror_location=float(spec.box[2]) / 2 if len(spec.image_pairs) else 0.0)
+    r = RH.RefHost(spec, params, "mixed")
+    assert r.h, r.error
+    t, th = O.build_tables(spec, params), r.thermostat()
+    assert th["num_tg"] == t["num_tg"]
+    assert np.array_equal(th["dof"], t["dof"]), (th["dof"], t["dof"])
+    assert np.array_equal(th["nkbt"], t["nkbt"])
+    assert np.array_equal(th["eta_mass"][:, :3], t["eta_mass"][:, :3])
+    r.close()
+
+
+@have
+def test_reference_refuses_what_the_oracle_refuses():
+    spec, params = make_spec("edl")
+    spec.particles_ld = spec.particles_ld + [int(spec.drude_pairs[-1, 0])]         # a Drude in the Langevin set, the rest of its molecule in NH
+    r = RH.RefHost(spec, params, "mixed")
+    assert not r.h and r.error
+    with pytest.raises(O.OracleError) as e:
+        O.build_tables(spec, params)
+    assert str(e.value) == r.error == "NH and Langevin thermostat cannot be applied on the same molecule"
+
+
+@have
+def test_goldens_are_current():
+    """The committed fixtures are what the reference build produces today."""
+    for name in sorted(CONFIGS):
+        g = np.load(os.path.join(GOLDEN, f"refhost_{name}.npz"))
+        for prec in precisions_of(name):
+            spec, params, r, _ = _pair(name, prec, int(g["steps"]))
+            r.step(int(g["steps"]))
+            assert np.array_equal(r.velm, g[f"velm_{prec}"]) and np.array_equal(r.posq, g[f"posq_{prec}"])
+            r.close()
+
+
+@pytest.mark.parametrize("prec", O.PRECISIONS)
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_oracle_reproduces_reference_pipeline_goldens(name, prec):
+    """Runs everywhere: the oracle's whole step against trajectories + constants recorded from the reference's own host + kernel code."""
+    if prec not in precisions_of(name):
+        pytest.skip("no reference run exists for image pairs outside mixed precision")
+    g = np.load(os.path.join(GOLDEN, f"refhost_{name}.npz"))
+    steps = int(g["steps"])
+    spec, params = make_spec(name)
+    rnd, force = inputs_for(spec, params, steps)
+    o = O.OracleSystem(spec, params, prec, random=rnd, force_mode=0)
+    o.state["force"][:] = force
+    o.step(steps)
+    assert np.array_equal(o.velm.view(np.uint8), g[f"velm_{prec}"].view(np.uint8))
+    assert np.array_equal(o.posq.view(np.uint8), g[f"posq_{prec}"].view(np.uint8))
+    t = O.build_tables(spec, params)
+    if int(g["num_tg"]):
+        assert int(g["num_tg"]) == t["num_tg"]
+        assert np.array_equal(g["dof"], t["dof"]) and np.array_equal(g["nkbt"], t["nkbt"])
+        assert np.array_equal(g["eta_mass"][:, :params.num_chains], t["eta_mass"][:, :params.num_chains])
+
+
+MIDDLE = ["integrateMiddleVel", "integrateMiddlePos1"]
+TGNH = ["calcCOMVelocities", "normalizeVelocities", "computeNormalizedKineticEnergies", "sumNormalizedKineticEnergies", "scaleVelocity"]
+DRIFT = ["integrateMiddlePos2", "integrateMiddlePos3"]
+BIAS_OUT, BIAS_IN = ["calcPeriodicVelocityBias", "sumV", "removePeriodicVelocityBias"], ["restorePeriodicVelocityBias"]
+VV1 = ["velocityVerletIntegrateVelocities", "velocityVerletIntegratePositions"]
+EXPECTED = {   # one step of the reference, as its own host code launches it (DESIGN.md section 2 maps each name to a fused stage)
+    "bulk_middle": MIDDLE + TGNH + DRIFT + ["applyHardWallConstraints"],
+    "bulk_middle_cos": ["resetExtraForce", "addCosAcceleration"] + MIDDLE + BIAS_OUT + TGNH + BIAS_IN + DRIFT + ["applyHardWallConstraints"],
+    "bulk_classic": TGNH + VV1 + ["applyHardWallConstraints", "velocityVerletIntegrateVelocities"] + TGNH,
+    "bulk_classic_cos": BIAS_OUT + TGNH + BIAS_IN + VV1 + ["applyHardWallConstraints", "resetExtraForce", "addCosAcceleration",
+                                                       "velocityVerletIntegrateVelocities"] + BIAS_OUT + TGNH + BIAS_IN,
+    "bulk_nocom": MIDDLE + TGNH[2:] + DRIFT + ["applyHardWallConstraints"],
+    "edl": ["resetExtraForce", "addExtraForceDrudeLangevin", "addExtraForceElectricField"] + MIDDLE + TGNH + DRIFT
+           + ["applyHardWallConstraints", "updateImagePositions"],
+    "langevin_only": ["resetExtraForce", "addExtraForceDrudeLangevin"] + MIDDLE + DRIFT,
+    "nondrude": MIDDLE + TGNH[2:] + DRIFT,
+    "nondrude_com": MIDDLE + TGNH + DRIFT,
+}
+
+
+def test_reference_launch_order_per_step():
+    """The reference's per-step launch lists, recorded from its own host code (tests/golden/refhost_launches.json)."""
+    with open(LAUNCHES) as f:
+        rec = json.load(f)
+    assert sorted(rec) == sorted(CONFIGS)
+    for name, want in EXPECTED.items():
+        assert rec[name] == want, name
+
+
+@have
+def test_reference_launch_order_live():
+    with open(LAUNCHES) as f:
+        rec = json.load(f)
+    for name in sorted(CONFIGS):
+        _, _, r, _ = _pair(name, "mixed", 2)
+        r.launches()
+        r.step(1)
+        first = r.launches()
+        r.step(1)
+        assert first == rec[name] and r.launches() == rec[name], name
+        r.close()
