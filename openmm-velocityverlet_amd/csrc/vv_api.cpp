@@ -105,6 +105,7 @@ struct vvhip_plan {
     bool mass_tab_a = false, mass_tab_b = true;   // kernel A / B launches read the tables (defaults follow the build; VVHIP_MTAB_A / VVHIP_MTAB_B override: comparison runs)
     bool mass_tab_valid = false;   // tables match the bound velm.w (vvhip_bind / vvhip_masses_changed reset it)
     double* d_seg_mass = nullptr;  // static (mass, 1/mass) per COM segment
+    int* d_seg_base = nullptr;     // per wave: COM segments in the waves before it
     double* d_comw = nullptr;      // per-segment mass-weighted mean of cos(kz) (moment form of the cos perturbation)
     double* d_cosz = nullptr;      // per-lane cos(2 pi z / Lz) of the current step
     unsigned long long* d_acc = nullptr;   // [2 parities][NUM_ACC][ACC_SLOTS]
@@ -278,6 +279,7 @@ vv::KArgs make_args(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
     a.comv = p->d_comv;
     a.comw = p->d_comw;
     a.seg_mass = p->d_seg_mass;
+    a.seg_base = p->d_seg_base;
     a.cosz = p->d_cosz;
     a.slots = p->d_slots;
     a.slot_m = p->d_slot_m;
@@ -546,7 +548,7 @@ void vvhip_plan_destroy(vvhip_plan* p) {
     if (p->bound) {
         (void) hipStreamSynchronize(p->stream);
         for (void* ptr : {(void*) p->d_slots, (void*) p->d_slot_image, (void*) p->d_slot_rand, (void*) p->d_slot_shake, (void*) p->d_slot_shake_param, (void*) p->d_slot_big, (void*) p->d_bigacc, (void*) p->d_image_pairs,
-                          p->d_fextra, p->d_old_delta, p->d_pos_delta, p->d_comv, (void*) p->d_comw, (void*) p->d_seg_mass, (void*) p->d_slot_m, (void*) p->d_slot_f, (void*) p->d_cosz, (void*) p->d_epoch, (void*) p->d_acc, (void*) p->d_nh, (void*) p->d_lane_const, (void*) p->d_dbg, (void*) p->d_dbg_span})
+                          p->d_fextra, p->d_old_delta, p->d_pos_delta, p->d_comv, (void*) p->d_comw, (void*) p->d_seg_mass, (void*) p->d_seg_base, (void*) p->d_slot_m, (void*) p->d_slot_f, (void*) p->d_cosz, (void*) p->d_epoch, (void*) p->d_acc, (void*) p->d_nh, (void*) p->d_lane_const, (void*) p->d_dbg, (void*) p->d_dbg_span})
             if (ptr) (void) hipFree(ptr);
         drop_graphs(p);
         if (p->comm) (void) rccl_api().commDestroy(p->comm);
@@ -627,14 +629,17 @@ int vvhip_bind(vvhip_plan* p, const vvhip_buffers* b) {
     HIP_TRY(p, hipMemset(p->d_old_delta, 0, nloc * 4 * ms));
     HIP_TRY(p, hipMalloc((void**) &p->d_cosz, nslots * sizeof(double)));
     HIP_TRY(p, hipMemset(p->d_cosz, 0, nslots * sizeof(double)));
-    HIP_TRY(p, hipMalloc(&p->d_comv, nslots * 4 * ms));
-    HIP_TRY(p, hipMemset(p->d_comv, 0, nslots * 4 * ms));
+    const size_t nseg = std::max<size_t>(hp.seg_mass.size() / 2, 1);
+    HIP_TRY(p, hipMalloc(&p->d_comv, nseg * 4 * ms));
+    HIP_TRY(p, hipMemset(p->d_comv, 0, nseg * 4 * ms));
+    HIP_TRY(p, hipMalloc((void**) &p->d_seg_base, hp.seg_base.size() * sizeof(int32_t)));
+    HIP_TRY(p, hipMemcpy(p->d_seg_base, hp.seg_base.data(), hp.seg_base.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     HIP_TRY(p, hipMalloc((void**) &p->d_seg_mass, hp.seg_mass.size() * sizeof(double)));
     HIP_TRY(p, hipMemcpy(p->d_seg_mass, hp.seg_mass.data(), hp.seg_mass.size() * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(p, hipMalloc((void**) &p->d_slot_m, nslots * sizeof(double)));
     HIP_TRY(p, hipMalloc((void**) &p->d_slot_f, nslots * sizeof(double)));
-    HIP_TRY(p, hipMalloc((void**) &p->d_comw, nslots * sizeof(double)));
-    HIP_TRY(p, hipMemset(p->d_comw, 0, nslots * sizeof(double)));
+    HIP_TRY(p, hipMalloc((void**) &p->d_comw, nseg * sizeof(double)));
+    HIP_TRY(p, hipMemset(p->d_comw, 0, nseg * sizeof(double)));
     HIP_TRY(p, hipMalloc(&p->d_pos_delta, nloc * 4 * ms));
     HIP_TRY(p, hipMemset(p->d_pos_delta, 0, nloc * 4 * ms));
     HIP_TRY(p, hipMalloc((void**) &p->d_epoch, sizeof(unsigned long long)));

@@ -474,6 +474,26 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
     info.num_waves = nwaves;
     info.num_slots_used = used;
     hp.seg_mass.resize((size_t) nwaves * 128, 0.0);
+    {   // compact the per-segment table: segments numbered wave by wave, inside a wave by the lane of their leader (what the kernels
+        // recompute as seg_base[wave] + popcount of the leader lanes below: one 32-byte COM velocity per segment, stored back to back,
+        // instead of one at every segment's first-lane position of a 64-entry page per wave)
+        std::vector<double> dense;
+        hp.seg_base.assign((size_t) nwaves + 1, 0);
+        for (int w = 0; w < nwaves; w++) {
+            hp.seg_base[w] = (int32_t) (dense.size() / 2);
+            for (int l = 0; l < 64; l++) {
+                if (slots[(size_t) w * 128 + 2 * l] < 0) continue;
+                const uint32_t meta = (uint32_t) slots[(size_t) w * 128 + 2 * l + 1];
+                if (!(meta & META_COM_LEADER)) continue;
+                const int first = (meta >> META_SEGFIRST_SHIFT) & 63;
+                dense.push_back(hp.seg_mass[((size_t) w * 64 + first) * 2]);
+                dense.push_back(hp.seg_mass[((size_t) w * 64 + first) * 2 + 1]);
+            }
+        }
+        hp.seg_base[nwaves] = (int32_t) (dense.size() / 2);
+        if (dense.empty()) dense.assign(2, 0.0);
+        hp.seg_mass.swap(dense);
+    }
 
     if (hp.has_images) {
         hp.slot_image.assign((size_t) nwaves * 64, -1);

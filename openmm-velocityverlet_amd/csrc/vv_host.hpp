@@ -64,7 +64,8 @@ struct HostPlan {
     std::vector<int32_t> slot_image;   // [64*waves] shard-relative image particle of this lane's particle, or -1
     // [2*64*waves] at the slot of a COM segment's first lane: mass of the segment's thermostatted particles, summed in particle order as
     // the reference does (K/drudeNoseHoover.cu:15-25), and its reciprocal -- static, so kernel A need not scan the masses every step
-    std::vector<double> seg_mass;
+    std::vector<double> seg_mass;      // (mass, 1/mass) per COM segment, DENSE: entry seg_base[wave] + (number of COM-leader lanes below the segment's leader lane)
+    std::vector<int32_t> seg_base;     // [num_waves + 1] number of COM segments in the waves before this one (last entry: the total)
     std::vector<int32_t> slot_rand;    // [64*waves] offset into the Langevin slice of the random buffer, or -1
     // in-kernel SHAKE (hydrogen-type clusters): per lane a packed word and, for central lanes, OpenMM-style cluster parameters
     //   word: bit0 central, bit1 peripheral, bits2-3 = #peripherals (central) or own index (peripheral),

@@ -56,6 +56,7 @@ __device__ __forceinline__ void store16_wt(void* base, unsigned byte_offset, con
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0xFFFFFFFF, 0x00020000);
     __builtin_amdgcn_raw_buffer_store_b128(*(const vv_u4*) src, rsrc, (int) byte_offset, 0, VV_WT_AUX);
 }
+
 template <class V>
 __device__ __forceinline__ void store_vec(V* base, int index, const V& val, bool write_through) {
     if (write_through) {
@@ -91,6 +92,11 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_fetch(float x) {
     return __int_as_float(dpp_fetch32<CTRL, ROW_MASK>(__float_as_int(x)));
 }
+// number of set bits of a 64-lane mask below the calling lane
+__device__ __forceinline__ unsigned lanes_below(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned) (mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) mask, 0u));
+}
+
 template <class T>
 __device__ __forceinline__ T wave_scan(T x) {
     x += dpp_fetch<0x111, 0xF>(x);   // row_shr:1
@@ -578,7 +584,11 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const int2* __restrict__ pre_
             if (role != ROLE_LD_NORMAL) rnd_b = a.random[ri + 1];
         }
         double2 seg_mw = {0, 0};                 // (mass, 1/mass) of this lane's COM segment, one 16-byte entry per segment
-        if ((F & A_KE) && act && (meta & META_COM_LEADER)) seg_mw = ((const double2*) a.seg_mass)[(size_t) wave * 64 + ((meta >> META_SEGFIRST_SHIFT) & 63)];
+        // dense index of this lane's COM segment: segments are numbered wave by wave and, inside a wave, by the lane of their leader
+        // (= last) lane, so every lane of a segment counts the same leaders below itself (vv_host.cpp: seg_base)
+        int segi = 0;
+        if (F & A_KE) segi = a.seg_base[__builtin_amdgcn_readfirstlane(wave)] + (int) lanes_below(__ballot((meta & META_COM_LEADER) != 0));
+        if ((F & A_KE) && act && (meta & META_COM_LEADER)) seg_mw = ((const double2*) a.seg_mass)[segi];
         // Static per-lane masses (A_MTAB): m = RECIP(velm.w) and, for the members of a Drude pair, the mass fraction m / (m1 + m2), both
         // formed ONCE by vv_kernel_mass_table with the very operations the stages below used to repeat every step (IEEE quotients of the
         // mode's `mixed` type), so every value is bit-identical to the per-step one; velm.w never changes during a run.
@@ -593,6 +603,12 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const int2* __restrict__ pre_
         auto mass_exact = [&]() -> mixed { return (F & A_MTAB) ? tab_m : P::RECIP(v.w); };
         auto mass_sum = [&]() -> mixed { return (F & A_MTAB) ? tab_m : P::RECIP_SUM(v.w); };
 
+#ifdef VV_EXP_A_LOADONLY     // probe: the loads of a tile and nothing else (what the memory system alone allows for this access pattern)
+        if (SF != 0) {
+            double t0 = ((double) v.x + (double) v.w + (double) ((fx ^ fy ^ fz) & 1) + seg_mw.x) * 1e-30;
+            k_atom += t0; continue;
+        }
+#endif
         real4 pq = {0, 0, 0, 0};
         const bool need_pos = ((F & (A_COS | A_BIAS | A_UNBIAS_ACC)) && !(F & A_CZ_LOAD)) || ((F & A_EF) && (meta & META_EFIELD));
         if (act && need_pos) pq = ((const real4*) a.posq)[atom];
@@ -797,12 +813,12 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const int2* __restrict__ pre_
                     }
                     const mixed Vx = Tx * Vw, Vy = Ty * Vw, Vz = Tz * Vw;        // V = P * RECIP(M), comVelm.w = RECIP(M)
                     const mixed4 cv = {Vx, Vy, Vz, Vw};
-                    ((mixed4*) a.comv)[(size_t) wave * 64 + first] = cv;         // the reference's comVelm[id_mol], handed to kernel B
+                    ((mixed4*) a.comv)[segi] = cv;                                // the reference's comVelm[id_mol], handed to kernel B
                     const bool counts = Vw != 0 && (!(meta & META_BIGMOL) || (meta & META_BIG_FIRST));
                     if (counts) k_com += (double) ((Vx * Vx + Vy * Vy + Vz * Vz) * Vm);
                     if (F & A_KE_MOM) {
                         const mixed Wx = Tw * Vw;                                // mass-weighted mean of cos(kz) over the molecule
-                        a.comw[(size_t) wave * 64 + first] = (double) Wx;
+                        a.comw[segi] = (double) Wx;
                         if (counts) { m_ab[1] += (double) (Vx * Wx * Vm); m_bb[1] += (double) (Wx * Wx * Vm); }
                     }
                 }
@@ -1199,6 +1215,9 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const int2* __restrict__ pre_
         // cos(2 pi z / Lz) of this lane, cached by kernel A (A_CZ_STORE): requested with the particle data
         double cz_early = 0;
         if ((F & B_CZ_LOAD) && valid) cz_early = a.cosz[(size_t) wave * 64 + lane];
+#ifdef VV_EXP_B_LOADSTORE
+        const mixed4 v_in = v;
+#endif
         if ((F & B_KICK) && act && (meta & META_MASSIVE)) {
             const long long fx = a.force[atom], fy = a.force[atom + a.padded], fz = a.force[atom + 2 * a.padded];
             real3 fe = {0, 0, 0};
@@ -1216,10 +1235,12 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const int2* __restrict__ pre_
         mixed Vx = 0, Vy = 0, Vz = 0, Vw = 0, com_w = 0;
         // COM velocity of this lane's molecule as kernel A's KE stage left it (of the bias-free velocities when a bias is
         // removed): one 32-byte entry per molecule, the same address for every lane of the segment
+        const unsigned long long leaders = (F & B_SCALE) ? __ballot((meta & META_COM_LEADER) != 0) : 0ull;     // in every lane: a wave-wide vote
         if ((F & B_SCALE) && nh && use_com) {
-            const mixed4 cv = ((const mixed4*) a.comv)[(size_t) wave * 64 + ((meta >> META_SEGFIRST_SHIFT) & 63)];
+            const int segi = a.seg_base[__builtin_amdgcn_readfirstlane(wave)] + (int) lanes_below(leaders);
+            const mixed4 cv = ((const mixed4*) a.comv)[segi];
             Vx = cv.x; Vy = cv.y; Vz = cv.z; Vw = cv.w;
-            if (F & B_KE_MOM) com_w = (mixed) a.comw[(size_t) wave * 64 + ((meta >> META_SEGFIRST_SHIFT) & 63)];
+            if (F & B_KE_MOM) com_w = (mixed) a.comw[segi];
         }
 
         // Factor-independent half of the scaling: velocities relative to the molecular COM, the Drude partner's over the shuffle
@@ -1256,6 +1277,22 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const int2* __restrict__ pre_
                 rx = a2x - a1x; ry = a2y - a1y; rz = a2z - a1z;
             }
         };
+#ifdef VV_EXP_B_LOADSTORE    // probe: the loads and stores of a tile and nothing else
+        if (SF != 0) {
+            if (need_scales) { need_scales = false; if (has_cw) __syncthreads(); if (!valid) break; }
+            mixed4 vo = v_in;
+            vo.x += (tab_f + Vx + Vw + v.x + v.y + v.z) * (mixed) 0.0;
+#ifndef VV_EXP_B_NOSTORE
+            if (act) store_vec(velm, atom, vo, false);
+#endif
+#ifndef VV_EXP_B_NOSTORE
+            if (act) IO::store(a.posq, a.corr, atom, x, y, z, q, false);
+#else
+            if (act && vo.x + x + y + z == (mixed) 1e300) store_vec(velm, atom, vo, false);
+#endif
+            continue;
+        }
+#endif
         const bool prep_early = (F & B_SCALE) && !(F & (B_UNBIAS | B_BIAS_REMOVE));
         VV_STAMP(wib, 1);
         if (prep_early) scale_prep();

@@ -129,7 +129,7 @@ struct KArgs {
     void* posq;
     void* corr;
     const long long* force;
-    void* comv;                    // mixed4 [64*nwaves]: COM velocity of the segment starting at that lane, written by A_KE, read by B_SCALE
+    void* comv;                    // mixed4 [num segments]: COM velocity of each COM segment (dense index, see seg_base), written by A_KE, read by B_SCALE
     unsigned long long* acc;        // accumulators of the current parity (A adds, B consumes)
     const NHDevState* nh;           // thermostat state of the current parity
     const ChainLaneBlock* lane_const;   // [VVHIP_NUM_TG] chain constants, one row per group, in device memory (kernel B's thermostat wave)
@@ -147,8 +147,9 @@ struct KArgs {
     void* pos_delta;
     void* old_delta;
     double* cosz;                  // [64*nwaves] per-lane cos(2 pi z / Lz) cache of the current step
-    const double* seg_mass;        // [2*64*nwaves] (mass, 1/mass) of the COM segment starting at that lane (static; vv_host.hpp)
-    double* comw;                  // [64*nwaves] mass-weighted mean of cos(kz) over the same segment (A_KE_MOM -> B_KE_MOM)
+    const double* seg_mass;        // [2*num segments] (mass, 1/mass) of each COM segment (static; vv_host.hpp)
+    const int* seg_base;           // [nwaves+1] segments in the waves before this one: segment index of a lane = seg_base[wave] + leader lanes below it
+    double* comw;                  // [num segments] mass-weighted mean of cos(kz) over the same segment (A_KE_MOM -> B_KE_MOM)
     const double* slot_m;           // [64*nwaves] RECIP(velm.w) of the lane's particle in the mode's `mixed` type, widened (0 = massless / idle)
     const double* slot_f;           // [64*nwaves] Drude-pair lanes: invTotalMass * own mass (K/drudeNoseHoover.cu:173-180), else 0
     const int32_t* slot_image;
