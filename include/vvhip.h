@@ -123,7 +123,8 @@ typedef struct {
     int32_t num_shake_clusters;                  /* hydrogen-type constraint clusters solved in-kernel (SHAKE; 0 if none / not possible) */
     int32_t constraints_fused;                   /* 1: no constraints, or all of them are handled in-kernel => fused steps are valid */
     int32_t num_settle_clusters;                 /* rigid three-site molecules solved in-kernel (SETTLE) */
-    int32_t reserved_;
+    int32_t periodic_layout;                     /* 1: the work-item layout is arithmetic (runs of identical molecules): the fused kernels compute
+                                                    particle indices instead of loading them (vv_host.hpp: PeriodicLayout) */
 } vvhip_plan_info;
 
 /* Nose-Hoover chain state + last reduction results (HOST: CudaVVKernels.h:206-215).  The reference

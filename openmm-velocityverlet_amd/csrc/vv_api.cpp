@@ -86,6 +86,9 @@ struct vvhip_plan {
     bool fextra_external = false;  // the host asked for the pointer (vvhip_force_extra) and may write to it: never assume zeros
     bool no_moments = false;       // VVHIP_NO_MOMENTS=1: keep the three-launch cos sequence (comparison runs)
     bool wt_stores = false;        // write-through stores in the fused kernels (VVHIP_WT=1; tuning experiment)
+    // with an arithmetic work-item layout (HostPlan::per) kernel B computes particle indices instead of loading slot words (VVHIP_PERIODIC_K=0: comparison runs);
+    // kernel A has the same path (VVHIP_PERIODIC_A=1) but does not gain from it: 113.6 vs 115.7 us at 8.9 M particles
+    bool periodic_kernels = true, periodic_a = false;
     bool rekick = true;            // fused middle step: kick repeated in kernel B instead of a velm store in kernel A (use_rekick)
     // plan-owned device state
     int2* d_slots = nullptr;
@@ -315,6 +318,7 @@ vv::KArgs make_args(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
     a.acc_rows = p->hp.params.cos_acceleration != 0 ? vv::NUM_ACC : 4;
     a.flags = flags;
     a.random_index = random_index;
+    a.per = vv::periodic_args(p->hp.per);
     a.dt = q.step_size;
     // the same IEEE quotients the kernels used to form per lane: (mixed) 1 / (mixed) dt and 1.0 / (mixed) dt
     a.inv_dt_mixed = p->hp.precision == VVHIP_SINGLE ? (double) (1.0f / (float) q.step_size) : 1.0 / q.step_size;
@@ -422,6 +426,7 @@ int ensure_mass_table(vvhip_plan* p) {
 }
 int run_a(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
     if (p->mass_tab_a) { flags |= vv::A_MTAB; TRY(ensure_mass_table(p)); }
+    if (p->hp.per.enabled && p->periodic_kernels && p->periodic_a) flags |= vv::A_PERIODIC;
     if (p->wt_stores && (flags & (vv::A_KICK_FULL | vv::A_KICK_HALF))) flags |= vv::A_WT_STORES;
     ScopedTimer t(p, T_A);
     HIP_TRY(p, vv::launch_a(p->hp.precision, make_args(p, flags, random_index), p->block_threads, p->grid_cap_a, p->stream));
@@ -429,6 +434,8 @@ int run_a(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
 }
 int run_b(vvhip_plan* p, uint32_t flags) {
     if (p->mass_tab_b) { flags |= vv::B_MTAB; TRY(ensure_mass_table(p)); }
+    // (not next to the mailbox exchange: that combination timed out when two ranks shared one GPU, the only multi-rank set-up at hand)
+    if (p->hp.per.enabled && p->periodic_kernels && !(flags & vv::B_MAILBOX)) flags |= vv::B_PERIODIC;
     if (p->wt_stores) flags |= vv::B_WT_STORES;
     ScopedTimer t(p, T_B);
     HIP_TRY(p, vv::launch_b(p->hp.precision, make_args(p, flags, 0), p->block_threads, p->grid_cap_b, p->stream));
@@ -523,6 +530,8 @@ int vvhip_plan_create(const vvhip_system_desc* system, const vvhip_params* param
         if (const char* e = std::getenv("VVHIP_WT")) p->wt_stores = std::atoi(e) != 0;
         if (const char* e = std::getenv("VVHIP_NO_MOMENTS")) p->no_moments = std::atoi(e) != 0;
         if (const char* e = std::getenv("VVHIP_REKICK")) p->rekick = std::atoi(e) != 0;
+        if (const char* e = std::getenv("VVHIP_PERIODIC_K")) p->periodic_kernels = std::atoi(e) != 0;
+        if (const char* e = std::getenv("VVHIP_PERIODIC_A")) p->periodic_a = std::atoi(e) != 0;
         p->mass_tab_a = vv::sf_kernels_use_mass_table(0);
         p->mass_tab_b = vv::sf_kernels_use_mass_table(1);
         if (const char* e = std::getenv("VVHIP_MTAB_A")) p->mass_tab_a = std::atoi(e) != 0;

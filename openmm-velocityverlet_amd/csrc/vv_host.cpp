@@ -377,11 +377,128 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
     }
     info.max_cluster = max_cluster;
 
+    // ---- periodic layout: runs of identical repeat units, possibly repeated cell after cell (vv_host.hpp: PeriodicLayout)
+    struct Region { uint64_t sig; int p, reps, atoms, segs; };      // unit of p clusters repeated reps times
+    std::vector<Region> regions;
+    std::vector<int32_t> unit_offsets;                               // lane offset of each cluster inside its unit (per region of cell 0 .. R-1, flattened)
+    PeriodicLayout per;
+    int per_R = 0, per_clusters_per_cell = 0;
+    std::vector<int> reg_cluster_start;                              // first cluster (cell-local) of region r
+    auto try_periodic = [&]() -> bool {
+        // Measured on MI355X (same box, alternating runs): with 8.9 M particles kernel B 305 -> 277 us, with 0.9 M 27.9 -> 26.7 us; with
+        // 111 k particles the block's copy of the pattern rows and its barrier cost more than the slot load did (kernel B 6.0 -> 6.4 us)
+        // and best-fit packing needs 13 % fewer waves.  So: large systems only, unless VVHIP_PERIODIC=1 / 0 says always / never.
+        size_t lanes = 0;
+        for (const Cluster& c : clusters) lanes += c.members.size();
+        bool want = lanes >= 640000;
+        if (const char* e = std::getenv("VVHIP_PERIODIC")) want = std::atoi(e) != 0;
+        if (!want) return false;
+        if (hp.has_ld || hp.has_images || hp.num_big > 0 || !shakes.empty() || clusters.empty()) return false;
+        const size_t K = clusters.size();
+        std::vector<uint64_t> sig(K);
+        int expect = sb;
+        for (size_t k = 0; k < K; k++) {
+            const Cluster& c = clusters[k];
+            if (c.first != expect || c.members.size() > 64) return false;                 // particles must be consecutive, cluster after cluster
+            uint64_t h = 1469598103934665603ull;
+            auto mix = [&](uint64_t v) { for (int b = 0; b < 8; b++) { h ^= (v >> (8 * b)) & 0xff; h *= 1099511628211ull; } };
+            mix(c.members.size()); mix(c.com_segment ? 1 : 0);
+            for (size_t j = 0; j < c.members.size(); j++) {
+                const int i = c.members[j];
+                if (i != c.first + (int) j) return false;
+                uint64_t mb; std::memcpy(&mb, &sys.masses[i], 8);
+                mix(mb);
+                mix((uint64_t) (is_nh[i] ? 1 : 0) | (in_pair[i] ? 2 : 0) | (is_drude[i] ? 4 : 0) | (is_el[i] ? 8 : 0));
+                mix(in_pair[i] ? (uint64_t) (int64_t) (partner[i] - c.first) : 0);
+            }
+            sig[k] = h;
+            expect += (int) c.members.size();
+        }
+        if (expect != se) return false;
+        // greedy decomposition into regions: at each position the unit length (clusters adding up to <= 64 lanes) that covers the most clusters
+        regions.clear();
+        for (size_t i = 0; i < K;) {
+            int best_p = 1, best_reps = 1;
+            size_t best_cover = 0;
+            for (int pp = 1; pp <= 64 && i + pp <= K; pp++) {
+                int atoms = 0;
+                for (int j = 0; j < pp; j++) atoms += (int) clusters[i + j].members.size();
+                if (atoms > 64) break;
+                size_t j = i + pp;
+                while (j < K && sig[j] == sig[j - pp]) j++;
+                const int reps = (int) ((j - i) / pp);
+                if ((size_t) reps * pp > best_cover) { best_cover = (size_t) reps * pp; best_p = pp; best_reps = reps; }
+            }
+            Region r{0, best_p, best_reps, 0, 0};
+            uint64_t h = 1469598103934665603ull;
+            for (int j = 0; j < best_p; j++) {
+                h = (h ^ sig[i + j]) * 1099511628211ull;
+                r.atoms += (int) clusters[i + j].members.size();
+                r.segs += clusters[i + j].com_segment ? 1 : 0;
+            }
+            r.sig = h;
+            regions.push_back(r);
+            i += (size_t) best_p * best_reps;
+            if (regions.size() > 4096) return false;
+        }
+        // period of the region list
+        const int L = (int) regions.size();
+        int R = 0;
+        for (int cand = 1; cand <= 4 && cand <= L && !R; cand++) {
+            if (L % cand) continue;
+            bool ok = true;
+            for (int i = cand; i < L && ok; i++)
+                ok = regions[i].sig == regions[i - cand].sig && regions[i].p == regions[i - cand].p && regions[i].reps == regions[i - cand].reps;
+            if (ok) R = cand;
+        }
+        if (!R) return false;
+        per = PeriodicLayout{};
+        per.nreg = R;
+        per.ncells = L / R;
+        reg_cluster_start.assign(R + 1, 0);
+        unit_offsets.clear();
+        int w = 0, at = 0, sg = 0, cl = 0;
+        for (int r = 0; r < R; r++) {
+            const Region& g = regions[r];
+            const int m = 64 / g.atoms;
+            per.reg_wave_start[r] = w; per.reg_atom_start[r] = at; per.reg_seg_start[r] = sg;
+            per.reg_P[r] = m * g.atoms; per.reg_spw[r] = m * g.segs;
+            reg_cluster_start[r] = cl;
+            w += (g.reps + m - 1) / m; at += g.atoms * g.reps; sg += g.segs * g.reps; cl += g.p * g.reps;
+            per.reg_atom_end[r] = at;
+        }
+        reg_cluster_start[R] = cl;
+        per.wpc = w; per.apc = at; per.spc = sg;
+        per_R = R; per_clusters_per_cell = cl;
+        const long total_waves = (long) per.wpc * per.ncells;
+        if (total_waves > (1l << 26)) return false;
+        per.magic = per.ncells > 1 ? (uint32_t) ((1ull << 32) / (uint64_t) per.wpc + 1) : 0u;
+        return true;
+    };
+    // (wave, first lane) of cluster k under the periodic layout
+    auto periodic_place = [&](size_t k, int& wave_out, int& lane_out) {
+        const int cell = (int) (k / (size_t) per_clusters_per_cell), kl = (int) (k % (size_t) per_clusters_per_cell);
+        int r = 0;
+        while (r + 1 < per_R && kl >= reg_cluster_start[r + 1]) r++;
+        const Region& g = regions[r];
+        const int ku = kl - reg_cluster_start[r], unit = ku / g.p, j = ku % g.p, m = 64 / g.atoms;
+        int off = 0;
+        for (int t = 0; t < j; t++) off += (int) clusters[k - j + t].members.size();
+        wave_out = cell * per.wpc + per.reg_wave_start[r] + unit / m;
+        lane_out = (unit % m) * g.atoms + off;
+    };
+
     // ---- wave packing: clusters are visited in particle order and placed best-fit -- into the open wave whose free lanes
     // they fill most tightly, else into a new wave.  Visiting in order keeps neighbouring molecules in neighbouring waves
     // (coalescing, L2 locality); best-fit lets e.g. a 10-particle anion complete a wave that two 27-particle cations left at 54
-    // lanes (C3: 87 % -> 99 % lane use, 13 % fewer waves).  O(64) per cluster via free-lane buckets.
+    // lanes (C3: 87 % -> 99 % lane use, 13 % fewer waves).  O(64) per cluster via free-lane buckets.  With a periodic layout the
+    // position of every cluster is given by the formula instead.
     std::vector<int32_t>& slots = hp.slots;
+    std::vector<int32_t> lane_of, wave_of;
+    int nwaves = 0;
+    auto fill_slots = [&](bool periodic) {
+    slots.clear();
+    hp.seg_mass.clear();
     int lane = 0, wave = -1, num_waves_alloc = 0;
     std::vector<int32_t> fill;                          // lanes used per wave
     std::vector<std::vector<int32_t> > open_by_free(65);  // waves with exactly f free lanes (stacks)
@@ -392,7 +509,8 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
         for (int l = 0; l < 64; l++) { slots[(size_t) w * 128 + 2 * l] = -1; slots[(size_t) w * 128 + 2 * l + 1] = 0; }
         return w;
     };
-    std::vector<int32_t> lane_of(n, -1), wave_of(n, -1);
+    lane_of.assign(n, -1); wave_of.assign(n, -1);
+    if (periodic) for (long w = 0; w < (long) per.wpc * per.ncells; w++) new_wave();
     int used = 0;
     // Measured on MI355X: best-fit wins while the working set is cache resident (111 k particles: +3 %, 0.9 M: +4 %) and loses
     // once the kernels are HBM bound (8.9 M: -5 %, segments from distant index ranges cost partial cache lines), so very large
@@ -401,20 +519,25 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
     for (const Cluster& c : clusters) total_lanes += c.members.size();
     const bool best_fit = total_lanes < ((size_t) 1 << 20);
     int last_wave = -1;
+    size_t cluster_index = 0;
     for (const Cluster& c : clusters) {
         const int sz = (int) c.members.size();
         wave = -1;
-        if (best_fit) {
+        if (periodic) {
+            periodic_place(cluster_index, wave, lane);
+            fill[wave] = lane;
+        } else if (best_fit) {
             for (int f = sz; f <= 63 && wave < 0; f++)
                 if (!open_by_free[f].empty()) { wave = open_by_free[f].back(); open_by_free[f].pop_back(); }
         } else if (last_wave >= 0 && fill[last_wave] + sz <= 64) {
             wave = last_wave;
         }
+        cluster_index++;
         if (wave < 0) wave = new_wave();
         last_wave = wave;
         lane = fill[wave];
         fill[wave] += sz;
-        if (best_fit && fill[wave] < 64) open_by_free[64 - fill[wave]].push_back(wave);
+        if (!periodic && best_fit && fill[wave] < 64) open_by_free[64 - fill[wave]].push_back(wave);
         const int first_lane = lane, last_lane = lane + sz - 1;
         for (int k = 0; k < sz; k++) { lane_of[c.members[k]] = lane + k; wave_of[c.members[k]] = wave; }
         if (c.com_segment) {
@@ -455,7 +578,7 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
         }
     }
     // partner lanes were only known for the earlier member of each pair: fix them up
-    const int nwaves = std::max(num_waves_alloc, 1);
+    nwaves = std::max(num_waves_alloc, 1);
     if (num_waves_alloc == 0) new_wave();
     for (int w = 0; w < nwaves; w++)
         for (int l = 0; l < 64; l++) {
@@ -494,6 +617,44 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
         if (dense.empty()) dense.assign(2, 0.0);
         hp.seg_mass.swap(dense);
     }
+
+    };   // fill_slots
+
+    // Does the formula reproduce the table?  Particle index, role word (against the pattern wave: the region's first wave of cell 0)
+    // and segment mass (against the pattern wave's segments) of every lane.
+    auto periodic_matches = [&]() -> bool {
+        if (nwaves != per.wpc * per.ncells) return false;
+        for (int w = 0; w < nwaves; w++) {
+            const int cell = per.ncells > 1 ? (int) (((uint64_t) (uint32_t) w * per.magic) >> 32) : 0;
+            if (cell != w / per.wpc) return false;
+            const int wl = w - cell * per.wpc;
+            int r = 0;
+            for (int k = 1; k < 4; k++) if (wl >= per.reg_wave_start[k]) r = k;
+            const int wr = wl - per.reg_wave_start[r], a0 = per.reg_atom_start[r] + wr * per.reg_P[r];
+            const int count = std::min(per.reg_P[r], per.reg_atom_end[r] - a0);
+            const int pw = per.reg_wave_start[r];
+            int ord = 0;
+            for (int l = 0; l < 64; l++) {
+                const int32_t at = slots[(size_t) w * 128 + 2 * l];
+                const uint32_t meta = (uint32_t) slots[(size_t) w * 128 + 2 * l + 1];
+                if (l >= count) { if (at >= 0) return false; continue; }
+                if (at != cell * per.apc + a0 + l) return false;
+                if (meta != (uint32_t) slots[(size_t) pw * 128 + 2 * l + 1]) return false;
+                if (meta & META_COM_LEADER) {
+                    const size_t here = (size_t) hp.seg_base[w] + ord, pat = (size_t) per.reg_seg_start[r] + ord;
+                    if ((int) here != cell * per.spc + per.reg_seg_start[r] + wr * per.reg_spw[r] + ord) return false;
+                    if (std::memcmp(&hp.seg_mass[2 * here], &hp.seg_mass[2 * pat], 16) != 0) return false;
+                    ord++;
+                }
+            }
+        }
+        return true;
+    };
+    bool periodic = try_periodic();
+    fill_slots(periodic);
+    if (periodic && !periodic_matches()) { periodic = false; fill_slots(false); }
+    if (periodic) { per.enabled = 1; hp.per = per; }
+    info.periodic_layout = periodic ? 1 : 0;
 
     if (hp.has_images) {
         hp.slot_image.assign((size_t) nwaves * 64, -1);

@@ -52,7 +52,25 @@ inline uint32_t meta_role(uint32_t m) { return m & META_ROLE_MASK; }
 
 struct ResolvedParams : vvhip_params {};
 
+// Arithmetic ("periodic") work-item layout.  Most systems are a few runs of identical molecules (250 cations, 250 anions, ...), often
+// repeated cell after cell.  Then the slot table is a pure function of the wave index: a wave of region r holds reg_P[r] consecutive
+// particles (whole repeat units), cell c of the system starts apc particles / wpc waves / spc COM segments after cell c - 1, and the
+// role words of every wave of a region equal those of the region's first wave in cell 0.  The kernels then compute the particle index
+// instead of loading it -- no dependent memory round trip in front of the particle loads, no 8 bytes per lane of index traffic -- and
+// read the role words of that one pattern wave.  analyze() only enables this when the formula reproduces the explicit slot table
+// (which is always built and stays the reference for every other kernel) lane for lane.
+struct PeriodicLayout {
+    int32_t enabled = 0, nreg = 0, ncells = 1;
+    int32_t apc = 0, wpc = 0, spc = 0;     // particles / waves / COM segments per cell
+    uint32_t magic = 0;                    // cell = umulhi(wave, magic) (= wave / wpc for every wave of the plan); 0 when ncells == 1
+    int32_t reg_wave_start[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};   // cell-local first wave of region r (unused: INT_MAX)
+    int32_t reg_atom_start[4] = {0, 0, 0, 0}, reg_atom_end[4] = {0, 0, 0, 0};       // cell-local particle range of region r
+    int32_t reg_seg_start[4] = {0, 0, 0, 0};                                        // cell-local first COM segment of region r
+    int32_t reg_P[4] = {0, 0, 0, 0}, reg_spw[4] = {0, 0, 0, 0};                     // particles / COM segments per full wave
+};
+
 struct HostPlan {
+    PeriodicLayout per;
     int precision = VVHIP_MIXED;
     vvhip_params params{};          // after the auto rules of API:106-121
     vvhip_plan_info info{};

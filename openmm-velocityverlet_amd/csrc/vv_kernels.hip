@@ -92,6 +92,32 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_fetch(float x) {
     return __int_as_float(dpp_fetch32<CTRL, ROW_MASK>(__float_as_int(x)));
 }
+
+// Arithmetic layout (vv_host.hpp: PeriodicLayout): everything a lane used to read from its slot words, from the wave index alone.
+struct PeriodicWave {
+    int atom0, count, region, seg0;
+};
+__device__ __forceinline__ PeriodicWave periodic_wave(const PeriodicArgs& q, int wave_uniform) {
+    const int w = __builtin_amdgcn_readfirstlane(wave_uniform);
+    const int cell = (int) __umulhi((unsigned) w, q.magic);                 // = w / wpc (checked for every wave by analyze()); 0 for one cell
+    const int wl = w - cell * q.wpc;
+    int ws = q.d_wave[0], as = q.d_atom_start[0], ae = q.d_atom_end[0], ss = q.d_seg[0], P = q.d_P[0], spw = q.d_spw[0], region = 0;
+#pragma unroll
+    for (int k = 1; k < 4; k++) {
+        const bool in = wl >= q.wave_start[k];
+        region += in ? 1 : 0;
+        ws += in ? q.d_wave[k] : 0; as += in ? q.d_atom_start[k] : 0; ae += in ? q.d_atom_end[k] : 0;
+        ss += in ? q.d_seg[k] : 0; P += in ? q.d_P[k] : 0; spw += in ? q.d_spw[k] : 0;
+    }
+    const int wr = wl - ws, a0 = as + wr * P;
+    PeriodicWave r;
+    r.atom0 = cell * q.apc + a0;
+    r.count = min(P, ae - a0);
+    r.region = region;
+    r.seg0 = cell * q.spc + ss + wr * spw;
+    return r;
+}
+
 // number of set bits of a 64-lane mask below the calling lane
 __device__ __forceinline__ unsigned lanes_below(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((unsigned) (mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) mask, 0u));
@@ -541,7 +567,8 @@ __shared__ long long vv_stamps[8][16];
 // (one of three dependent memory round trips of ~0.4 us each in front of a tile's arithmetic, profiles/r02a_timeline_*) leaves
 // the critical path; everything else in KArgs is fetched in the shadow of that first load.
 template <class real, class mixed, uint32_t SF>   // SF != 0: the stage bits are a compile-time constant (hot paths)
-__global__ void __launch_bounds__(512) vv_kernel_a(const int2* __restrict__ pre_slots, const int pre_nwaves, const int pre_wpb, const KArgs a) {
+__global__ void __launch_bounds__(512) vv_kernel_a(const int2* __restrict__ pre_slots, const int pre_nwaves, const int pre_wpb, void* pre_velm, const long long* __restrict__ pre_force,
+                                                   const int pre_padded, const KArgs a) {
     using real4 = typename Vec<real>::v4;
     using real3 = typename Vec<real>::v3;
     using mixed4 = typename Vec<mixed>::v4;
@@ -559,21 +586,57 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const int2* __restrict__ pre_
     VV_SPAN_BEGIN;
     // (Requesting the NEXT tile's slot words one tile ahead in this grid-stride loop was measured, same box, three alternating runs:
     // 8.9 M particles A 237.7 -> 236.1 us, B 264.1 -> 267.7 us; 111 k particles A 5.27 -> 5.47 us.  Not kept.)
+    // Periodic layout: the role words and segment masses of a region's waves are those of its pattern wave (the region's first wave of
+    // cell 0).  The block copies the rows of all (<= 4) regions into LDS once: thousands of waves re-reading the same few cache lines
+    // tile after tile queue up on the L2 channels that hold them (measured at 8.9 M particles: kernel A 110 -> 117 us).
+    __shared__ unsigned sh_pat_meta[4][64];
+    __shared__ double2 sh_pat_segm[4][64];
+    if (F & A_PERIODIC) {
+        for (int row = threadIdx.x >> 6; row < 4; row += pre_wpb) {
+            const int ws = a.per.wave_start[row];
+            unsigned m = 0;
+            if (ws != 0x7fffffff) m = (unsigned) pre_slots[(size_t) ws * 64 + lane].y;
+            sh_pat_meta[row][lane] = m;
+            int ss = a.per.d_seg[0];
+#pragma unroll
+            for (int k = 1; k < 4; k++) ss += k <= row ? a.per.d_seg[k] : 0;
+            const int below = (int) lanes_below(__ballot((m & META_COM_LEADER) != 0));
+            double2 sm = {0, 0};
+            if ((F & A_KE) && (m & META_COM_LEADER)) sm = ((const double2*) a.seg_mass)[ss + below];
+            sh_pat_segm[row][lane] = sm;
+        }
+        __syncthreads();
+    }
     for (int wave = blockIdx.x * pre_wpb + (threadIdx.x >> 6); wave < pre_nwaves; wave += gridDim.x * pre_wpb) {
-        const int2 slot = pre_slots[(size_t) wave * 64 + lane];
-        const int atom = slot.x;
-        const unsigned meta = (unsigned) slot.y;
+        int atom;
+        unsigned meta;
+        PeriodicWave pw = {0, 0, 0, 0};
+        mixed4* velm = (mixed4*) a.velm;
+        mixed4 v = {0, 0, 0, 0};
+        long long fx = 0, fy = 0, fz = 0;
+        if (F & A_PERIODIC) {
+            // the particle index is arithmetic: velocity and force are requested at once, no slot word in front of them
+            pw = periodic_wave(a.per, wave);
+            const bool in = lane < pw.count;
+            atom = in ? pw.atom0 + lane : -1;
+            if (in) v = ((const mixed4*) pre_velm)[atom];
+            if ((F & (A_KICK_FULL | A_KICK_HALF)) && in) { fx = pre_force[atom]; fy = pre_force[atom + pre_padded]; fz = pre_force[atom + 2 * pre_padded]; }
+            meta = in ? sh_pat_meta[pw.region][lane] : 0u;
+        } else {
+            const int2 slot = pre_slots[(size_t) wave * 64 + lane];
+            atom = slot.x;
+            meta = (unsigned) slot.y;
+        }
         const unsigned role = meta & META_ROLE_MASK;
         const int partner = (meta >> META_PARTNER_SHIFT) & 63;
         const bool act = atom >= 0;
-        mixed4* velm = (mixed4*) a.velm;
-        mixed4 v = {0, 0, 0, 0};
-        if (act) v = velm[atom];
-        // the forces are requested together with the velocity: waiting for velm.w to learn that the particle is massive would put a
-        // third dependent memory round trip in front of the kick (timeline: 0.6 us); the role word carries the same fact
-        long long fx = 0, fy = 0, fz = 0;
-        if ((F & (A_KICK_FULL | A_KICK_HALF)) && act && (meta & META_MASSIVE)) {
-            fx = a.force[atom]; fy = a.force[atom + a.padded]; fz = a.force[atom + 2 * a.padded];
+        if (!(F & A_PERIODIC)) {
+            if (act) v = velm[atom];
+            // the forces are requested together with the velocity: waiting for velm.w to learn that the particle is massive would put a
+            // third dependent memory round trip in front of the kick (timeline: 0.6 us); the role word carries the same fact
+            if ((F & (A_KICK_FULL | A_KICK_HALF)) && act && (meta & META_MASSIVE)) {
+                fx = a.force[atom]; fy = a.force[atom + a.padded]; fz = a.force[atom + 2 * a.padded];
+            }
         }
         // Langevin lanes: slot of the normal deviates and the deviates themselves, requested with the particle data (keyed by the role
         // word) instead of after velm.w has arrived
@@ -587,8 +650,11 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const int2* __restrict__ pre_
         // dense index of this lane's COM segment: segments are numbered wave by wave and, inside a wave, by the lane of their leader
         // (= last) lane, so every lane of a segment counts the same leaders below itself (vv_host.cpp: seg_base)
         int segi = 0;
-        if (F & A_KE) segi = a.seg_base[__builtin_amdgcn_readfirstlane(wave)] + (int) lanes_below(__ballot((meta & META_COM_LEADER) != 0));
-        if ((F & A_KE) && act && (meta & META_COM_LEADER)) seg_mw = ((const double2*) a.seg_mass)[segi];
+        if (F & A_KE) {
+            const int below = (int) lanes_below(__ballot((meta & META_COM_LEADER) != 0));
+            segi = ((F & A_PERIODIC) ? pw.seg0 : a.seg_base[__builtin_amdgcn_readfirstlane(wave)]) + below;
+            if (act && (meta & META_COM_LEADER)) seg_mw = (F & A_PERIODIC) ? sh_pat_segm[pw.region][lane] : ((const double2*) a.seg_mass)[segi];
+        }
         // Static per-lane masses (A_MTAB): m = RECIP(velm.w) and, for the members of a Drude pair, the mass fraction m / (m1 + m2), both
         // formed ONCE by vv_kernel_mass_table with the very operations the stages below used to repeat every step (IEEE quotients of the
         // mode's `mixed` type), so every value is bit-identical to the per-step one; velm.w never changes during a run.
@@ -1086,6 +1152,23 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const int2* __restrict__ pre_
     const int tiles_per_block = has_cw ? nwb - 1 : nwb;
     __shared__ double sh_scales[4];
     double sc0 = 1.0, sc1 = 1.0, sc2 = 1.0, scb = 0.0;
+    // Periodic layout: role words and pair mass fractions of the regions' pattern waves, copied into LDS once per block (kernel A)
+    __shared__ unsigned sh_pat_meta[4][64];
+    __shared__ double sh_pat_f[4][64];
+    if (F & B_PERIODIC) {
+        for (int row = threadIdx.x >> 6; row < 4; row += nwb) {
+            const int ws = a.per.wave_start[row];
+            unsigned m = 0;
+            double f = 0;
+            if (ws != 0x7fffffff) {
+                m = (unsigned) pre_slots[(size_t) ws * 64 + lane].y;
+                if ((F & B_MTAB) && (F & B_SCALE)) f = a.slot_f[(size_t) ws * 64 + lane];
+            }
+            sh_pat_meta[row][lane] = m;
+            sh_pat_f[row][lane] = f;
+        }
+        __syncthreads();
+    }
 
     // ---------------- thermostat wave: scale factors for the whole block, then done
     VV_SPAN_BEGIN;
@@ -1180,13 +1263,24 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const int2* __restrict__ pre_
         const bool valid = wave < pre_nwaves;
         int atom = -1;
         unsigned meta = 0;
-        if (valid) { const int2 slot = pre_slots[(size_t) wave * 64 + lane]; atom = slot.x; meta = (unsigned) slot.y; }
+        PeriodicWave pw = {0, 0, 0, 0};
+        mixed4* velm = (mixed4*) a.velm;
+        mixed4 v = {0, 0, 0, 0};
+        if (F & B_PERIODIC) {
+            if (valid) {          // (uniform) particle index from the wave index: the particle loads do not wait for a slot word
+                pw = periodic_wave(a.per, wave);
+                const bool in = lane < pw.count;
+                atom = in ? pw.atom0 + lane : -1;
+                if (in) v = velm[atom];
+                meta = in ? sh_pat_meta[pw.region][lane] : 0u;
+            }
+        } else if (valid) {
+            const int2 slot = pre_slots[(size_t) wave * 64 + lane]; atom = slot.x; meta = (unsigned) slot.y;
+        }
         const unsigned role = meta & META_ROLE_MASK;
         const int partner = (meta >> META_PARTNER_SHIFT) & 63;
         const bool act = atom >= 0;
-        mixed4* velm = (mixed4*) a.velm;
-        mixed4 v = {0, 0, 0, 0};
-        if (act) v = velm[atom];
+        if (!(F & B_PERIODIC) && act) v = velm[atom];
         const bool massive = act && v.w != 0;
         const mixed stepSize = (mixed) a.dt;
         const bool touches_pos = F & (B_DRIFT_MIDDLE | B_POS3 | B_VV_POS | B_VV_KICK | B_HARDWALL | B_IMAGE | B_UNBIAS | B_BIAS_REMOVE | B_BIAS_RESTORE);
@@ -1218,14 +1312,17 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const int2* __restrict__ pre_
 #ifdef VV_EXP_B_LOADSTORE
         const mixed4 v_in = v;
 #endif
-        if ((F & B_KICK) && act && (meta & META_MASSIVE)) {
+        // (periodic: the force loads must not wait for the role word; a massless particle's force is read and not used)
+        if ((F & B_KICK) && act && ((F & B_PERIODIC) || (meta & META_MASSIVE))) {
             const long long fx = a.force[atom], fy = a.force[atom + a.padded], fz = a.force[atom + 2 * a.padded];
             real3 fe = {0, 0, 0};
             if (F & B_UNBIAS) fe.x += (real) a.cos_accel * cz_early * P::RECIP(v.w);      // K/cosineAccelerate.cu:9, kernel A's A_COS term to the bit
             const mixed fscale = stepSize / (mixed) 0x100000000;
-            v.x += stepSize * v.w * fe.x + fscale * v.w * fx;
-            v.y += stepSize * v.w * fe.y + fscale * v.w * fy;
-            v.z += stepSize * v.w * fe.z + fscale * v.w * fz;
+            if (v.w != 0) {          // K/middle.cu:11: massive particles only
+                v.x += stepSize * v.w * fe.x + fscale * v.w * fx;
+                v.y += stepSize * v.w * fe.y + fscale * v.w * fy;
+                v.z += stepSize * v.w * fe.z + fscale * v.w * fz;
+            }
         }
         const mixed4 v_old = v;          // velocity after the kick, before the thermostat (Pos1 uses it)
         bool vel_dirty = (F & B_KICK) != 0, pos_dirty = false;
@@ -1237,7 +1334,7 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const int2* __restrict__ pre_
         // removed): one 32-byte entry per molecule, the same address for every lane of the segment
         const unsigned long long leaders = (F & B_SCALE) ? __ballot((meta & META_COM_LEADER) != 0) : 0ull;     // in every lane: a wave-wide vote
         if ((F & B_SCALE) && nh && use_com) {
-            const int segi = a.seg_base[__builtin_amdgcn_readfirstlane(wave)] + (int) lanes_below(leaders);
+            const int segi = ((F & B_PERIODIC) ? pw.seg0 : a.seg_base[__builtin_amdgcn_readfirstlane(wave)]) + (int) lanes_below(leaders);
             const mixed4 cv = ((const mixed4*) a.comv)[segi];
             Vx = cv.x; Vy = cv.y; Vz = cv.z; Vw = cv.w;
             if (F & B_KE_MOM) com_w = (mixed) a.comw[segi];
@@ -1251,7 +1348,7 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const int2* __restrict__ pre_
         // on the same inverse masses, so they are the per-step values bit for bit): one 8-byte load per pair lane, requested with the
         // particle data, instead of two IEEE fp64 divisions per lane and step
         mixed tab_f = 0;
-        if ((F & B_MTAB) && (F & B_SCALE) && act && (role == ROLE_NH_DRUDE || role == ROLE_NH_PARENT)) tab_f = (mixed) a.slot_f[(size_t) wave * 64 + lane];
+        if ((F & B_MTAB) && (F & B_SCALE) && act && (role == ROLE_NH_DRUDE || role == ROLE_NH_PARENT)) tab_f = (F & B_PERIODIC) ? (mixed) sh_pat_f[pw.region][lane] : (mixed) a.slot_f[(size_t) wave * 64 + lane];
         auto scale_prep = [&]() {
             ux = v.x; uy = v.y; uz = v.z;
             if (nh) { ux -= Vx; uy -= Vy; uz -= Vz; }
@@ -1725,6 +1822,13 @@ constexpr uint32_t SF_B_MIDDLE_MB_K = SF_B_MIDDLE_MB | B_KICK;
 constexpr uint32_t SF_A_COS_MOM_NS = SF_A_COS_MOM | A_NOSTORE;                         // ... and with the cos perturbation (BASELINE C4)
 constexpr uint32_t SF_B_COS_HW_MOM_K = SF_B_COS_HW_MOM | B_KICK;
 constexpr uint32_t SF_B_COS_HW_MOM_MB_K = SF_B_COS_HW_MOM_MB | B_KICK;
+// ... with the arithmetic work-item layout (runs of identical molecules: every BASELINE bulk configuration)
+constexpr uint32_t SF_A_MIDDLE_NS_P = SF_A_MIDDLE_NS | A_PERIODIC;
+constexpr uint32_t SF_A_COS_MOM_NS_P = SF_A_COS_MOM_NS | A_PERIODIC;
+constexpr uint32_t SF_B_MIDDLE_HW_K_P = SF_B_MIDDLE_HW_K | B_PERIODIC;
+constexpr uint32_t SF_B_MIDDLE_K_P = SF_B_MIDDLE_K | B_PERIODIC;
+constexpr uint32_t SF_B_MIDDLE_HW_NC_K_P = SF_B_MIDDLE_HW_NC_K | B_PERIODIC;
+constexpr uint32_t SF_B_COS_HW_MOM_K_P = SF_B_COS_HW_MOM_K | B_PERIODIC;
 
 // Which specialised kernels are compiled with the static mass tables; a launch whose flags disagree with the build falls through to
 // the generic kernel.  Measured on MI355X (gpurun_out/r02c-e): kernel B gains at every size (two IEEE fp64 divisions per pair lane
@@ -1747,7 +1851,9 @@ hipError_t launch_a(int precision, const KArgs& a, int block_threads, int grid_c
     vv_last_grid_value = g.x;
     const dim3 b(block_threads);
     constexpr uint32_t XM = SF_AM;
-#define VV_PRE_ARGS a.slots, a.nwaves, (int) (b.x >> 6)
+#define VV_PRE_ARGS a.slots, a.nwaves, (int) (b.x >> 6), a.velm, a.force, a.padded
+    VV_TRY_SF(vv_kernel_a, SF_A_MIDDLE_NS_P)
+    VV_TRY_SF(vv_kernel_a, SF_A_COS_MOM_NS_P)
     VV_TRY_SF(vv_kernel_a, SF_A_MIDDLE_NS)
     VV_TRY_SF(vv_kernel_a, SF_A_COS_MOM_NS)
     VV_TRY_SF(vv_kernel_a, SF_A_MIDDLE)
@@ -1785,6 +1891,10 @@ hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_c
         VV_DISPATCH_SF(vv_kernel_b, 0u, g, b, 0, s, VV_PRE_ARGS, a);
         return hipGetLastError();
     }
+    VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_HW_K_P)
+    VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_K_P)
+    VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_HW_NC_K_P)
+    VV_TRY_SF(vv_kernel_b, SF_B_COS_HW_MOM_K_P)
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_HW_K)
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_K)
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_HW_NC_K)

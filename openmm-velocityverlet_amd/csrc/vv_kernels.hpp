@@ -6,6 +6,7 @@
 #include <cstdint>
 
 #include "../../include/vvhip.h"
+#include "vv_host.hpp"
 
 namespace vv {
 
@@ -31,6 +32,8 @@ enum : uint32_t {
                              // (accumulators 0-2, 4-6, 7-9); kernel B combines them once V is known: 2KE = Saa - 2 V Sab + V^2 Sbb
     A_MTAB = 1u << 18,       // own mass and Drude-pair mass fraction from the static per-lane tables (slot_m, slot_f) instead of
                              // reciprocals / IEEE divisions of velm.w in every step
+    A_PERIODIC = 1u << 20,   // particle index, activity and segment index of a lane from the wave index (KArgs::per), role word from the pattern wave:
+                             // no slot load in front of the particle loads (vv_host.hpp: PeriodicLayout)
     A_NOSTORE = 1u << 19,    // the kicked velocities stay in registers (KE stage) and are NOT written back: kernel B repeats the kick
                              // itself (B_KICK) from velm + force -- 24 bytes of force read there instead of 32 bytes written here and
                              // 3.5 MB less dirty data behind this launch at the headline size (the kernel boundary waits for it)
@@ -57,6 +60,7 @@ enum : uint32_t {
     B_KE_MOM = 1u << 15,      // the accumulators hold moments (A_KE_MOM): combine them with V, unbias the stored COM velocities with comw
     B_KICK = 1u << 17,        // v += dt*invM*Fe + dt/2^32*invM*F (K/middle.cu:6-23) on the freshly loaded velocities: partner of A_NOSTORE, the
                               // very expression kernel A evaluated (same operands, same order: same bits); Fe = the cos force with B_UNBIAS
+    B_PERIODIC = 1u << 18,    // as A_PERIODIC
     B_MTAB = 1u << 16,        // Drude-pair mass fractions from the static per-lane table (slot_f) instead of two IEEE divisions per lane
     B_WT_STORES = 1u << 27,   // write-through (sc1) stores for the particle arrays: the dirty lines leave L2 during the kernel, not at its end
     B_DBG_NOFOLD = 1u << 28,  // timing experiments only: skip the accumulator fold / the chain arithmetic
@@ -120,6 +124,29 @@ struct ChainLaneBlock {
     double dt2, dt4, dt8, pad_;
 };
 
+// PeriodicLayout as the kernels take it: per quantity the value of region 0 and the INCREMENTS from region to region, so that the
+// value of a wave's region is base + sum of the increments of the region starts at or below the wave -- selects between a loaded
+// scalar and zero.  (Selecting among the array elements themselves makes the compiler index the argument block dynamically, which
+// it can only do through scratch memory: measured, kernel A 4.2 -> 5.7 us.)
+struct PeriodicArgs {
+    uint32_t magic;
+    int32_t wpc, apc, spc;
+    int32_t wave_start[4];                                    // absolute (cell-local); unused regions: INT_MAX
+    int32_t d_wave[4], d_atom_start[4], d_atom_end[4], d_seg[4], d_P[4], d_spw[4];
+};
+inline PeriodicArgs periodic_args(const PeriodicLayout& q) {
+    PeriodicArgs r{};
+    r.magic = q.magic; r.wpc = q.wpc; r.apc = q.apc; r.spc = q.spc;
+    for (int k = 0; k < 4; k++) {
+        const bool used = k < q.nreg;
+        r.wave_start[k] = used ? q.reg_wave_start[k] : 0x7fffffff;
+        auto inc = [&](const int32_t* v) { return !used ? 0 : (k == 0 ? v[0] : v[k] - v[k - 1]); };
+        r.d_wave[k] = inc(q.reg_wave_start); r.d_atom_start[k] = inc(q.reg_atom_start); r.d_atom_end[k] = inc(q.reg_atom_end);
+        r.d_seg[k] = inc(q.reg_seg_start); r.d_P[k] = inc(q.reg_P); r.d_spw[k] = inc(q.reg_spw);
+    }
+    return r;
+}
+
 // One argument block for kernels A and B (passed by value); pointer types are erased so that the
 // same struct serves the three precision modes.
 struct KArgs {
@@ -137,6 +164,7 @@ struct KArgs {
     int32_t nwaves;
     uint32_t flags;
     uint32_t random_index;
+    PeriodicArgs per;          // arithmetic work-item layout (A_PERIODIC / B_PERIODIC; vv_host.hpp: PeriodicLayout)
     double dt;                 // step size
     double inv_dt_mixed;       // 1 / dt evaluated in the mode's `mixed` type on the host (K/middle.cu:71), widened
     double inv_dt_double;      // 1.0 / dt in double (K/velocityVerlet.cu:43)

@@ -1,0 +1,76 @@
+"""-m gpu: the arithmetic ("periodic") work-item layout -- particle indices computed from the wave index, role words from the pattern wave
+(vv_host.hpp: PeriodicLayout) -- forced on small systems (it is automatic from ~0.64 M particles) and compared with the oracle like
+every other path, in kernel B alone (the default where the layout is on) and in both kernels; plus bit-equality of the trajectory with
+the explicit-slot kernels on the same layout, which is what the change must preserve."""
+import importlib
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pkg = importlib.import_module("openmm-velocityverlet_amd")
+H, I, systems = pkg.vvhip, pkg.integrator, pkg.systems
+pytestmark = pytest.mark.gpu
+
+
+def _run(spec, prec, nsteps, env, monkeypatch, cos=0.0, maxd=0.02, T=333.0, dt=0.001, graph=False):
+    for k in ("VVHIP_PERIODIC", "VVHIP_PERIODIC_K", "VVHIP_PERIODIC_A"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    it = I.VVIntegrator(T, 10.0, 1.0, 40.0, dt)
+    it.setMaxDrudeDistance(maxd)
+    it.setCosAcceleration(cos)
+    ctx = I.Context(spec, it, precision=prec, force_provider="tether")
+    try:
+        if graph:
+            ctx.run_graph(nsteps, nsteps)
+        else:
+            it.step(nsteps)
+        return ctx.info.periodic_layout, ctx.getVelm(), ctx.getPosq(), ctx.getPosqCorrection(), np.array(list(ctx.getNHState().ke2))
+    finally:
+        ctx.close()
+
+
+SYSTEMS = {
+    "bulk": lambda: (systems.drude_il(cells=(1, 1, 1), pairs_per_cell=70, seed=7), dict(maxd=0.02)),               # 70 cations, 70 anions: partial last waves
+    "bulk_cells": lambda: (systems.make_config("C3", scale=0.25), dict(maxd=0.02)),                                # cells of the reference topology
+    "water": lambda: (systems.spce_water(500, seed=5), dict(maxd=0.0, T=300.0, dt=0.002)),
+    "nondrude": lambda: (systems.nondrude_il(num_pairs=40, seed=3), dict(maxd=0.0)),
+}
+
+
+@pytest.mark.parametrize("prec", ["mixed", "double", "single"])
+@pytest.mark.parametrize("cos", [0.0, 0.02])
+@pytest.mark.parametrize("name", sorted(SYSTEMS))
+def test_periodic_kernels_equal_explicit_kernels_and_oracle(name, cos, prec, monkeypatch):
+    spec, kw = SYSTEMS[name]()
+    nsteps = 2 if prec == "single" else 12
+    flag, v_b, p_b, c_b, ke_b = _run(spec, prec, nsteps, {"VVHIP_PERIODIC": "1"}, monkeypatch, cos=cos, **kw)                                   # kernel B periodic
+    assert flag == 1, "layout not recognised as periodic"
+    _, v_ab, p_ab, c_ab, ke_ab = _run(spec, prec, nsteps, {"VVHIP_PERIODIC": "1", "VVHIP_PERIODIC_A": "1"}, monkeypatch, cos=cos, **kw)       # both kernels
+    _, v_e, p_e, c_e, ke_e = _run(spec, prec, nsteps, {"VVHIP_PERIODIC": "1", "VVHIP_PERIODIC_K": "0"}, monkeypatch, cos=cos, **kw)           # same layout, slot words loaded
+    flag0, v_0, p_0, _, _ = _run(spec, prec, nsteps, {"VVHIP_PERIODIC": "0"}, monkeypatch, cos=cos, **kw)                                      # best-fit layout
+    assert flag0 == 0
+    # same layout => same summation order => the very same bits, whichever way the slot words come
+    for a, b in ((v_b, v_e), (p_b, p_e), (c_b, c_e), (v_ab, v_e), (p_ab, p_e), (c_ab, c_e)):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+    assert np.array_equal(ke_b, ke_e) and np.array_equal(ke_ab, ke_e)
+    # against the oracle (and the other layout: different summation order, same physics)
+    p = O.Params(temperature=kw.get("T", 333.0), drude_temperature=1.0, step_size=kw.get("dt", 0.001), max_drude_distance=kw["maxd"], cos_acceleration=cos)
+    osys = O.OracleSystem(spec, p, prec, force_mode=1)
+    osys.step(nsteps)
+    tol = 1e-5
+    massive = osys.velm[:, 3] != 0
+    for v, x in ((v_b, p_b), (v_0, p_0)):
+        ev = np.abs(v[massive, :3].astype(np.float64) - osys.velm[massive, :3]).max() / np.abs(osys.velm[massive, :3]).max()
+        ex = np.abs(x[:, :3].astype(np.float64) - osys.posq[:, :3]).max() / np.abs(osys.posq[:, :3]).max()
+        assert ev < tol and ex < tol, f"{name}/{prec}/cos={cos}: rel err vel {ev:.2e} pos {ex:.2e}"
+
+
+def test_periodic_kernels_under_graph_replay(monkeypatch):
+    spec, kw = SYSTEMS["bulk_cells"]()
+    _, v_g, p_g, c_g, _ = _run(spec, "mixed", 40, {"VVHIP_PERIODIC": "1", "VVHIP_PERIODIC_A": "1"}, monkeypatch, graph=True, **kw)
+    _, v_e, p_e, c_e, _ = _run(spec, "mixed", 40, {"VVHIP_PERIODIC": "1", "VVHIP_PERIODIC_K": "0"}, monkeypatch, **kw)
+    assert np.array_equal(v_g.view(np.uint8), v_e.view(np.uint8)) and np.array_equal(p_g.view(np.uint8), p_e.view(np.uint8))

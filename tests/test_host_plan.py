@@ -191,3 +191,37 @@ def test_rigid_water_is_recognised_as_settle_clusters():
     mix = systems.constrain_hydrogens(systems.drude_il(cells=(1, 1, 1), pairs_per_cell=3, seed=2))
     cm = O.build_constraint_clusters(mix)
     assert len(cm["settle_atoms"]) == 0 and len(cm["shake_atoms"]) > 0
+
+
+@pytest.mark.parametrize("cfg,expect", [("C1", 1), ("C2", 1), ("C3", 1), ("C4", 1), ("C5", 0)])
+def test_periodic_layout_is_found_for_runs_of_identical_molecules(cfg, expect, monkeypatch):
+    """vv_host.hpp PeriodicLayout: the BASELINE bulk boxes are runs of identical molecules (C3: 12 cells of 250 cations + 250 anions), the
+    electrode slab with its image particles is not.  Forced on here (auto only from ~0.64 M particles); analyze() itself verifies, lane
+    for lane, that the arithmetic layout reproduces the explicit slot table before enabling it -- these are the invariants seen from outside."""
+    monkeypatch.setenv("VVHIP_PERIODIC", "1")
+    spec = systems.make_config(cfg)
+    p = O.Params(temperature=333.0, drude_temperature=1.0, max_drude_distance=0.02 if len(spec.drude_pairs) else 0.0)
+    info, slots = I.plan_layout(spec, _integrator(p))
+    assert info.periodic_layout == expect
+    atoms = slots[:, 0]
+    if expect:
+        # every wave holds consecutive particles from lane 0 on, waves in particle order
+        used = atoms >= 0
+        a2 = atoms.reshape(-1, 64)
+        u2 = used.reshape(-1, 64)
+        cnt = u2.sum(axis=1)
+        assert all(u2[w, :cnt[w]].all() and not u2[w, cnt[w]:].any() for w in range(a2.shape[0]))
+        assert np.array_equal(atoms[used], np.arange(spec.num_atoms))
+    monkeypatch.setenv("VVHIP_PERIODIC", "0")
+    info0, slots0 = I.plan_layout(spec, _integrator(p))
+    assert info0.periodic_layout == 0 and info0.num_waves <= info.num_waves
+    assert np.array_equal(np.sort(slots0[:, 0][slots0[:, 0] >= 0]), np.sort(atoms[atoms >= 0]))
+
+
+def test_periodic_layout_auto_threshold():
+    spec = systems.make_config("C3", scale=8)
+    info, _ = I.plan_layout(spec, _integrator(O.Params(temperature=333.0, max_drude_distance=0.02)))
+    assert info.periodic_layout == 1 and info.num_waves == 8 * 2004
+    spec = systems.make_config("C3")
+    info, _ = I.plan_layout(spec, _integrator(O.Params(temperature=333.0, max_drude_distance=0.02)))
+    assert info.periodic_layout == 0
