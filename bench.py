@@ -259,7 +259,26 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def healthy_fence():
+    def kernel_times(ctx, reps, batches):
+    """Average launch duration [ms] of kernel A and kernel B with the fused step's stage bits, from HIP events on the plan's stream.
+    Bandwidth regime (>= 12288 waves, where a launch takes >= 10 us): events around EVERY launch of eager steps, i.e. each kernel
+    timed in its real place in the step (what rocprofv3 --kernel-trace reports; kernel B right behind kernel A finds part of velm /
+    force in the Infinity Cache, kernel A behind kernel B does not).  Latency regime: two events around `reps` back-to-back launches
+    of the same kernel, median of `batches` -- per-launch events around 4-6 us kernels starve the GPU and read up to 2x high there."""
+    import statistics
+    if ctx.info.num_waves >= 12288:
+        ctx.run_eager(4)
+        ctx.timing(True)
+        ctx.run_eager(max(10, reps // 2))
+        r = ctx.timing_read()
+        ctx.timing(False)
+        if r["launches"][0] > 0 and r["launches"][1] > 0:
+            return r["ms_a"] / r["launches"][0], r["ms_b"] / r["launches"][1], "in sequence: HIP events around every launch of eager steps"
+    return (statistics.median(ctx.time_kernel(0, reps) for _ in range(batches)), statistics.median(ctx.time_kernel(1, reps) for _ in range(batches)),
+            "back to back: two HIP events around %d launches of the same kernel, median of %d" % (reps, batches))
+
+
+def healthy_fence():
         """fence() on every rank; False on ALL ranks if any rank's plan reported a failure (the run is void then)."""
         ok = True
         try:
@@ -386,8 +405,7 @@ def main():
         # (per-launch events in an eager stream starve the GPU and read ~2x high; the rocprofv3 averages under
         # profiles/ are the cross-check).  Runs after the headline measurement: it scrambles the physical state.
         import statistics
-        ms_a = statistics.median(ctx.time_kernel(0, 100) for _ in range(5))      # median of 5 batches: one hiccup must not
-        ms_b = statistics.median(ctx.time_kernel(1, 100) for _ in range(5))      # decide which kernel is called dominant
+        ms_a, ms_b, how = kernel_times(ctx, 100, 5)
         dom = "B" if ms_b >= ms_a else "A"
         ms = ms_b if dom == "B" else ms_a
         n_local = bounds[rank][1] - bounds[rank][0]
@@ -407,7 +425,7 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": f"vv_kernel_{dom.lower()}", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                                "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_bytes_per_particle": algo,
-                               "avg_launch_us": {"A": round(ms_a * 1e3, 3), "B": round(ms_b * 1e3, 3)},
+                               "avg_launch_us": {"A": round(ms_a * 1e3, 3), "B": round(ms_b * 1e3, 3)}, "launch_timing": how,
                                "note": (("working set (%.0f MB) is L2 / Infinity-Cache resident at this size: the launch is latency bound, "
                                          "see config.large_n for the bandwidth-bound regime" % (228e-6 * n_local)) if n_local < 2_000_000 else
                                         "bandwidth-bound regime (working set far beyond the 256 MB Infinity Cache)")
@@ -422,11 +440,10 @@ def main():
             it_l.setMaxDrudeDistance(0.02)
             ctx_l = I.Context(spec_l, it_l, precision=args.precision, force_provider="tether", device=local_rank)
             sps_l = secondary(ctx_l, 40)
-            la = statistics.median(ctx_l.time_kernel(0, 20) for _ in range(3))
-            lb = statistics.median(ctx_l.time_kernel(1, 20) for _ in range(3))
+            la, lb, how_l = kernel_times(ctx_l, 20, 3)
             nl = spec_l.num_atoms
             blk = {"workload": f"{args.large_n}: {nl} particles, {spec_l.num_molecules} molecules (the C3 cell tiled along z)",
-                   "steps_per_s": round(sps_l, 1), "atom_steps_per_s": round(sps_l * nl, 1), "roofline": {}}
+                   "steps_per_s": round(sps_l, 1), "atom_steps_per_s": round(sps_l * nl, 1), "launch_timing": how_l, "roofline": {}}
             algo_l = dict(zip("AB", ctx_l.algorithmic_bytes()))
             for k, ms in (("A", la), ("B", lb)):
                 by = algo_l[k] * nl

@@ -543,6 +543,8 @@ int vvhip_plan_create(const vvhip_system_desc* system, const vvhip_params* param
             const int b = std::atoi(e);
             if (b >= 64 && b <= 448 && b % 64 == 0) { p->block_threads = b; p->grid_cap_a = 2048; p->grid_cap_b = 1024; p->launch_shape_forced = true; }
         }
+        if (const char* e = std::getenv("VVHIP_CAP_A")) { const int c = std::atoi(e); if (c > 0) { p->grid_cap_a = c; p->launch_shape_forced = true; } }
+        if (const char* e = std::getenv("VVHIP_CAP_B")) { const int c = std::atoi(e); if (c > 0) { p->grid_cap_b = c; p->launch_shape_forced = true; } }
         *plan_out = p;
         return VVHIP_OK;
     } catch (const vv::Error& e) {

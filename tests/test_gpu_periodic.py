@@ -74,3 +74,23 @@ def test_periodic_kernels_under_graph_replay(monkeypatch):
     _, v_g, p_g, c_g, _ = _run(spec, "mixed", 40, {"VVHIP_PERIODIC": "1", "VVHIP_PERIODIC_A": "1"}, monkeypatch, graph=True, **kw)
     _, v_e, p_e, c_e, _ = _run(spec, "mixed", 40, {"VVHIP_PERIODIC": "1", "VVHIP_PERIODIC_K": "0"}, monkeypatch, **kw)
     assert np.array_equal(v_g.view(np.uint8), v_e.view(np.uint8)) and np.array_equal(p_g.view(np.uint8), p_e.view(np.uint8))
+
+
+@pytest.mark.parametrize("cos", [0.0, 0.02])
+def test_periodic_kernels_in_the_large_system_launch_shape(cos, monkeypatch):
+    """What systems beyond ~0.7 M particles run -- the chain as its own launch, kernel B without a thermostat wave, 256-thread blocks
+    striding over tiles -- forced at a testable size, with the periodic layout, against the oracle and against the explicit-slot kernels."""
+    monkeypatch.setenv("VVHIP_SPLIT_CHAIN_WAVES", "1")
+    monkeypatch.setenv("VVHIP_CAP_A", "8")           # few blocks: every wave strides over several tiles
+    monkeypatch.setenv("VVHIP_CAP_B", "8")
+    spec, kw = SYSTEMS["bulk_cells"]()
+    _, v_p, p_p, c_p, ke_p = _run(spec, "mixed", 12, {"VVHIP_PERIODIC": "1", "VVHIP_PERIODIC_A": "1"}, monkeypatch, cos=cos, **kw)
+    _, v_e, p_e, c_e, ke_e = _run(spec, "mixed", 12, {"VVHIP_PERIODIC": "1", "VVHIP_PERIODIC_K": "0"}, monkeypatch, cos=cos, **kw)
+    assert np.array_equal(v_p.view(np.uint8), v_e.view(np.uint8)) and np.array_equal(p_p.view(np.uint8), p_e.view(np.uint8))
+    assert np.array_equal(c_p.view(np.uint8), c_e.view(np.uint8)) and np.array_equal(ke_p, ke_e)
+    p = O.Params(temperature=333.0, drude_temperature=1.0, step_size=0.001, max_drude_distance=kw["maxd"], cos_acceleration=cos)
+    osys = O.OracleSystem(spec, p, "mixed", force_mode=1)
+    osys.step(12)
+    ev = np.abs(v_p[:, :3] - osys.velm[:, :3]).max() / np.abs(osys.velm[:, :3]).max()
+    ex = np.abs(p_p[:, :3].astype(np.float64) - osys.posq[:, :3]).max() / np.abs(osys.posq[:, :3]).max()
+    assert ev < 1e-9 and ex < 2e-7, f"rel err vel {ev:.2e} pos {ex:.2e}"
