@@ -24,6 +24,25 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured float4 copy)
 
 
+def kernel_times(ctx, reps, batches):
+    """Average launch duration [ms] of kernel A and kernel B with the fused step's stage bits, from HIP events on the plan's stream.
+    Bandwidth regime (>= 12288 waves, where a launch takes >= 10 us): events around EVERY launch of eager steps, i.e. each kernel
+    timed in its real place in the step (what rocprofv3 --kernel-trace reports; kernel B right behind kernel A finds part of velm /
+    force in the Infinity Cache, kernel A behind kernel B does not).  Latency regime: two events around `reps` back-to-back launches
+    of the same kernel, median of `batches` -- per-launch events around 4-6 us kernels starve the GPU and read up to 2x high there."""
+    import statistics
+    if ctx.info.num_waves >= 12288:
+        ctx.run_eager(4)
+        ctx.timing(True)
+        ctx.run_eager(max(10, reps // 2))
+        r = ctx.timing_read()
+        ctx.timing(False)
+        if r["launches"][0] > 0 and r["launches"][1] > 0:
+            return r["ms_a"] / r["launches"][0], r["ms_b"] / r["launches"][1], "in sequence: HIP events around every launch of eager steps"
+    return (statistics.median(ctx.time_kernel(0, reps) for _ in range(batches)), statistics.median(ctx.time_kernel(1, reps) for _ in range(batches)),
+            "back to back: two HIP events around %d launches of the same kernel, median of %d" % (reps, batches))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -259,26 +278,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def kernel_times(ctx, reps, batches):
-    """Average launch duration [ms] of kernel A and kernel B with the fused step's stage bits, from HIP events on the plan's stream.
-    Bandwidth regime (>= 12288 waves, where a launch takes >= 10 us): events around EVERY launch of eager steps, i.e. each kernel
-    timed in its real place in the step (what rocprofv3 --kernel-trace reports; kernel B right behind kernel A finds part of velm /
-    force in the Infinity Cache, kernel A behind kernel B does not).  Latency regime: two events around `reps` back-to-back launches
-    of the same kernel, median of `batches` -- per-launch events around 4-6 us kernels starve the GPU and read up to 2x high there."""
-    import statistics
-    if ctx.info.num_waves >= 12288:
-        ctx.run_eager(4)
-        ctx.timing(True)
-        ctx.run_eager(max(10, reps // 2))
-        r = ctx.timing_read()
-        ctx.timing(False)
-        if r["launches"][0] > 0 and r["launches"][1] > 0:
-            return r["ms_a"] / r["launches"][0], r["ms_b"] / r["launches"][1], "in sequence: HIP events around every launch of eager steps"
-    return (statistics.median(ctx.time_kernel(0, reps) for _ in range(batches)), statistics.median(ctx.time_kernel(1, reps) for _ in range(batches)),
-            "back to back: two HIP events around %d launches of the same kernel, median of %d" % (reps, batches))
-
-
-def healthy_fence():
+    def healthy_fence():
         """fence() on every rank; False on ALL ranks if any rank's plan reported a failure (the run is void then)."""
         ok = True
         try:
