@@ -11,6 +11,8 @@
 #include "openmm/Platform.h"
 #include "openmm/System.h"
 
+#include "openmm/FusedVVStepKernel.h"
+
 namespace OpenMM {
 
 class VVIntegrator;
@@ -84,17 +86,7 @@ public:
     virtual void calcViscosity(ContextImpl& context, const VVIntegrator& integrator, double& vMax, double& invVis) = 0;
 };
 
-// Optional capability of a step kernel (not in the reference): everything between two force evaluations in as few
-// launches as the data dependencies allow.  VVIntegrator uses it only when canFuse() says no solver must interleave.
-class FusedVVStepKernel {
-public:
-    virtual ~FusedVVStepKernel() {}
-    virtual bool canFuse(ContextImpl& context, const VVIntegrator& integrator) const = 0;
-    virtual void fusedMiddleStep(ContextImpl& context, const VVIntegrator& integrator) = 0;          // VVIntegrator.cpp:237-268 of the reference
-    virtual void fusedVVFirstHalf(ContextImpl& context, const VVIntegrator& integrator) = 0;         // :294-310
-    virtual void fusedVVSecondHalf(ContextImpl& context, const VVIntegrator& integrator) = 0;        // :315-336
-};
-
+// (the optional fused-step capability of a step kernel -- not in the reference -- lives in openmm/FusedVVStepKernel.h)
 #undef VV_KERNEL_HEAD
 }  // namespace OpenMM
 #endif

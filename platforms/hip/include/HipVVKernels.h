@@ -9,6 +9,7 @@
 #include "HipCompat.h"          // with a real OpenMM: "HipContext.h", "HipArray.h", "HipIntegrationUtilities.h"
 #include "openmm/VVIntegrator.h"
 #include "openmm/VVKernels.h"
+#include "openmm/FusedVVStepKernel.h"
 #include "vvhip.h"
 
 namespace OpenMM {

@@ -103,6 +103,53 @@ def test_cpp_integrator_through_plugin_matches_oracle(tmp_path, middle, cons, co
         assert np.abs(r * r - cdist ** 2).max() < 2e-5 * cdist[0] ** 2, np.abs(r - cdist).max()
 
 
+REF_DRIVER = os.path.join(ROOT, "oracle", "_ref", "refplugin", "vv_plugin_driver")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_DRIVER), reason="oracle/_ref/refplugin not built (reference sources absent)")
+def test_plugin_registers_under_the_reference_api():
+    """The HIP plugin compiled against the REFERENCE's own openmmapi headers, next to the reference's own VVIntegrator.cpp compiled in
+    place (oracle/Makefile: refplugin): same seven kernel names, same error texts -- from the reference's code this time."""
+    out = subprocess.run([REF_DRIVER, "registry"], capture_output=True, text=True, check=True).stdout
+    assert "REGISTRY OK" in out and "This Integrator is not bound to a context!" in out
+    for name in ("IntegrateMiddleStep", "IntegrateVVStep", "ModifyDrudeNose", "ModifyLangevin", "ModifyImageCharge",
+                 "ModifyElectricField", "ModifyCosineAccelerate"):
+        assert f"kernel {name}: registered" in out
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(REF_DRIVER), reason="oracle/_ref/refplugin not built (reference sources absent)")
+@pytest.mark.parametrize("middle,cons,cos", [(1, 0, 0.0), (1, 1, 0.0), (1, 0, 0.02), (1, 1, 0.02), (0, 0, 0.0), (0, 1, 0.02)])
+def test_reference_integrator_drives_the_hip_kernels(tmp_path, middle, cons, cos):
+    """Drop-in at the KernelImpl boundary with the reference on top: the reference's VVIntegrator::step (its own stepMiddle / stepVV,
+    compiled in place) calls this repository's seven HIP kernels through the reference's virtuals, stage by stage (it does not know the
+    optional fused interface); trajectory against the oracle, and against this repository's own VVIntegrator on the fused path."""
+    nsteps = 12
+    dump_r, dump_o = str(tmp_path / "ref.bin"), str(tmp_path / "own.bin")
+    r = subprocess.run([REF_DRIVER, "run", dump_r, str(middle), str(cons), str(cos), str(nsteps)], capture_output=True, text=True)
+    assert r.returncode == 0 and "RUN OK" in r.stdout and f"stepCount={nsteps}" in r.stdout, r.stdout + r.stderr
+    o = subprocess.run([DRIVER, "run", dump_o, str(middle), str(cons), str(cos), str(nsteps)], capture_output=True, text=True)
+    assert o.returncode == 0 and "RUN OK" in o.stdout, o.stdout + o.stderr
+    masses, charges, mol, pairs, cns, pos, vel, velm, posq, corr, vis, cdist = _read(dump_r)
+    own = _read(dump_o)
+    n = masses.shape[0]
+    spec = systems.SystemSpec(name="cpp", masses=masses, charges=charges, positions=pos.reshape(n, 3), velocities=vel.reshape(n, 3),
+                              box=np.array([3.0, 3.0, 3.0]), mol_id=mol, drude_pairs=pairs.reshape(-1, 2),
+                              constraints=cns.reshape(-1, 2), has_cm_motion_remover=True)
+    p = O.Params(temperature=333.0, drude_temperature=1.0, max_drude_distance=0.02, cos_acceleration=cos, use_middle_scheme=bool(middle))
+    osys = O.OracleSystem(spec, p, "mixed", force_mode=1)
+    osys.step(nsteps)
+    x_g = posq.reshape(n, 4)[:, :3].astype(np.float64) + corr.reshape(n, 4)[:, :3].astype(np.float64)
+    v_g = velm.reshape(n, 4)[:, :3]
+    ex = np.abs(x_g - osys.positions()).max() / np.abs(osys.positions()).max()
+    ev = np.abs(v_g - osys.velm[:, :3]).max() / np.abs(osys.velm[:, :3]).max()
+    assert ex < 1e-9 and ev < 1e-9, (ex, ev)
+    # the two host classes end in the same state to rounding (different launch granularity, same arithmetic)
+    assert np.allclose(velm, own[7], rtol=0, atol=1e-9 * np.abs(velm).max()) and np.allclose(posq, own[8], rtol=0, atol=2e-7 * np.abs(posq).max())
+    if cos != 0:
+        assert vis[0] == pytest.approx(osys.viscosity()[0], rel=1e-6, abs=1e-12)
+
+
 def test_cmake_build_produces_the_same_plugin(tmp_path):
     """The CMake route (what a maintainer of an OpenMM installation would use) configures and builds the API library, the plugin and
     the driver against the stand-in headers, reusing the in-tree libvvhip.so; the plugin exports the three registration symbols."""
