@@ -4,7 +4,9 @@
 // openmm/VVKernels.h by calling the C ABI of libvvhip (include/vvhip.h); all seven share ONE vvhip_plan per
 // HipContext (the reference shares only forceExtra, through getForceExtra(): CudaVVKernels.h:86-88).
 // Counterpart of platforms/cuda/include/CudaVVKernels.h.
+#include <functional>
 #include <memory>
+#include <vector>
 
 #include "HipCompat.h"          // with a real OpenMM: "HipContext.h", "HipArray.h", "HipIntegrationUtilities.h"
 #include "openmm/VVIntegrator.h"
@@ -26,7 +28,26 @@ public:
     bool constraintFree() const { return noConstraints; }
     static std::shared_ptr<HipVVPlan> find(HipContext& cu);    // the plan the step kernel created for this context
     static std::shared_ptr<HipVVPlan> create(HipContext& cu, const System&, const VVIntegrator&, const DrudeForce*);
+
+    // ---- deferred fusion.  A host class that does not know FusedVVStepKernel -- the reference's own VVIntegrator -- calls the seven
+    // kernels stage by stage (VVIntegrator.cpp:232-338), with nothing read back in between.  The adapters therefore only RECORD a stage
+    // while the calls follow the sequence the reference's stepMiddle / stepVV produce for the integrator's configuration, and the stage
+    // that completes the sequence launches the fused step (2 launches instead of 8).  Any other call order runs what was recorded through
+    // the stage-by-stage entry points first, in order, and then the new stage: same results either way.  Off with constraints OpenMM's
+    // solver must interleave, or VVHIP_PLUGIN_DEFER=0.
+    enum Stage { ST_RESET, ST_LD, ST_EF, ST_COS, ST_FIRST, ST_CALCBIAS, ST_RMBIAS, ST_SCALE, ST_RESTORE, ST_SECOND };
+    // true: recorded, or the sequence is complete and the fused step has been launched -- the caller is done; false: the caller runs its stage now
+    bool defer(Stage stage, const VVIntegrator& integrator, std::function<void()> stageByStage);
+    void flush();                                              // run what is recorded, stage by stage
+    std::function<void(const VVIntegrator&, uint32_t)> fusedMiddle, fusedFirst, fusedSecond;    // set by the step kernel of the context
+    uint32_t pendingRandomIndex = 0;                           // slice of the random buffer applyLangevinForce reserved for the recorded step
+    bool imagesFresh = false;                                  // the fused step has already mirrored the image particles
+    long fusedSteps = 0, stagedCalls = 0;                      // diagnostics: fused launches through deferral / stages run one by one
 private:
+    std::vector<Stage> pattern;
+    std::vector<std::function<void()> > pending;
+    int classicHalf = 0;
+    bool deferEnabled = true;
     HipContext& cu;
     vvhip_plan* plan;
     vvhip_params last;
@@ -61,6 +82,10 @@ public:
     void fusedMiddleStep(ContextImpl& context, const VVIntegrator& integrator);
     void fusedVVFirstHalf(ContextImpl& context, const VVIntegrator& integrator);
     void fusedVVSecondHalf(ContextImpl& context, const VVIntegrator& integrator);
+private:
+    void firstIntegrateNow(const VVIntegrator& integrator);
+    void secondIntegrateNow(const VVIntegrator& integrator);
+    void fusedMiddleWith(const VVIntegrator& integrator, uint32_t randomIndex);
 };
 
 class HipIntegrateVVStepKernel : public IntegrateVVStepKernel, public FusedVVStepKernel, private HipVVStepCommon {
@@ -76,6 +101,11 @@ public:
     void fusedMiddleStep(ContextImpl& context, const VVIntegrator& integrator);
     void fusedVVFirstHalf(ContextImpl& context, const VVIntegrator& integrator);
     void fusedVVSecondHalf(ContextImpl& context, const VVIntegrator& integrator);
+private:
+    void firstIntegrateNow(const VVIntegrator& integrator);
+    void secondIntegrateNow(const VVIntegrator& integrator);
+    void fusedFirstNow(const VVIntegrator& integrator);
+    void fusedSecondWith(const VVIntegrator& integrator, uint32_t randomIndex);
 };
 
 class HipModifyDrudeNoseKernel : public ModifyDrudeNoseKernel {
@@ -84,6 +114,7 @@ public:
     void initialize(const System& system, const VVIntegrator& integrator, const DrudeForce* force);
     void scaleVelocity(ContextImpl& context, const VVIntegrator& integrator);
 private:
+    void scaleVelocityNow(const VVIntegrator& integrator);
     HipContext& cu;
     std::shared_ptr<HipVVPlan> plan;
 };

@@ -3,6 +3,7 @@
 #include "HipVVKernels.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <iostream>
 #include <map>
 #include <mutex>
@@ -88,6 +89,7 @@ HipVVPlan::HipVVPlan(HipContext& cu, const System& system, const VVIntegrator& i
     vvhip_plan_get_info(plan, &info);
     ldRandoms = std::max(info.num_normal_ld, 1) + 2 * std::max(info.num_pairs_ld, 1);   // HOST:806-807,863: array sizes are max(n,1)
     noConstraints = info.constraints_fused != 0;      // no constraints at all, or all of them solved inside the kernels
+    if (const char* e = std::getenv("VVHIP_PLUGIN_DEFER")) deferEnabled = std::atoi(e) != 0;
     HipIntegrationUtilities& integration = cu.getIntegrationUtilities();
     vvhip_buffers b = {};
     // getDevicePointer() is an lvalue device-pointer handle in OpenMM (the reference passes its address as a kernel argument,
@@ -137,6 +139,58 @@ std::shared_ptr<HipVVPlan> HipVVPlan::find(HipContext& cu) {
     return p;
 }
 
+// ------------------------------------------------------------------------------------------ deferred fusion
+void HipVVPlan::flush() {
+    std::vector<std::function<void()> > run;
+    run.swap(pending);
+    pattern.clear();
+    for (auto& f : run) { f(); stagedCalls++; }
+}
+bool HipVVPlan::defer(Stage stage, const VVIntegrator& it, std::function<void()> stageByStage) {
+    if (!deferEnabled || !noConstraints) return false;
+    if (pending.empty()) {
+        // the sequence the reference's VVIntegrator produces for this configuration (VVIntegrator.cpp:238-267; 295-310 and 316-336)
+        vvhip_plan_info info;
+        vvhip_plan_get_info(plan, &info);
+        const bool nh = info.num_particles_nh > 0, cos = it.getCosAcceleration() != 0, ld = !it.getParticlesLD().empty(), ef = !it.getParticlesElectrolyte().empty();
+        std::vector<Stage> extra, thermo;
+        if (ld || ef || cos) extra.push_back(ST_RESET);
+        if (ld) extra.push_back(ST_LD);
+        if (ef) extra.push_back(ST_EF);
+        if (cos) extra.push_back(ST_COS);
+        if (nh) { if (cos) { thermo.push_back(ST_CALCBIAS); thermo.push_back(ST_RMBIAS); } thermo.push_back(ST_SCALE); if (cos) thermo.push_back(ST_RESTORE); }
+        pattern.clear();
+        if (it.getUseMiddleScheme()) {
+            pattern = extra; pattern.push_back(ST_FIRST); pattern.insert(pattern.end(), thermo.begin(), thermo.end()); pattern.push_back(ST_SECOND);
+        } else {
+            std::vector<Stage> first = thermo, second = extra;
+            first.push_back(ST_FIRST);
+            second.push_back(ST_SECOND); second.insert(second.end(), thermo.begin(), thermo.end());
+            if (stage == first[0] && stage != second[0]) classicHalf = 0;
+            else if (stage == second[0] && stage != first[0]) classicHalf = 1;
+            pattern = classicHalf == 0 ? first : second;
+        }
+    }
+    if (pending.size() < pattern.size() && pattern[pending.size()] == stage) {
+        if (pending.empty()) imagesFresh = false;
+        pending.push_back(std::move(stageByStage));
+        if (pending.size() == pattern.size()) {            // complete: one fused step instead of the recorded stages
+            pending.clear();
+            pattern.clear();
+            const uint32_t ri = pendingRandomIndex;
+            if (it.getUseMiddleScheme()) { fusedMiddle(it, ri); imagesFresh = true; }
+            else if (classicHalf == 0) { fusedFirst(it, ri); classicHalf = 1; imagesFresh = true; }      // (both mirror the images with their position update)
+            else { fusedSecond(it, ri); classicHalf = 0; }
+            fusedSteps++;
+        }
+        return true;
+    }
+    flush();                                               // not the reference's order: what was recorded runs now, then the caller's stage
+    imagesFresh = false;
+    stagedCalls++;
+    return false;
+}
+
 // ------------------------------------------------------------------------------------------ step kernels
 void HipVVStepCommon::create(const System& system, const VVIntegrator& it, const DrudeForce* force) {
     ContextSelector selector(cu);                                                                       // HOST:60, 246
@@ -162,9 +216,20 @@ void HipVVStepCommon::advanceClock(const VVIntegrator& it) {      // HOST:219-22
 }
 uint32_t HipVVStepCommon::nextRandomIndex() { return (uint32_t) cu.getIntegrationUtilities().prepareRandomNumbers(plan->numLangevinRandoms()); }
 
-void HipIntegrateMiddleStepKernel::initialize(const System& s, const VVIntegrator& it, const DrudeForce* f) { create(s, it, f); }
-void HipIntegrateMiddleStepKernel::resetExtraForce(ContextImpl&, const VVIntegrator&) { cu.setAsCurrent(); plan->check(vvhip_reset_extra_force(plan->get())); }
-void HipIntegrateMiddleStepKernel::firstIntegrate(ContextImpl&, const VVIntegrator& it) {              // HOST:129-159
+void HipIntegrateMiddleStepKernel::initialize(const System& s, const VVIntegrator& it, const DrudeForce* f) {
+    create(s, it, f);
+    plan->fusedMiddle = [this](const VVIntegrator& integ, uint32_t randomIndex) { fusedMiddleWith(integ, randomIndex); };
+}
+void HipIntegrateMiddleStepKernel::resetExtraForce(ContextImpl&, const VVIntegrator& it) {
+    if (plan->defer(HipVVPlan::ST_RESET, it, [this] { cu.setAsCurrent(); plan->check(vvhip_reset_extra_force(plan->get())); })) return;
+    cu.setAsCurrent();
+    plan->check(vvhip_reset_extra_force(plan->get()));
+}
+void HipIntegrateMiddleStepKernel::firstIntegrate(ContextImpl& context, const VVIntegrator& it) {      // HOST:129-159
+    if (plan->defer(HipVVPlan::ST_FIRST, it, [this, &it] { firstIntegrateNow(it); })) return;
+    firstIntegrateNow(it);
+}
+void HipIntegrateMiddleStepKernel::firstIntegrateNow(const VVIntegrator& it) {
     cu.setAsCurrent();
     plan->syncParameters(it);
     announceStepSize(it, false);
@@ -174,6 +239,10 @@ void HipIntegrateMiddleStepKernel::firstIntegrate(ContextImpl&, const VVIntegrat
     plan->check(vvhip_middle_half_drift1(plan->get()));
 }
 void HipIntegrateMiddleStepKernel::secondIntegrate(ContextImpl&, const VVIntegrator& it) {             // HOST:161-231
+    if (plan->defer(HipVVPlan::ST_SECOND, it, [this, &it] { secondIntegrateNow(it); })) return;
+    secondIntegrateNow(it);
+}
+void HipIntegrateMiddleStepKernel::secondIntegrateNow(const VVIntegrator& it) {
     cu.setAsCurrent();
     if (it.getDebugEnabled()) std::cout << "HipIntegrateMiddleStepKernel secondIntegrate" << std::endl;
     plan->check(vvhip_middle_half_drift2(plan->get()));
@@ -184,15 +253,20 @@ void HipIntegrateMiddleStepKernel::secondIntegrate(ContextImpl&, const VVIntegra
     advanceClock(it);
 }
 double HipIntegrateMiddleStepKernel::computeKineticEnergy(ContextImpl&, const VVIntegrator&) {
+    plan->flush();
     return cu.getIntegrationUtilities().computeKineticEnergy(0);                                        // HOST:233-235 (OpenMM's)
 }
 bool HipIntegrateMiddleStepKernel::canFuse(ContextImpl&, const VVIntegrator&) const { return plan->constraintFree(); }
 void HipIntegrateMiddleStepKernel::fusedMiddleStep(ContextImpl&, const VVIntegrator& it) {
+    plan->flush();
+    fusedMiddleWith(it, it.getParticlesLD().empty() ? 0 : nextRandomIndex());
+}
+void HipIntegrateMiddleStepKernel::fusedMiddleWith(const VVIntegrator& it, uint32_t randomIndex) {
     cu.setAsCurrent();
     plan->syncParameters(it);
     announceStepSize(it, false);
     if (it.getDebugEnabled()) std::cout << "HipIntegrateMiddleStepKernel fusedMiddleStep" << std::endl;
-    plan->check(vvhip_step_middle(plan->get(), it.getParticlesLD().empty() ? 0 : nextRandomIndex()));
+    plan->check(vvhip_step_middle(plan->get(), randomIndex));
     cu.getIntegrationUtilities().computeVirtualSites();      // as the un-fused path and the reference after every position update (HOST:214)
     cu.reorderAtoms();
     advanceClock(it);
@@ -200,9 +274,21 @@ void HipIntegrateMiddleStepKernel::fusedMiddleStep(ContextImpl&, const VVIntegra
 void HipIntegrateMiddleStepKernel::fusedVVFirstHalf(ContextImpl&, const VVIntegrator&) { throw OpenMMException("middle-scheme kernel asked for a classic step"); }
 void HipIntegrateMiddleStepKernel::fusedVVSecondHalf(ContextImpl&, const VVIntegrator&) { throw OpenMMException("middle-scheme kernel asked for a classic step"); }
 
-void HipIntegrateVVStepKernel::initialize(const System& s, const VVIntegrator& it, const DrudeForce* f) { create(s, it, f); }
-void HipIntegrateVVStepKernel::resetExtraForce(ContextImpl&, const VVIntegrator&) { cu.setAsCurrent(); plan->check(vvhip_reset_extra_force(plan->get())); }
+void HipIntegrateVVStepKernel::initialize(const System& s, const VVIntegrator& it, const DrudeForce* f) {
+    create(s, it, f);
+    plan->fusedFirst = [this](const VVIntegrator& integ, uint32_t) { fusedFirstNow(integ); };
+    plan->fusedSecond = [this](const VVIntegrator& integ, uint32_t randomIndex) { fusedSecondWith(integ, randomIndex); };
+}
+void HipIntegrateVVStepKernel::resetExtraForce(ContextImpl&, const VVIntegrator& it) {
+    if (plan->defer(HipVVPlan::ST_RESET, it, [this] { cu.setAsCurrent(); plan->check(vvhip_reset_extra_force(plan->get())); })) return;
+    cu.setAsCurrent();
+    plan->check(vvhip_reset_extra_force(plan->get()));
+}
 void HipIntegrateVVStepKernel::firstIntegrate(ContextImpl&, const VVIntegrator& it) {                   // HOST:296-382
+    if (plan->defer(HipVVPlan::ST_FIRST, it, [this, &it] { firstIntegrateNow(it); })) return;
+    firstIntegrateNow(it);
+}
+void HipIntegrateVVStepKernel::firstIntegrateNow(const VVIntegrator& it) {
     cu.setAsCurrent();
     plan->syncParameters(it);
     announceStepSize(it, true);
@@ -213,15 +299,20 @@ void HipIntegrateVVStepKernel::firstIntegrate(ContextImpl&, const VVIntegrator& 
     cu.reorderAtoms();                                   // after the first half, so Langevin indices stay valid (HOST:376-381)
 }
 void HipIntegrateVVStepKernel::secondIntegrate(ContextImpl&, const VVIntegrator& it) {                  // HOST:395-442
+    if (plan->defer(HipVVPlan::ST_SECOND, it, [this, &it] { secondIntegrateNow(it); })) return;
+    secondIntegrateNow(it);
+}
+void HipIntegrateVVStepKernel::secondIntegrateNow(const VVIntegrator& it) {
     cu.setAsCurrent();
     plan->check(vvhip_vv_half_kick(plan->get(), 0));
     cu.getIntegrationUtilities().applyVelocityConstraints(it.getConstraintTolerance());
     advanceClock(it);
 }
-double HipIntegrateVVStepKernel::computeKineticEnergy(ContextImpl&, const VVIntegrator&) { return cu.getIntegrationUtilities().computeKineticEnergy(0); }
+double HipIntegrateVVStepKernel::computeKineticEnergy(ContextImpl&, const VVIntegrator&) { plan->flush(); return cu.getIntegrationUtilities().computeKineticEnergy(0); }
 bool HipIntegrateVVStepKernel::canFuse(ContextImpl&, const VVIntegrator&) const { return plan->constraintFree(); }
 void HipIntegrateVVStepKernel::fusedMiddleStep(ContextImpl&, const VVIntegrator&) { throw OpenMMException("classic kernel asked for a middle-scheme step"); }
-void HipIntegrateVVStepKernel::fusedVVFirstHalf(ContextImpl&, const VVIntegrator& it) {
+void HipIntegrateVVStepKernel::fusedVVFirstHalf(ContextImpl&, const VVIntegrator& it) { plan->flush(); fusedFirstNow(it); }
+void HipIntegrateVVStepKernel::fusedFirstNow(const VVIntegrator& it) {
     cu.setAsCurrent();
     plan->syncParameters(it);
     announceStepSize(it, true);
@@ -230,14 +321,22 @@ void HipIntegrateVVStepKernel::fusedVVFirstHalf(ContextImpl&, const VVIntegrator
     cu.reorderAtoms();
 }
 void HipIntegrateVVStepKernel::fusedVVSecondHalf(ContextImpl&, const VVIntegrator& it) {
+    plan->flush();
+    fusedSecondWith(it, it.getParticlesLD().empty() ? 0 : nextRandomIndex());
+}
+void HipIntegrateVVStepKernel::fusedSecondWith(const VVIntegrator& it, uint32_t randomIndex) {
     cu.setAsCurrent();
-    plan->check(vvhip_step_vv_second(plan->get(), it.getParticlesLD().empty() ? 0 : nextRandomIndex()));
+    plan->check(vvhip_step_vv_second(plan->get(), randomIndex));
     advanceClock(it);
 }
 
 // ------------------------------------------------------------------------------------------ modifier kernels
 void HipModifyDrudeNoseKernel::initialize(const System&, const VVIntegrator&, const DrudeForce*) { ContextSelector selector(cu); plan = HipVVPlan::find(cu); }
 void HipModifyDrudeNoseKernel::scaleVelocity(ContextImpl&, const VVIntegrator& it) {                    // HOST:670-754
+    if (plan->defer(HipVVPlan::ST_SCALE, it, [this, &it] { scaleVelocityNow(it); })) return;
+    scaleVelocityNow(it);
+}
+void HipModifyDrudeNoseKernel::scaleVelocityNow(const VVIntegrator& it) {
     cu.setAsCurrent();
     plan->syncParameters(it);
     plan->check(vvhip_scale_velocity(plan->get()));
@@ -246,13 +345,18 @@ void HipModifyDrudeNoseKernel::scaleVelocity(ContextImpl&, const VVIntegrator& i
 void HipModifyDrudeLangevinKernel::initialize(const System&, const VVIntegrator&, const DrudeForce*, Kernel&) { ContextSelector selector(cu); plan = HipVVPlan::find(cu); }
 void HipModifyDrudeLangevinKernel::applyLangevinForce(ContextImpl&, const VVIntegrator& it) {            // HOST:826-872
     cu.setAsCurrent();
-    plan->syncParameters(it);
-    const int randomIndex = cu.getIntegrationUtilities().prepareRandomNumbers(plan->numLangevinRandoms());
-    plan->check(vvhip_apply_langevin_force(plan->get(), (uint32_t) randomIndex));
+    // the slice of the random buffer is reserved NOW, as the reference does (HOST:863), whether the stage runs now or inside the fused step
+    const uint32_t randomIndex = (uint32_t) cu.getIntegrationUtilities().prepareRandomNumbers(plan->numLangevinRandoms());
+    auto now = [this, &it, randomIndex] { cu.setAsCurrent(); plan->syncParameters(it); plan->check(vvhip_apply_langevin_force(plan->get(), randomIndex)); };
+    plan->pendingRandomIndex = randomIndex;
+    if (plan->defer(HipVVPlan::ST_LD, it, now)) return;
+    now();
 }
 
 void HipModifyImageChargeKernel::initialize(const System&, const VVIntegrator&) { ContextSelector selector(cu); plan = HipVVPlan::find(cu); }
 void HipModifyImageChargeKernel::updateImagePositions(ContextImpl&, const VVIntegrator& it) {            // HOST:904-934
+    plan->flush();
+    if (plan->imagesFresh) { plan->imagesFresh = false; return; }      // the fused step that has just run mirrored them with its position update
     cu.setAsCurrent();
     plan->syncParameters(it);
     plan->check(vvhip_update_image_positions(plan->get()));
@@ -260,17 +364,34 @@ void HipModifyImageChargeKernel::updateImagePositions(ContextImpl&, const VVInte
 
 void HipModifyElectricFieldKernel::initialize(const System&, const VVIntegrator&, Kernel&) { ContextSelector selector(cu); plan = HipVVPlan::find(cu); }
 void HipModifyElectricFieldKernel::applyElectricForce(ContextImpl&, const VVIntegrator& it) {            // HOST:971-992
-    cu.setAsCurrent();
-    plan->syncParameters(it);
-    plan->check(vvhip_apply_electric_force(plan->get()));
+    auto now = [this, &it] { cu.setAsCurrent(); plan->syncParameters(it); plan->check(vvhip_apply_electric_force(plan->get())); };
+    if (plan->defer(HipVVPlan::ST_EF, it, now)) return;
+    now();
 }
 
 void HipModifyCosineAccelerateKernel::initialize(const System&, const VVIntegrator&, Kernel&) { ContextSelector selector(cu); plan = HipVVPlan::find(cu); }
-void HipModifyCosineAccelerateKernel::applyCosineForce(ContextImpl&, const VVIntegrator& it) { cu.setAsCurrent(); plan->syncParameters(it); plan->check(vvhip_apply_cosine_force(plan->get())); }
-void HipModifyCosineAccelerateKernel::calcVelocityBias(ContextImpl&, const VVIntegrator&) { cu.setAsCurrent(); plan->check(vvhip_calc_velocity_bias(plan->get())); }
-void HipModifyCosineAccelerateKernel::removeVelocityBias(ContextImpl&, const VVIntegrator&) { cu.setAsCurrent(); plan->check(vvhip_remove_velocity_bias(plan->get())); }
-void HipModifyCosineAccelerateKernel::restoreVelocityBias(ContextImpl&, const VVIntegrator&) { cu.setAsCurrent(); plan->check(vvhip_restore_velocity_bias(plan->get())); }
+void HipModifyCosineAccelerateKernel::applyCosineForce(ContextImpl&, const VVIntegrator& it) {
+    auto now = [this, &it] { cu.setAsCurrent(); plan->syncParameters(it); plan->check(vvhip_apply_cosine_force(plan->get())); };
+    if (plan->defer(HipVVPlan::ST_COS, it, now)) return;
+    now();
+}
+void HipModifyCosineAccelerateKernel::calcVelocityBias(ContextImpl&, const VVIntegrator& it) {
+    auto now = [this] { cu.setAsCurrent(); plan->check(vvhip_calc_velocity_bias(plan->get())); };
+    if (plan->defer(HipVVPlan::ST_CALCBIAS, it, now)) return;
+    now();
+}
+void HipModifyCosineAccelerateKernel::removeVelocityBias(ContextImpl&, const VVIntegrator& it) {
+    auto now = [this] { cu.setAsCurrent(); plan->check(vvhip_remove_velocity_bias(plan->get())); };
+    if (plan->defer(HipVVPlan::ST_RMBIAS, it, now)) return;
+    now();
+}
+void HipModifyCosineAccelerateKernel::restoreVelocityBias(ContextImpl&, const VVIntegrator& it) {
+    auto now = [this] { cu.setAsCurrent(); plan->check(vvhip_restore_velocity_bias(plan->get())); };
+    if (plan->defer(HipVVPlan::ST_RESTORE, it, now)) return;
+    now();
+}
 void HipModifyCosineAccelerateKernel::calcViscosity(ContextImpl&, const VVIntegrator& it, double& vMax, double& invVis) {   // HOST:1112-1134
+    plan->flush();
     cu.setAsCurrent();
     plan->syncParameters(it);
     plan->check(vvhip_calc_viscosity(plan->get(), &vMax, &invVis));

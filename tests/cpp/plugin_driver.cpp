@@ -78,7 +78,7 @@ static int run(const char* out, bool middle, int consMode, double cosacc, int ns
     registerHipVVKernelFactories();
     Platform& hip = Platform::getPlatformByName("HIP");
     const int nmol = 40, per = 8;              // [heavy, drude, heavy, drude, heavy, drude, H, H] per molecule
-    const int n = nmol * per;
+    const int nLiq = nmol * per;
     System system;
     DrudeForce* drude = new DrudeForce();
     std::vector<double> masses, charges;
@@ -95,8 +95,21 @@ static int run(const char* out, bool middle, int consMode, double cosacc, int ns
             molecules[m].push_back(i);
             if (isDrude) { drude->addParticle(i, i - 1, -1, -1, -1, -2.0, 0.001, 1, 1); pairs.push_back(i); pairs.push_back(i - 1); }
         }
+    // consMode 3 ("electrode"): 16 Langevin-thermostatted wall atoms (each its own molecule), a massless image of every liquid particle in its
+    // parent's molecule, the liquid in the electrolyte set -- the machinery of examples/run-edl.py (Langevin force, field force, image mirror)
+    const int nLiquid = nLiq, nWall = consMode == 3 ? 16 : 0, nImages = consMode == 3 ? nLiquid : 0, nAll = nLiquid + nWall + nImages;
+    for (int w = 0; w < nWall; w++) {
+        system.addParticle(32.06);
+        masses.push_back(32.06); charges.push_back(0.0); molId.push_back(nmol + w);
+        molecules.push_back(std::vector<int>(1, nLiquid + w));
+    }
+    for (int k = 0; k < nImages; k++) {
+        system.addParticle(0.0);
+        masses.push_back(0.0); charges.push_back(-charges[k]); molId.push_back(molId[k]);
+        molecules[molId[k]].push_back(nLiquid + nWall + k);
+    }
     system.addForce(drude);
-    system.addForce(new CMMotionRemover());
+    if (consMode != 3) system.addForce(new CMMotionRemover());
     // consMode 1: a chain H-heavy-H-H in molecule 0 -- neither a hydrogen-type cluster nor a rigid triangle, so the plan leaves constraints to OpenMM's solver
     //             and VVIntegrator takes the un-fused path (the stand-in solver is a no-op; only the path and the DOF matter);
     // consMode 2: both hydrogens of every molecule constrained to the heavy particle 4 -- solved inside the fused kernels.
@@ -107,7 +120,8 @@ static int run(const char* out, bool middle, int consMode, double cosacc, int ns
     if (consMode == 2)
         for (int m = 0; m < nmol; m++) { addCons(m * per + 6, m * per + 4, 0.1); addCons(m * per + 7, m * per + 4, 0.1); }
     const double box[3] = {3.0, 3.0, 3.0}, kB = (1.380649e-23 * 6.02214076e23) / 1000.0;
-    std::vector<double> pos(3 * n), vel(3 * n);
+    std::vector<double> pos(3 * nAll, 0.0), vel(3 * nAll, 0.0);
+    const double mirror = 3.5;
     for (int m = 0; m < nmol; m++) {
         double c[3] = {uniform() * box[0], uniform() * box[1], uniform() * box[2]};
         for (int k = 0; k < per; k++) {
@@ -128,12 +142,33 @@ static int run(const char* out, bool middle, int consMode, double cosacc, int ns
             for (int d = 0; d < 3; d++) { u[d] /= len; pos[3 * h + d] = pos[3 * o + d] + consDist[c] * u[d]; along += (vel[3 * h + d] - vel[3 * o + d]) * u[d]; }
             for (int d = 0; d < 3; d++) vel[3 * h + d] -= along * u[d];
         }
+    for (int w = 0; w < nWall; w++)
+        for (int d = 0; d < 3; d++) {
+            pos[3 * (nLiquid + w) + d] = d < 2 ? uniform() * box[d] : 0.05 + 0.1 * uniform();
+            vel[3 * (nLiquid + w) + d] = gauss() * std::sqrt(kB * 333.0 / 32.06);
+        }
+    for (int k = 0; k < nImages; k++) {
+        const int i = nLiquid + nWall + k;
+        pos[3 * i] = pos[3 * k]; pos[3 * i + 1] = pos[3 * k + 1]; pos[3 * i + 2] = 2 * mirror - pos[3 * k + 2];
+    }
     ProbeIntegrator it(333.0, 10.0, 1.0, 40.0, 0.001);
     it.setMaxDrudeDistance(0.02);
     it.setUseMiddleScheme(middle);
     it.setCosAcceleration(cosacc);
+    std::vector<int> ldList, imgList, elList;
+    if (consMode == 3) {
+        it.setMirrorLocation(mirror);
+        it.setElectricField(2.0 / box[2] * 1.602176634e-22);
+        for (int w = 0; w < nWall; w++) { it.addParticleLangevin(nLiquid + w); ldList.push_back(nLiquid + w); }
+        for (int k = 0; k < nImages; k++) { it.addImagePair(nLiquid + nWall + k, k); imgList.push_back(nLiquid + nWall + k); imgList.push_back(k); }
+        for (int k = 0; k < nLiquid; k++) { it.addParticleElectrolyte(k); elList.push_back(k); }
+    }
+    const int n = nAll;                        // (shadows the liquid's particle count from here on)
     Context ctx(system, it, hip);
     HipContext cu(n, false, true);             // HipPrecision = mixed
+    std::vector<float> normals(4 * 2048);
+    for (float& v : normals) v = (float) gauss();
+    if (consMode == 3) { cu.getIntegrationUtilities().getRandom().initialize(2048, 16); cu.getIntegrationUtilities().getRandom().upload(normals.data()); }
     cu.setPeriodicBoxSize(box[0], box[1], box[2]);
     std::vector<double> velm(4 * n);
     std::vector<float> posq(4 * n), corr(4 * n, 0.f);
@@ -162,6 +197,7 @@ static int run(const char* out, bool middle, int consMode, double cosacc, int ns
     std::ofstream f(out, std::ios::binary);
     put(f, masses); put(f, charges); put(f, molId); put(f, pairs); put(f, cons); put(f, pos); put(f, vel);
     put(f, velm); put(f, posq); put(f, corr); put(f, vis); put(f, consDist);
+    put(f, ldList); put(f, imgList); put(f, elList); put(f, normals);
     std::printf("RUN OK steps=%d time=%.6f stepCount=%lld vMax=%.9g\n", nsteps, cu.getTime(), cu.getStepCount(), vis[0]);
     // how the adapters used the context services (the reference's pattern: HOST:60-63, 136-141, 214-216, 307-319)
     double ss[2] = {-1, -1};
@@ -171,6 +207,10 @@ static int run(const char* out, bool middle, int consMode, double cosacc, int ns
                 "applyConstraints=%d applyVelocityConstraints=%d setAsCurrent=%d\n", cu.selectorUses, cu.selectorDepth, pd.initializeContextsCalls,
                 c.initRandom, c.setNextStepSize, ss[0], ss[1], c.computeVirtualSites, cu.reorderCalls, c.applyConstraints, c.applyVelocityConstraints,
                 cu.setAsCurrentCalls);
+    {   // deferred fusion in the adapters (HipVVKernels.h): fused steps launched on a completed stage sequence / stages run one by one
+        std::shared_ptr<HipVVPlan> plan = HipVVPlan::find(cu);
+        std::printf("DEFER fused=%ld staged=%ld\n", plan->fusedSteps, plan->stagedCalls);
+    }
     return 0;
 }
 

@@ -46,7 +46,9 @@ def _read(path):
     raw = open(path, "rb").read()
     off = 0
     out = []
-    for dt in ("f8", "f8", "i4", "i4", "i4", "f8", "f8", "f8", "f4", "f4", "f8", "f8"):
+    for dt in ("f8", "f8", "i4", "i4", "i4", "f8", "f8", "f8", "f4", "f4", "f8", "f8", "i4", "i4", "i4", "f4"):
+        if off >= len(raw):
+            break
         (n,) = struct.unpack_from("<q", raw, off)
         off += 8
         a = np.frombuffer(raw, dtype=dt, count=n, offset=off).copy()
@@ -55,9 +57,33 @@ def _read(path):
     return out
 
 
+def _oracle_for(arrays, middle, cons, cos, nsteps):
+    """The oracle stepped on the system the C++ driver dumped (cons == 3: wall atoms with Langevin thermostat, image particles, field)."""
+    masses, charges, mol, pairs, cns, pos, vel = arrays[:7]
+    cdist = arrays[11]
+    n = masses.shape[0]
+    spec = systems.SystemSpec(name="cpp", masses=masses, charges=charges, positions=pos.reshape(n, 3), velocities=vel.reshape(n, 3),
+                              box=np.array([3.0, 3.0, 3.0]), mol_id=mol, drude_pairs=pairs.reshape(-1, 2),
+                              constraints=cns.reshape(-1, 2), has_cm_motion_remover=cons != 3)
+    if cons == 2:       # hydrogen-type clusters: solved in the fused kernels, and by the oracle's SHAKE (cons == 1: see the driver)
+        spec.constraint_distances = cdist
+    p = O.Params(temperature=333.0, drude_temperature=1.0, max_drude_distance=0.02, cos_acceleration=cos, use_middle_scheme=bool(middle))
+    rnd = None
+    if cons == 3:
+        ld, img, el, normals = arrays[12:16]
+        spec.particles_ld = [int(i) for i in ld]
+        spec.image_pairs = [(int(a), int(b)) for a, b in img.reshape(-1, 2)]
+        spec.particles_electrolyte = [int(i) for i in el]
+        p.mirror_location, p.electric_field = 3.5, 2.0 / 3.0 * 1.602176634e-22
+        rnd = normals.reshape(-1, 4)
+    osys = O.OracleSystem(spec, p, "mixed", random=rnd, force_mode=1)
+    osys.step(nsteps)
+    return osys
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("middle,cons,cos", [(1, 0, 0.0), (1, 1, 0.0), (1, 0, 0.02), (1, 1, 0.02), (0, 0, 0.0), (0, 1, 0.02),
-                                             (1, 2, 0.0), (1, 2, 0.02), (0, 2, 0.0)])
+                                             (1, 2, 0.0), (1, 2, 0.02), (0, 2, 0.0), (1, 3, 0.0), (0, 3, 0.0)])
 def test_cpp_integrator_through_plugin_matches_oracle(tmp_path, middle, cons, cos):
     nsteps = 12
     dump = str(tmp_path / "run.bin")
@@ -70,7 +96,7 @@ def test_cpp_integrator_through_plugin_matches_oracle(tmp_path, middle, cons, co
     # and atoms reordered after every position update, also on the fused path (:214-216, 374-381)
     import re
     sv = dict(re.findall(r"(\w+)=(\([^)]*\)|\S+)", next(ln for ln in r.stdout.splitlines() if ln.startswith("SERVICES"))))
-    nkern = 2 + (1 if cos else 0)                        # step kernel + Nose-Hoover (+ cos) initialize() calls
+    nkern = 2 + (1 if cos else 0) + (3 if cons == 3 else 0)      # step kernel + Nose-Hoover (+ cos; + Langevin, image, field) initialize() calls
     assert int(sv["selector"]) == nkern and int(sv["depth"]) == 0 and int(sv["initializeContexts"]) == 1 and int(sv["initRandom"]) == 1
     assert int(sv["setNextStepSize"]) == (1 if middle else 0)
     assert sv["stepSize"] == "(0,0.001)"
@@ -80,20 +106,15 @@ def test_cpp_integrator_through_plugin_matches_oracle(tmp_path, middle, cons, co
         assert int(sv["applyConstraints"]) == nsteps and int(sv["applyVelocityConstraints"]) == nsteps
     else:
         assert int(sv["applyConstraints"]) == 0 and int(sv["applyVelocityConstraints"]) == 0
-    masses, charges, mol, pairs, cns, pos, vel, velm, posq, corr, vis, cdist = _read(dump)
+    arrays = _read(dump)
+    masses, charges, mol, pairs, cns, pos, vel, velm, posq, corr, vis, cdist = arrays[:12]
     n = masses.shape[0]
-    spec = systems.SystemSpec(name="cpp", masses=masses, charges=charges, positions=pos.reshape(n, 3), velocities=vel.reshape(n, 3),
-                              box=np.array([3.0, 3.0, 3.0]), mol_id=mol, drude_pairs=pairs.reshape(-1, 2),
-                              constraints=cns.reshape(-1, 2), has_cm_motion_remover=True)
-    if cons == 2:       # hydrogen-type clusters: solved in the fused kernels, and by the oracle's SHAKE (cons == 1: see the driver)
-        spec.constraint_distances = cdist
-    p = O.Params(temperature=333.0, drude_temperature=1.0, max_drude_distance=0.02, cos_acceleration=cos, use_middle_scheme=bool(middle))
-    osys = O.OracleSystem(spec, p, "mixed", force_mode=1)
-    osys.step(nsteps)
+    osys = _oracle_for(arrays, middle, cons, cos, nsteps)
     x_g = posq.reshape(n, 4)[:, :3].astype(np.float64) + corr.reshape(n, 4)[:, :3].astype(np.float64)
     v_g = velm.reshape(n, 4)[:, :3]
+    massive = masses != 0
     ex = np.abs(x_g - osys.positions()).max() / np.abs(osys.positions()).max()
-    ev = np.abs(v_g - osys.velm[:, :3]).max() / np.abs(osys.velm[:, :3]).max()
+    ev = np.abs(v_g[massive] - osys.velm[massive, :3]).max() / np.abs(osys.velm[massive, :3]).max()
     assert ex < 1e-5 and ev < 1e-5, (ex, ev)
     if cos != 0:
         assert vis[0] == pytest.approx(osys.viscosity()[0], rel=1e-6, abs=1e-12)
@@ -119,7 +140,7 @@ def test_plugin_registers_under_the_reference_api():
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.exists(REF_DRIVER), reason="oracle/_ref/refplugin not built (reference sources absent)")
-@pytest.mark.parametrize("middle,cons,cos", [(1, 0, 0.0), (1, 1, 0.0), (1, 0, 0.02), (1, 1, 0.02), (0, 0, 0.0), (0, 1, 0.02)])
+@pytest.mark.parametrize("middle,cons,cos", [(1, 0, 0.0), (1, 1, 0.0), (1, 0, 0.02), (1, 1, 0.02), (0, 0, 0.0), (0, 1, 0.02), (1, 3, 0.0), (0, 3, 0.0)])
 def test_reference_integrator_drives_the_hip_kernels(tmp_path, middle, cons, cos):
     """Drop-in at the KernelImpl boundary with the reference on top: the reference's VVIntegrator::step (its own stepMiddle / stepVV,
     compiled in place) calls this repository's seven HIP kernels through the reference's virtuals, stage by stage (it does not know the
@@ -128,24 +149,33 @@ def test_reference_integrator_drives_the_hip_kernels(tmp_path, middle, cons, cos
     dump_r, dump_o = str(tmp_path / "ref.bin"), str(tmp_path / "own.bin")
     r = subprocess.run([REF_DRIVER, "run", dump_r, str(middle), str(cons), str(cos), str(nsteps)], capture_output=True, text=True)
     assert r.returncode == 0 and "RUN OK" in r.stdout and f"stepCount={nsteps}" in r.stdout, r.stdout + r.stderr
+    # deferred fusion (HipVVKernels.h): the reference's stage-by-stage calls complete the expected sequence once per step (twice in the
+    # classic scheme) and each completion launched ONE fused step; with constraints OpenMM's solver must interleave nothing is deferred
+    import re
+    fused, staged = map(int, re.search(r"DEFER fused=(\d+) staged=(\d+)", r.stdout).groups())
+    assert (fused, staged) == ((nsteps if middle else 2 * nsteps, 0) if cons in (0, 3) else (0, 0)), r.stdout
+    # ... and the same run with the deferral switched off (every stage its own launch) ends in the same state to rounding
+    dump_s = str(tmp_path / "staged.bin")
+    st = subprocess.run([REF_DRIVER, "run", dump_s, str(middle), str(cons), str(cos), str(nsteps)], capture_output=True, text=True,
+                        env=dict(os.environ, VVHIP_PLUGIN_DEFER="0"))
+    assert st.returncode == 0 and "DEFER fused=0" in st.stdout, st.stdout + st.stderr
+    staged_run = _read(dump_s)
     o = subprocess.run([DRIVER, "run", dump_o, str(middle), str(cons), str(cos), str(nsteps)], capture_output=True, text=True)
     assert o.returncode == 0 and "RUN OK" in o.stdout, o.stdout + o.stderr
-    masses, charges, mol, pairs, cns, pos, vel, velm, posq, corr, vis, cdist = _read(dump_r)
+    arrays = _read(dump_r)
+    masses, charges, mol, pairs, cns, pos, vel, velm, posq, corr, vis, cdist = arrays[:12]
     own = _read(dump_o)
     n = masses.shape[0]
-    spec = systems.SystemSpec(name="cpp", masses=masses, charges=charges, positions=pos.reshape(n, 3), velocities=vel.reshape(n, 3),
-                              box=np.array([3.0, 3.0, 3.0]), mol_id=mol, drude_pairs=pairs.reshape(-1, 2),
-                              constraints=cns.reshape(-1, 2), has_cm_motion_remover=True)
-    p = O.Params(temperature=333.0, drude_temperature=1.0, max_drude_distance=0.02, cos_acceleration=cos, use_middle_scheme=bool(middle))
-    osys = O.OracleSystem(spec, p, "mixed", force_mode=1)
-    osys.step(nsteps)
+    osys = _oracle_for(arrays, middle, cons, cos, nsteps)
     x_g = posq.reshape(n, 4)[:, :3].astype(np.float64) + corr.reshape(n, 4)[:, :3].astype(np.float64)
     v_g = velm.reshape(n, 4)[:, :3]
+    massive = masses != 0
     ex = np.abs(x_g - osys.positions()).max() / np.abs(osys.positions()).max()
-    ev = np.abs(v_g - osys.velm[:, :3]).max() / np.abs(osys.velm[:, :3]).max()
+    ev = np.abs(v_g[massive] - osys.velm[massive, :3]).max() / np.abs(osys.velm[massive, :3]).max()
     assert ex < 1e-9 and ev < 1e-9, (ex, ev)
     # the two host classes end in the same state to rounding (different launch granularity, same arithmetic)
     assert np.allclose(velm, own[7], rtol=0, atol=1e-9 * np.abs(velm).max()) and np.allclose(posq, own[8], rtol=0, atol=2e-7 * np.abs(posq).max())
+    assert np.allclose(velm, staged_run[7], rtol=0, atol=1e-9 * np.abs(velm).max()) and np.allclose(posq, staged_run[8], rtol=0, atol=2e-7 * np.abs(posq).max())
     if cos != 0:
         assert vis[0] == pytest.approx(osys.viscosity()[0], rel=1e-6, abs=1e-12)
 
