@@ -385,12 +385,13 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
     int per_R = 0, per_clusters_per_cell = 0;
     std::vector<int> reg_cluster_start;                              // first cluster (cell-local) of region r
     auto try_periodic = [&]() -> bool {
-        // Measured on MI355X (same box, alternating runs): with 8.9 M particles kernel B 305 -> 277 us, with 0.9 M 27.9 -> 26.7 us; with
-        // 111 k particles the block's copy of the pattern rows and its barrier cost more than the slot load did (kernel B 6.0 -> 6.4 us)
-        // and best-fit packing needs 13 % fewer waves.  So: large systems only, unless VVHIP_PERIODIC=1 / 0 says always / never.
+        // Measured on MI355X (same box, alternating runs): with 8.9 M particles kernel B 305 -> 277 us; whole steps per second with 222 k / 333 k /
+        // 555 k particles +3 / +5 / +7 %; with 111 k particles the block's copy of the pattern rows and its barrier cost more than the slot
+        // load did (kernel B 6.0 -> 6.4 us) and best-fit packing needs 13 % fewer waves.  So: from 0.2 M lanes, unless VVHIP_PERIODIC=1 / 0
+        // says always / never.
         size_t lanes = 0;
         for (const Cluster& c : clusters) lanes += c.members.size();
-        bool want = lanes >= 640000;
+        bool want = lanes >= 200000;
         if (const char* e = std::getenv("VVHIP_PERIODIC")) want = std::atoi(e) != 0;
         if (!want) return false;
         if (hp.has_ld || hp.has_images || hp.num_big > 0 || !shakes.empty() || clusters.empty()) return false;

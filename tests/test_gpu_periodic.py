@@ -1,5 +1,5 @@
 """-m gpu: the arithmetic ("periodic") work-item layout -- particle indices computed from the wave index, role words from the pattern wave
-(vv_host.hpp: PeriodicLayout) -- forced on small systems (it is automatic from ~0.64 M particles) and compared with the oracle like
+(vv_host.hpp: PeriodicLayout) -- forced on small systems (it is automatic from ~0.2 M particles) and compared with the oracle like
 every other path, in kernel B alone (the default where the layout is on) and in both kernels; plus bit-equality of the trajectory with
 the explicit-slot kernels on the same layout, which is what the change must preserve."""
 import importlib

@@ -196,7 +196,7 @@ def test_rigid_water_is_recognised_as_settle_clusters():
 @pytest.mark.parametrize("cfg,expect", [("C1", 1), ("C2", 1), ("C3", 1), ("C4", 1), ("C5", 0)])
 def test_periodic_layout_is_found_for_runs_of_identical_molecules(cfg, expect, monkeypatch):
     """vv_host.hpp PeriodicLayout: the BASELINE bulk boxes are runs of identical molecules (C3: 12 cells of 250 cations + 250 anions), the
-    electrode slab with its image particles is not.  Forced on here (auto only from ~0.64 M particles); analyze() itself verifies, lane
+    electrode slab with its image particles is not.  Forced on here (auto only from ~0.2 M particles); analyze() itself verifies, lane
     for lane, that the arithmetic layout reproduces the explicit slot table before enabling it -- these are the invariants seen from outside."""
     monkeypatch.setenv("VVHIP_PERIODIC", "1")
     spec = systems.make_config(cfg)
