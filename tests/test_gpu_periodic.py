@@ -94,3 +94,18 @@ def test_periodic_kernels_in_the_large_system_launch_shape(cos, monkeypatch):
     ev = np.abs(v_p[:, :3] - osys.velm[:, :3]).max() / np.abs(osys.velm[:, :3]).max()
     ex = np.abs(p_p[:, :3].astype(np.float64) - osys.posq[:, :3]).max() / np.abs(osys.posq[:, :3]).max()
     assert ev < 1e-9 and ex < 2e-7, f"rel err vel {ev:.2e} pos {ex:.2e}"
+
+
+def test_periodic_layout_switches_itself_on_and_matches_the_oracle_at_that_size(monkeypatch):
+    """C3 tiled twice (222 000 particles): the first size at which the arithmetic layout is chosen without being asked for."""
+    for k in ("VVHIP_PERIODIC", "VVHIP_PERIODIC_K", "VVHIP_PERIODIC_A"):
+        monkeypatch.delenv(k, raising=False)
+    spec = systems.make_config("C3", scale=2)
+    flag, v, x, c, ke = _run(spec, "mixed", 6, {}, monkeypatch, maxd=0.02)
+    assert flag == 1
+    osys = O.OracleSystem(spec, O.Params(temperature=333.0, drude_temperature=1.0, max_drude_distance=0.02), "mixed", force_mode=1, num_threads=8)
+    osys.step(6)
+    ev = np.abs(v[:, :3] - osys.velm[:, :3]).max() / np.abs(osys.velm[:, :3]).max()
+    ex = np.abs(x[:, :3].astype(np.float64) - osys.posq[:, :3]).max() / np.abs(osys.posq[:, :3]).max()
+    assert ev < 1e-9 and ex < 2e-7, f"rel err vel {ev:.2e} pos {ex:.2e}"
+    assert np.allclose(ke[:3], osys.ke2()[:3], rtol=1e-9)
