@@ -134,3 +134,89 @@ def test_shards_partition_the_lanes(inv, world):
         live = slots[:, 0] >= 0
         assert (slots[live, 0] < e - b).all()                                                   # shard-relative particle indices
     assert total == full.num_slots_used
+
+
+@st.composite
+def repeated_inventories(draw):
+    """Systems made of runs of identical molecules, cell after cell, optionally with one odd molecule somewhere: what the arithmetic
+    work-item layout (vv_host.hpp: PeriodicLayout) is for, and what it must decline gracefully."""
+    templates = []
+    for _ in range(draw(st.integers(1, 3))):
+        size = draw(st.sampled_from([1, 2, 3, 4, 7, 10, 19, 27, 33, 64]))
+        units, k = [], 0
+        while k < size:
+            if draw(st.booleans()) and k + 2 <= size:
+                units.append("pair"); k += 2
+            else:
+                units.append(draw(st.sampled_from(["heavy", "hydrogen"]))); k += 1
+        templates.append((units, 12.0 + draw(st.integers(0, 2))))
+    counts = [draw(st.integers(1, 14)) for _ in templates]
+    cells = draw(st.integers(1, 4))
+    defect = draw(st.sampled_from([None, None, "middle", "end"]))
+    masses, mol_id, pairs = [], [], []
+    mol = 0
+    def add(units, heavy):
+        nonlocal mol
+        for u in units:
+            if u == "pair":
+                masses.extend([heavy - 0.4, 0.4]); pairs.append((len(masses) - 1, len(masses) - 2)); mol_id.extend([mol, mol])
+            else:
+                masses.append(heavy if u == "heavy" else 1.008); mol_id.append(mol)
+        mol += 1
+    for c in range(cells):
+        for (units, heavy), cnt in zip(templates, counts):
+            for j in range(cnt):
+                add(units, heavy)
+                if defect == "middle" and c == cells // 2 and j == cnt // 2 and (units, heavy) == templates[0]:
+                    add(["heavy", "heavy", "heavy"], 15.5)
+    if defect == "end":
+        add(["heavy", "pair"], 15.5)
+    return masses, mol_id, pairs, draw(st.booleans()), draw(st.integers(0, 2 ** 31 - 1))
+
+
+@settings(max_examples=150, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@given(repeated_inventories())
+def test_periodic_layout_on_random_repeated_inventories(inv):
+    import os
+    masses, mol_id, pairs, use_com, seed = inv
+    spec = _spec(masses, mol_id, pairs, seed)
+    it = I.VVIntegrator(300.0, 10, 1.0, 40, 0.001)
+    it.setUseCOMTempGroup(use_com)
+    old = os.environ.get("VVHIP_PERIODIC")
+    try:
+        os.environ["VVHIP_PERIODIC"] = "0"
+        info0, slots0 = I.plan_layout(spec, it)
+        os.environ["VVHIP_PERIODIC"] = "1"
+        it1 = I.VVIntegrator(300.0, 10, 1.0, 40, 0.001)
+        it1.setUseCOMTempGroup(use_com)
+        info1, slots1 = I.plan_layout(spec, it1)
+    finally:
+        if old is None:
+            os.environ.pop("VVHIP_PERIODIC", None)
+        else:
+            os.environ["VVHIP_PERIODIC"] = old
+    event(f"periodic={info1.periodic_layout} com={use_com}")
+    assert info0.periodic_layout == 0
+    # the thermostat constants do not depend on the layout
+    assert list(info0.dof) == list(info1.dof) and list(info0.nkbt) == list(info1.nkbt) and info0.num_pairs_nh == info1.num_pairs_nh
+    for slots in (slots0, slots1):
+        atoms, meta = slots[:, 0], slots[:, 1].astype(np.uint32)
+        used = atoms >= 0
+        assert np.array_equal(np.sort(atoms[used]), np.arange(spec.num_atoms))          # every particle exactly one lane (all are massive here)
+        lane, wave = np.arange(slots.shape[0]) % 64, np.arange(slots.shape[0]) // 64
+        slot_of = np.empty(spec.num_atoms, np.int64)
+        slot_of[atoms[used]] = np.nonzero(used)[0]
+        for d, par in spec.drude_pairs:
+            assert wave[slot_of[d]] == wave[slot_of[par]]
+            assert ((meta[slot_of[d]] >> 4) & 63) == lane[slot_of[par]] and ((meta[slot_of[par]] >> 4) & 63) == lane[slot_of[d]]
+        if use_com:                                                                        # a molecule = one segment of one wave
+            first, last = (meta >> 10) & 63, (meta >> 16) & 63
+            for m in np.unique(spec.mol_id):
+                sl = slot_of[np.nonzero(spec.mol_id == m)[0]]
+                assert len(set(wave[sl])) == 1 and len(set(first[sl])) == 1 and len(set(last[sl])) == 1
+                assert int(last[sl][0]) - int(first[sl][0]) + 1 == len(sl)
+    if info1.periodic_layout:
+        a2, u2 = slots1[:, 0].reshape(-1, 64), (slots1[:, 0] >= 0).reshape(-1, 64)
+        cnt = u2.sum(axis=1)
+        assert all(u2[w, :cnt[w]].all() and not u2[w, cnt[w]:].any() for w in range(a2.shape[0]))
+        assert np.array_equal(slots1[:, 0][slots1[:, 0] >= 0], np.arange(spec.num_atoms))
