@@ -1132,7 +1132,8 @@ __global__ void __launch_bounds__(64) vv_kernel_chain(const NHConst c, NHDevStat
 
 template <class real, class mixed, uint32_t SF>
 __global__ void __launch_bounds__(512) vv_kernel_b(const int2* __restrict__ pre_slots, const int pre_nwaves, const int pre_wpb, const unsigned long long* __restrict__ pre_acc,
-                                                   const NHDevState* __restrict__ pre_nh, const ChainLaneBlock* __restrict__ pre_lane_const, const KArgs a) {
+                                                   const NHDevState* __restrict__ pre_nh, const ChainLaneBlock* __restrict__ pre_lane_const, const int* __restrict__ pre_seg_base,
+                                                   const KArgs a) {
     using real4 = typename Vec<real>::v4;
     using real3 = typename Vec<real>::v3;
     using mixed4 = typename Vec<mixed>::v4;
@@ -1334,7 +1335,8 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const int2* __restrict__ pre_
         // removed): one 32-byte entry per molecule, the same address for every lane of the segment
         const unsigned long long leaders = (F & B_SCALE) ? __ballot((meta & META_COM_LEADER) != 0) : 0ull;     // in every lane: a wave-wide vote
         if ((F & B_SCALE) && nh && use_com) {
-            const int segi = ((F & B_PERIODIC) ? pw.seg0 : a.seg_base[__builtin_amdgcn_readfirstlane(wave)]) + (int) lanes_below(leaders);
+            // (pre_seg_base: a preloaded argument, so that this scalar load does not queue behind the loads of the argument block)
+            const int segi = ((F & B_PERIODIC) ? pw.seg0 : pre_seg_base[__builtin_amdgcn_readfirstlane(wave)]) + (int) lanes_below(leaders);
             const mixed4 cv = ((const mixed4*) a.comv)[segi];
             Vx = cv.x; Vy = cv.y; Vz = cv.z; Vw = cv.w;
             if (F & B_KE_MOM) com_w = (mixed) a.comw[segi];
@@ -1886,7 +1888,7 @@ hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_c
     vv_last_grid_value = g.x;
     const dim3 b(block_threads + ((a.flags & B_CHAIN) ? 64 : 0));
     constexpr uint32_t XM = SF_BM;
-#define VV_PRE_ARGS a.slots, a.nwaves, (int) (b.x >> 6), (const unsigned long long*) a.acc, a.nh, a.lane_const
+#define VV_PRE_ARGS a.slots, a.nwaves, (int) (b.x >> 6), (const unsigned long long*) a.acc, a.nh, a.lane_const, a.seg_base
     if ((a.flags & B_CHAIN) && a.chain.num_chains != 3) {       // the specialised kernels carry the three-link chain only
         VV_DISPATCH_SF(vv_kernel_b, 0u, g, b, 0, s, VV_PRE_ARGS, a);
         return hipGetLastError();
