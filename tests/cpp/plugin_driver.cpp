@@ -4,6 +4,7 @@
 //   vv_plugin_driver registry                 (no GPU needed) checks registration, names and error behaviour
 //   vv_plugin_driver chain                    (no GPU needed) prints VVIntegrator::propagateNHChain on fixed inputs
 //   vv_plugin_driver run OUT middle cons cos N   (GPU) runs N steps on a small Drude system and dumps system + result
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -190,7 +191,12 @@ static int run(const char* out, bool middle, int consMode, double cosacc, int ns
     ForceUser fu = {&cu, &site};
     ctx.getImpl().setForceCallback(tether, &fu);
     ctx.initialize();
+    (void) hipDeviceSynchronize();
+    const auto t0 = std::chrono::steady_clock::now();
     it.step(nsteps);
+    (void) hipDeviceSynchronize();
+    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::printf("TIMING steps=%d wall_s=%.6f steps_per_s=%.1f (host-launched, no graph)\n", nsteps, wall, nsteps / wall);
     std::vector<double> vis = it.getViscosity();
     (void) hipDeviceSynchronize();
     cu.getVelm().download(velm.data()); cu.getPosq().download(posq.data()); cu.getPosqCorrection().download(corr.data());
