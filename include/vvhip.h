@@ -309,6 +309,22 @@ int vvhip_set_trace(vvhip_plan* plan, int enable);
 int vvhip_timing_enable(vvhip_plan* plan, int enable);
 int vvhip_timing_read(vvhip_plan* plan, double* ms_pass_a, double* ms_pass_b, double* ms_other, int32_t launches[3]);
 
+/* ---------------------------------------------------------------- environment (read once, at vvhip_plan_create)
+ * Behaviour switches, all optional; defaults are what the measurements in DESIGN.md section 7 selected.
+ *   VVHIP_PERIODIC=1|0        arithmetic work-item layout (vv_host.hpp: PeriodicLayout) always / never; default: from 0.2 M lanes, when the
+ *                             system is runs of identical molecules (vvhip_plan_info.periodic_layout tells)
+ *   VVHIP_PERIODIC_K=0        keep that layout but let kernel B load its slot words (comparison runs);  VVHIP_PERIODIC_A=1: kernel A
+ *                             computes its particle indices too (no gain measured)
+ *   VVHIP_REKICK=0            kernel A stores the kicked velocities, kernel B does not repeat the kick
+ *   VVHIP_MTAB_A=1 / VVHIP_MTAB_B=0   static mass tables in kernel A (off) / kernel B (on)
+ *   VVHIP_NO_MOMENTS=1        cos perturbation as three launches (bias, sums, scale) instead of two
+ *   VVHIP_SPLIT_CHAIN_WAVES=n the thermostat chain becomes its own 1-wave launch from n waves on (default 12288)
+ *   VVHIP_BLOCK=t, VVHIP_CAP_A=b, VVHIP_CAP_B=b   launch shape: threads per block (multiple of 64), most blocks per launch of kernel A / B
+ *   VVHIP_WT=1                write-through stores in the fused kernels (tuning experiment)
+ *   VVHIP_ROCTX=1             roctx ranges (see vvhip_set_trace)
+ * and in the OpenMM adapters (platforms/hip): VVHIP_PLUGIN_DEFER=0 -- run every KernelImpl call as its own launch(es) instead of answering a
+ * completed stage-by-stage sequence with the fused step. */
+
 /* ---------------------------------------------------------------- test hooks
  * Used by tests/ to drive single stages against the oracle; not needed by an integrating host.
  * kernel: 0 = A (produce), 1 = B (consume), 2 = chain; flags are the stage bits of csrc/vv_kernels.hpp. */
