@@ -71,6 +71,22 @@ CONFIGS = {
 }
 
 
+# The BASELINE configurations at their FULL size (reference topologies): too large to commit whole, so the fixture keeps every 97th particle's
+# velocity / position after FULL_STEPS steps plus the global quantities every particle depends on (2KE per group, scale factors, DOF).
+FULL = {
+    "C3_full": lambda: (systems.make_config("C3"), O.Params(temperature=333.0, max_drude_distance=0.02)),
+    "C4_full": lambda: (systems.make_config("C4"), O.Params(temperature=333.0, max_drude_distance=0.02, cos_acceleration=0.01)),
+    "C5_full": lambda: _c5_full(),
+}
+FULL_STEPS, FULL_STRIDE = 4, 97
+
+
+def _c5_full():
+    spec = systems.make_config("C5")
+    return spec, O.Params(temperature=333.0, max_drude_distance=0.02, mirror_location=float(spec.box[2]) / 2,
+                          electric_field=2.0 / float(spec.box[2]) * 1.602176634e-22)
+
+
 def precisions_of(name):
     """The reference passes posqCorrection = 0 to updateImagePositions outside mixed mode (CudaVVKernels.cpp:928) and the kernel
     dereferences it unconditionally (kernels/imageCharge.cu:15-16): with image pairs only mixed precision can run (here: a segfault)."""
@@ -115,6 +131,20 @@ def main():
         print(name, "ok", launches[name])
     with open(LAUNCHES, "w") as f:
         json.dump(launches, f, indent=1)
+    for name in sorted(FULL):
+        spec, params = FULL[name]()
+        rnd, force = inputs_for(spec, params, FULL_STEPS)
+        r = RH.RefHost(spec, params, "mixed", random=rnd, force=force)
+        assert r.h, r.error
+        r.step(FULL_STEPS)
+        th = r.thermostat()
+        idx = np.arange(0, spec.num_atoms, FULL_STRIDE)
+        np.savez_compressed(os.path.join(GOLDEN, f"refhost_{name}.npz"), steps=np.int32(FULL_STEPS), index=idx.astype(np.int32),
+                            velm=r.velm[idx], posq=r.posq[idx], posq_corr=r.state["posq_corr"][idx], ke2=th["ke2"], vscale=th["vscale"],
+                            dof=th["dof"], nkbt=th["nkbt"], num_tg=np.int32(th["num_tg"]),
+                            sum_velm=r.velm[:, :3].sum(axis=0), sum_posq=r.posq[:, :3].astype(np.float64).sum(axis=0))
+        r.close()
+        print(name, "ok", spec.num_atoms, "particles,", len(idx), "sampled")
 
 
 if __name__ == "__main__":

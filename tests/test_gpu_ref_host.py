@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from oracle.make_golden_refhost import CONFIGS, GOLDEN, inputs_for, make_spec, precisions_of
+from oracle.make_golden_refhost import CONFIGS, FULL, FULL_STEPS, GOLDEN, inputs_for, make_spec, precisions_of
 
 pkg = importlib.import_module("openmm-velocityverlet_amd")
 H, I = pkg.vvhip, pkg.integrator
@@ -63,5 +63,39 @@ def test_product_reproduces_reference_pipeline(name, prec):
         assert ev < TOL[prec] and ep < ptol, f"{name}/{prec}: rel err vel {ev:.2e} pos {ep:.2e}"
         assert np.array_equal(velm[:, 3], rv[:, 3]) and np.array_equal(posq[:, 3], rp[:, 3])      # inverse masses / charges untouched
         print(f"{name}/{prec}: vs the reference's own pipeline, rel err vel {ev:.2e} pos {ep:.2e}")
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("name", sorted(FULL))
+def test_product_reproduces_reference_pipeline_at_full_baseline_size(name):
+    """The BASELINE configurations at full size on the reference's own topologies: product (fused path, hipGraph-free stepping) against a run
+    of the reference's whole step -- every 97th particle, the group kinetic energies, the scale factors, the velocity sum."""
+    g = np.load(os.path.join(GOLDEN, f"refhost_{name}.npz"))
+    spec, params = FULL[name]()
+    rnd, force = inputs_for(spec, params, FULL_STEPS)
+    it = _integrator(params)
+    ctx = I.Context(spec, it, precision="mixed", force_provider="static", random=rnd)
+    try:
+        ctx.force.upload(force)
+        ntg = int(g["num_tg"])
+        assert ctx.info.num_temp_groups == ntg and np.array_equal(np.array(list(ctx.info.dof)), g["dof"])
+        assert np.array_equal(np.array(list(ctx.info.nkbt))[:ntg], g["nkbt"][:ntg])
+        it.step(int(g["steps"]))
+        velm, posq, corr = ctx.getVelm(), ctx.getPosq(), ctx.getPosqCorrection()
+        idx = g["index"]
+        rv, rp, rc = g["velm"], g["posq"], g["posq_corr"]
+        massive = rv[:, 3] != 0
+        ev = np.abs(velm[idx][massive, :3] - rv[massive, :3]).max() / np.abs(rv[massive, :3]).max()
+        x = posq[idx][:, :3].astype(np.float64) + corr[idx][:, :3].astype(np.float64)
+        xr = rp[:, :3].astype(np.float64) + rc[:, :3].astype(np.float64)
+        ex = np.abs(x - xr).max() / np.abs(xr).max()
+        assert ev < 1e-9 and ex < 1e-9, f"{name}: rel err vel {ev:.2e} pos {ex:.2e}"
+        st = ctx.getNHState()
+        assert np.allclose(np.array(list(st.ke2))[:ntg], g["ke2"][:ntg], rtol=1e-10)
+        assert np.allclose(np.array(list(st.vscale))[:ntg], g["vscale"][:ntg], rtol=0, atol=1e-12)
+        sv = velm[:, :3].sum(axis=0)
+        assert np.allclose(sv, g["sum_velm"], rtol=0, atol=1e-9 * np.abs(velm[:, :3]).sum())
+        print(f"{name}: vs the reference's own pipeline at full size, rel err vel {ev:.2e} pos {ex:.2e}")
     finally:
         ctx.close()

@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as O, refhost as RH
-from oracle.make_golden_refhost import CONFIGS, GOLDEN, LAUNCHES, inputs_for, make_spec, precisions_of
+from oracle.make_golden_refhost import CONFIGS, FULL, FULL_STEPS, GOLDEN, LAUNCHES, inputs_for, make_spec, precisions_of
 
 systems = importlib.import_module("openmm-velocityverlet_amd.systems")
 have = pytest.mark.skipif(not all(RH.available(p) for p in O.PRECISIONS), reason="oracle/_ref/libvvref_host_* not built (reference sources absent)")
@@ -186,3 +186,24 @@ def test_reference_launch_order_live():
         r.step(1)
         assert first == rec[name] and r.launches() == rec[name], name
         r.close()
+
+
+@pytest.mark.parametrize("name", sorted(FULL))
+def test_oracle_reproduces_reference_pipeline_at_full_baseline_size(name):
+    """C3 / C4 / C5 on the reference's own topologies, all 111 000 / 40 310 particles: the fixture holds every 97th particle and the global sums
+    of a run of the reference's whole step (host classes + kernels, CPU build); the oracle must reproduce them bit for bit."""
+    g = np.load(os.path.join(GOLDEN, f"refhost_{name}.npz"))
+    spec, params = FULL[name]()
+    rnd, force = inputs_for(spec, params, FULL_STEPS)
+    o = O.OracleSystem(spec, params, "mixed", random=rnd, force_mode=0)      # one thread: the serial summation order of the reference run
+    o.state["force"][:] = force
+    o.step(int(g["steps"]))
+    idx = g["index"]
+    assert np.array_equal(o.velm[idx].view(np.uint8), g["velm"].view(np.uint8))
+    assert np.array_equal(o.posq[idx].view(np.uint8), g["posq"].view(np.uint8))
+    assert np.array_equal(o.posq_corr[idx].view(np.uint8), g["posq_corr"].view(np.uint8))
+    ntg = int(g["num_tg"])
+    assert np.array_equal(o.ke2()[:ntg], g["ke2"][:ntg]) and np.array_equal(o.vscale()[:ntg], g["vscale"][:ntg])
+    t = O.build_tables(spec, params)
+    assert np.array_equal(t["dof"], g["dof"]) and np.array_equal(t["nkbt"], g["nkbt"])
+    assert np.array_equal(o.velm[:, :3].sum(axis=0), g["sum_velm"])
