@@ -77,6 +77,9 @@ FULL = {
     "C3_full": lambda: (systems.make_config("C3"), O.Params(temperature=333.0, max_drude_distance=0.02)),
     "C4_full": lambda: (systems.make_config("C4"), O.Params(temperature=333.0, max_drude_distance=0.02, cos_acceleration=0.01)),
     "C5_full": lambda: _c5_full(),
+    "C1_full": lambda: (systems.make_config("C1"), O.Params(temperature=333.0)),
+    "C2_full": lambda: (systems.make_config("C2"), O.Params(temperature=300.0, step_size=0.002)),
+    "C3_classic_full": lambda: (systems.make_config("C3"), O.Params(temperature=333.0, max_drude_distance=0.02, use_middle_scheme=False)),
 }
 FULL_STEPS, FULL_STRIDE = 4, 97
 
