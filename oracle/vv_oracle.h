@@ -15,8 +15,12 @@
  * VVIntegrator::propagateNHChain (openmmapi/src/VVIntegrator.cpp:340-376, compiled in
  * place by `make refapi` against the stand-in OpenMM headers of compat/:
  * oracle/_ref/libvvref_api.so) through tests/golden/refapi_chain.npz and live in this
- * container (tests/test_ref_api.py).  Both reference builds need a stand-in for
- * something OpenMM supplies (the JIT prelude; the headers), so by the tier's rule the
+ * container (tests/test_ref_api.py).  The whole step (vvo_step: sequencing, host constants, DOF accounting)
+ * is checked bit-for-bit against the reference's WHOLE pipeline -- its VVIntegrator.cpp, CudaVVKernels.cpp,
+ * CudaVVKernelFactory.cpp and kernels compiled in place on stand-in CUDA-platform classes (`make refhost`,
+ * oracle/_ref/libvvref_host_*.so; tests/test_ref_host.py, goldens tests/golden/refhost_*) -- for twelve small
+ * configurations in three precisions and for every BASELINE configuration at full size.  All reference builds need a stand-in for
+ * something OpenMM supplies (the JIT prelude; the headers; the CUDA platform classes), so by the tier's rule the
  * oracle stays "parity unpinned" formally -- see DESIGN.md section 2 for what executed
  * reference code stands behind which statement.  vvo_tether_force is our own
  * synthetic force provider; the SHAKE / SETTLE statements follow OpenMM's published
