@@ -440,7 +440,7 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
             r.sig = h;
             regions.push_back(r);
             i += (size_t) best_p * best_reps;
-            if (regions.size() > 4096) return false;
+            if (regions.size() > ((size_t) 1 << 22)) return false;
         }
         // period of the region list
         const int L = (int) regions.size();
