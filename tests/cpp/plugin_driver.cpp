@@ -75,7 +75,7 @@ static void tether(ContextImpl&, void* user) {
 
 template <class T> static void put(std::ofstream& f, const std::vector<T>& v) { long long n = (long long) v.size(); f.write((const char*) &n, 8); f.write((const char*) v.data(), n * sizeof(T)); }
 
-static int run(const char* out, bool middle, int consMode, double cosacc, int nsteps) {
+static int run(const char* out, bool middle, int consMode, double cosacc, int nsteps, int hostMode = 0) {
     registerHipVVKernelFactories();
     Platform& hip = Platform::getPlatformByName("HIP");
     const int nmol = 40, per = 8;              // [heavy, drude, heavy, drude, heavy, drude, H, H] per molecule
@@ -192,8 +192,27 @@ static int run(const char* out, bool middle, int consMode, double cosacc, int ns
     ctx.getImpl().setForceCallback(tether, &fu);
     ctx.initialize();
     (void) hipDeviceSynchronize();
+    Kernel vv, nh;                             // hostMode 1 / 2: the hand-driven kernel objects (alive until the counters are printed)
     const auto t0 = std::chrono::steady_clock::now();
-    it.step(nsteps);
+    if (hostMode == 0) {
+        it.step(nsteps);
+    } else {
+        // A host that is neither VVIntegrator: its own kernel objects, driven by hand through the KernelImpl virtuals (middle scheme, no
+        // modifiers).  hostMode 1: the reference's order (VVIntegrator.cpp:238-262) -- the adapters' deferred fusion must recognise it;
+        // hostMode 2: a kinetic-energy query between firstIntegrate and scaleVelocity -- not the reference's order: the recorded stage must
+        // run before the query is answered, the remaining stages one by one, and the trajectory must equal that of hostMode 1.
+        vv = hip.createKernel(IntegrateMiddleStepKernel::Name(), ctx.getImpl());
+        nh = hip.createKernel(ModifyDrudeNoseKernel::Name(), ctx.getImpl());
+        vv.getAs<IntegrateMiddleStepKernel>().initialize(system, it, drude);
+        nh.getAs<ModifyDrudeNoseKernel>().initialize(system, it, drude);
+        for (int s = 0; s < nsteps; s++) {
+            ctx.getImpl().calcForcesAndEnergy(true, false);
+            vv.getAs<IntegrateMiddleStepKernel>().firstIntegrate(ctx.getImpl(), it);
+            if (hostMode == 2) (void) vv.getAs<IntegrateMiddleStepKernel>().computeKineticEnergy(ctx.getImpl(), it);
+            nh.getAs<ModifyDrudeNoseKernel>().scaleVelocity(ctx.getImpl(), it);
+            vv.getAs<IntegrateMiddleStepKernel>().secondIntegrate(ctx.getImpl(), it);
+        }
+    }
     (void) hipDeviceSynchronize();
     const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::printf("TIMING steps=%d wall_s=%.6f steps_per_s=%.1f (host-launched, no graph)\n", nsteps, wall, nsteps / wall);
@@ -224,11 +243,11 @@ int main(int argc, char** argv) {
     try {
         if (argc >= 2 && !std::strcmp(argv[1], "registry")) return registry();
         if (argc >= 2 && !std::strcmp(argv[1], "chain")) return chain();
-        if (argc >= 7 && !std::strcmp(argv[1], "run")) return run(argv[2], std::atoi(argv[3]) != 0, std::atoi(argv[4]), std::atof(argv[5]), std::atoi(argv[6]));
+        if (argc >= 7 && !std::strcmp(argv[1], "run")) return run(argv[2], std::atoi(argv[3]) != 0, std::atoi(argv[4]), std::atof(argv[5]), std::atoi(argv[6]), argc >= 8 ? std::atoi(argv[7]) : 0);
     } catch (const std::exception& e) {
         std::fprintf(stderr, "exception: %s\n", e.what());
         return 2;
     }
-    std::fprintf(stderr, "usage: vv_plugin_driver registry | chain | run OUT middle cons cos nsteps\n");
+    std::fprintf(stderr, "usage: vv_plugin_driver registry | chain | run OUT middle cons cos nsteps [hostMode]\n");
     return 64;
 }

@@ -180,6 +180,26 @@ def test_reference_integrator_drives_the_hip_kernels(tmp_path, middle, cons, cos
         assert vis[0] == pytest.approx(osys.viscosity()[0], rel=1e-6, abs=1e-12)
 
 
+@pytest.mark.gpu
+def test_deferred_fusion_only_answers_the_reference_call_order(tmp_path):
+    """A host driving the KernelImpl virtuals by hand (tests/cpp/plugin_driver.cpp, hostMode): in the reference's order every step is
+    answered with one fused step; with a kinetic-energy query between firstIntegrate and scaleVelocity nothing is fused -- the recorded
+    stage runs before the query, the others as they come -- and both end where VVIntegrator::step ends."""
+    import re
+    nsteps, dumps, counts = 12, {}, {}
+    for mode in (0, 1, 2):
+        d = str(tmp_path / f"m{mode}.bin")
+        r = subprocess.run([DRIVER, "run", d, "1", "0", "0.0", str(nsteps), str(mode)], capture_output=True, text=True)
+        assert r.returncode == 0 and "RUN OK" in r.stdout and f"stepCount={nsteps}" in r.stdout, r.stdout + r.stderr
+        dumps[mode] = _read(d)
+        counts[mode] = tuple(map(int, re.search(r"DEFER fused=(\d+) staged=(\d+)", r.stdout).groups()))
+    assert counts[1] == (nsteps, 0), counts
+    assert counts[2] == (0, 3 * nsteps), counts
+    for mode in (1, 2):
+        assert np.allclose(dumps[mode][7], dumps[0][7], rtol=0, atol=1e-9 * np.abs(dumps[0][7]).max())       # velm
+        assert np.allclose(dumps[mode][8], dumps[0][8], rtol=0, atol=2e-7 * np.abs(dumps[0][8]).max())       # posq
+
+
 def test_cmake_build_produces_the_same_plugin(tmp_path):
     """The CMake route (what a maintainer of an OpenMM installation would use) configures and builds the API library, the plugin and
     the driver against the stand-in headers, reusing the in-tree libvvhip.so; the plugin exports the three registration symbols."""
