@@ -148,6 +148,7 @@ void HipVVPlan::flush() {
 }
 bool HipVVPlan::defer(Stage stage, const VVIntegrator& it, std::function<void()> stageByStage) {
     if (!deferEnabled || !noConstraints) return false;
+    if (it.getUseMiddleScheme() ? !fusedMiddle : !(fusedFirst && fusedSecond)) return false;      // the context's step kernel is not the scheme's
     if (pending.empty()) {
         // the sequence the reference's VVIntegrator produces for this configuration (VVIntegrator.cpp:238-267; 295-310 and 316-336)
         vvhip_plan_info info;
