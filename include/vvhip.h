@@ -313,6 +313,7 @@ int vvhip_timing_read(vvhip_plan* plan, double* ms_pass_a, double* ms_pass_b, do
  * Behaviour switches, all optional; defaults are what the measurements in DESIGN.md section 7 selected.
  *   VVHIP_PERIODIC=1|0        arithmetic work-item layout (vv_host.hpp: PeriodicLayout) always / never; default: from 0.2 M lanes, when the
  *                             system is runs of identical molecules (vvhip_plan_info.periodic_layout tells)
+ *   VVHIP_PERIODIC_DEBUG=1    the decomposition into regions and why the layout was (not) enabled, on stderr
  *   VVHIP_PERIODIC_K=0        keep that layout but let kernel B load its slot words (comparison runs);  VVHIP_PERIODIC_A=1: kernel A
  *                             computes its particle indices too (no gain measured)
  *   VVHIP_REKICK=0            kernel A stores the kicked velocities, kernel B does not repeat the kick

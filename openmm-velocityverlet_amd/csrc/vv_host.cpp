@@ -1,3 +1,4 @@
+#include <cstdio>
 // vv_host.cpp -- see vv_host.hpp.  "API" = openmmapi/src/VVIntegrator.cpp, "HOST" =
 // platforms/cuda/src/CudaVVKernels.cpp of the reference.
 #include "vv_host.hpp"
@@ -428,6 +429,7 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
                 size_t j = i + pp;
                 while (j < K && sig[j] == sig[j - pp]) j++;
                 const int reps = (int) ((j - i) / pp);
+                if (reps < 2 && pp > 1) continue;         // a unit must repeat: 13 anions followed by 4 waters are not one 17-cluster unit
                 if ((size_t) reps * pp > best_cover) { best_cover = (size_t) reps * pp; best_p = pp; best_reps = reps; }
             }
             Region r{0, best_p, best_reps, 0, 0};
@@ -442,6 +444,8 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
             i += (size_t) best_p * best_reps;
             if (regions.size() > ((size_t) 1 << 22)) return false;
         }
+        if (std::getenv("VVHIP_PERIODIC_DEBUG"))
+            for (size_t r = 0; r < regions.size() && r < 16; r++) std::fprintf(stderr, "  region %zu: unit of %d cluster(s), %d atoms, x%d\n", r, regions[r].p, regions[r].atoms, regions[r].reps);
         // period of the region list
         const int L = (int) regions.size();
         int R = 0;
@@ -652,8 +656,9 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
         return true;
     };
     bool periodic = try_periodic();
+    if (std::getenv("VVHIP_PERIODIC_DEBUG")) std::fprintf(stderr, "periodic: try=%d regions=%zu R=%d cells=%d wpc=%d apc=%d\n", (int) periodic, regions.size(), per_R, per.ncells, per.wpc, per.apc);
     fill_slots(periodic);
-    if (periodic && !periodic_matches()) { periodic = false; fill_slots(false); }
+    if (periodic && !periodic_matches()) { if (std::getenv("VVHIP_PERIODIC_DEBUG")) std::fprintf(stderr, "periodic: formula does not reproduce the table\n"); periodic = false; fill_slots(false); }
     if (periodic) { per.enabled = 1; hp.per = per; }
     info.periodic_layout = periodic ? 1 : 0;
 

@@ -109,3 +109,44 @@ def test_periodic_layout_switches_itself_on_and_matches_the_oracle_at_that_size(
     ex = np.abs(x[:, :3].astype(np.float64) - osys.posq[:, :3]).max() / np.abs(osys.posq[:, :3]).max()
     assert ev < 1e-9 and ex < 2e-7, f"rel err vel {ev:.2e} pos {ex:.2e}"
     assert np.allclose(ke[:3], osys.ke2()[:3], rtol=1e-9)
+
+
+def _four_species(cells=3, seed=4):
+    """Four kinds of molecules (Drude pairs and plain atoms), each kind in a run, the four runs repeated cell after cell: four regions."""
+    templates = [(["pair", "pair", "pair", "hydrogen"], 12.0), (["pair", "heavy", "heavy"], 14.0), (["heavy", "hydrogen", "hydrogen"], 15.9994), (["heavy"], 35.45)]
+    counts = [9, 13, 20, 30]
+    masses, mol_id, pairs = [], [], []
+    mol = 0
+    for _ in range(cells):
+        for (units, heavy), cnt in zip(templates, counts):
+            for _ in range(cnt):
+                for u in units:
+                    if u == "pair":
+                        masses.extend([heavy - 0.4, 0.4]); pairs.append((len(masses) - 1, len(masses) - 2)); mol_id.extend([mol, mol])
+                    else:
+                        masses.append(heavy if u == "heavy" else 1.008); mol_id.append(mol)
+                mol += 1
+    n = len(masses)
+    rng = np.random.default_rng(seed)
+    masses = np.array(masses)
+    pos = rng.uniform(0, 3, (n, 3))
+    vel = rng.standard_normal((n, 3)) * np.sqrt(systems.BOLTZ * 333.0 / masses)[:, None]
+    pairs = np.array(pairs, np.int32)
+    pos[pairs[:, 0]] = pos[pairs[:, 1]] + rng.normal(0, 2e-4, (len(pairs), 3))           # Drudes next to their parents
+    vel[pairs[:, 0]] = vel[pairs[:, 1]] + rng.standard_normal((len(pairs), 3)) * np.sqrt(systems.BOLTZ * 1.0 / 0.4)
+    return systems.SystemSpec(name="four_species", masses=masses, charges=np.zeros(n), positions=pos, velocities=vel, box=np.array([3.0, 3.0, 3.0]),
+                              mol_id=np.array(mol_id, np.int32), drude_pairs=pairs, constraints=np.zeros((0, 2), np.int32), has_cm_motion_remover=True)
+
+
+@pytest.mark.parametrize("cos", [0.0, 0.02])
+def test_periodic_layout_with_four_regions_per_cell(cos, monkeypatch):
+    spec = _four_species()
+    flag, v_p, p_p, c_p, ke_p = _run(spec, "mixed", 10, {"VVHIP_PERIODIC": "1", "VVHIP_PERIODIC_A": "1"}, monkeypatch, cos=cos, maxd=0.02)
+    assert flag == 1
+    _, v_e, p_e, c_e, ke_e = _run(spec, "mixed", 10, {"VVHIP_PERIODIC": "1", "VVHIP_PERIODIC_K": "0"}, monkeypatch, cos=cos, maxd=0.02)
+    assert np.array_equal(v_p.view(np.uint8), v_e.view(np.uint8)) and np.array_equal(p_p.view(np.uint8), p_e.view(np.uint8)) and np.array_equal(ke_p, ke_e)
+    osys = O.OracleSystem(spec, O.Params(temperature=333.0, drude_temperature=1.0, max_drude_distance=0.02, cos_acceleration=cos), "mixed", force_mode=1)
+    osys.step(10)
+    ev = np.abs(v_p[:, :3] - osys.velm[:, :3]).max() / np.abs(osys.velm[:, :3]).max()
+    ex = np.abs(p_p[:, :3].astype(np.float64) - osys.posq[:, :3]).max() / np.abs(osys.posq[:, :3]).max()
+    assert ev < 1e-9 and ex < 2e-7, f"rel err vel {ev:.2e} pos {ex:.2e}"

@@ -225,3 +225,15 @@ def test_periodic_layout_auto_threshold():
     spec = systems.make_config("C3")
     info, _ = I.plan_layout(spec, _integrator(O.Params(temperature=333.0, max_drude_distance=0.02)))
     assert info.periodic_layout == 0
+
+
+def test_periodic_layout_units_must_repeat(monkeypatch):
+    """Short runs: 13 molecules of one kind followed by 20 of another are two regions, not one long non-repeating unit (the first version of the
+    greedy decomposition took whatever covered the most clusters)."""
+    monkeypatch.setenv("VVHIP_PERIODIC", "1")
+    import tests.test_gpu_periodic as G
+    spec = G._four_species()
+    it = I.VVIntegrator(333.0, 10, 1.0, 40, 0.001)
+    it.setMaxDrudeDistance(0.02)
+    info, slots = I.plan_layout(spec, it)
+    assert info.periodic_layout == 1 and info.num_waves == 3 * 4       # 3 cells x (9x7 | 13x4 | 20x3 | 30x1 atoms: one wave each)
