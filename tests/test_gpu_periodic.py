@@ -150,3 +150,57 @@ def test_periodic_layout_with_four_regions_per_cell(cos, monkeypatch):
     ev = np.abs(v_p[:, :3] - osys.velm[:, :3]).max() / np.abs(osys.velm[:, :3]).max()
     ex = np.abs(p_p[:, :3].astype(np.float64) - osys.posq[:, :3]).max() / np.abs(osys.posq[:, :3]).max()
     assert ev < 1e-9 and ex < 2e-7, f"rel err vel {ev:.2e} pos {ex:.2e}"
+
+
+def _random_repeated(seed):
+    rng = np.random.default_rng(seed)
+    templates = []
+    for _ in range(int(rng.integers(1, 4))):
+        size = int(rng.choice([1, 2, 3, 4, 7, 10, 19, 27, 33, 64]))
+        units, k = [], 0
+        while k < size:
+            if rng.random() < 0.5 and k + 2 <= size:
+                units.append("pair"); k += 2
+            else:
+                units.append("heavy" if rng.random() < 0.6 else "hydrogen"); k += 1
+        templates.append((units, 12.0 + int(rng.integers(0, 3))))
+    counts = [int(rng.integers(1, 15)) for _ in templates]
+    cells = int(rng.integers(1, 5))
+    masses, mol_id, pairs, mol = [], [], [], 0
+    for _ in range(cells):
+        for (units, heavy), cnt in zip(templates, counts):
+            for _ in range(cnt):
+                for u in units:
+                    if u == "pair":
+                        masses.extend([heavy - 0.4, 0.4]); pairs.append((len(masses) - 1, len(masses) - 2)); mol_id.extend([mol, mol])
+                    else:
+                        masses.append(heavy if u == "heavy" else 1.008); mol_id.append(mol)
+                mol += 1
+    n = len(masses)
+    masses = np.array(masses)
+    pos = rng.uniform(0, 3, (n, 3))
+    vel = rng.standard_normal((n, 3)) * np.sqrt(systems.BOLTZ * 333.0 / masses)[:, None]
+    pairs = np.array(pairs, np.int32).reshape(-1, 2)
+    if len(pairs):
+        pos[pairs[:, 0]] = pos[pairs[:, 1]] + rng.normal(0, 2e-4, (len(pairs), 3))
+        vel[pairs[:, 0]] = vel[pairs[:, 1]] + rng.standard_normal((len(pairs), 3)) * np.sqrt(systems.BOLTZ * 1.0 / 0.4)
+    return systems.SystemSpec(name=f"rand{seed}", masses=masses, charges=np.zeros(n), positions=pos, velocities=vel, box=np.array([3.0, 3.0, 3.0]),
+                              mol_id=np.array(mol_id, np.int32), drude_pairs=pairs, constraints=np.zeros((0, 2), np.int32), has_cm_motion_remover=True)
+
+
+def test_periodic_kernels_on_random_repeated_inventories(monkeypatch):
+    """Forty random inventories of repeated molecules (1-3 kinds, 1-14 of each, 1-4 cells; with and without Drude pairs, with and without the COM
+    temperature group): wherever the layout is recognised, computing the slot words must not change a bit of the trajectory."""
+    recognised = 0
+    for seed in range(40):
+        spec = _random_repeated(seed)
+        maxd = 0.02 if len(spec.drude_pairs) else 0.0
+        flag, v_p, p_p, c_p, ke_p = _run(spec, "mixed", 5, {"VVHIP_PERIODIC": "1", "VVHIP_PERIODIC_A": "1"}, monkeypatch, maxd=maxd)
+        if not flag:
+            continue
+        recognised += 1
+        _, v_e, p_e, c_e, ke_e = _run(spec, "mixed", 5, {"VVHIP_PERIODIC": "1", "VVHIP_PERIODIC_K": "0"}, monkeypatch, maxd=maxd)
+        assert np.array_equal(v_p.view(np.uint8), v_e.view(np.uint8)) and np.array_equal(p_p.view(np.uint8), p_e.view(np.uint8)), seed
+        assert np.array_equal(c_p.view(np.uint8), c_e.view(np.uint8)) and np.array_equal(ke_p, ke_e), seed
+        assert np.isfinite(v_p).all() and np.isfinite(p_p).all(), seed
+    assert recognised >= 25, recognised
