@@ -426,7 +426,8 @@ int ensure_mass_table(vvhip_plan* p) {
 }
 int run_a(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
     if (p->mass_tab_a) { flags |= vv::A_MTAB; TRY(ensure_mass_table(p)); }
-    if (p->hp.per.enabled && p->periodic_kernels && p->periodic_a) flags |= vv::A_PERIODIC;
+    // (kernel A takes the arithmetic path where it also saves the 20 bytes per lane of constraint tables; else it does not gain, see periodic_a)
+    if (p->hp.per.enabled && p->periodic_kernels && (p->periodic_a || (flags & vv::A_SHAKE_V))) flags |= vv::A_PERIODIC;
     if (p->wt_stores && (flags & (vv::A_KICK_FULL | vv::A_KICK_HALF))) flags |= vv::A_WT_STORES;
     ScopedTimer t(p, T_A);
     HIP_TRY(p, vv::launch_a(p->hp.precision, make_args(p, flags, random_index), p->block_threads, p->grid_cap_a, p->stream));

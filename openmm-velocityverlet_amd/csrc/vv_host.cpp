@@ -395,7 +395,7 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
         bool want = lanes >= 200000;
         if (const char* e = std::getenv("VVHIP_PERIODIC")) want = std::atoi(e) != 0;
         if (!want) return false;
-        if (hp.has_ld || hp.has_images || hp.num_big > 0 || !shakes.empty() || clusters.empty()) return false;
+        if (hp.has_ld || hp.has_images || hp.num_big > 0 || clusters.empty()) return false;
         const size_t K = clusters.size();
         std::vector<uint64_t> sig(K);
         int expect = sb;
@@ -412,6 +412,15 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
                 mix(mb);
                 mix((uint64_t) (is_nh[i] ? 1 : 0) | (in_pair[i] ? 2 : 0) | (is_drude[i] ? 4 : 0) | (is_el[i] ? 8 : 0));
                 mix(in_pair[i] ? (uint64_t) (int64_t) (partner[i] - c.first) : 0);
+                if (shake_of[i] >= 0) {                  // in-kernel constraint cluster: same shape, distances and position inside the unit
+                    const Shake& sh = shakes[shake_of[i]];
+                    uint64_t db, pb; std::memcpy(&db, &sh.d, 8); std::memcpy(&pb, &sh.d_pp, 8);
+                    int role = 0;
+                    for (size_t q = 0; q < sh.periph.size(); q++) if (sh.periph[q] == i) role = 1 + (int) q;
+                    mix(1 + (uint64_t) role); mix((uint64_t) (int64_t) (sh.center - c.first)); mix(sh.periph.size()); mix(db); mix(pb); mix(sh.settle ? 1 : 0);
+                } else {
+                    mix(0);
+                }
             }
             sig[k] = h;
             expect += (int) c.members.size();
@@ -695,6 +704,23 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
             if (s.settle) { prm[0] = (float) s.d; prm[1] = (float) s.d_pp; prm[2] = 0; prm[3] = 0; info.num_settle_clusters++; }   // apex-partner and partner-partner distance
             else { prm[0] = (float) imc; prm[1] = (float) (0.5 / (imc + imp)); prm[2] = (float) (s.d * s.d); prm[3] = (float) imp; info.num_shake_clusters++; }
         }
+    }
+    if (hp.per.enabled && !shakes.empty()) {
+        // the constraint words and parameters of every wave must be those of its region's pattern wave too
+        const PeriodicLayout& q = hp.per;
+        bool same = true;
+        for (int w = 0; w < nwaves && same; w++) {
+            const int wl = w % q.wpc;
+            int r = 0;
+            for (int k = 1; k < 4; k++) if (wl >= q.reg_wave_start[k]) r = k;
+            const int pw = q.reg_wave_start[r];
+            for (int l = 0; l < 64 && same; l++) {
+                if (slots[(size_t) w * 128 + 2 * l] < 0) continue;
+                same = hp.slot_shake[(size_t) w * 64 + l] == hp.slot_shake[(size_t) pw * 64 + l] &&
+                       std::memcmp(&hp.slot_shake_param[((size_t) w * 64 + l) * 4], &hp.slot_shake_param[((size_t) pw * 64 + l) * 4], 16) == 0;
+            }
+        }
+        if (!same) { hp.per.enabled = 0; info.periodic_layout = 0; hp.info.periodic_layout = 0; }      // the layout stays, the kernels load their slot words
     }
     if (hp.num_big > 0) {
         hp.slot_big.assign((size_t) nwaves * 64, -1);

@@ -591,12 +591,19 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const int2* __restrict__ pre_
     // tile after tile queue up on the L2 channels that hold them (measured at 8.9 M particles: kernel A 110 -> 117 us).
     __shared__ unsigned sh_pat_meta[4][64];
     __shared__ double2 sh_pat_segm[4][64];
+    __shared__ unsigned sh_pat_shake[4][64];        // constraint cluster words / parameters of the pattern waves (A_SHAKE_V)
+    __shared__ float4 sh_pat_prm[4][64];
     if (F & A_PERIODIC) {
         for (int row = threadIdx.x >> 6; row < 4; row += pre_wpb) {
             const int ws = a.per.wave_start[row];
             unsigned m = 0;
             if (ws != 0x7fffffff) m = (unsigned) pre_slots[(size_t) ws * 64 + lane].y;
             sh_pat_meta[row][lane] = m;
+            if (F & A_SHAKE_V) {
+                const bool member = ws != 0x7fffffff && (m & META_SHAKE);
+                sh_pat_shake[row][lane] = member ? (unsigned) a.slot_shake[(size_t) ws * 64 + lane] : 0u;
+                sh_pat_prm[row][lane] = member ? a.slot_shake_param[(size_t) ws * 64 + lane] : make_float4(0, 0, 0, 0);
+            }
             int ss = a.per.d_seg[0];
 #pragma unroll
             for (int k = 1; k < 4; k++) ss += k <= row ? a.per.d_seg[k] : 0;
@@ -764,8 +771,8 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const int2* __restrict__ pre_
             // cluster word, parameters and position are requested together, keyed by the role word's META_SHAKE bit (not one after
             // the other, keyed by the cluster word: that put two more dependent memory round trips into this kernel)
             const bool member = act && (meta & META_SHAKE);
-            const unsigned word = member ? (unsigned) a.slot_shake[(size_t) wave * 64 + lane] : 0u;
-            const float4 prm = member ? a.slot_shake_param[(size_t) wave * 64 + lane] : make_float4(0, 0, 0, 0);
+            const unsigned word = !member ? 0u : ((F & A_PERIODIC) ? sh_pat_shake[pw.region][lane] : (unsigned) a.slot_shake[(size_t) wave * 64 + lane]);
+            const float4 prm = !member ? make_float4(0, 0, 0, 0) : ((F & A_PERIODIC) ? sh_pat_prm[pw.region][lane] : a.slot_shake_param[(size_t) wave * 64 + lane]);
             mixed sx = 0, sy = 0, sz = 0, sq = 0;
             real sraw = 0;
             if (member) PosIO<real, mixed>::load(a.posq, a.corr, atom, sx, sy, sz, sq, sraw);
@@ -1156,6 +1163,8 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const int2* __restrict__ pre_
     // Periodic layout: role words and pair mass fractions of the regions' pattern waves, copied into LDS once per block (kernel A)
     __shared__ unsigned sh_pat_meta[4][64];
     __shared__ double sh_pat_f[4][64];
+    __shared__ unsigned sh_pat_shake[4][64];        // constraint cluster words / parameters of the pattern waves (B_SHAKE)
+    __shared__ float4 sh_pat_prm[4][64];
     if (F & B_PERIODIC) {
         for (int row = threadIdx.x >> 6; row < 4; row += nwb) {
             const int ws = a.per.wave_start[row];
@@ -1167,6 +1176,11 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const int2* __restrict__ pre_
             }
             sh_pat_meta[row][lane] = m;
             sh_pat_f[row][lane] = f;
+            if (F & B_SHAKE) {
+                const bool member = ws != 0x7fffffff && (m & META_SHAKE);
+                sh_pat_shake[row][lane] = member ? (unsigned) a.slot_shake[(size_t) ws * 64 + lane] : 0u;
+                sh_pat_prm[row][lane] = member ? a.slot_shake_param[(size_t) ws * 64 + lane] : make_float4(0, 0, 0, 0);
+            }
         }
         __syncthreads();
     }
@@ -1293,8 +1307,8 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const int2* __restrict__ pre_
         unsigned shake_word = 0;
         float4 shake_prm = make_float4(0, 0, 0, 0);
         if ((F & B_SHAKE) && act && (meta & META_SHAKE)) {
-            shake_word = (unsigned) a.slot_shake[(size_t) wave * 64 + lane];
-            shake_prm = a.slot_shake_param[(size_t) wave * 64 + lane];
+            shake_word = (F & B_PERIODIC) ? sh_pat_shake[pw.region][lane] : (unsigned) a.slot_shake[(size_t) wave * 64 + lane];
+            shake_prm = (F & B_PERIODIC) ? sh_pat_prm[pw.region][lane] : a.slot_shake_param[(size_t) wave * 64 + lane];
         }
         // image particle of this lane's particle: its index and its present content (the charge and the correction's w survive the
         // mirror update) are requested now, so that nothing has to be read after the position store at the end of the tile
@@ -1831,6 +1845,11 @@ constexpr uint32_t SF_B_MIDDLE_HW_K_P = SF_B_MIDDLE_HW_K | B_PERIODIC;
 constexpr uint32_t SF_B_MIDDLE_K_P = SF_B_MIDDLE_K | B_PERIODIC;
 constexpr uint32_t SF_B_MIDDLE_HW_NC_K_P = SF_B_MIDDLE_HW_NC_K | B_PERIODIC;
 constexpr uint32_t SF_B_COS_HW_MOM_K_P = SF_B_COS_HW_MOM_K | B_PERIODIC;
+// large constrained boxes (the chain as its own launch): HBonds clusters solved in kernel B without the thermostat wave
+constexpr uint32_t SF_B_MIDDLE_HW_NC_SHAKE = SF_B_MIDDLE_HW_NC | B_SHAKE;
+constexpr uint32_t SF_B_MIDDLE_HW_NC_SHAKE_P = SF_B_MIDDLE_HW_NC_SHAKE | B_PERIODIC;
+constexpr uint32_t SF_B_MIDDLE_HW_SHAKE_P = SF_B_MIDDLE_HW_SHAKE | B_PERIODIC;
+constexpr uint32_t SF_A_MIDDLE_SHAKE_P = SF_A_MIDDLE_SHAKE | A_PERIODIC;
 
 // Which specialised kernels are compiled with the static mass tables; a launch whose flags disagree with the build falls through to
 // the generic kernel.  Measured on MI355X (gpurun_out/r02c-e): kernel B gains at every size (two IEEE fp64 divisions per pair lane
@@ -1865,6 +1884,7 @@ hipError_t launch_a(int precision, const KArgs& a, int block_threads, int grid_c
     VV_TRY_SF(vv_kernel_a, SF_A_COS_MOM)
     VV_TRY_SF(vv_kernel_a, SF_A_EDL)
     VV_TRY_SF(vv_kernel_a, SF_A_MIDDLE_SHAKE)
+    VV_TRY_SF(vv_kernel_a, SF_A_MIDDLE_SHAKE_P)
     VV_TRY_SF(vv_kernel_a, SF_A_COS_MOM_SHAKE)
     VV_TRY_SF(vv_kernel_a, SF_A_EDL_SHAKE)
     VV_TRY_SF(vv_kernel_a, SF_A_LD)
@@ -1914,6 +1934,9 @@ hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_c
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_HW_MB)
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_MB)
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_HW_SHAKE)
+    VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_HW_NC_SHAKE)
+    VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_HW_NC_SHAKE_P)
+    VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_HW_SHAKE_P)
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_SHAKE)
     VV_TRY_SF(vv_kernel_b, SF_B_COS_HW_MOM_SHAKE)
     VV_TRY_SF(vv_kernel_b, SF_B_EDL_SHAKE)

@@ -204,3 +204,36 @@ def test_periodic_kernels_on_random_repeated_inventories(monkeypatch):
         assert np.array_equal(c_p.view(np.uint8), c_e.view(np.uint8)) and np.array_equal(ke_p, ke_e), seed
         assert np.isfinite(v_p).all() and np.isfinite(p_p).all(), seed
     assert recognised >= 25, recognised
+
+
+CONSTRAINED = {
+    "bulk_hbonds": lambda: (systems.make_config("C3", scale=0.25, hbonds=True), dict(maxd=0.02)),            # SHAKE clusters (C-H, CH2, CH3) next to Drude pairs
+    "rigid_water": lambda: (systems.rigid_water(systems.spce_water(500, seed=5)), dict(maxd=0.0, T=300.0, dt=0.002)),      # SETTLE
+}
+
+
+@pytest.mark.parametrize("large_shape", [False, True])
+@pytest.mark.parametrize("name", sorted(CONSTRAINED))
+def test_periodic_kernels_with_in_kernel_constraints(name, large_shape, monkeypatch):
+    """Constraint cluster words and parameters come from the pattern wave as well (both kernels take the arithmetic path here): bit-equal with
+    the loaded tables, constraint lengths kept, oracle within the constraint tolerance."""
+    if large_shape:
+        monkeypatch.setenv("VVHIP_SPLIT_CHAIN_WAVES", "1")
+        monkeypatch.setenv("VVHIP_CAP_A", "8")
+        monkeypatch.setenv("VVHIP_CAP_B", "8")
+    spec, kw = CONSTRAINED[name]()
+    flag, v_p, p_p, c_p, ke_p = _run(spec, "mixed", 10, {"VVHIP_PERIODIC": "1"}, monkeypatch, **kw)
+    assert flag == 1
+    _, v_e, p_e, c_e, ke_e = _run(spec, "mixed", 10, {"VVHIP_PERIODIC": "1", "VVHIP_PERIODIC_K": "0"}, monkeypatch, **kw)
+    assert np.array_equal(v_p.view(np.uint8), v_e.view(np.uint8)) and np.array_equal(p_p.view(np.uint8), p_e.view(np.uint8))
+    assert np.array_equal(c_p.view(np.uint8), c_e.view(np.uint8)) and np.array_equal(ke_p, ke_e)
+    x = p_p[:, :3].astype(np.float64) + c_p[:, :3].astype(np.float64)
+    c, dist = np.asarray(spec.constraints), np.asarray(spec.constraint_distances)
+    r = np.linalg.norm(x[c[:, 0]] - x[c[:, 1]], axis=1)
+    assert np.abs(r - dist).max() / dist.max() < 2e-5
+    p = O.Params(temperature=kw.get("T", 333.0), drude_temperature=1.0, step_size=kw.get("dt", 0.001), max_drude_distance=kw["maxd"])
+    osys = O.OracleSystem(spec, p, "mixed", force_mode=1)
+    osys.step(10)
+    ev = np.abs(v_p[:, :3] - osys.velm[:, :3]).max() / np.abs(osys.velm[:, :3]).max()
+    ex = np.abs(x - osys.positions()).max() / np.abs(osys.positions()).max()
+    assert ev < 1e-5 and ex < 1e-5, f"{name}: rel err vel {ev:.2e} pos {ex:.2e}"
