@@ -1850,6 +1850,14 @@ constexpr uint32_t SF_B_MIDDLE_HW_NC_SHAKE = SF_B_MIDDLE_HW_NC | B_SHAKE;
 constexpr uint32_t SF_B_MIDDLE_HW_NC_SHAKE_P = SF_B_MIDDLE_HW_NC_SHAKE | B_PERIODIC;
 constexpr uint32_t SF_B_MIDDLE_HW_SHAKE_P = SF_B_MIDDLE_HW_SHAKE | B_PERIODIC;
 constexpr uint32_t SF_A_MIDDLE_SHAKE_P = SF_A_MIDDLE_SHAKE | A_PERIODIC;
+// ... and the other stage sets large boxes produce (no thermostat wave in kernel B): without Drude pairs (water, plain ionic liquids), rigid
+// water, the cos perturbation in its three-launch form -- each with loaded and with computed slot words
+constexpr uint32_t SF_B_MIDDLE_NC_K = B_SCALE | B_DRIFT_MIDDLE | B_KICK;
+constexpr uint32_t SF_B_MIDDLE_NC_K_P = SF_B_MIDDLE_NC_K | B_PERIODIC;
+constexpr uint32_t SF_B_MIDDLE_NC_SHAKE = B_SCALE | B_DRIFT_MIDDLE | B_SHAKE;
+constexpr uint32_t SF_B_MIDDLE_NC_SHAKE_P = SF_B_MIDDLE_NC_SHAKE | B_PERIODIC;
+constexpr uint32_t SF_B_COS_HW_NC = B_SCALE | B_UNBIAS | B_CZ_LOAD | B_DRIFT_MIDDLE | B_HARDWALL;
+constexpr uint32_t SF_B_COS_HW_NC_P = SF_B_COS_HW_NC | B_PERIODIC;
 
 // Which specialised kernels are compiled with the static mass tables; a launch whose flags disagree with the build falls through to
 // the generic kernel.  Measured on MI355X (gpurun_out/r02c-e): kernel B gains at every size (two IEEE fp64 divisions per pair lane
@@ -1935,6 +1943,12 @@ hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_c
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_MB)
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_HW_SHAKE)
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_HW_NC_SHAKE)
+    VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_NC_K)
+    VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_NC_K_P)
+    VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_NC_SHAKE)
+    VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_NC_SHAKE_P)
+    VV_TRY_SF(vv_kernel_b, SF_B_COS_HW_NC)
+    VV_TRY_SF(vv_kernel_b, SF_B_COS_HW_NC_P)
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_HW_NC_SHAKE_P)
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_HW_SHAKE_P)
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_SHAKE)

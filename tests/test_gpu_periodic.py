@@ -76,6 +76,23 @@ def test_periodic_kernels_under_graph_replay(monkeypatch):
     assert np.array_equal(v_g.view(np.uint8), v_e.view(np.uint8)) and np.array_equal(p_g.view(np.uint8), p_e.view(np.uint8))
 
 
+@pytest.mark.parametrize("name", ["water", "nondrude"])
+def test_large_system_launch_shape_without_drude_pairs(name, monkeypatch):
+    """The stage sets big water / plain ionic-liquid boxes run (kernel B without thermostat wave and without hard wall), forced at a testable size."""
+    monkeypatch.setenv("VVHIP_SPLIT_CHAIN_WAVES", "1")
+    monkeypatch.setenv("VVHIP_CAP_A", "8")
+    monkeypatch.setenv("VVHIP_CAP_B", "8")
+    spec, kw = SYSTEMS[name]()
+    for env in ({"VVHIP_PERIODIC": "1"}, {"VVHIP_PERIODIC": "0"}):
+        _, v, x, c, ke = _run(spec, "mixed", 12, env, monkeypatch, **kw)
+        p = O.Params(temperature=kw.get("T", 333.0), drude_temperature=1.0, step_size=kw.get("dt", 0.001), max_drude_distance=kw["maxd"])
+        osys = O.OracleSystem(spec, p, "mixed", force_mode=1)
+        osys.step(12)
+        ev = np.abs(v[:, :3] - osys.velm[:, :3]).max() / np.abs(osys.velm[:, :3]).max()
+        ex = np.abs(x[:, :3].astype(np.float64) - osys.posq[:, :3]).max() / np.abs(osys.posq[:, :3]).max()
+        assert ev < 1e-9 and ex < 2e-7, f"{name}/{env}: rel err vel {ev:.2e} pos {ex:.2e}"
+
+
 @pytest.mark.parametrize("cos", [0.0, 0.02])
 def test_periodic_kernels_in_the_large_system_launch_shape(cos, monkeypatch):
     """What systems beyond ~0.7 M particles run -- the chain as its own launch, kernel B without a thermostat wave, 256-thread blocks
