@@ -1874,6 +1874,18 @@ constexpr uint32_t SF_AM = VV_SF_MTAB_A ? A_MTAB : 0u, SF_BM = VV_SF_MTAB_B ? B_
 bool sf_kernels_use_mass_table(int kernel) { return kernel == 0 ? VV_SF_MTAB_A != 0 : VV_SF_MTAB_B != 0; }
 #define VV_TRY_SF(KERNEL, SFV) if (a.flags == ((SFV) | XM)) { VV_DISPATCH_SF(KERNEL, ((SFV) | XM), g, b, 0, s, VV_PRE_ARGS, a); return hipGetLastError(); }
 
+// VVHIP_WARN_GENERIC=1: one line on stderr per stage set that has no compiled kernel of its own and runs the generic one (15-20 % slower)
+static void note_generic(const char* kernel, uint32_t flags) {
+    static const bool on = std::getenv("VVHIP_WARN_GENERIC") != nullptr;
+    if (!on) return;
+    static uint32_t seen[2][16];
+    static int nseen[2] = {0, 0};
+    const int k = kernel[0] == 'A' ? 0 : 1;
+    for (int i = 0; i < nseen[k]; i++) if (seen[k][i] == flags) return;
+    if (nseen[k] < 16) seen[k][nseen[k]++] = flags;
+    std::fprintf(stderr, "vvhip: kernel %s runs stage set 0x%x on the generic kernel (no compiled specialisation)\n", kernel, flags);
+}
+
 hipError_t launch_a(int precision, const KArgs& a, int block_threads, int grid_cap, hipStream_t s) {
     dim3 g = grid_for(a.nwaves, block_threads);
     if ((int) g.x > grid_cap) g.x = (unsigned) grid_cap;          // beyond that the kernel strides over tiles
@@ -1904,6 +1916,7 @@ hipError_t launch_a(int precision, const KArgs& a, int block_threads, int grid_c
     VV_TRY_SF(vv_kernel_a, SF_A_KICK)
     VV_TRY_SF(vv_kernel_a, SF_A_KICK_FE)
     VV_TRY_SF(vv_kernel_a, SF_A_POS1)
+    note_generic("A", a.flags);
     VV_DISPATCH_SF(vv_kernel_a, 0u, g, b, 0, s, VV_PRE_ARGS, a);
     return hipGetLastError();
 #undef VV_PRE_ARGS
@@ -1962,6 +1975,7 @@ hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_c
     VV_TRY_SF(vv_kernel_b, SF_B_POS2)
     VV_TRY_SF(vv_kernel_b, SF_B_POS3_HW)
     VV_TRY_SF(vv_kernel_b, SF_B_POS3)
+    note_generic("B", a.flags);
     VV_DISPATCH_SF(vv_kernel_b, 0u, g, b, 0, s, VV_PRE_ARGS, a);
     return hipGetLastError();
 #undef VV_PRE_ARGS
