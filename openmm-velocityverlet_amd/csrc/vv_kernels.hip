@@ -767,7 +767,9 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const int2* __restrict__ pre_
             }
         }
         if (F & A_SHAKE_V) {                   // integration.applyVelocityConstraints(tol) (HOST:151, 427), clusters solved in the wave
-            __shared__ mixed shake_page_a[8][64][7];
+            // one page per wave of the block, sized at launch (dynamic LDS): a static [8] cost 28 KB per block also where blocks have 4 waves
+            extern __shared__ double vv_dyn_lds[];
+            mixed (*shake_page_a)[64][7] = (mixed (*)[64][7]) vv_dyn_lds;
             // cluster word, parameters and position are requested together, keyed by the role word's META_SHAKE bit (not one after
             // the other, keyed by the cluster word: that put two more dependent memory round trips into this kernel)
             const bool member = act && (meta & META_SHAKE);
@@ -1484,7 +1486,8 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const int2* __restrict__ pre_
             ((mixed4*) a.old_delta)[atom] = od;
         }
         // per-wave LDS page of the in-kernel SHAKE (collective over the wave: every lane walks through it)
-        __shared__ mixed shake_page_b[8][64][7];
+        extern __shared__ double vv_dyn_lds[];
+        mixed (*shake_page_b)[64][7] = (mixed (*)[64][7]) vv_dyn_lds;      // one page per tile wave, sized at launch
         if (F & B_DRIFT_MIDDLE) {
             // Pos1 (K/middle.cu:36-38) with the pre-thermostat velocity, Pos2 (:54-56) with the scaled one.  Without constraints
             // posDelta == oldDelta and Pos3's velocity correction (K/middle.cu:77-79) adds (d - d)/dt == 0 exactly; with the
@@ -1872,7 +1875,7 @@ constexpr uint32_t SF_B_COS_HW_NC_P = SF_B_COS_HW_NC | B_PERIODIC;
 #endif
 constexpr uint32_t SF_AM = VV_SF_MTAB_A ? A_MTAB : 0u, SF_BM = VV_SF_MTAB_B ? B_MTAB : 0u;
 bool sf_kernels_use_mass_table(int kernel) { return kernel == 0 ? VV_SF_MTAB_A != 0 : VV_SF_MTAB_B != 0; }
-#define VV_TRY_SF(KERNEL, SFV) if (a.flags == ((SFV) | XM)) { VV_DISPATCH_SF(KERNEL, ((SFV) | XM), g, b, 0, s, VV_PRE_ARGS, a); return hipGetLastError(); }
+#define VV_TRY_SF(KERNEL, SFV) if (a.flags == ((SFV) | XM)) { VV_DISPATCH_SF(KERNEL, ((SFV) | XM), g, b, lds, s, VV_PRE_ARGS, a); return hipGetLastError(); }
 
 // VVHIP_WARN_GENERIC=1: one line on stderr per stage set that has no compiled kernel of its own and runs the generic one (15-20 % slower)
 static void note_generic(const char* kernel, uint32_t flags) {
@@ -1891,6 +1894,8 @@ hipError_t launch_a(int precision, const KArgs& a, int block_threads, int grid_c
     if ((int) g.x > grid_cap) g.x = (unsigned) grid_cap;          // beyond that the kernel strides over tiles
     vv_last_grid_value = g.x;
     const dim3 b(block_threads);
+    // per-wave LDS page of the in-kernel constraint solver (7 values of the mode's `mixed` type per lane)
+    const unsigned lds = (a.flags & A_SHAKE_V) ? (unsigned) (block_threads / 64) * 64u * 7u * (precision == VVHIP_SINGLE ? 4u : 8u) : 0u;
     constexpr uint32_t XM = SF_AM;
 #define VV_PRE_ARGS a.slots, a.nwaves, (int) (b.x >> 6), a.velm, a.force, a.padded
     VV_TRY_SF(vv_kernel_a, SF_A_MIDDLE_NS_P)
@@ -1917,7 +1922,7 @@ hipError_t launch_a(int precision, const KArgs& a, int block_threads, int grid_c
     VV_TRY_SF(vv_kernel_a, SF_A_KICK_FE)
     VV_TRY_SF(vv_kernel_a, SF_A_POS1)
     note_generic("A", a.flags);
-    VV_DISPATCH_SF(vv_kernel_a, 0u, g, b, 0, s, VV_PRE_ARGS, a);
+    VV_DISPATCH_SF(vv_kernel_a, 0u, g, b, lds, s, VV_PRE_ARGS, a);
     return hipGetLastError();
 #undef VV_PRE_ARGS
 }
@@ -1928,10 +1933,11 @@ hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_c
     if ((int) g.x > grid_cap) g.x = (unsigned) grid_cap;
     vv_last_grid_value = g.x;
     const dim3 b(block_threads + ((a.flags & B_CHAIN) ? 64 : 0));
+    const unsigned lds = (a.flags & B_SHAKE) ? (unsigned) (block_threads / 64) * 64u * 7u * (precision == VVHIP_SINGLE ? 4u : 8u) : 0u;      // one page per tile wave
     constexpr uint32_t XM = SF_BM;
 #define VV_PRE_ARGS a.slots, a.nwaves, (int) (b.x >> 6), (const unsigned long long*) a.acc, a.nh, a.lane_const, a.seg_base
     if ((a.flags & B_CHAIN) && a.chain.num_chains != 3) {       // the specialised kernels carry the three-link chain only
-        VV_DISPATCH_SF(vv_kernel_b, 0u, g, b, 0, s, VV_PRE_ARGS, a);
+        VV_DISPATCH_SF(vv_kernel_b, 0u, g, b, lds, s, VV_PRE_ARGS, a);
         return hipGetLastError();
     }
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_HW_K_P)
@@ -1976,7 +1982,7 @@ hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_c
     VV_TRY_SF(vv_kernel_b, SF_B_POS3_HW)
     VV_TRY_SF(vv_kernel_b, SF_B_POS3)
     note_generic("B", a.flags);
-    VV_DISPATCH_SF(vv_kernel_b, 0u, g, b, 0, s, VV_PRE_ARGS, a);
+    VV_DISPATCH_SF(vv_kernel_b, 0u, g, b, lds, s, VV_PRE_ARGS, a);
     return hipGetLastError();
 #undef VV_PRE_ARGS
 }
