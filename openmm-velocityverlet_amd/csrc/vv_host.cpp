@@ -381,7 +381,6 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
     // ---- periodic layout: runs of identical repeat units, possibly repeated cell after cell (vv_host.hpp: PeriodicLayout)
     struct Region { uint64_t sig; int p, reps, atoms, segs; };      // unit of p clusters repeated reps times
     std::vector<Region> regions;
-    std::vector<int32_t> unit_offsets;                               // lane offset of each cluster inside its unit (per region of cell 0 .. R-1, flattened)
     PeriodicLayout per;
     int per_R = 0, per_clusters_per_cell = 0;
     std::vector<int> reg_cluster_start;                              // first cluster (cell-local) of region r
@@ -470,7 +469,6 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
         per.nreg = R;
         per.ncells = L / R;
         reg_cluster_start.assign(R + 1, 0);
-        unit_offsets.clear();
         int w = 0, at = 0, sg = 0, cl = 0;
         for (int r = 0; r < R; r++) {
             const Region& g = regions[r];
@@ -654,6 +652,7 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
                 if (l >= count) { if (at >= 0) return false; continue; }
                 if (at != cell * per.apc + a0 + l) return false;
                 if (meta != (uint32_t) slots[(size_t) pw * 128 + 2 * l + 1]) return false;
+                if (sys.masses[at + sb] != sys.masses[slots[(size_t) pw * 128 + 2 * l] + sb]) return false;      // (the per-lane mass tables are pattern rows too)
                 if (meta & META_COM_LEADER) {
                     const size_t here = (size_t) hp.seg_base[w] + ord, pat = (size_t) per.reg_seg_start[r] + ord;
                     if ((int) here != cell * per.spc + per.reg_seg_start[r] + wr * per.reg_spw[r] + ord) return false;
