@@ -1861,6 +1861,11 @@ constexpr uint32_t SF_B_MIDDLE_NC_SHAKE = B_SCALE | B_DRIFT_MIDDLE | B_SHAKE;
 constexpr uint32_t SF_B_MIDDLE_NC_SHAKE_P = SF_B_MIDDLE_NC_SHAKE | B_PERIODIC;
 constexpr uint32_t SF_B_COS_HW_NC = B_SCALE | B_UNBIAS | B_CZ_LOAD | B_DRIFT_MIDDLE | B_HARDWALL;
 constexpr uint32_t SF_B_COS_HW_NC_P = SF_B_COS_HW_NC | B_PERIODIC;
+// the classic scheme's two thermostat applications in large boxes: scale + half kick + positions (+ hard wall), and scale alone
+constexpr uint32_t SF_B_VV1_HW_NC = B_SCALE | B_VV_KICK | B_HARDWALL;
+constexpr uint32_t SF_B_VV1_HW_NC_P = SF_B_VV1_HW_NC | B_PERIODIC;
+constexpr uint32_t SF_B_SCALE_NC = B_SCALE;
+constexpr uint32_t SF_B_SCALE_NC_P = SF_B_SCALE_NC | B_PERIODIC;
 
 // Which specialised kernels are compiled with the static mass tables; a launch whose flags disagree with the build falls through to
 // the generic kernel.  Measured on MI355X (gpurun_out/r02c-e): kernel B gains at every size (two IEEE fp64 divisions per pair lane
@@ -1968,6 +1973,10 @@ hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_c
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_NC_SHAKE_P)
     VV_TRY_SF(vv_kernel_b, SF_B_COS_HW_NC)
     VV_TRY_SF(vv_kernel_b, SF_B_COS_HW_NC_P)
+    VV_TRY_SF(vv_kernel_b, SF_B_VV1_HW_NC)
+    VV_TRY_SF(vv_kernel_b, SF_B_VV1_HW_NC_P)
+    VV_TRY_SF(vv_kernel_b, SF_B_SCALE_NC)
+    VV_TRY_SF(vv_kernel_b, SF_B_SCALE_NC_P)
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_HW_NC_SHAKE_P)
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_HW_SHAKE_P)
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_SHAKE)

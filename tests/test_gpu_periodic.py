@@ -14,7 +14,7 @@ H, I, systems = pkg.vvhip, pkg.integrator, pkg.systems
 pytestmark = pytest.mark.gpu
 
 
-def _run(spec, prec, nsteps, env, monkeypatch, cos=0.0, maxd=0.02, T=333.0, dt=0.001, graph=False):
+def _run(spec, prec, nsteps, env, monkeypatch, cos=0.0, maxd=0.02, T=333.0, dt=0.001, graph=False, middle=True):
     for k in ("VVHIP_PERIODIC", "VVHIP_PERIODIC_K", "VVHIP_PERIODIC_A"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
@@ -22,6 +22,7 @@ def _run(spec, prec, nsteps, env, monkeypatch, cos=0.0, maxd=0.02, T=333.0, dt=0
     it = I.VVIntegrator(T, 10.0, 1.0, 40.0, dt)
     it.setMaxDrudeDistance(maxd)
     it.setCosAcceleration(cos)
+    it.setUseMiddleScheme(middle)
     ctx = I.Context(spec, it, precision=prec, force_provider="tether")
     try:
         if graph:
@@ -254,3 +255,20 @@ def test_periodic_kernels_with_in_kernel_constraints(name, large_shape, monkeypa
     ev = np.abs(v_p[:, :3] - osys.velm[:, :3]).max() / np.abs(osys.velm[:, :3]).max()
     ex = np.abs(x - osys.positions()).max() / np.abs(osys.positions()).max()
     assert ev < 1e-5 and ex < 1e-5, f"{name}: rel err vel {ev:.2e} pos {ex:.2e}"
+
+
+@pytest.mark.parametrize("periodic", ["1", "0"])
+def test_classic_scheme_in_the_large_system_launch_shape(periodic, monkeypatch):
+    """stepVV's two thermostat applications as big boxes run them (scale + half kick + positions + hard wall, and scale alone, kernel B without a
+    thermostat wave), forced at a testable size, with computed and with loaded slot words."""
+    monkeypatch.setenv("VVHIP_SPLIT_CHAIN_WAVES", "1")
+    monkeypatch.setenv("VVHIP_CAP_A", "8")
+    monkeypatch.setenv("VVHIP_CAP_B", "8")
+    spec, kw = SYSTEMS["bulk_cells"]()
+    _, v, x, c, ke = _run(spec, "mixed", 12, {"VVHIP_PERIODIC": periodic}, monkeypatch, middle=False, **kw)
+    p = O.Params(temperature=333.0, drude_temperature=1.0, step_size=0.001, max_drude_distance=kw["maxd"], use_middle_scheme=False)
+    osys = O.OracleSystem(spec, p, "mixed", force_mode=1)
+    osys.step(12)
+    ev = np.abs(v[:, :3] - osys.velm[:, :3]).max() / np.abs(osys.velm[:, :3]).max()
+    ex = np.abs(x[:, :3].astype(np.float64) - osys.posq[:, :3]).max() / np.abs(osys.posq[:, :3]).max()
+    assert ev < 1e-9 and ex < 2e-7, f"rel err vel {ev:.2e} pos {ex:.2e}"
