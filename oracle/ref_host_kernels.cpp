@@ -42,7 +42,7 @@ void addExtraForceElectricField(real4*, real3*, const int*, real);
 void updateImagePositions(real4*, real4*, const int2*, mixed);
 }
 
-extern "C" vvref_sizes_t vvref_sizes = {};       // the size macros of ref_prelude.h read this (this build has no ref_glue.cpp)
+extern "C" { vvref_sizes_t vvref_sizes = {}; }   // the size macros of ref_prelude.h read this (this build has no ref_glue.cpp)
 mixed temp[64];                                  // backing store of the kernels' `extern __shared__ mixed temp[]` (1 thread: temp[0..NUM_TG-1])
 
 namespace {
