@@ -321,8 +321,6 @@ int vvhip_timing_read(vvhip_plan* plan, double* ms_pass_a, double* ms_pass_b, do
  *   VVHIP_NO_MOMENTS=1        cos perturbation as three launches (bias, sums, scale) instead of two
  *   VVHIP_SPLIT_CHAIN_WAVES=n the thermostat chain becomes its own 1-wave launch from n waves on (default 12288)
  *   VVHIP_BLOCK=t, VVHIP_CAP_A=b, VVHIP_CAP_B=b   launch shape: threads per block (multiple of 64), most blocks per launch of kernel A / B
- *   VVHIP_XCD=1|2             bandwidth regime: XCD-aware tile order (workgroups of XCD x sweep the x-th eighth of the tiles) in both kernels / in
- *                             kernel A only; measured at 8.9 M particles: within 1 % of the plain order, so off by default
  *   VVHIP_WT=1                write-through stores in the fused kernels (tuning experiment)
  *   VVHIP_ROCTX=1             roctx ranges (see vvhip_set_trace)
  *   VVHIP_WARN_GENERIC=1      one line on stderr per stage set that runs on the generic kernel (no compiled specialisation: 15-20 % slower)

@@ -89,7 +89,6 @@ struct vvhip_plan {
     // with an arithmetic work-item layout (HostPlan::per) kernel B computes particle indices instead of loading slot words (VVHIP_PERIODIC_K=0: comparison runs);
     // kernel A has the same path (VVHIP_PERIODIC_A=1) but does not gain from it: 113.6 vs 115.7 us at 8.9 M particles
     bool periodic_kernels = true, periodic_a = false;
-    int xcd_map = 0;               // XCD-aware tile order in the bandwidth regime: 1 both kernels, 2 kernel A only (VVHIP_XCD)
     bool rekick = true;            // fused middle step: kick repeated in kernel B instead of a velm store in kernel A (use_rekick)
     // plan-owned device state
     int2* d_slots = nullptr;
@@ -320,7 +319,6 @@ vv::KArgs make_args(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
     a.flags = flags;
     a.random_index = random_index;
     a.per = vv::periodic_args(p->hp.per);
-    a.xcd_map = (p->xcd_map && p->hp.info.num_waves >= p->split_chain_waves) ? p->xcd_map : 0;
     a.dt = q.step_size;
     // the same IEEE quotients the kernels used to form per lane: (mixed) 1 / (mixed) dt and 1.0 / (mixed) dt
     a.inv_dt_mixed = p->hp.precision == VVHIP_SINGLE ? (double) (1.0f / (float) q.step_size) : 1.0 / q.step_size;
@@ -441,9 +439,7 @@ int run_b(vvhip_plan* p, uint32_t flags) {
     if (p->hp.per.enabled && p->periodic_kernels && !(flags & vv::B_MAILBOX)) flags |= vv::B_PERIODIC;
     if (p->wt_stores) flags |= vv::B_WT_STORES;
     ScopedTimer t(p, T_B);
-    vv::KArgs ka = make_args(p, flags, 0);
-    if (ka.xcd_map == 2) ka.xcd_map = 0;      // mode 2: kernel A only
-    HIP_TRY(p, vv::launch_b(p->hp.precision, ka, p->block_threads, p->grid_cap_b, p->stream));
+    HIP_TRY(p, vv::launch_b(p->hp.precision, make_args(p, flags, 0), p->block_threads, p->grid_cap_b, p->stream));
     if (flags & vv::B_CHAIN) p->parity ^= 1;     // the advanced thermostat state now lives in the other copy
     return VVHIP_OK;
 }
@@ -537,7 +533,6 @@ int vvhip_plan_create(const vvhip_system_desc* system, const vvhip_params* param
         if (const char* e = std::getenv("VVHIP_REKICK")) p->rekick = std::atoi(e) != 0;
         if (const char* e = std::getenv("VVHIP_PERIODIC_K")) p->periodic_kernels = std::atoi(e) != 0;
         if (const char* e = std::getenv("VVHIP_PERIODIC_A")) p->periodic_a = std::atoi(e) != 0;
-        if (const char* e = std::getenv("VVHIP_XCD")) p->xcd_map = std::atoi(e);
         p->mass_tab_a = vv::sf_kernels_use_mass_table(0);
         p->mass_tab_b = vv::sf_kernels_use_mass_table(1);
         if (const char* e = std::getenv("VVHIP_MTAB_A")) p->mass_tab_a = std::atoi(e) != 0;

@@ -614,16 +614,7 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const int2* __restrict__ pre_
         }
         __syncthreads();
     }
-    // Tile order.  Plain: block b strides over tiles b, b + G, ...  XCD-aware (KArgs::xcd_map, grids that are multiples of 8): the workgroups of
-    // XCD x = b % 8 (round-robin dispatch) sweep the x-th eighth of the tiles, so that neighbouring tiles -- which share cache lines of the
-    // dense per-molecule tables -- meet in the same L2.
-    const bool xm = a.xcd_map != 0 && (gridDim.x & 7u) == 0;
-    const int tile_base = xm ? (int) (blockIdx.x & 7u) * ((pre_nwaves + 7) >> 3) : 0;
-    const int tile_count = xm ? (pre_nwaves + 7) >> 3 : pre_nwaves;
-    const int tile_step = (int) (xm ? gridDim.x >> 3 : gridDim.x) * pre_wpb;
-    for (int local = (int) (xm ? blockIdx.x >> 3 : blockIdx.x) * pre_wpb + (threadIdx.x >> 6); local < tile_count; local += tile_step) {
-        const int wave = tile_base + local;
-        if (wave >= pre_nwaves) break;
+    for (int wave = blockIdx.x * pre_wpb + (threadIdx.x >> 6); wave < pre_nwaves; wave += gridDim.x * pre_wpb) {
         int atom;
         unsigned meta;
         PeriodicWave pw = {0, 0, 0, 0};
@@ -1285,13 +1276,8 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const int2* __restrict__ pre_
     // pays the fold + chain once and then streams many tiles; the first tile's loads overlap the thermostat wave.
     bool need_scales = true;
     VV_STAMP(wib, 0);
-    const bool xm = a.xcd_map != 0 && (gridDim.x & 7u) == 0;          // tile order: see kernel A
-    const int tile_base = xm ? (int) (blockIdx.x & 7u) * ((pre_nwaves + 7) >> 3) : 0;
-    const int tile_count = xm ? (pre_nwaves + 7) >> 3 : pre_nwaves;
-    const int tile_step = (int) (xm ? gridDim.x >> 3 : gridDim.x) * tiles_per_block;
-    for (int local = (int) (xm ? blockIdx.x >> 3 : blockIdx.x) * tiles_per_block + wib; need_scales || local < tile_count; local += tile_step) {
-        const int wave = tile_base + local;
-        const bool valid = local < tile_count && wave < pre_nwaves;
+    for (int wave = blockIdx.x * tiles_per_block + wib; need_scales || wave < pre_nwaves; wave += gridDim.x * tiles_per_block) {
+        const bool valid = wave < pre_nwaves;
         int atom = -1;
         unsigned meta = 0;
         PeriodicWave pw = {0, 0, 0, 0};

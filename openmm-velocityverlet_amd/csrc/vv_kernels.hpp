@@ -164,7 +164,6 @@ struct KArgs {
     int32_t nwaves;
     uint32_t flags;
     uint32_t random_index;
-    int32_t xcd_map, pad0_;    // 1: XCD-aware tile order (vv_kernels.hip, kernel A's tile loop)
     PeriodicArgs per;          // arithmetic work-item layout (A_PERIODIC / B_PERIODIC; vv_host.hpp: PeriodicLayout)
     double dt;                 // step size
     double inv_dt_mixed;       // 1 / dt evaluated in the mode's `mixed` type on the host (K/middle.cu:71), widened

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _run(spec, prec, nsteps, env, monkeypatch, cos=0.0, maxd=0.02, T=333.0, dt=0.001, graph=False, middle=True):
-    for k in ("VVHIP_PERIODIC", "VVHIP_PERIODIC_K", "VVHIP_PERIODIC_A", "VVHIP_XCD"):
+    for k in ("VVHIP_PERIODIC", "VVHIP_PERIODIC_K", "VVHIP_PERIODIC_A"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -272,19 +272,3 @@ def test_classic_scheme_in_the_large_system_launch_shape(periodic, monkeypatch):
     ev = np.abs(v[:, :3] - osys.velm[:, :3]).max() / np.abs(osys.velm[:, :3]).max()
     ex = np.abs(x[:, :3].astype(np.float64) - osys.posq[:, :3]).max() / np.abs(osys.posq[:, :3]).max()
     assert ev < 1e-9 and ex < 2e-7, f"rel err vel {ev:.2e} pos {ex:.2e}"
-
-
-@pytest.mark.parametrize("mode", ["1", "2"])
-def test_xcd_aware_tile_order(mode, monkeypatch):
-    """VVHIP_XCD: the workgroups of XCD x sweep the x-th eighth of the tiles (both kernels, or kernel A only).  Which workgroup handles a tile only
-    changes the order in which a block's double-precision partial sums are formed before they become fixed point: last-bit noise in the group
-    kinetic energies, nothing else."""
-    monkeypatch.setenv("VVHIP_SPLIT_CHAIN_WAVES", "1")
-    monkeypatch.setenv("VVHIP_CAP_A", "16")
-    monkeypatch.setenv("VVHIP_CAP_B", "8")
-    spec, kw = SYSTEMS["bulk_cells"]()
-    for per in ("1", "0"):
-        _, v0, x0, c0, ke0 = _run(spec, "mixed", 12, {"VVHIP_PERIODIC": per}, monkeypatch, **kw)
-        _, v1, x1, c1, ke1 = _run(spec, "mixed", 12, {"VVHIP_PERIODIC": per, "VVHIP_XCD": mode}, monkeypatch, **kw)
-        assert np.allclose(ke0, ke1, rtol=1e-13) and np.allclose(v0, v1, rtol=0, atol=1e-12 * np.abs(v0).max())
-        assert np.allclose(x0, x1, rtol=0, atol=2e-7 * np.abs(x0).max())
