@@ -174,7 +174,7 @@ def repeated_inventories(draw):
     return masses, mol_id, pairs, draw(st.booleans()), draw(st.integers(0, 2 ** 31 - 1))
 
 
-@settings(max_examples=150, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@settings(max_examples=150, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.too_slow])
 @given(repeated_inventories())
 def test_periodic_layout_on_random_repeated_inventories(inv):
     import os
