@@ -89,6 +89,8 @@ struct vvhip_plan {
     // with an arithmetic work-item layout (HostPlan::per) kernel B computes particle indices instead of loading slot words (VVHIP_PERIODIC_K=0: comparison runs);
     // kernel A has the same path (VVHIP_PERIODIC_A=1) but does not gain from it: 113.6 vs 115.7 us at 8.9 M particles
     bool periodic_kernels = true, periodic_a = false;
+    int shake_mode = 1;            // hydrogen-type constraint clusters: 1 = all constraints of a cluster at once (direct velocity solve, coupled Newton
+                                   // for positions), 0 = Gauss-Seidel sweeps by the central lane (OpenMM's iteration; generic kernels) -- VVHIP_SHAKE_MODE
     bool rekick = true;            // fused middle step: kick repeated in kernel B instead of a velm store in kernel A (use_rekick)
     // plan-owned device state
     int2* d_slots = nullptr;
@@ -427,8 +429,9 @@ int ensure_mass_table(vvhip_plan* p) {
 int run_a(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
     if (p->mass_tab_a) { flags |= vv::A_MTAB; TRY(ensure_mass_table(p)); }
     // (kernel A takes the arithmetic path where it also saves the 20 bytes per lane of constraint tables; else it does not gain, see periodic_a)
-    if (p->hp.per.enabled && p->periodic_kernels && (p->periodic_a || (flags & vv::A_SHAKE_V))) flags |= vv::A_PERIODIC;
+    if (p->hp.per.enabled && p->periodic_kernels && (p->periodic_a || (flags & vv::A_CONS))) flags |= vv::A_PERIODIC;
     if (p->wt_stores && (flags & (vv::A_KICK_FULL | vv::A_KICK_HALF))) flags |= vv::A_WT_STORES;
+    if ((flags & vv::A_SHAKE_V) && p->shake_mode == 0) flags |= vv::A_SHAKE_GS;
     ScopedTimer t(p, T_A);
     HIP_TRY(p, vv::launch_a(p->hp.precision, make_args(p, flags, random_index), p->block_threads, p->grid_cap_a, p->stream));
     return VVHIP_OK;
@@ -438,6 +441,7 @@ int run_b(vvhip_plan* p, uint32_t flags) {
     // (not next to the mailbox exchange: that combination timed out when two ranks shared one GPU, the only multi-rank set-up at hand)
     if (p->hp.per.enabled && p->periodic_kernels && !(flags & vv::B_MAILBOX)) flags |= vv::B_PERIODIC;
     if (p->wt_stores) flags |= vv::B_WT_STORES;
+    if ((flags & vv::B_SHAKE) && p->shake_mode == 0) flags |= vv::B_SHAKE_GS;
     ScopedTimer t(p, T_B);
     HIP_TRY(p, vv::launch_b(p->hp.precision, make_args(p, flags, 0), p->block_threads, p->grid_cap_b, p->stream));
     if (flags & vv::B_CHAIN) p->parity ^= 1;     // the advanced thermostat state now lives in the other copy
@@ -504,6 +508,9 @@ uint32_t tail_flags(const vvhip_plan* p) {      // what follows every position u
 }
 bool cos_on(const vvhip_plan* p) { return p->hp.params.cos_acceleration != 0; }
 bool shake_on(const vvhip_plan* p) { return !p->hp.slot_shake.empty(); }
+// stage bits of the in-kernel constraints the plan holds: hydrogen-type clusters and / or rigid three-site molecules
+uint32_t cons_a(const vvhip_plan* p) { return (p->hp.info.num_shake_clusters > 0 ? vv::A_SHAKE_V : 0u) | (p->hp.info.num_settle_clusters > 0 ? vv::A_SETTLE : 0u); }
+uint32_t cons_b(const vvhip_plan* p) { return (p->hp.info.num_shake_clusters > 0 ? vv::B_SHAKE : 0u) | (p->hp.info.num_settle_clusters > 0 ? vv::B_SETTLE : 0u); }
 #define NEED_FUSABLE(p)                                                                                                   \
     do {                                                                                                                \
         if (!(p)->hp.info.constraints_fused)                                                                            \
@@ -531,6 +538,7 @@ int vvhip_plan_create(const vvhip_system_desc* system, const vvhip_params* param
         if (const char* e = std::getenv("VVHIP_WT")) p->wt_stores = std::atoi(e) != 0;
         if (const char* e = std::getenv("VVHIP_NO_MOMENTS")) p->no_moments = std::atoi(e) != 0;
         if (const char* e = std::getenv("VVHIP_REKICK")) p->rekick = std::atoi(e) != 0;
+        if (const char* e = std::getenv("VVHIP_SHAKE_MODE")) p->shake_mode = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("VVHIP_PERIODIC_K")) p->periodic_kernels = std::atoi(e) != 0;
         if (const char* e = std::getenv("VVHIP_PERIODIC_A")) p->periodic_a = std::atoi(e) != 0;
         p->mass_tab_a = vv::sf_kernels_use_mass_table(0);
@@ -601,7 +609,16 @@ int vvhip_bind(vvhip_plan* p, const vvhip_buffers* b) {
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0)
         return fail(p, VVHIP_ERR_NO_DEVICE, "no HIP device: libvvhip has no CPU path");
-    if (p->bound && b->velm != p->buf.velm) { p->mass_tab_valid = false; drop_graphs(p); }   // another velm array: its inverse masses are re-read
+    if (p->bound) {
+        // The captured graphs bake EVERY caller-owned pointer (make_args): a re-bind that swaps any of them must drop both
+        // executables, or vvhip_run_graph would replay kernels on the old arrays without a word.  The stream is not part of a
+        // captured node.  Only another velm array invalidates the mass tables (its inverse masses are re-read).
+        const vvhip_buffers& o = p->buf;
+        const bool same = b->velm == o.velm && b->posq == o.posq && b->posq_correction == o.posq_correction && b->force == o.force &&
+                          b->pos_delta == o.pos_delta && b->random == o.random && b->random_size == o.random_size;
+        if (b->velm != o.velm) p->mass_tab_valid = false;
+        if (!same) drop_graphs(p);
+    }
     p->buf = *b;
     p->stream = (hipStream_t) b->stream;
     if (p->bound) return VVHIP_OK;      // re-binding only swaps the caller-owned pointers
@@ -763,8 +780,8 @@ int vvhip_step_middle_phase(vvhip_plan* p, int phase, uint32_t random_index) {
     NEED_BOUND(p);
     NEED_FUSABLE(p);
     const bool rk = use_rekick(p);
-    const uint32_t kick = vv::A_KICK_FULL | extra_flags(p) | (shake_on(p) ? vv::A_SHAKE_V : 0) | (rk ? vv::A_NOSTORE : 0);
-    const uint32_t drift = vv::B_DRIFT_MIDDLE | tail_flags(p) | (shake_on(p) ? vv::B_SHAKE : 0) | (rk ? vv::B_KICK : 0);
+    const uint32_t kick = vv::A_KICK_FULL | extra_flags(p) | cons_a(p) | (rk ? vv::A_NOSTORE : 0);
+    const uint32_t drift = vv::B_DRIFT_MIDDLE | tail_flags(p) | cons_b(p) | (rk ? vv::B_KICK : 0);
     if (!p->hp.has_nh) {                                   // API:251: no NH particles, nothing to reduce
         if (phase != 0) return fail(p, VVHIP_ERR_INVALID, "phase out of range");
         TRY(run_a(p, kick, random_index));
@@ -847,7 +864,7 @@ static int nh_half(vvhip_plan* p, uint32_t a_first, uint32_t random_index, uint3
 int vvhip_step_vv_first(vvhip_plan* p) {                   // API:295-310 (forces for the old positions are in `force`)
     NEED_BOUND(p);
     NEED_FUSABLE(p);
-    return nh_half(p, 0, 0, vv::B_VV_KICK | tail_flags(p) | (shake_on(p) ? vv::B_SHAKE : 0));
+    return nh_half(p, 0, 0, vv::B_VV_KICK | tail_flags(p) | cons_b(p));
 }
 
 int vvhip_step_vv_second(vvhip_plan* p, uint32_t random_index) {   // API:316-336 (forces for the new positions)
@@ -855,7 +872,7 @@ int vvhip_step_vv_second(vvhip_plan* p, uint32_t random_index) {   // API:316-33
     uint32_t ex = extra_flags(p);
     if (ex) { ex |= vv::A_FE_STORE; p->fextra_dirty = true; }   // the first half of the NEXT step kicks with these (API:316-323)
     NEED_FUSABLE(p);
-    return nh_half(p, vv::A_KICK_HALF | ex | (shake_on(p) ? vv::A_SHAKE_V : 0), random_index, 0);
+    return nh_half(p, vv::A_KICK_HALF | ex | cons_a(p), random_index, 0);
 }
 
 // ------------------------------------------------------------------------------------------ kernel-interface level
@@ -1126,9 +1143,9 @@ int vvhip_time_kernel(vvhip_plan* p, int kernel, uint32_t flags, int reps, doubl
     if (flags == 0xFFFFFFFFu) {     // the stage bits vvhip_step_middle uses for this plan
         const uint32_t mom_a = use_moments(p) ? (vv::A_KE | vv::A_KE_MOM) : 0, mom_b = use_moments(p) ? vv::B_KE_MOM : 0;
         const bool rk = use_rekick(p);
-        if (kernel == 0) flags = vv::A_KICK_FULL | (rk ? vv::A_NOSTORE : 0) | extra_flags(p) | (shake_on(p) ? vv::A_SHAKE_V : 0) | (p->hp.has_nh ? (cos_on(p) ? (vv::A_BIAS | vv::A_CZ_STORE | mom_a) : vv::A_KE) : 0);
+        if (kernel == 0) flags = vv::A_KICK_FULL | (rk ? vv::A_NOSTORE : 0) | extra_flags(p) | cons_a(p) | (p->hp.has_nh ? (cos_on(p) ? (vv::A_BIAS | vv::A_CZ_STORE | mom_a) : vv::A_KE) : 0);
         const bool split = p->hp.info.num_waves >= p->split_chain_waves && !use_mailbox(p);    // as run_chain_and_b decides
-        if (kernel != 0) flags = vv::B_DRIFT_MIDDLE | (rk ? vv::B_KICK : 0) | tail_flags(p) | (shake_on(p) ? vv::B_SHAKE : 0) | (p->hp.has_nh ? (((p->hp.params.num_nh_chains <= 4 && !split) ? vv::B_CHAIN : 0) | vv::B_SCALE | (cos_on(p) ? (vv::B_UNBIAS | vv::B_CZ_LOAD | mom_b) : 0)) : 0);
+        if (kernel != 0) flags = vv::B_DRIFT_MIDDLE | (rk ? vv::B_KICK : 0) | tail_flags(p) | cons_b(p) | (p->hp.has_nh ? (((p->hp.params.num_nh_chains <= 4 && !split) ? vv::B_CHAIN : 0) | vv::B_SCALE | (cos_on(p) ? (vv::B_UNBIAS | vv::B_CZ_LOAD | mom_b) : 0)) : 0);
     }
     hipEvent_t e0, e1;
     HIP_TRY(p, hipEventCreate(&e0));

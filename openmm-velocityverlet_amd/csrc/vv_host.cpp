@@ -690,18 +690,28 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
         for (const Shake& s : shakes) {
             if (!in_shard(s.center)) continue;
             const int w = wave_of[s.center], lc = lane_of[s.center];
-            uint32_t word = 1u | ((uint32_t) s.periph.size() << 2) | (s.settle ? vv::SHAKE_WORD_SETTLE : 0u);
-            for (size_t k = 0; k < s.periph.size(); k++) {
-                const int q = s.periph[k];
-                if (wave_of[q] != w) throw Error(VVHIP_ERR_UNSUPPORTED, "a constraint cluster does not fit into one wave with its molecule");
-                word |= (uint32_t) lane_of[q] << (4 + 6 * k);
-                hp.slot_shake[(size_t) w * 64 + lane_of[q]] = (int32_t) (2u | ((uint32_t) k << 2) | ((uint32_t) lc << 4));
+            // every member's word lists the whole cluster (vv_host.hpp: SHAKE_WORD_*), every member carries the parameters
+            uint32_t common = ((uint32_t) s.periph.size() << 2) | ((uint32_t) lc << vv::SHAKE_WORD_CENTRAL_SHIFT) | (s.settle ? vv::SHAKE_WORD_SETTLE : 0u);
+            for (size_t k = 0; k < 3; k++) {
+                int lane = lc;
+                if (k < s.periph.size()) {
+                    const int q = s.periph[k];
+                    if (wave_of[q] != w) throw Error(VVHIP_ERR_UNSUPPORTED, "a constraint cluster does not fit into one wave with its molecule");
+                    lane = lane_of[q];
+                }
+                common |= (uint32_t) lane << (4 + 6 * k);
             }
-            hp.slot_shake[(size_t) w * 64 + lc] = (int32_t) word;
             const double imc = 1.0 / sys.masses[s.center], imp = 1.0 / sys.masses[s.periph[0]];
-            float* prm = &hp.slot_shake_param[((size_t) w * 64 + lc) * 4];
+            float prm[4];
             if (s.settle) { prm[0] = (float) s.d; prm[1] = (float) s.d_pp; prm[2] = 0; prm[3] = 0; info.num_settle_clusters++; }   // apex-partner and partner-partner distance
             else { prm[0] = (float) imc; prm[1] = (float) (0.5 / (imc + imp)); prm[2] = (float) (s.d * s.d); prm[3] = (float) imp; info.num_shake_clusters++; }
+            hp.slot_shake[(size_t) w * 64 + lc] = (int32_t) (common | 1u);
+            std::memcpy(&hp.slot_shake_param[((size_t) w * 64 + lc) * 4], prm, sizeof(prm));
+            for (size_t k = 0; k < s.periph.size(); k++) {
+                const int lq = lane_of[s.periph[k]];
+                hp.slot_shake[(size_t) w * 64 + lq] = (int32_t) (common | 2u | ((uint32_t) k << vv::SHAKE_WORD_OWN_SHIFT));
+                std::memcpy(&hp.slot_shake_param[((size_t) w * 64 + lq) * 4], prm, sizeof(prm));
+            }
         }
     }
     if (hp.per.enabled && !shakes.empty()) {

@@ -43,7 +43,13 @@ constexpr uint32_t META_PAIR = 1u << 25;       // member of a DrudeForce pair (h
 constexpr uint32_t META_IS_DRUDE = 1u << 26;   // the Drude (pair.x) of that pair
 constexpr uint32_t META_MASSIVE = 1u << 27;    // mass != 0 (velm.w != 0)
 constexpr uint32_t META_BIGMOL = 1u << 28;     // lane belongs to a molecule too large for one wave: its COM comes from bigacc
-constexpr uint32_t SHAKE_WORD_SETTLE = 1u << 30;  // slot_shake word of an apex lane: the cluster is a rigid triangle (SETTLE)
+// slot_shake word of a lane that belongs to a constraint cluster (0 otherwise); every member carries the whole cluster, so that each
+// lane can gather its mates' data itself: bit 0 central (apex) lane, bit 1 peripheral lane, bits 2-3 number of peripherals np,
+// bits 4-9 / 10-15 / 16-21 lanes of peripherals 0 / 1 / 2 (unused ones: the central lane), bits 22-27 lane of the central particle,
+// bits 28-29 the lane's own index among the peripherals, bit 30 the cluster is a rigid triangle (SETTLE)
+constexpr int SHAKE_WORD_CENTRAL_SHIFT = 22;
+constexpr int SHAKE_WORD_OWN_SHIFT = 28;
+constexpr uint32_t SHAKE_WORD_SETTLE = 1u << 30;
 constexpr uint32_t META_SHAKE = 1u << 30;      // member of an in-kernel constraint cluster: the kernels fetch its cluster word, parameters and
                                                // position in the same round of loads as the velocity, not after reading the cluster word
 constexpr uint32_t META_BIG_FIRST = 1u << 29;  // leader of the FIRST chunk of such a molecule (adds M*V^2 once, clears bigacc)

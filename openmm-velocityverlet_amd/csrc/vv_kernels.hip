@@ -359,128 +359,282 @@ __device__ __forceinline__ void settle_velocities_math(mixed m0, mixed m1,
         v2x += (eCAx * tca - eBCx * tbc) * iC; v2y += (eCAy * tca - eBCy * tbc) * iC; v2z += (eCAz * tca - eBCz * tbc) * iC;
 }
 
+// ---- constraint clusters: hand-over page and solvers
+// Per-wave LDS page, component-major: page[c * 64 + lane], c = 0..2 position, 3..5 the vector being constrained (velocity or step
+// displacement), 6 inverse mass (SETTLE only).  Lane-major rows of 7 values put the lanes of a wave on 32 banks two by two; this way a
+// row of 64 lanes covers every bank once, for the writes and for the gathers by cluster lane alike.  A wave executes its LDS
+// operations in order, so the "barriers" below are compiler fences only.
+#define VV_WAVE_LDS_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 template <class mixed>
-__device__ __forceinline__ void shake_positions(int lane, unsigned word, float4 prm, mixed tol, mixed x, mixed y, mixed z, mixed invm,
-                                                mixed& dx, mixed& dy, mixed& dz, mixed (*page)[7]) {
-    if (word & 2u) { page[lane][0] = x; page[lane][1] = y; page[lane][2] = z; page[lane][3] = dx; page[lane][4] = dy; page[lane][5] = dz; page[lane][6] = invm; }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if ((word & 1u) && (word & SHAKE_WORD_SETTLE)) {
-        const int l1 = (int) ((word >> 4) & 63u), l2 = (int) ((word >> 10) & 63u);
-        mixed d1x = page[l1][3], d1y = page[l1][4], d1z = page[l1][5], d2x = page[l2][3], d2y = page[l2][4], d2z = page[l2][5];
-        settle_positions_math<mixed>((mixed) 1 / invm, (mixed) 1 / page[l1][6], (mixed) prm.x, (mixed) prm.y, x, y, z,
-                                     page[l1][0], page[l1][1], page[l1][2], page[l2][0], page[l2][1], page[l2][2], dx, dy, dz, d1x, d1y, d1z, d2x, d2y, d2z);
-        page[l1][3] = d1x; page[l1][4] = d1y; page[l1][5] = d1z; page[l2][3] = d2x; page[l2][4] = d2y; page[l2][5] = d2z;
-    } else if (word & 1u) {
-        const int np = (int) ((word >> 2) & 3u);
-        const mixed invMassCentral = prm.x, avgMass = prm.y, d2 = prm.z, invMassPeripheral = prm.w;
-        mixed rij[3][3], rijsq[3], ld[3], xpj[3][3];
-        int pl[3];
+__device__ __forceinline__ mixed dot3(const mixed (&a)[3], const mixed (&b)[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+// Cofactors and reciprocal determinant of a symmetric 3 x 3 matrix (oracle/vv_oracle.c: sym3_cofactors, same operations in the same order)
+template <class mixed> struct Sym3Inv { mixed c00, c01, c02, c11, c12, c22, inv; };
+template <class mixed>
+__device__ __forceinline__ Sym3Inv<mixed> sym3_cofactors(mixed A00, mixed A01, mixed A02, mixed A11, mixed A12, mixed A22) {
+    Sym3Inv<mixed> q;
+    q.c00 = A11 * A22 - A12 * A12;
+    q.c01 = A02 * A12 - A01 * A22;
+    q.c02 = A01 * A12 - A02 * A11;
+    q.c11 = A00 * A22 - A02 * A02;
+    q.c12 = A01 * A02 - A00 * A12;
+    q.c22 = A00 * A11 - A01 * A01;
+    const mixed det = A00 * q.c00 + A01 * q.c01 + A02 * q.c02;
+    q.inv = 1 / det;
+    return q;
+}
+// What every lane of a hydrogen-type cluster needs: old bonds r_k = x_central - x_k and w_k = a_central - a_k (a = the velocity or the
+// step displacement) of all (<= 3) constraints, gathered from the page by the lanes the cluster word lists; rows beyond np are zero.
+template <class mixed>
+__device__ __forceinline__ void cluster_gather(const mixed* page, unsigned word, mixed (&c)[6], mixed (&r)[3][3], mixed (&w)[3][3]) {
+    // All 24 reads are unconditional and issued together (a read under `k < np` becomes a divergent block with its own wait: nine
+    // serialised LDS round trips in the first version of this).  The cluster word names the CENTRAL lane for the peripherals a
+    // cluster does not have, so their rows come out as c - c = 0 exactly, without a select.
+    const int lc = (int) ((word >> SHAKE_WORD_CENTRAL_SHIFT) & 63u);
+    const int p0 = (int) ((word >> 4) & 63u), p1 = (int) ((word >> 10) & 63u), p2 = (int) ((word >> 16) & 63u);
+    mixed q[3][6];
+#pragma unroll
+    for (int a = 0; a < 6; a++) { c[a] = page[a * 64 + lc]; q[0][a] = page[a * 64 + p0]; q[1][a] = page[a * 64 + p1]; q[2][a] = page[a * 64 + p2]; }
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int a = 0; a < 3; a++) { r[k][a] = c[a] - q[k][a]; w[k][a] = c[3 + a] - q[k][3 + a]; }
+}
+
+// Hydrogen-type clusters, ALL constraints of a cluster at once (default; oracle/vv_oracle.c: vvo_cluster_velocities_direct /
+// vvo_cluster_positions_newton state the same arithmetic).  Every lane of a cluster -- central and peripheral alike -- gathers the
+// cluster's bonds from the page and solves the k x k system (k <= 3) for itself: the wave executes ONE instruction stream whatever the
+// number of lanes that take part, so repeating the solve in four lanes costs nothing, while a central lane sweeping over its three
+// constraints one after the other (the Gauss-Seidel form below, OpenMM's iteration) is a three times longer serial chain of dependent
+// fp64 operations, repeated four times until its last sweep finds nothing to correct (measured: 2.8 us of an 18.3 us step at C3 with
+// its 33 000 constraints, profiles/r03a_shake_cost.txt).
+//   velocities: (u_k + imc sum_m l_m r_m + imp l_k r_k) . r_k = 0 is linear in the multipliers l: closed-form solve, no iteration;
+//   positions:  Newton on g_k(l) = |s_k + imc sum_m l_m r_m + imp l_k r_k|^2 - d^2 with the exact diagonal (imc + imp) b_k . r_k and the
+//               off-diagonals at the old bonds; OpenMM's convergence test (|g_k| < tol d^2 for every constraint of the cluster).
+// OpenMM's source is not under /root/reference: parity with OpenMM itself is unpinned either way.
+template <class mixed>
+__device__ __forceinline__ void cluster_velocities_direct(unsigned word, float4 prm, mixed x, mixed y, mixed z, mixed& vx, mixed& vy, mixed& vz, const mixed* page) {
+    mixed c[6], r[3][3], u[3][3];
+    cluster_gather<mixed>(page, word, c, r, u);
+    const int np = (int) ((word >> 2) & 3u);
+    const mixed imc = prm.x, imp = prm.w, ims = imc + imp;
+    const mixed b0 = dot3(u[0], r[0]), b1 = dot3(u[1], r[1]), b2 = dot3(u[2], r[2]);
+    const mixed A00 = ims * dot3(r[0], r[0]);
+    const mixed A11 = np > 1 ? ims * dot3(r[1], r[1]) : (mixed) 1;
+    const mixed A22 = np > 2 ? ims * dot3(r[2], r[2]) : (mixed) 1;
+    const mixed A01 = imc * dot3(r[0], r[1]), A02 = imc * dot3(r[0], r[2]), A12 = imc * dot3(r[1], r[2]);
+    const Sym3Inv<mixed> q = sym3_cofactors<mixed>(A00, A01, A02, A11, A12, A22);
+    const mixed l0 = -((q.c00 * b0 + q.c01 * b1 + q.c02 * b2) * q.inv);
+    const mixed l1 = -((q.c01 * b0 + q.c11 * b1 + q.c12 * b2) * q.inv);
+    const mixed l2 = -((q.c02 * b0 + q.c12 * b1 + q.c22 * b2) * q.inv);
+    if (word & 1u) {
+        vx += imc * (l0 * r[0][0] + l1 * r[1][0] + l2 * r[2][0]);
+        vy += imc * (l0 * r[0][1] + l1 * r[1][1] + l2 * r[2][1]);
+        vz += imc * (l0 * r[0][2] + l1 * r[1][2] + l2 * r[2][2]);
+    } else {
+        const int k = (int) ((word >> SHAKE_WORD_OWN_SHIFT) & 3u);
+        const mixed f = imp * (k == 0 ? l0 : (k == 1 ? l1 : l2));
+        vx -= f * (c[0] - x); vy -= f * (c[1] - y); vz -= f * (c[2] - z);      // own bond: the same bits as r[k]
+    }
+}
+template <class mixed>
+__device__ __forceinline__ void cluster_positions_newton(unsigned word, float4 prm, mixed tol, mixed x, mixed y, mixed z, mixed& dx, mixed& dy, mixed& dz, const mixed* page, bool member) {
+    mixed c[6], r[3][3], s[3][3], b[3][3];
+    int np = 0;
+    mixed imc = 0, imp = 0, ims = 0, d2 = 0, d2tol = 0, O01 = 0, O02 = 0, O12 = 0;
+    if (member) {
+        cluster_gather<mixed>(page, word, c, r, s);
+        np = (int) ((word >> 2) & 3u);
+        imc = prm.x; d2 = prm.z; imp = prm.w; ims = imc + imp; d2tol = d2 * tol;
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int a = 0; a < 3; a++) { s[k][a] = r[k][a] + s[k][a]; b[k][a] = s[k][a]; }
+        O01 = imc * dot3(r[0], r[1]); O02 = imc * dot3(r[0], r[2]); O12 = imc * dot3(r[1], r[2]);
+    }
+    mixed l0 = 0, l1 = 0, l2 = 0, tx = 0, ty = 0, tz = 0;
+    bool live = member;
+    for (int iteration = 0; iteration < 15; iteration++) {
+        mixed g0 = 0, g1 = 0, g2 = 0;
+        if (live) {
+            g0 = dot3(b[0], b[0]) - d2;
+            g1 = np > 1 ? dot3(b[1], b[1]) - d2 : (mixed) 0;
+            g2 = np > 2 ? dot3(b[2], b[2]) - d2 : (mixed) 0;
+            live = fabs(g0) >= d2tol || fabs(g1) >= d2tol || fabs(g2) >= d2tol;      // a cluster that is within tolerance stays there
+        }
+        if (!__any(live)) break;
+        if (live) {
+            const mixed D0 = ims * dot3(b[0], r[0]);
+            const mixed D1 = np > 1 ? ims * dot3(b[1], r[1]) : (mixed) 1;
+            const mixed D2 = np > 2 ? ims * dot3(b[2], r[2]) : (mixed) 1;
+            const Sym3Inv<mixed> q = sym3_cofactors<mixed>(D0, O01, O02, D1, O12, D2);
+            const mixed h0 = 0.5f * g0, h1 = 0.5f * g1, h2 = 0.5f * g2;
+            l0 -= (q.c00 * h0 + q.c01 * h1 + q.c02 * h2) * q.inv;
+            l1 -= (q.c01 * h0 + q.c11 * h1 + q.c12 * h2) * q.inv;
+            l2 -= (q.c02 * h0 + q.c12 * h1 + q.c22 * h2) * q.inv;
+            tx = imc * (l0 * r[0][0] + l1 * r[1][0] + l2 * r[2][0]);
+            ty = imc * (l0 * r[0][1] + l1 * r[1][1] + l2 * r[2][1]);
+            tz = imc * (l0 * r[0][2] + l1 * r[1][2] + l2 * r[2][2]);
+            const mixed f0 = imp * l0, f1 = imp * l1, f2 = imp * l2;
+            b[0][0] = (s[0][0] + tx) + f0 * r[0][0]; b[0][1] = (s[0][1] + ty) + f0 * r[0][1]; b[0][2] = (s[0][2] + tz) + f0 * r[0][2];
+            if (np > 1) { b[1][0] = (s[1][0] + tx) + f1 * r[1][0]; b[1][1] = (s[1][1] + ty) + f1 * r[1][1]; b[1][2] = (s[1][2] + tz) + f1 * r[1][2]; }
+            if (np > 2) { b[2][0] = (s[2][0] + tx) + f2 * r[2][0]; b[2][1] = (s[2][1] + ty) + f2 * r[2][1]; b[2][2] = (s[2][2] + tz) + f2 * r[2][2]; }
+        }
+    }
+    if (member) {
+        if (word & 1u) {
+            dx = dx + tx; dy = dy + ty; dz = dz + tz;
+        } else {
+            const int k = (int) ((word >> SHAKE_WORD_OWN_SHIFT) & 3u);
+            const mixed f = imp * (k == 0 ? l0 : (k == 1 ? l1 : l2));
+            dx -= f * (c[0] - x); dy -= f * (c[1] - y); dz -= f * (c[2] - z);
+        }
+    }
+}
+
+// Constraint clusters of the kind OpenMM's SHAKE kernels take, Gauss-Seidel form (VVHIP_SHAKE_MODE=0; generic kernels only): the
+// central lane iterates like OpenMM's applyShakeToPositions / applyShakeToVelocities (sweeps over the cluster's constraints, <= 15,
+// float cluster parameters, `mixed` arithmetic) and hands the peripherals their result through the page.
+template <class mixed>
+__device__ __forceinline__ void cluster_positions_sweeps(unsigned word, float4 prm, mixed tol, mixed x, mixed y, mixed z, mixed& dx, mixed& dy, mixed& dz, mixed* page) {
+    const int np = (int) ((word >> 2) & 3u);
+    const mixed invMassCentral = prm.x, avgMass = prm.y, d2 = prm.z, invMassPeripheral = prm.w;
+    mixed rij[3][3], rijsq[3], ld[3], xpj[3][3];
+    int pl[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        pl[k] = (int) ((word >> (4 + 6 * k)) & 63u);
+        if (k < np) {
+            rij[k][0] = x - page[pl[k]]; rij[k][1] = y - page[64 + pl[k]]; rij[k][2] = z - page[128 + pl[k]];
+            xpj[k][0] = page[192 + pl[k]]; xpj[k][1] = page[256 + pl[k]]; xpj[k][2] = page[320 + pl[k]];
+        } else {
+            rij[k][0] = rij[k][1] = rij[k][2] = 0; xpj[k][0] = xpj[k][1] = xpj[k][2] = 0;
+        }
+        rijsq[k] = rij[k][0] * rij[k][0] + rij[k][1] * rij[k][1] + rij[k][2] * rij[k][2];
+        ld[k] = d2 - rijsq[k];
+    }
+    mixed xpi[3] = {dx, dy, dz};
+    const mixed d2tol = d2 * tol;
+    bool converged = false;
+    for (int iteration = 0; iteration < 15 && !converged; iteration++) {
+        converged = true;
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            pl[k] = (int) ((word >> (4 + 6 * k)) & 63u);
             if (k < np) {
-                rij[k][0] = x - page[pl[k]][0]; rij[k][1] = y - page[pl[k]][1]; rij[k][2] = z - page[pl[k]][2];
-                xpj[k][0] = page[pl[k]][3]; xpj[k][1] = page[pl[k]][4]; xpj[k][2] = page[pl[k]][5];
-            } else {
-                rij[k][0] = rij[k][1] = rij[k][2] = 0; xpj[k][0] = xpj[k][1] = xpj[k][2] = 0;
-            }
-            rijsq[k] = rij[k][0] * rij[k][0] + rij[k][1] * rij[k][1] + rij[k][2] * rij[k][2];
-            ld[k] = d2 - rijsq[k];
-        }
-        mixed xpi[3] = {dx, dy, dz};
-        const mixed d2tol = d2 * tol;
-        bool converged = false;
-        for (int iteration = 0; iteration < 15 && !converged; iteration++) {
-            converged = true;
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                if (k < np) {
-                    const mixed rp0 = xpi[0] - xpj[k][0], rp1 = xpi[1] - xpj[k][1], rp2 = xpi[2] - xpj[k][2];
-                    const mixed rpsqij = rp0 * rp0 + rp1 * rp1 + rp2 * rp2;
-                    const mixed rrpr = rij[k][0] * rp0 + rij[k][1] * rp1 + rij[k][2] * rp2;
-                    // both quotients are started together (the wave is latency-bound here); values as in the branchy statement
-                    // OpenMM's test is fabs(..) / (d2 * tol) >= 1; the product form decides the same up to the last bit of the quotient
-                    // and saves an IEEE fp64 division per visit on this serial path (the oracle states it the same way)
-                    const mixed num = ld[k] - 2.0f * rrpr - rpsqij;
-                    const mixed acor = num * avgMass / (rrpr + rijsq[k]);
-                    if (fabs(num) >= d2tol) {
-                        const mixed d0 = rij[k][0] * acor, d1 = rij[k][1] * acor, d2v = rij[k][2] * acor;
-                        xpi[0] += d0 * invMassCentral; xpi[1] += d1 * invMassCentral; xpi[2] += d2v * invMassCentral;
-                        xpj[k][0] -= d0 * invMassPeripheral; xpj[k][1] -= d1 * invMassPeripheral; xpj[k][2] -= d2v * invMassPeripheral;
-                        converged = false;
-                    }
+                const mixed rp0 = xpi[0] - xpj[k][0], rp1 = xpi[1] - xpj[k][1], rp2 = xpi[2] - xpj[k][2];
+                const mixed rpsqij = rp0 * rp0 + rp1 * rp1 + rp2 * rp2;
+                const mixed rrpr = rij[k][0] * rp0 + rij[k][1] * rp1 + rij[k][2] * rp2;
+                // OpenMM's test is fabs(..) / (d2 * tol) >= 1; the product form decides the same up to the last bit of the quotient
+                // (the oracle states it the same way)
+                const mixed num = ld[k] - 2.0f * rrpr - rpsqij;
+                const mixed acor = num * avgMass / (rrpr + rijsq[k]);
+                if (fabs(num) >= d2tol) {
+                    const mixed d0 = rij[k][0] * acor, d1 = rij[k][1] * acor, d2v = rij[k][2] * acor;
+                    xpi[0] += d0 * invMassCentral; xpi[1] += d1 * invMassCentral; xpi[2] += d2v * invMassCentral;
+                    xpj[k][0] -= d0 * invMassPeripheral; xpj[k][1] -= d1 * invMassPeripheral; xpj[k][2] -= d2v * invMassPeripheral;
+                    converged = false;
                 }
             }
         }
-        dx = xpi[0]; dy = xpi[1]; dz = xpi[2];
-#pragma unroll
-        for (int k = 0; k < 3; k++)
-            if (k < np) { page[pl[k]][3] = xpj[k][0]; page[pl[k]][4] = xpj[k][1]; page[pl[k]][5] = xpj[k][2]; }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (word & 2u) { dx = page[lane][3]; dy = page[lane][4]; dz = page[lane][5]; }
+    dx = xpi[0]; dy = xpi[1]; dz = xpi[2];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        if (k < np) { page[192 + pl[k]] = xpj[k][0]; page[256 + pl[k]] = xpj[k][1]; page[320 + pl[k]] = xpj[k][2]; }
+}
+template <class mixed>
+__device__ __forceinline__ void cluster_velocities_sweeps(unsigned word, float4 prm, mixed tol, mixed x, mixed y, mixed z, mixed& vx, mixed& vy, mixed& vz, mixed* page) {
+    const int np = (int) ((word >> 2) & 3u);
+    const mixed invMassCentral = prm.x, avgMass = prm.y, invMassPeripheral = prm.w;
+    mixed rij[3][3], rijsq[3], vj[3][3];
+    int pl[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        pl[k] = (int) ((word >> (4 + 6 * k)) & 63u);
+        if (k < np) {
+            rij[k][0] = x - page[pl[k]]; rij[k][1] = y - page[64 + pl[k]]; rij[k][2] = z - page[128 + pl[k]];
+            vj[k][0] = page[192 + pl[k]]; vj[k][1] = page[256 + pl[k]]; vj[k][2] = page[320 + pl[k]];
+        } else {
+            rij[k][0] = rij[k][1] = rij[k][2] = 0; vj[k][0] = vj[k][1] = vj[k][2] = 0;
+        }
+        rijsq[k] = rij[k][0] * rij[k][0] + rij[k][1] * rij[k][1] + rij[k][2] * rij[k][2];
+        rijsq[k] = k < np ? (mixed) 1 / rijsq[k] : (mixed) 0;     // the bond does not move during the sweeps: one reciprocal, not one division per visit
+    }
+    mixed vi[3] = {vx, vy, vz};
+    bool converged = false;
+    for (int iteration = 0; iteration < 15 && !converged; iteration++) {
+        converged = true;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            if (k < np) {
+                const mixed rp0 = vi[0] - vj[k][0], rp1 = vi[1] - vj[k][1], rp2 = vi[2] - vj[k][2];
+                const mixed rrpr = rp0 * rij[k][0] + rp1 * rij[k][1] + rp2 * rij[k][2];
+                const mixed delta = -2.0f * avgMass * rrpr * rijsq[k];
+                const mixed d0 = rij[k][0] * delta, d1 = rij[k][1] * delta, d2v = rij[k][2] * delta;
+                vi[0] += d0 * invMassCentral; vi[1] += d1 * invMassCentral; vi[2] += d2v * invMassCentral;
+                vj[k][0] -= d0 * invMassPeripheral; vj[k][1] -= d1 * invMassPeripheral; vj[k][2] -= d2v * invMassPeripheral;
+                if (fabs(delta) > tol) converged = false;
+            }
+        }
+    }
+    vx = vi[0]; vy = vi[1]; vz = vi[2];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        if (k < np) { page[192 + pl[k]] = vj[k][0]; page[256 + pl[k]] = vj[k][1]; page[320 + pl[k]] = vj[k][2]; }
+}
+
+// One call per tile: every lane of the wave walks through it.  `word` = the lane's cluster word (0: not in a cluster).  has_shake /
+// has_settle: the plan holds hydrogen-type clusters / rigid three-site molecules (stage bits, compile-time constants in the
+// specialised kernels: a box of ionic liquid carries no SETTLE code, a box of water no cluster solver); gs = the Gauss-Seidel form
+// for the hydrogen-type clusters.  Rigid molecules: analytic, solved by the apex lane, partners' results handed back through the page.
+template <class mixed>
+__device__ __forceinline__ void shake_positions(int lane, unsigned word, float4 prm, mixed tol, mixed x, mixed y, mixed z, mixed invm,
+                                                mixed& dx, mixed& dy, mixed& dz, mixed* page, bool has_shake, bool has_settle, bool gs) {
+    const bool member = (word & 3u) != 0, settle = has_settle && (word & SHAKE_WORD_SETTLE) != 0;
+    if (member) {
+        page[lane] = x; page[64 + lane] = y; page[128 + lane] = z; page[192 + lane] = dx; page[256 + lane] = dy; page[320 + lane] = dz;
+        if (settle) page[384 + lane] = invm;
+    }
+    VV_WAVE_LDS_FENCE();
+    if (has_shake && !gs) cluster_positions_newton<mixed>(word, prm, tol, x, y, z, dx, dy, dz, page, member && !settle);
+    if (has_settle || (has_shake && gs)) {            // someone solves for its cluster mates and hands the results back
+        if ((word & 1u) && settle) {
+            const int l1 = (int) ((word >> 4) & 63u), l2 = (int) ((word >> 10) & 63u);
+            mixed d1x = page[192 + l1], d1y = page[256 + l1], d1z = page[320 + l1], d2x = page[192 + l2], d2y = page[256 + l2], d2z = page[320 + l2];
+            settle_positions_math<mixed>((mixed) 1 / invm, (mixed) 1 / page[384 + l1], (mixed) prm.x, (mixed) prm.y, x, y, z,
+                                         page[l1], page[64 + l1], page[128 + l1], page[l2], page[64 + l2], page[128 + l2], dx, dy, dz, d1x, d1y, d1z, d2x, d2y, d2z);
+            page[192 + l1] = d1x; page[256 + l1] = d1y; page[320 + l1] = d1z; page[192 + l2] = d2x; page[256 + l2] = d2y; page[320 + l2] = d2z;
+        } else if (has_shake && gs && (word & 1u)) {
+            cluster_positions_sweeps<mixed>(word, prm, tol, x, y, z, dx, dy, dz, page);
+        }
+        VV_WAVE_LDS_FENCE();
+        if ((word & 2u) && (settle || (has_shake && gs))) { dx = page[192 + lane]; dy = page[256 + lane]; dz = page[320 + lane]; }
+    }
 }
 
 template <class mixed>
 __device__ __forceinline__ void shake_velocities(int lane, unsigned word, float4 prm, mixed tol, mixed x, mixed y, mixed z, mixed invm,
-                                                 mixed& vx, mixed& vy, mixed& vz, mixed (*page)[7]) {
-    if (word & 2u) { page[lane][0] = x; page[lane][1] = y; page[lane][2] = z; page[lane][3] = vx; page[lane][4] = vy; page[lane][5] = vz; page[lane][6] = invm; }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if ((word & 1u) && (word & SHAKE_WORD_SETTLE)) {
-        const int l1 = (int) ((word >> 4) & 63u), l2 = (int) ((word >> 10) & 63u);
-        mixed u1x = page[l1][3], u1y = page[l1][4], u1z = page[l1][5], u2x = page[l2][3], u2y = page[l2][4], u2z = page[l2][5];
-        settle_velocities_math<mixed>((mixed) 1 / invm, (mixed) 1 / page[l1][6], x, y, z,
-                                      page[l1][0], page[l1][1], page[l1][2], page[l2][0], page[l2][1], page[l2][2], vx, vy, vz, u1x, u1y, u1z, u2x, u2y, u2z);
-        page[l1][3] = u1x; page[l1][4] = u1y; page[l1][5] = u1z; page[l2][3] = u2x; page[l2][4] = u2y; page[l2][5] = u2z;
-    } else if (word & 1u) {
-        const int np = (int) ((word >> 2) & 3u);
-        const mixed invMassCentral = prm.x, avgMass = prm.y, invMassPeripheral = prm.w;
-        mixed rij[3][3], rijsq[3], vj[3][3];
-        int pl[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            pl[k] = (int) ((word >> (4 + 6 * k)) & 63u);
-            if (k < np) {
-                rij[k][0] = x - page[pl[k]][0]; rij[k][1] = y - page[pl[k]][1]; rij[k][2] = z - page[pl[k]][2];
-                vj[k][0] = page[pl[k]][3]; vj[k][1] = page[pl[k]][4]; vj[k][2] = page[pl[k]][5];
-            } else {
-                rij[k][0] = rij[k][1] = rij[k][2] = 0; vj[k][0] = vj[k][1] = vj[k][2] = 0;
-            }
-            rijsq[k] = rij[k][0] * rij[k][0] + rij[k][1] * rij[k][1] + rij[k][2] * rij[k][2];
-            rijsq[k] = k < np ? (mixed) 1 / rijsq[k] : (mixed) 0;     // the bond does not move during the sweeps: one reciprocal, not one division per visit
-        }
-        mixed vi[3] = {vx, vy, vz};
-        bool converged = false;
-        for (int iteration = 0; iteration < 15 && !converged; iteration++) {
-            converged = true;
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                if (k < np) {
-                    const mixed rp0 = vi[0] - vj[k][0], rp1 = vi[1] - vj[k][1], rp2 = vi[2] - vj[k][2];
-                    const mixed rrpr = rp0 * rij[k][0] + rp1 * rij[k][1] + rp2 * rij[k][2];
-                    const mixed delta = -2.0f * avgMass * rrpr * rijsq[k];
-                    const mixed d0 = rij[k][0] * delta, d1 = rij[k][1] * delta, d2v = rij[k][2] * delta;
-                    vi[0] += d0 * invMassCentral; vi[1] += d1 * invMassCentral; vi[2] += d2v * invMassCentral;
-                    vj[k][0] -= d0 * invMassPeripheral; vj[k][1] -= d1 * invMassPeripheral; vj[k][2] -= d2v * invMassPeripheral;
-                    if (fabs(delta) > tol) converged = false;
-                }
-            }
-        }
-        vx = vi[0]; vy = vi[1]; vz = vi[2];
-#pragma unroll
-        for (int k = 0; k < 3; k++)
-            if (k < np) { page[pl[k]][3] = vj[k][0]; page[pl[k]][4] = vj[k][1]; page[pl[k]][5] = vj[k][2]; }
+                                                 mixed& vx, mixed& vy, mixed& vz, mixed* page, bool has_shake, bool has_settle, bool gs) {
+    const bool member = (word & 3u) != 0, settle = has_settle && (word & SHAKE_WORD_SETTLE) != 0;
+    if (member) {
+        page[lane] = x; page[64 + lane] = y; page[128 + lane] = z; page[192 + lane] = vx; page[256 + lane] = vy; page[320 + lane] = vz;
+        if (settle) page[384 + lane] = invm;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (word & 2u) { vx = page[lane][3]; vy = page[lane][4]; vz = page[lane][5]; }
+    VV_WAVE_LDS_FENCE();
+    if (has_shake && !gs && member && !settle) cluster_velocities_direct<mixed>(word, prm, x, y, z, vx, vy, vz, page);
+    if (has_settle || (has_shake && gs)) {
+        if ((word & 1u) && settle) {
+            const int l1 = (int) ((word >> 4) & 63u), l2 = (int) ((word >> 10) & 63u);
+            mixed u1x = page[192 + l1], u1y = page[256 + l1], u1z = page[320 + l1], u2x = page[192 + l2], u2y = page[256 + l2], u2z = page[320 + l2];
+            settle_velocities_math<mixed>((mixed) 1 / invm, (mixed) 1 / page[384 + l1], x, y, z,
+                                          page[l1], page[64 + l1], page[128 + l1], page[l2], page[64 + l2], page[128 + l2], vx, vy, vz, u1x, u1y, u1z, u2x, u2y, u2z);
+            page[192 + l1] = u1x; page[256 + l1] = u1y; page[320 + l1] = u1z; page[192 + l2] = u2x; page[256 + l2] = u2y; page[320 + l2] = u2z;
+        } else if (has_shake && gs && (word & 1u)) {
+            cluster_velocities_sweeps<mixed>(word, prm, tol, x, y, z, vx, vy, vz, page);
+        }
+        VV_WAVE_LDS_FENCE();
+        if ((word & 2u) && (settle || (has_shake && gs))) { vx = page[192 + lane]; vy = page[256 + lane]; vz = page[320 + lane]; }
+    }
 }
 
 // ================================================================================ multi-GPU mailbox (vv_kernels.hpp: Mailbox)
@@ -599,7 +753,7 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const int2* __restrict__ pre_
             unsigned m = 0;
             if (ws != 0x7fffffff) m = (unsigned) pre_slots[(size_t) ws * 64 + lane].y;
             sh_pat_meta[row][lane] = m;
-            if (F & A_SHAKE_V) {
+            if (F & A_CONS) {
                 const bool member = ws != 0x7fffffff && (m & META_SHAKE);
                 sh_pat_shake[row][lane] = member ? (unsigned) a.slot_shake[(size_t) ws * 64 + lane] : 0u;
                 sh_pat_prm[row][lane] = member ? a.slot_shake_param[(size_t) ws * 64 + lane] : make_float4(0, 0, 0, 0);
@@ -759,17 +913,17 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const int2* __restrict__ pre_
                     v.y += 0.5 * stepSize * v.w * fe.y + fscale * v.w * fy;
                     v.z += 0.5 * stepSize * v.w * fe.z + fscale * v.w * fz;
                 }
-                if (!(F & (A_SHAKE_V | A_NOSTORE))) store_vec(velm, atom, v, (F & A_WT_STORES) != 0);
+                if (!(F & (A_CONS | A_NOSTORE))) store_vec(velm, atom, v, (F & A_WT_STORES) != 0);
                 if (F & A_POSDELTA_VV) {                                    // K/velocityVerlet.cu:24-26
                     mixed4 d = {stepSize * v.x, stepSize * v.y, stepSize * v.z, 0};
                     ((mixed4*) a.pos_delta)[atom] = d;
                 }
             }
         }
-        if (F & A_SHAKE_V) {                   // integration.applyVelocityConstraints(tol) (HOST:151, 427), clusters solved in the wave
+        if (F & A_CONS) {                      // integration.applyVelocityConstraints(tol) (HOST:151, 427), clusters solved in the wave
             // one page per wave of the block, sized at launch (dynamic LDS): a static [8] cost 28 KB per block also where blocks have 4 waves
             extern __shared__ double vv_dyn_lds[];
-            mixed (*shake_page_a)[64][7] = (mixed (*)[64][7]) vv_dyn_lds;
+            mixed* shake_page_a = (mixed*) vv_dyn_lds + (threadIdx.x >> 6) * (7 * 64);
             // cluster word, parameters and position are requested together, keyed by the role word's META_SHAKE bit (not one after
             // the other, keyed by the cluster word: that put two more dependent memory round trips into this kernel)
             const bool member = act && (meta & META_SHAKE);
@@ -778,7 +932,8 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const int2* __restrict__ pre_
             mixed sx = 0, sy = 0, sz = 0, sq = 0;
             real sraw = 0;
             if (member) PosIO<real, mixed>::load(a.posq, a.corr, atom, sx, sy, sz, sq, sraw);
-            shake_velocities<mixed>(lane, word, prm, (mixed) a.shake_tol, sx, sy, sz, v.w, v.x, v.y, v.z, shake_page_a[threadIdx.x >> 6]);
+            shake_velocities<mixed>(lane, word, prm, (mixed) a.shake_tol, sx, sy, sz, v.w, v.x, v.y, v.z, shake_page_a,
+                                    (F & A_SHAKE_V) != 0, (F & A_SETTLE) != 0, (F & A_SHAKE_GS) != 0);
             if (massive) store_vec(velm, atom, v, (F & A_WT_STORES) != 0);
         }
         if ((F & A_POS1) && massive) {                                      // K/middle.cu:33-40
@@ -1178,7 +1333,7 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const int2* __restrict__ pre_
             }
             sh_pat_meta[row][lane] = m;
             sh_pat_f[row][lane] = f;
-            if (F & B_SHAKE) {
+            if (F & B_CONS) {
                 const bool member = ws != 0x7fffffff && (m & META_SHAKE);
                 sh_pat_shake[row][lane] = member ? (unsigned) a.slot_shake[(size_t) ws * 64 + lane] : 0u;
                 sh_pat_prm[row][lane] = member ? a.slot_shake_param[(size_t) ws * 64 + lane] : make_float4(0, 0, 0, 0);
@@ -1308,7 +1463,7 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const int2* __restrict__ pre_
         // barrier (they used to be read where they are needed, behind it: two exposed memory round trips per tile)
         unsigned shake_word = 0;
         float4 shake_prm = make_float4(0, 0, 0, 0);
-        if ((F & B_SHAKE) && act && (meta & META_SHAKE)) {
+        if ((F & B_CONS) && act && (meta & META_SHAKE)) {
             shake_word = (F & B_PERIODIC) ? sh_pat_shake[pw.region][lane] : (unsigned) a.slot_shake[(size_t) wave * 64 + lane];
             shake_prm = (F & B_PERIODIC) ? sh_pat_prm[pw.region][lane] : a.slot_shake_param[(size_t) wave * 64 + lane];
         }
@@ -1487,7 +1642,7 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const int2* __restrict__ pre_
         }
         // per-wave LDS page of the in-kernel SHAKE (collective over the wave: every lane walks through it)
         extern __shared__ double vv_dyn_lds[];
-        mixed (*shake_page_b)[64][7] = (mixed (*)[64][7]) vv_dyn_lds;      // one page per tile wave, sized at launch
+        mixed* shake_page_b = (mixed*) vv_dyn_lds + wib * (7 * 64);      // one page per tile wave, sized at launch
         if (F & B_DRIFT_MIDDLE) {
             // Pos1 (K/middle.cu:36-38) with the pre-thermostat velocity, Pos2 (:54-56) with the scaled one.  Without constraints
             // posDelta == oldDelta and Pos3's velocity correction (K/middle.cu:77-79) adds (d - d)/dt == 0 exactly; with the
@@ -1499,8 +1654,9 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const int2* __restrict__ pre_
                 ddx += halfdt * v.x; ddy += halfdt * v.y; ddz += halfdt * v.z;
             }
             const mixed odx = ddx, ody = ddy, odz = ddz;
-            if (F & B_SHAKE)                                                       // integration.applyConstraints(tol), HOST:176
-                shake_positions<mixed>(lane, shake_word, shake_prm, (mixed) a.shake_tol, x, y, z, v.w, ddx, ddy, ddz, shake_page_b[wib]);
+            if (F & B_CONS)                                                        // integration.applyConstraints(tol), HOST:176
+                shake_positions<mixed>(lane, shake_word, shake_prm, (mixed) a.shake_tol, x, y, z, v.w, ddx, ddy, ddz, shake_page_b,
+                                       (F & B_SHAKE) != 0, (F & B_SETTLE) != 0, (F & B_SHAKE_GS) != 0);
             if (massive) {
                 const mixed invDt = (mixed) a.inv_dt_mixed;      // = 1 / stepSize, formed once on the host
                 v.x += (ddx - odx) * invDt; v.y += (ddy - ody) * invDt; v.z += (ddz - odz) * invDt;
@@ -1520,8 +1676,9 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const int2* __restrict__ pre_
                 const mixed4 d = ((const mixed4*) a.pos_delta)[atom];
                 dx = d.x; dy = d.y; dz = d.z;
             }
-            if (F & B_SHAKE)                                                       // integration.applyConstraints(tol), HOST:351
-                shake_positions<mixed>(lane, shake_word, shake_prm, (mixed) a.shake_tol, x, y, z, v.w, dx, dy, dz, shake_page_b[wib]);
+            if (F & B_CONS)                                                        // integration.applyConstraints(tol), HOST:351
+                shake_positions<mixed>(lane, shake_word, shake_prm, (mixed) a.shake_tol, x, y, z, v.w, dx, dy, dz, shake_page_b,
+                                       (F & B_SHAKE) != 0, (F & B_SETTLE) != 0, (F & B_SHAKE_GS) != 0);
             if (massive) {
                 const mixed invStepSize = (mixed) a.inv_dt_double; // = 1.0 / stepSize, formed once on the host
                 x += dx; y += dy; z += dz;
@@ -1803,6 +1960,8 @@ constexpr uint32_t SF_B_MIDDLE_HW_MB = SF_B_MIDDLE_HW | B_MAILBOX;
 constexpr uint32_t SF_A_MIDDLE_SHAKE = SF_A_MIDDLE | A_SHAKE_V;                         // HBonds constraints solved in-kernel
 constexpr uint32_t SF_B_MIDDLE_HW_SHAKE = SF_B_MIDDLE_HW | B_SHAKE;
 constexpr uint32_t SF_B_MIDDLE_SHAKE = SF_B_MIDDLE | B_SHAKE;
+constexpr uint32_t SF_A_MIDDLE_SETTLE = SF_A_MIDDLE | A_SETTLE;                       // rigid water (BASELINE C2 made physical): SETTLE only
+constexpr uint32_t SF_B_MIDDLE_SETTLE = SF_B_MIDDLE | B_SETTLE;
 
 // Further stage sets with their own compiled kernel (the generic kernel with run-time stage bits is 15-20 % slower: C5 went from
 // 74 k to 88 k steps/s when it got its own pair): the classic scheme's two halves and the stages of the un-fused entry points.
@@ -1859,6 +2018,9 @@ constexpr uint32_t SF_B_MIDDLE_NC_K = B_SCALE | B_DRIFT_MIDDLE | B_KICK;
 constexpr uint32_t SF_B_MIDDLE_NC_K_P = SF_B_MIDDLE_NC_K | B_PERIODIC;
 constexpr uint32_t SF_B_MIDDLE_NC_SHAKE = B_SCALE | B_DRIFT_MIDDLE | B_SHAKE;
 constexpr uint32_t SF_B_MIDDLE_NC_SHAKE_P = SF_B_MIDDLE_NC_SHAKE | B_PERIODIC;
+constexpr uint32_t SF_B_MIDDLE_NC_SETTLE = B_SCALE | B_DRIFT_MIDDLE | B_SETTLE;
+constexpr uint32_t SF_B_MIDDLE_NC_SETTLE_P = SF_B_MIDDLE_NC_SETTLE | B_PERIODIC;
+constexpr uint32_t SF_A_MIDDLE_SETTLE_P = SF_A_MIDDLE_SETTLE | A_PERIODIC;
 constexpr uint32_t SF_B_COS_HW_NC = B_SCALE | B_UNBIAS | B_CZ_LOAD | B_DRIFT_MIDDLE | B_HARDWALL;
 constexpr uint32_t SF_B_COS_HW_NC_P = SF_B_COS_HW_NC | B_PERIODIC;
 // the classic scheme's two thermostat applications in large boxes: scale + half kick + positions (+ hard wall), and scale alone
@@ -1900,7 +2062,7 @@ hipError_t launch_a(int precision, const KArgs& a, int block_threads, int grid_c
     vv_last_grid_value = g.x;
     const dim3 b(block_threads);
     // per-wave LDS page of the in-kernel constraint solver (7 values of the mode's `mixed` type per lane)
-    const unsigned lds = (a.flags & A_SHAKE_V) ? (unsigned) (block_threads / 64) * 64u * 7u * (precision == VVHIP_SINGLE ? 4u : 8u) : 0u;
+    const unsigned lds = (a.flags & A_CONS) ? (unsigned) (block_threads / 64) * 64u * 7u * (precision == VVHIP_SINGLE ? 4u : 8u) : 0u;
     constexpr uint32_t XM = SF_AM;
 #define VV_PRE_ARGS a.slots, a.nwaves, (int) (b.x >> 6), a.velm, a.force, a.padded
     VV_TRY_SF(vv_kernel_a, SF_A_MIDDLE_NS_P)
@@ -1915,6 +2077,8 @@ hipError_t launch_a(int precision, const KArgs& a, int block_threads, int grid_c
     VV_TRY_SF(vv_kernel_a, SF_A_EDL)
     VV_TRY_SF(vv_kernel_a, SF_A_MIDDLE_SHAKE)
     VV_TRY_SF(vv_kernel_a, SF_A_MIDDLE_SHAKE_P)
+    VV_TRY_SF(vv_kernel_a, SF_A_MIDDLE_SETTLE)
+    VV_TRY_SF(vv_kernel_a, SF_A_MIDDLE_SETTLE_P)
     VV_TRY_SF(vv_kernel_a, SF_A_COS_MOM_SHAKE)
     VV_TRY_SF(vv_kernel_a, SF_A_EDL_SHAKE)
     VV_TRY_SF(vv_kernel_a, SF_A_LD)
@@ -1938,7 +2102,7 @@ hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_c
     if ((int) g.x > grid_cap) g.x = (unsigned) grid_cap;
     vv_last_grid_value = g.x;
     const dim3 b(block_threads + ((a.flags & B_CHAIN) ? 64 : 0));
-    const unsigned lds = (a.flags & B_SHAKE) ? (unsigned) (block_threads / 64) * 64u * 7u * (precision == VVHIP_SINGLE ? 4u : 8u) : 0u;      // one page per tile wave
+    const unsigned lds = (a.flags & B_CONS) ? (unsigned) (block_threads / 64) * 64u * 7u * (precision == VVHIP_SINGLE ? 4u : 8u) : 0u;      // one page per tile wave
     constexpr uint32_t XM = SF_BM;
 #define VV_PRE_ARGS a.slots, a.nwaves, (int) (b.x >> 6), (const unsigned long long*) a.acc, a.nh, a.lane_const, a.seg_base
     if ((a.flags & B_CHAIN) && a.chain.num_chains != 3) {       // the specialised kernels carry the three-link chain only
@@ -1971,6 +2135,9 @@ hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_c
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_NC_K_P)
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_NC_SHAKE)
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_NC_SHAKE_P)
+    VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_SETTLE)
+    VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_NC_SETTLE)
+    VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_NC_SETTLE_P)
     VV_TRY_SF(vv_kernel_b, SF_B_COS_HW_NC)
     VV_TRY_SF(vv_kernel_b, SF_B_COS_HW_NC_P)
     VV_TRY_SF(vv_kernel_b, SF_B_VV1_HW_NC)

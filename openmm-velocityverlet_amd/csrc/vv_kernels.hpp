@@ -27,7 +27,8 @@ enum : uint32_t {
     A_COMPART = 1u << 12,    // molecules larger than a wave: add each chunk's sum(m v), sum(m) to the molecule's accumulator
     A_CZ_STORE = 1u << 13,   // keep cos(2 pi z / Lz) of every lane for the later kernels of this step (positions do not move in between)
     A_CZ_LOAD = 1u << 14,    // ... and take it from there instead of evaluating a double-precision cosine again
-    A_SHAKE_V = 1u << 16,    // velocity constraints of the SHAKE clusters right after the kick (OpenMM applyVelocityConstraints)
+    A_SHAKE_V = 1u << 16,    // velocity constraints of the hydrogen-type clusters right after the kick (OpenMM applyVelocityConstraints)
+    A_SETTLE = 1u << 22,     // ... of the rigid three-site molecules (one or both bits: what the plan holds)
     A_KE_MOM = 1u << 17,     // with A_BIAS | A_KE in ONE launch: the group sums as moments Saa, Sab, Sbb of the still biased velocities
                              // (accumulators 0-2, 4-6, 7-9); kernel B combines them once V is known: 2KE = Saa - 2 V Sab + V^2 Sbb
     A_MTAB = 1u << 18,       // own mass and Drude-pair mass fraction from the static per-lane tables (slot_m, slot_f) instead of
@@ -37,6 +38,8 @@ enum : uint32_t {
     A_NOSTORE = 1u << 19,    // the kicked velocities stay in registers (KE stage) and are NOT written back: kernel B repeats the kick
                              // itself (B_KICK) from velm + force -- 24 bytes of force read there instead of 32 bytes written here and
                              // 3.5 MB less dirty data behind this launch at the headline size (the kernel boundary waits for it)
+    A_SHAKE_GS = 1u << 21,   // hydrogen-type clusters by Gauss-Seidel sweeps of the central lane (OpenMM's iteration; VVHIP_SHAKE_MODE=0, generic
+                             // kernel only) instead of the direct solve of the cluster's velocity constraints
     A_WT_STORES = 1u << 27,  // write-through (sc1) store of the kicked velocities
     A_KE_PLAIN = 1u << 15,   // sum m v^2 over every massive particle into accumulator 0 (kinetic-energy query)
 };
@@ -55,17 +58,20 @@ enum : uint32_t {
     B_IMAGE = 1u << 10,       // mirror copy to the image particle     (K/imageCharge.cu:2-28)
     B_CHAIN = 1u << 11,       // run the NH chain in the kernel head from the accumulators (else read nh->scales)
     B_CZ_LOAD = 1u << 12,     // cos(2 pi z / Lz) from the per-lane cache written by kernel A (A_CZ_STORE)
-    B_SHAKE = 1u << 13,       // position constraints of the SHAKE clusters on the step's displacement (OpenMM applyConstraints)
+    B_SHAKE = 1u << 13,       // position constraints of the hydrogen-type clusters on the step's displacement (OpenMM applyConstraints)
+    B_SETTLE = 1u << 20,      // ... of the rigid three-site molecules
     B_MAILBOX = 1u << 14,     // multi-GPU mailbox: block 0's thermostat wave stores this rank's totals into every peer, all blocks sum all ranks' totals
     B_KE_MOM = 1u << 15,      // the accumulators hold moments (A_KE_MOM): combine them with V, unbias the stored COM velocities with comw
     B_KICK = 1u << 17,        // v += dt*invM*Fe + dt/2^32*invM*F (K/middle.cu:6-23) on the freshly loaded velocities: partner of A_NOSTORE, the
                               // very expression kernel A evaluated (same operands, same order: same bits); Fe = the cos force with B_UNBIAS
     B_PERIODIC = 1u << 18,    // as A_PERIODIC
     B_MTAB = 1u << 16,        // Drude-pair mass fractions from the static per-lane table (slot_f) instead of two IEEE divisions per lane
+    B_SHAKE_GS = 1u << 19,    // as A_SHAKE_GS, for the position constraints (instead of the coupled Newton iteration)
     B_WT_STORES = 1u << 27,   // write-through (sc1) stores for the particle arrays: the dirty lines leave L2 during the kernel, not at its end
     B_DBG_NOFOLD = 1u << 28,  // timing experiments only: skip the accumulator fold / the chain arithmetic
     B_DBG_NOMATH = 1u << 29,
 };
+constexpr uint32_t A_CONS = A_SHAKE_V | A_SETTLE, B_CONS = B_SHAKE | B_SETTLE;      // in-kernel constraints of either kind
 // ---- chain kernel --------------------------------------------------------------------------------
 enum : uint32_t { C_CHAIN = 1u << 0, C_BIAS = 1u << 1 };
 
@@ -182,8 +188,8 @@ struct KArgs {
     const double* slot_f;           // [64*nwaves] Drude-pair lanes: invTotalMass * own mass (K/drudeNoseHoover.cu:173-180), else 0
     const int32_t* slot_image;
     const int32_t* slot_rand;
-    const int32_t* slot_shake;      // packed SHAKE cluster word per lane (vv_host.hpp), NULL without in-kernel constraints
-    const float4* slot_shake_param; // central lanes: 1/m_c, 0.5/(1/m_c+1/m_p), d^2, 1/m_p
+    const int32_t* slot_shake;      // packed cluster word per lane (vv_host.hpp: SHAKE_WORD_*), NULL without in-kernel constraints
+    const float4* slot_shake_param; // every lane of a cluster: 1/m_c, 0.5/(1/m_c+1/m_p), d^2, 1/m_p (SETTLE: the two distances)
     double shake_tol;
     const int32_t* slot_big;        // big-molecule index per lane (only with molecules larger than a wave)
     unsigned long long* bigacc;     // int64 fixed point [num_big][4]: sum m vx, m vy, m vz, m

@@ -318,6 +318,7 @@ class _System(C.Structure):
         ("forces_valid", C.c_int), ("num_threads", C.c_int),
         ("num_shake", C.c_int), ("shake_atoms", C.c_void_p), ("shake_params", C.c_void_p), ("constraint_tolerance", C.c_double),
         ("num_settle", C.c_int), ("settle_atoms", C.c_void_p), ("settle_params", C.c_void_p),
+        ("shake_mode", C.c_int),
     ]
 
 
@@ -358,7 +359,10 @@ class OracleSystem:
     """One system + integrator configuration living in host memory, stepped by vv_oracle.c."""
 
     def __init__(self, spec, params: Params, prec: str = "mixed", random: np.ndarray | None = None,
-                 force_mode: int = 1, k_tether: float = 1000.0, k_drude: float = 209200.0, num_threads: int = 1):
+                 force_mode: int = 1, k_tether: float = 1000.0, k_drude: float = 209200.0, num_threads: int = 1,
+                 shake_mode: int | None = None):
+        """shake_mode: 0 = Gauss-Seidel sweeps over a constraint cluster, 1 = the cluster's constraints at once (vv_oracle.c:
+        vvo_cluster_*); None follows VVHIP_SHAKE_MODE like the product (default 1)."""
         self.prec, self.spec = prec, spec
         self.L = lib(prec)
         R, M = REAL[prec], MIXED[prec]
@@ -411,6 +415,7 @@ class OracleSystem:
         s.forces_valid, s.num_threads = 0, num_threads
         self.clusters = build_constraint_clusters(spec)
         s.constraint_tolerance = 1e-5
+        s.shake_mode = int(os.environ.get("VVHIP_SHAKE_MODE", "1")) if shake_mode is None else int(shake_mode)
         if self.clusters is not None:
             cl = self.clusters
             if len(cl["shake_atoms"]):

@@ -694,6 +694,133 @@ void vvo_shake_velocities(int nclusters, const int* atoms, const float* params, 
     }
 }
 
+/* ------------------------------------------------------------------ the same clusters, all constraints of a cluster at once
+ * (shake_mode 1, what the product runs by default; the Gauss-Seidel sweeps above stay as shake_mode 0).
+ * Multipliers l_k, one per constraint: the central particle moves by imc * sum_m l_m r_m, peripheral k by -imp * l_k r_k, with
+ * r_k = x_central - x_k the bond BEFORE the step (OpenMM's rij) and imc / imp the float inverse masses of the cluster parameters.
+ *   velocities: (u_k + imc sum_m l_m r_m + imp l_k r_k) . r_k = 0 is LINEAR in l: one symmetric k x k system (k <= 3), solved in
+ *               closed form (cofactors); no iteration, no tolerance.
+ *   positions:  g_k(l) = |s_k + imc sum_m l_m r_m + imp l_k r_k|^2 - d^2 = 0, s_k the unconstrained new bond.  Newton on the k x k
+ *               system with the exact diagonal (imc + imp) b_k . r_k (b_k the current bond: OpenMM's rrpr + rijsq) and the
+ *               off-diagonals imc r_k . r_m taken at the old bonds (they differ from imc b_k . r_m by the bond's rotation during one
+ *               step, a few percent of an entry that is itself 3 % of the diagonal for C-H clusters): one corrective iteration
+ *               where the sweeps need four.  Same convergence test as OpenMM's: |d^2 - |b_k|^2| < tol d^2 for every constraint.
+ * Unused rows (np < 3) are identity rows.  Every product and sum in the order written: the device code repeats them verbatim. */
+#define DOT3(a, b) ((a)[0] * (b)[0] + (a)[1] * (b)[1] + (a)[2] * (b)[2])
+typedef struct { mixed c00, c01, c02, c11, c12, c22, inv; } sym3inv;
+static inline sym3inv sym3_cofactors(mixed A00, mixed A01, mixed A02, mixed A11, mixed A12, mixed A22) {
+    sym3inv q;
+    q.c00 = A11 * A22 - A12 * A12;
+    q.c01 = A02 * A12 - A01 * A22;
+    q.c02 = A01 * A12 - A02 * A11;
+    q.c11 = A00 * A22 - A02 * A02;
+    q.c12 = A01 * A02 - A00 * A12;
+    q.c22 = A00 * A11 - A01 * A01;
+    const mixed det = A00 * q.c00 + A01 * q.c01 + A02 * q.c02;
+    q.inv = 1 / det;
+    return q;
+}
+void vvo_cluster_velocities_direct(int nclusters, const int* atoms, const float* params, const real4* posq, const real4* posq_corr, mixed4* velm) {
+    PAR_FOR
+    for (int c = 0; c < nclusters; c++) {
+        const int ic = atoms[4 * c];
+        const mixed imc = params[4 * c], imp = params[4 * c + 3];
+        mixed xc[3], w;
+        load_pos(posq, posq_corr, ic, &xc[0], &xc[1], &xc[2], &w);
+        const mixed vc[3] = { velm[ic].x, velm[ic].y, velm[ic].z };
+        mixed r[3][3], b[3];
+        int np = 0;
+        for (int k = 0; k < 3; k++) {
+            const int j = atoms[4 * c + 1 + k];
+            if (j >= 0 && np == k) {
+                mixed xp[3];
+                load_pos(posq, posq_corr, j, &xp[0], &xp[1], &xp[2], &w);
+                const mixed u[3] = { vc[0] - velm[j].x, vc[1] - velm[j].y, vc[2] - velm[j].z };
+                for (int a = 0; a < 3; a++) r[k][a] = xc[a] - xp[a];
+                b[k] = DOT3(u, r[k]);
+                np++;
+            } else {
+                r[k][0] = r[k][1] = r[k][2] = 0; b[k] = 0;
+            }
+        }
+        const mixed ims = imc + imp;
+        const mixed A00 = ims * DOT3(r[0], r[0]);
+        const mixed A11 = np > 1 ? ims * DOT3(r[1], r[1]) : (mixed) 1;
+        const mixed A22 = np > 2 ? ims * DOT3(r[2], r[2]) : (mixed) 1;
+        const mixed A01 = imc * DOT3(r[0], r[1]), A02 = imc * DOT3(r[0], r[2]), A12 = imc * DOT3(r[1], r[2]);
+        const sym3inv q = sym3_cofactors(A00, A01, A02, A11, A12, A22);
+        mixed l[3];
+        l[0] = -((q.c00 * b[0] + q.c01 * b[1] + q.c02 * b[2]) * q.inv);
+        l[1] = -((q.c01 * b[0] + q.c11 * b[1] + q.c12 * b[2]) * q.inv);
+        l[2] = -((q.c02 * b[0] + q.c12 * b[1] + q.c22 * b[2]) * q.inv);
+        mixed t[3];
+        for (int a = 0; a < 3; a++) t[a] = l[0] * r[0][a] + l[1] * r[1][a] + l[2] * r[2][a];
+        velm[ic].x += imc * t[0]; velm[ic].y += imc * t[1]; velm[ic].z += imc * t[2];
+        for (int k = 0; k < np; k++) {
+            const int j = atoms[4 * c + 1 + k];
+            const mixed f = imp * l[k];
+            velm[j].x -= f * r[k][0]; velm[j].y -= f * r[k][1]; velm[j].z -= f * r[k][2];
+        }
+    }
+}
+void vvo_cluster_positions_newton(int nclusters, const int* atoms, const float* params, mixed tol, const real4* posq,
+                                  const real4* posq_corr, mixed4* pos_delta) {
+    PAR_FOR
+    for (int c = 0; c < nclusters; c++) {
+        const int ic = atoms[4 * c];
+        const mixed imc = params[4 * c], d2 = params[4 * c + 2], imp = params[4 * c + 3];
+        mixed xc[3], w;
+        load_pos(posq, posq_corr, ic, &xc[0], &xc[1], &xc[2], &w);
+        const mixed dc[3] = { pos_delta[ic].x, pos_delta[ic].y, pos_delta[ic].z };
+        mixed r[3][3], s[3][3], b[3][3];
+        int np = 0;
+        for (int k = 0; k < 3; k++) {
+            const int j = atoms[4 * c + 1 + k];
+            if (j >= 0 && np == k) {
+                mixed xp[3];
+                load_pos(posq, posq_corr, j, &xp[0], &xp[1], &xp[2], &w);
+                const mixed dk[3] = { pos_delta[j].x, pos_delta[j].y, pos_delta[j].z };
+                for (int a = 0; a < 3; a++) { r[k][a] = xc[a] - xp[a]; s[k][a] = r[k][a] + (dc[a] - dk[a]); }
+                np++;
+            } else {
+                for (int a = 0; a < 3; a++) r[k][a] = s[k][a] = 0;
+            }
+            for (int a = 0; a < 3; a++) b[k][a] = s[k][a];
+        }
+        const mixed ims = imc + imp, d2tol = d2 * tol;
+        const mixed O01 = imc * DOT3(r[0], r[1]), O02 = imc * DOT3(r[0], r[2]), O12 = imc * DOT3(r[1], r[2]);
+        mixed l[3] = { 0, 0, 0 }, t[3] = { 0, 0, 0 };
+        for (int iteration = 0; iteration < 15; iteration++) {
+            mixed g[3];
+            int active = 0;
+            for (int k = 0; k < 3; k++) {
+                g[k] = k < np ? DOT3(b[k], b[k]) - d2 : (mixed) 0;
+                if (fabs(g[k]) >= d2tol) active = 1;
+            }
+            if (!active) break;
+            const mixed D0 = ims * DOT3(b[0], r[0]);
+            const mixed D1 = np > 1 ? ims * DOT3(b[1], r[1]) : (mixed) 1;
+            const mixed D2 = np > 2 ? ims * DOT3(b[2], r[2]) : (mixed) 1;
+            const sym3inv q = sym3_cofactors(D0, O01, O02, D1, O12, D2);
+            const mixed h0 = 0.5f * g[0], h1 = 0.5f * g[1], h2 = 0.5f * g[2];
+            l[0] -= (q.c00 * h0 + q.c01 * h1 + q.c02 * h2) * q.inv;
+            l[1] -= (q.c01 * h0 + q.c11 * h1 + q.c12 * h2) * q.inv;
+            l[2] -= (q.c02 * h0 + q.c12 * h1 + q.c22 * h2) * q.inv;
+            for (int a = 0; a < 3; a++) t[a] = imc * (l[0] * r[0][a] + l[1] * r[1][a] + l[2] * r[2][a]);
+            for (int k = 0; k < np; k++) {
+                const mixed f = imp * l[k];
+                for (int a = 0; a < 3; a++) b[k][a] = (s[k][a] + t[a]) + f * r[k][a];
+            }
+        }
+        pos_delta[ic].x = dc[0] + t[0]; pos_delta[ic].y = dc[1] + t[1]; pos_delta[ic].z = dc[2] + t[2];
+        for (int k = 0; k < np; k++) {
+            const int j = atoms[4 * c + 1 + k];
+            const mixed f = imp * l[k];
+            pos_delta[j].x -= f * r[k][0]; pos_delta[j].y -= f * r[k][1]; pos_delta[j].z -= f * r[k][2];
+        }
+    }
+}
+
 /* ------------------------------------------------------------------ SETTLE for rigid three-site molecules (see vv_oracle.h) */
 typedef struct { mixed x, y, z; } v3;
 static inline v3 v3_make(mixed x, mixed y, mixed z) { v3 r = { x, y, z }; return r; }
@@ -946,19 +1073,27 @@ static void hard_wall(vvo_system* s) {             /* HOST:189-212 / 307-372 */
                             (mixed) s->max_drude_distance, (mixed) hardwallScaleDrude);
     }
 }
+static void shake_v(vvo_system* s) {                /* shake_mode 0: Gauss-Seidel sweeps, 1: all constraints of a cluster at once */
+    if (s->shake_mode == 0) vvo_shake_velocities(s->num_shake, s->shake_atoms, s->shake_params, (mixed) s->constraint_tolerance, s->posq, s->posq_corr, s->velm);
+    else vvo_cluster_velocities_direct(s->num_shake, s->shake_atoms, s->shake_params, s->posq, s->posq_corr, s->velm);
+}
+static void shake_x(vvo_system* s) {
+    if (s->shake_mode == 0) vvo_shake_positions(s->num_shake, s->shake_atoms, s->shake_params, (mixed) s->constraint_tolerance, s->posq, s->posq_corr, s->pos_delta);
+    else vvo_cluster_positions_newton(s->num_shake, s->shake_atoms, s->shake_params, (mixed) s->constraint_tolerance, s->posq, s->posq_corr, s->pos_delta);
+}
 static void step_middle(vvo_system* s) {           /* API:232-270; constraints/virtual sites/reorder are OpenMM's */
     const int n = s->num_atoms;
     calc_forces(s);
     apply_extra_forces(s);
     vvo_integrate_middle_vel(n, s->padded_num_atoms, s->velm, s->force, s->force_extra, (mixed) s->dt);  /* HOST:144-148 */
     if (s->num_shake > 0)   /* integration.applyVelocityConstraints, HOST:151 */
-        vvo_shake_velocities(s->num_shake, s->shake_atoms, s->shake_params, (mixed) s->constraint_tolerance, s->posq, s->posq_corr, s->velm);
+        shake_v(s);
     if (s->num_settle > 0) vvo_settle_velocities(s->num_settle, s->settle_atoms, s->posq, s->posq_corr, s->velm);
     vvo_integrate_middle_pos1(n, s->velm, s->pos_delta, s->old_delta, (mixed) s->dt);                     /* HOST:154-158 */
     nh_half(s);
     vvo_integrate_middle_pos2(n, s->velm, s->pos_delta, s->old_delta, (mixed) s->dt);                     /* HOST:169-173 */
     if (s->num_shake > 0)   /* integration.applyConstraints, HOST:176 */
-        vvo_shake_positions(s->num_shake, s->shake_atoms, s->shake_params, (mixed) s->constraint_tolerance, s->posq, s->posq_corr, s->pos_delta);
+        shake_x(s);
     if (s->num_settle > 0) vvo_settle_positions(s->num_settle, s->settle_atoms, s->settle_params, s->posq, s->posq_corr, s->velm, s->pos_delta);
     vvo_integrate_middle_pos3(n, s->posq, s->posq_corr, s->pos_delta, s->old_delta, s->velm, (mixed) s->dt); /* HOST:179-185 */
     hard_wall(s);
@@ -976,7 +1111,7 @@ static void step_vv(vvo_system* s) {               /* API:272-338 */
     vvo_vv_integrate_velocities(n, s->padded_num_atoms, s->velm, s->force, s->force_extra, s->pos_delta,
                                 (mixed) s->dt, (mixed) fscale, 1);                                        /* HOST:341-348 */
     if (s->num_shake > 0)   /* HOST:351 */
-        vvo_shake_positions(s->num_shake, s->shake_atoms, s->shake_params, (mixed) s->constraint_tolerance, s->posq, s->posq_corr, s->pos_delta);
+        shake_x(s);
     if (s->num_settle > 0) vvo_settle_positions(s->num_settle, s->settle_atoms, s->settle_params, s->posq, s->posq_corr, s->velm, s->pos_delta);
     vvo_vv_integrate_positions(n, s->posq, s->posq_corr, s->pos_delta, s->velm, (mixed) s->dt);           /* HOST:355-360 */
     hard_wall(s);
@@ -988,7 +1123,7 @@ static void step_vv(vvo_system* s) {               /* API:272-338 */
     vvo_vv_integrate_velocities(n, s->padded_num_atoms, s->velm, s->force, s->force_extra, s->pos_delta,
                                 (mixed) s->dt, (mixed) fscale, 0);                                        /* HOST:417-424 */
     if (s->num_shake > 0)   /* HOST:427 */
-        vvo_shake_velocities(s->num_shake, s->shake_atoms, s->shake_params, (mixed) s->constraint_tolerance, s->posq, s->posq_corr, s->velm);
+        shake_v(s);
     if (s->num_settle > 0) vvo_settle_velocities(s->num_settle, s->settle_atoms, s->posq, s->posq_corr, s->velm);
     nh_half(s);
 }

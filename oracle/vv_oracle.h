@@ -118,6 +118,8 @@ typedef struct {
     /* rigid three-site molecules (SETTLE), see vvo_settle_positions */
     int num_settle; const int* settle_atoms;  /* [3*n]: apex, partner, partner */
     const float* settle_params;               /* [2*n]: apex-partner distance, partner-partner distance */
+    int shake_mode;                           /* 0: Gauss-Seidel sweeps over the cluster (OpenMM's iteration); 1: the cluster's constraints
+                                                 at once (direct solve for velocities, coupled Newton for positions), see vvo_cluster_* */
 } vvo_system;
 
 #ifdef __cplusplus
@@ -180,6 +182,11 @@ void vvo_shake_positions(int nclusters, const int* atoms, const float* params, v
                          const vvo_real4* posq_corr, vvo_mixed4* pos_delta);
 void vvo_shake_velocities(int nclusters, const int* atoms, const float* params, vvo_mixed tol, const vvo_real4* posq,
                           const vvo_real4* posq_corr, vvo_mixed4* velm);
+/* The same clusters with all their constraints solved together (vv_oracle.c; what the product runs unless VVHIP_SHAKE_MODE=0). */
+void vvo_cluster_velocities_direct(int nclusters, const int* atoms, const float* params, const vvo_real4* posq,
+                                   const vvo_real4* posq_corr, vvo_mixed4* velm);
+void vvo_cluster_positions_newton(int nclusters, const int* atoms, const float* params, vvo_mixed tol, const vvo_real4* posq,
+                                  const vvo_real4* posq_corr, vvo_mixed4* pos_delta);
 /* SETTLE (Miyamoto & Kollman 1992) for rigid three-site molecules, on the step displacement / on the velocities; masses from
  * velm.w.  Written independently of the device code (vector form, the velocity multipliers by Cramer's rule); same unpinned status
  * as vvo_shake_*: OpenMM's source is not under /root/reference. */

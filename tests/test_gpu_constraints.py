@@ -135,6 +135,54 @@ def test_drude_il_hbonds(prec, middle, use_com):
         ctx.close()
 
 
+@pytest.mark.parametrize("prec", O.PRECISIONS)
+@pytest.mark.parametrize("middle", [True, False])
+def test_drude_il_hbonds_gauss_seidel_sweeps(prec, middle, monkeypatch):
+    """VVHIP_SHAKE_MODE=0: the hydrogen-type clusters by Gauss-Seidel sweeps of the central lane (OpenMM's iteration, generic kernels)
+    instead of the default coupled solve; the oracle follows the same switch.  Both forms end within the tolerance of the same
+    constraint surface: their trajectories agree to a few tolerances."""
+    monkeypatch.setenv("VVHIP_SHAKE_MODE", "0")
+    spec = systems.constrain_hydrogens(systems.drude_il(cells=(1, 1, 1), pairs_per_cell=40, seed=7))
+    osys, ctx, it = _pair(spec, prec, middle, NSTEPS[prec])
+    try:
+        assert osys.s.shake_mode == 0
+        _parity(osys, ctx, prec, f"il-shake-sweeps/{prec}/middle={middle}")
+        _invariants(spec, ctx, prec, middle, f"il-shake-sweeps/{prec}/middle={middle}")
+        x0, v0 = ctx.getPositions(), ctx.getVelocities()
+    finally:
+        ctx.close()
+    monkeypatch.setenv("VVHIP_SHAKE_MODE", "1")
+    osys, ctx, it = _pair(spec, prec, middle, NSTEPS[prec])
+    try:
+        assert osys.s.shake_mode == 1
+        x1, v1 = ctx.getPositions(), ctx.getVelocities()
+        assert np.abs(x1 - x0).max() / np.abs(x0).max() < 1e-5
+        assert np.abs(v1 - v0).max() / np.abs(v0).max() < (2e-3 if prec != "single" else 5e-3)
+    finally:
+        ctx.close()
+
+
+def test_coupled_solve_leaves_no_bond_parallel_velocity():
+    """The direct solve of the velocity constraints is exact (no tolerance): right after kernel A the relative velocity along every
+    constrained bond vanishes to rounding.  Seen through the classic scheme without thermostatted Drude pairs on the bonded carbons:
+    a non-polarisable ionic liquid, where the second half's thermostat scales all velocities of a molecule by common factors."""
+    spec = systems.constrain_hydrogens(systems.nondrude_il(num_pairs=60, seed=4))
+    it = I.VVIntegrator(333.0, 10, 1.0, 40, 0.001)
+    it.setUseMiddleScheme(False)
+    it.setUseCOMTempGroup(False)
+    ctx = I.Context(spec, it, precision="double", force_provider="tether")
+    try:
+        assert ctx.info.num_shake_clusters > 0
+        it.step(10)
+        x, v = ctx.getPositions(), ctx.getVelocities()
+        c = np.asarray(spec.constraints)
+        r = x[c[:, 0]] - x[c[:, 1]]
+        rel = ((v[c[:, 0]] - v[c[:, 1]]) * r).sum(1) / np.sqrt((r * r).sum(1))
+        assert np.abs(rel).max() < 1e-12, np.abs(rel).max()
+    finally:
+        ctx.close()
+
+
 def test_constraints_hold_over_a_long_run_and_graph_replay_is_identical():
     spec = systems.constrain_hydrogens(systems.drude_il(cells=(1, 1, 1), pairs_per_cell=60, seed=11))
     res = []
