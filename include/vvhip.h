@@ -306,6 +306,11 @@ int vvhip_time_kernel(vvhip_plan* plan, int kernel, uint32_t flags, int reps, do
  * VVIntegrator::setDebugEnabled and prints the reference's per-call lines itself (VVIntegrator.h:417-419, CudaVVKernels.cpp:57,120,...).
  * Also VVHIP_ROCTX=1 in the environment.  libroctx64 is resolved at run time. */
 int vvhip_set_trace(vvhip_plan* plan, int enable);
+/* Per-launch timing of eager (not captured) launches, summed per class until vvhip_timing_read.  Kernels A and B: the dispatch's own
+ * begin / end timestamps (hipExtLaunchKernel with start / stop events: nothing is added to the stream; what rocprofv3's kernel trace
+ * reports).  enable = 1: everything else ("other": force provider, chain launch, collectives) bracketed by recorded events as well;
+ * enable = 2: kernels A and B only, so that the stream holds exactly what an untimed run enqueues; enable = n > 2: as 2, with n events
+ * created now instead of during the timed launches.  0 switches it off. */
 int vvhip_timing_enable(vvhip_plan* plan, int enable);
 int vvhip_timing_read(vvhip_plan* plan, double* ms_pass_a, double* ms_pass_b, double* ms_other, int32_t launches[3]);
 

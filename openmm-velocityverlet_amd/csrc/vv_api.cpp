@@ -121,7 +121,9 @@ struct vvhip_plan {
     uint32_t random_pos = 0;                // prepareRandomNumbers cursor for the plan-driven loops (vvhip_run_*)
     // HIP-event timing (eager launches only)
     bool timing = false;
+    bool timing_kernels_only = false;   // vvhip_timing_enable(plan, 2): dispatch timestamps of kernels A and B only, nothing added to the stream
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events[3];
+    std::vector<hipEvent_t> event_pool;  // events of earlier timing sessions, reused (hipEventCreate per launch would make the host the bottleneck)
     // captured graph for vvhip_run_graph
     // One executable per thermostat parity (the state is double-buffered by step parity, so a graph captured at parity q only
     // replays correctly when the plan is at parity q again).  Captured by vvhip_graph_prepare / the first vvhip_run_graph that
@@ -397,21 +399,31 @@ struct ScopedTimer {
     int cls;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     bool on, ranged = false;
-    ScopedTimer(vvhip_plan* p_, int cls_) : p(p_), cls(cls_), on(p_->timing && !p_->capturing) {
+    // dispatch = true: the launcher delivers the dispatch's own begin / end timestamps into e0 / e1 (kernels A and B: vv_launch);
+    // otherwise the events are recorded around the enqueued work (adds two barrier packets to the stream)
+    bool dispatch;
+    static hipEvent_t take(vvhip_plan* p) {
+        hipEvent_t e = nullptr;
+        if (!p->event_pool.empty()) { e = p->event_pool.back(); p->event_pool.pop_back(); }
+        else (void) hipEventCreate(&e);
+        return e;
+    }
+    ScopedTimer(vvhip_plan* p_, int cls_, bool dispatch_ = false)
+        : p(p_), cls(cls_), on(p_->timing && !p_->capturing && (cls_ != T_OTHER || !p_->timing_kernels_only)), dispatch(dispatch_) {
         if (p->trace && !p->capturing) {
             static const char* names[3] = {"vvhip kernel A (kick / extra forces / sums)", "vvhip kernel B (thermostat / drift / hard wall)", "vvhip other"};
             if (roctx_api().push) { roctx_api().push(names[cls]); ranged = true; }
         }
         if (on) {
-            (void) hipEventCreate(&e0);
-            (void) hipEventCreate(&e1);
-            (void) hipEventRecord(e0, p->stream);
+            e0 = take(p);
+            e1 = take(p);
+            if (!dispatch) (void) hipEventRecord(e0, p->stream);
         }
     }
     ~ScopedTimer() {
         if (ranged) roctx_api().pop();
         if (on) {
-            (void) hipEventRecord(e1, p->stream);
+            if (!dispatch) (void) hipEventRecord(e1, p->stream);
             p->events[cls].emplace_back(e0, e1);
         }
     }
@@ -432,8 +444,8 @@ int run_a(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
     if (p->hp.per.enabled && p->periodic_kernels && (p->periodic_a || (flags & vv::A_CONS))) flags |= vv::A_PERIODIC;
     if (p->wt_stores && (flags & (vv::A_KICK_FULL | vv::A_KICK_HALF))) flags |= vv::A_WT_STORES;
     if ((flags & vv::A_SHAKE_V) && p->shake_mode == 0) flags |= vv::A_SHAKE_GS;
-    ScopedTimer t(p, T_A);
-    HIP_TRY(p, vv::launch_a(p->hp.precision, make_args(p, flags, random_index), p->block_threads, p->grid_cap_a, p->stream));
+    ScopedTimer t(p, T_A, true);
+    HIP_TRY(p, vv::launch_a(p->hp.precision, make_args(p, flags, random_index), p->block_threads, p->grid_cap_a, p->stream, t.e0, t.e1));
     return VVHIP_OK;
 }
 int run_b(vvhip_plan* p, uint32_t flags) {
@@ -442,8 +454,8 @@ int run_b(vvhip_plan* p, uint32_t flags) {
     if (p->hp.per.enabled && p->periodic_kernels && !(flags & vv::B_MAILBOX)) flags |= vv::B_PERIODIC;
     if (p->wt_stores) flags |= vv::B_WT_STORES;
     if ((flags & vv::B_SHAKE) && p->shake_mode == 0) flags |= vv::B_SHAKE_GS;
-    ScopedTimer t(p, T_B);
-    HIP_TRY(p, vv::launch_b(p->hp.precision, make_args(p, flags, 0), p->block_threads, p->grid_cap_b, p->stream));
+    ScopedTimer t(p, T_B, true);
+    HIP_TRY(p, vv::launch_b(p->hp.precision, make_args(p, flags, 0), p->block_threads, p->grid_cap_b, p->stream, t.e0, t.e1));
     if (flags & vv::B_CHAIN) p->parity ^= 1;     // the advanced thermostat state now lives in the other copy
     return VVHIP_OK;
 }
@@ -576,6 +588,7 @@ void vvhip_plan_destroy(vvhip_plan* p) {
         if (p->h_status) (void) hipHostFree(p->h_status);
         for (auto& v : p->events)
             for (auto& e : v) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
+        for (hipEvent_t e : p->event_pool) (void) hipEventDestroy(e);
     }
     delete p;
 }
@@ -1018,10 +1031,10 @@ int vvhip_stream_destroy(void* stream) { return hipStreamDestroy((hipStream_t) s
 int vvhip_synth_tether_force(vvhip_plan* p, const void* site, double k_tether, double k_drude) {
     NEED_BOUND(p);
     if (!site) return VVHIP_ERR_INVALID;
-    ScopedTimer t(p, T_OTHER);
+    ScopedTimer t(p, T_OTHER, true);
     vv::TetherArgs ta{p->buf.posq, site, p->buf.velm, (long long*) p->buf.force, p->d_slots,
                       p->hp.padded_num_atoms, p->hp.info.num_waves, k_tether, k_drude};
-    HIP_TRY(p, vv::launch_tether(p->hp.precision, ta, p->block_threads, p->stream));
+    HIP_TRY(p, vv::launch_tether(p->hp.precision, ta, p->block_threads, p->stream, t.e0, t.e1));
     return VVHIP_OK;
 }
 
@@ -1390,6 +1403,11 @@ int vvhip_set_trace(vvhip_plan* p, int enable) {
 int vvhip_timing_enable(vvhip_plan* p, int enable) {
     if (!p) return VVHIP_ERR_INVALID;
     p->timing = enable != 0;
+    p->timing_kernels_only = enable == 2;
+    if (enable > 2) {                  // enable = n > 2: as 2, with n events prepared now (a timed run of n / 2 launches creates none)
+        p->timing_kernels_only = true;
+        for (int i = (int) p->event_pool.size(); i < enable; i++) { hipEvent_t e = nullptr; if (hipEventCreate(&e) == hipSuccess) p->event_pool.push_back(e); }
+    }
     return VVHIP_OK;
 }
 int vvhip_timing_read(vvhip_plan* p, double* ms_a, double* ms_b, double* ms_other, int32_t* launches) {
@@ -1401,8 +1419,8 @@ int vvhip_timing_read(vvhip_plan* p, double* ms_a, double* ms_b, double* ms_othe
         for (auto& e : p->events[c]) {
             float ms = 0;
             if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) { tot[c] += ms; n[c]++; }
-            (void) hipEventDestroy(e.first);
-            (void) hipEventDestroy(e.second);
+            p->event_pool.push_back(e.first);
+            p->event_pool.push_back(e.second);
         }
         p->events[c].clear();
     }

@@ -18,6 +18,8 @@
 // there is no contraction on this path (HBM / latency / fp64-issue bound).
 #include "vv_kernels.hpp"
 
+#include <hip/hip_ext.h>
+
 #include "vv_host.hpp"
 
 namespace vv {
@@ -1928,6 +1930,14 @@ static inline dim3 grid_for(int nwaves, int block_threads) {
     const int wpb = block_threads / 64;
     return dim3((unsigned) ((nwaves + wpb - 1) / wpb));
 }
+// Launch with the dispatch's own begin / end timestamps delivered into a pair of events (hipExtLaunchKernelGGL: no barrier packets
+// around the kernel, the times are those of the dispatch packet's completion signal -- what rocprofv3's kernel trace reports);
+// without events, the plain launch (also the only form used inside a graph capture).
+template <typename F, typename... Args>
+static inline void vv_launch(F kernel, dim3 g, dim3 b, unsigned lds, hipStream_t s, hipEvent_t e0, hipEvent_t e1, Args... args) {
+    if (e0 || e1) hipExtLaunchKernelGGL(kernel, g, b, lds, s, e0, e1, 0, args...);
+    else hipLaunchKernelGGL(kernel, g, b, lds, s, args...);
+}
 #define VV_DISPATCH(KERNEL, ...)                                                                       \
     switch (precision) {                                                                               \
         case VVHIP_SINGLE: hipLaunchKernelGGL((KERNEL<float, float>), __VA_ARGS__); break;             \
@@ -1936,9 +1946,9 @@ static inline dim3 grid_for(int nwaves, int block_threads) {
     }
 #define VV_DISPATCH_SF(KERNEL, SFV, ...)                                                               \
     switch (precision) {                                                                               \
-        case VVHIP_SINGLE: hipLaunchKernelGGL((KERNEL<float, float, SFV>), __VA_ARGS__); break;        \
-        case VVHIP_MIXED: hipLaunchKernelGGL((KERNEL<float, double, SFV>), __VA_ARGS__); break;        \
-        default: hipLaunchKernelGGL((KERNEL<double, double, SFV>), __VA_ARGS__); break;                \
+        case VVHIP_SINGLE: vv_launch((KERNEL<float, float, SFV>), __VA_ARGS__); break;                 \
+        case VVHIP_MIXED: vv_launch((KERNEL<float, double, SFV>), __VA_ARGS__); break;                 \
+        default: vv_launch((KERNEL<double, double, SFV>), __VA_ARGS__); break;                         \
     }
 
 // Stage-bit sets with their own compiled kernel: the fused middle step of a Drude system with / without hard wall
@@ -2042,7 +2052,7 @@ constexpr uint32_t SF_B_SCALE_NC_P = SF_B_SCALE_NC | B_PERIODIC;
 #endif
 constexpr uint32_t SF_AM = VV_SF_MTAB_A ? A_MTAB : 0u, SF_BM = VV_SF_MTAB_B ? B_MTAB : 0u;
 bool sf_kernels_use_mass_table(int kernel) { return kernel == 0 ? VV_SF_MTAB_A != 0 : VV_SF_MTAB_B != 0; }
-#define VV_TRY_SF(KERNEL, SFV) if (a.flags == ((SFV) | XM)) { VV_DISPATCH_SF(KERNEL, ((SFV) | XM), g, b, lds, s, VV_PRE_ARGS, a); return hipGetLastError(); }
+#define VV_TRY_SF(KERNEL, SFV) if (a.flags == ((SFV) | XM)) { VV_DISPATCH_SF(KERNEL, ((SFV) | XM), g, b, lds, s, ev0, ev1, VV_PRE_ARGS, a); return hipGetLastError(); }
 
 // VVHIP_WARN_GENERIC=1: one line on stderr per stage set that has no compiled kernel of its own and runs the generic one (15-20 % slower)
 static void note_generic(const char* kernel, uint32_t flags) {
@@ -2056,7 +2066,7 @@ static void note_generic(const char* kernel, uint32_t flags) {
     std::fprintf(stderr, "vvhip: kernel %s runs stage set 0x%x on the generic kernel (no compiled specialisation)\n", kernel, flags);
 }
 
-hipError_t launch_a(int precision, const KArgs& a, int block_threads, int grid_cap, hipStream_t s) {
+hipError_t launch_a(int precision, const KArgs& a, int block_threads, int grid_cap, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     dim3 g = grid_for(a.nwaves, block_threads);
     if ((int) g.x > grid_cap) g.x = (unsigned) grid_cap;          // beyond that the kernel strides over tiles
     vv_last_grid_value = g.x;
@@ -2091,11 +2101,11 @@ hipError_t launch_a(int precision, const KArgs& a, int block_threads, int grid_c
     VV_TRY_SF(vv_kernel_a, SF_A_KICK_FE)
     VV_TRY_SF(vv_kernel_a, SF_A_POS1)
     note_generic("A", a.flags);
-    VV_DISPATCH_SF(vv_kernel_a, 0u, g, b, lds, s, VV_PRE_ARGS, a);
+    VV_DISPATCH_SF(vv_kernel_a, 0u, g, b, lds, s, ev0, ev1, VV_PRE_ARGS, a);
     return hipGetLastError();
 #undef VV_PRE_ARGS
 }
-hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_cap, hipStream_t s) {
+hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_cap, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     // block_threads counts the tile waves; B_CHAIN adds the block's thermostat wave.  Beyond grid_cap blocks the kernel strides
     // over tiles and the per-block thermostat work is amortised.
     dim3 g = grid_for(a.nwaves, block_threads);
@@ -2106,7 +2116,7 @@ hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_c
     constexpr uint32_t XM = SF_BM;
 #define VV_PRE_ARGS a.slots, a.nwaves, (int) (b.x >> 6), (const unsigned long long*) a.acc, a.nh, a.lane_const, a.seg_base
     if ((a.flags & B_CHAIN) && a.chain.num_chains != 3) {       // the specialised kernels carry the three-link chain only
-        VV_DISPATCH_SF(vv_kernel_b, 0u, g, b, lds, s, VV_PRE_ARGS, a);
+        VV_DISPATCH_SF(vv_kernel_b, 0u, g, b, lds, s, ev0, ev1, VV_PRE_ARGS, a);
         return hipGetLastError();
     }
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_HW_K_P)
@@ -2158,7 +2168,7 @@ hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_c
     VV_TRY_SF(vv_kernel_b, SF_B_POS3_HW)
     VV_TRY_SF(vv_kernel_b, SF_B_POS3)
     note_generic("B", a.flags);
-    VV_DISPATCH_SF(vv_kernel_b, 0u, g, b, lds, s, VV_PRE_ARGS, a);
+    VV_DISPATCH_SF(vv_kernel_b, 0u, g, b, lds, s, ev0, ev1, VV_PRE_ARGS, a);
     return hipGetLastError();
 #undef VV_PRE_ARGS
 }
@@ -2166,8 +2176,12 @@ hipError_t launch_chain(const NHConst& c, NHDevState* st, unsigned long long* ac
     hipLaunchKernelGGL(vv_kernel_chain, dim3(1), dim3(64), 0, s, c, st, acc);
     return hipGetLastError();
 }
-hipError_t launch_tether(int precision, const TetherArgs& t, int block_threads, hipStream_t s) {
-    VV_DISPATCH(vv_kernel_tether, grid_for(t.nwaves, block_threads), dim3(block_threads), 0, s, t.slots, t.nwaves, block_threads / 64, t);
+hipError_t launch_tether(int precision, const TetherArgs& t, int block_threads, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    switch (precision) {
+        case VVHIP_SINGLE: vv_launch((vv_kernel_tether<float, float>), grid_for(t.nwaves, block_threads), dim3(block_threads), 0, s, ev0, ev1, t.slots, t.nwaves, block_threads / 64, t); break;
+        case VVHIP_MIXED: vv_launch((vv_kernel_tether<float, double>), grid_for(t.nwaves, block_threads), dim3(block_threads), 0, s, ev0, ev1, t.slots, t.nwaves, block_threads / 64, t); break;
+        default: vv_launch((vv_kernel_tether<double, double>), grid_for(t.nwaves, block_threads), dim3(block_threads), 0, s, ev0, ev1, t.slots, t.nwaves, block_threads / 64, t); break;
+    }
     return hipGetLastError();
 }
 hipError_t launch_mass_table(int precision, const void* velm, const int2* slots, int nwaves, double* slot_m, double* slot_f, hipStream_t s) {

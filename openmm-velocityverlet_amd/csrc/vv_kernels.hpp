@@ -227,10 +227,11 @@ struct TetherArgs {
 
 // launchers (precision = VVHIP_SINGLE / MIXED / DOUBLE); return hipError_t of the launch
 // block_threads = 64 x tile waves per block; grid_cap = most blocks to launch (the kernels stride over tiles beyond that)
-hipError_t launch_a(int precision, const KArgs& a, int block_threads, int grid_cap, hipStream_t s);
-hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_cap, hipStream_t s);
+// ev0 / ev1 (optional): events that receive the dispatch's own begin / end timestamps (timing runs; never inside a graph capture)
+hipError_t launch_a(int precision, const KArgs& a, int block_threads, int grid_cap, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_cap, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 hipError_t launch_chain(const NHConst& c, NHDevState* st, unsigned long long* acc, hipStream_t s);
-hipError_t launch_tether(int precision, const TetherArgs& t, int block_threads, hipStream_t s);
+hipError_t launch_tether(int precision, const TetherArgs& t, int block_threads, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 // Fills the static per-lane mass tables from the inverse masses in velm.w (once per binding; see A_MTAB / B_MTAB).
 hipError_t launch_mass_table(int precision, const void* velm, const int2* slots, int nwaves, double* slot_m, double* slot_f, hipStream_t s);
 // whether the specialised kernels A (kernel = 0) / B (1) of this build were compiled with the mass tables (they then carry A_MTAB /

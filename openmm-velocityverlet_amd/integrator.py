@@ -438,7 +438,9 @@ class Context:
         H.check(H.lib.vvhip_calc_viscosity(self.plan, C.byref(v), C.byref(inv)), self.plan)
         return (v.value, inv.value)
 
-    def timing(self, enable: bool):
+    def timing(self, enable):
+        """0 / False off; 1 / True every launch group; 2 kernels A and B only (dispatch timestamps, nothing added to the stream);
+        n > 2 as 2 with n events prepared beforehand (vvhip_timing_enable)."""
         H.check(H.lib.vvhip_timing_enable(self.plan, int(enable)), self.plan)
 
     def timing_read(self):
