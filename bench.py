@@ -25,22 +25,135 @@ HBM_PEAK_GBS = 8000.0      # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB
 
 
 def kernel_times(ctx, reps, batches):
-    """Average launch duration [ms] of kernel A and kernel B with the fused step's stage bits, from HIP events on the plan's stream.
-    Bandwidth regime (>= 12288 waves, where a launch takes >= 10 us): events around EVERY launch of eager steps, i.e. each kernel
-    timed in its real place in the step (what rocprofv3 --kernel-trace reports; kernel B right behind kernel A finds part of velm /
-    force in the Infinity Cache, kernel A behind kernel B does not).  Latency regime: two events around `reps` back-to-back launches
-    of the same kernel, median of `batches` -- per-launch events around 4-6 us kernels starve the GPU and read up to 2x high there."""
+    """Average launch duration [ms] of kernel A and kernel B with the fused step's stage bits, two clocks:
+      in sequence   every launch of `reps` eager steps (force provider -> A -> B, enqueued from C) timed by the dispatch's own begin /
+                    end timestamps (hipExtLaunchKernel start / stop events: nothing is added to the stream; the timestamps rocprofv3's
+                    kernel trace reports) -- the kernel in its real place in the step, behind its predecessor's dirty lines.  This is
+                    the clock of roofline.frac at EVERY size; profiles/r03*_kernel_stats*.csv (rocprofv3 of the same command) is the
+                    cross-check (kernel B: within 1 %);
+      back to back  two HIP events around `reps` launches of the same kernel, median of `batches`: kinder to a kernel than its place
+                    in the step (it finds its own output in the cache), reported beside the other for comparison only."""
     import statistics
-    if ctx.info.num_waves >= 12288:
-        ctx.run_eager(4)
-        ctx.timing(True)
-        ctx.run_eager(max(10, reps // 2))
-        r = ctx.timing_read()
-        ctx.timing(False)
-        if r["launches"][0] > 0 and r["launches"][1] > 0:
-            return r["ms_a"] / r["launches"][0], r["ms_b"] / r["launches"][1], "in sequence: HIP events around every launch of eager steps"
-    return (statistics.median(ctx.time_kernel(0, reps) for _ in range(batches)), statistics.median(ctx.time_kernel(1, reps) for _ in range(batches)),
-            "back to back: two HIP events around %d launches of the same kernel, median of %d" % (reps, batches))
+    ctx.run_eager(8)
+    ctx.timing(4 * reps + 16)
+    ctx.run_eager(reps)
+    r = ctx.timing_read()
+    ctx.timing(0)
+    seq_a = r["ms_a"] / max(r["launches"][0], 1)
+    seq_b = r["ms_b"] / max(r["launches"][1], 1)
+    bb_a = statistics.median(ctx.time_kernel(0, reps) for _ in range(batches))
+    bb_b = statistics.median(ctx.time_kernel(1, reps) for _ in range(batches))
+    return {"A": seq_a, "B": seq_b, "A_back_to_back": bb_a, "B_back_to_back": bb_b,
+            "how": "in sequence: dispatch timestamps (hipExtLaunchKernel start/stop events) of every launch of %d eager steps; "
+                   "back to back: two HIP events around %d launches of the same kernel, median of %d" % (reps, reps, batches)}
+
+
+def openmm_cpu_baseline(spec, cfg, dt, seconds):
+    """BASELINE.json's named (non-target) baseline: OpenMM's own CPU platform with its built-in NoseHooverIntegrator (no Drude pairs) /
+    DrudeNoseHooverIntegrator on this host's cores, same particles, same synthetic tether + Drude-spring forces.  Returns a dict, or a
+    string saying why it could not run (OpenMM is not part of this image; the block is written against the OpenMM >= 8.1 Python API
+    and has never been executed here)."""
+    try:
+        import openmm as mm
+        from openmm import unit as u
+    except Exception as e:                                       # noqa: BLE001
+        return f"not installed (import openmm: {type(e).__name__}: {e}); the port above is the only CPU figure of this run"
+    try:
+        import numpy as np
+        system = mm.System()
+        for m in spec.masses:
+            system.addParticle(float(m))
+        lx, ly, lz = (float(b) for b in spec.box)
+        system.setDefaultPeriodicBoxVectors(mm.Vec3(lx, 0, 0), mm.Vec3(0, ly, 0), mm.Vec3(0, 0, lz))
+        tether = mm.CustomExternalForce("0.5*k*((x-x0)^2+(y-y0)^2+(z-z0)^2)")
+        tether.addGlobalParameter("k", 1000.0)
+        for name in ("x0", "y0", "z0"):
+            tether.addPerParticleParameter(name)
+        pos = np.asarray(spec.positions, dtype=np.float64)
+        for i in range(spec.num_atoms):
+            if spec.masses[i] != 0:
+                tether.addParticle(i, [float(c) for c in pos[i]])
+        system.addForce(tether)
+        pairs = np.asarray(spec.drude_pairs).reshape(-1, 2)
+        if len(pairs):
+            drude = mm.DrudeForce()
+            for d, par in pairs:                                 # k_D = q^2 / (4 pi eps0 alpha): charge and polarisability chosen to give 209 200 kJ/mol/nm^2
+                drude.addParticle(int(d), int(par), -1, -1, -1, 1.0, 138.935456 / 209200.0, 0.0, 0.0)
+            system.addForce(drude)
+            integ = mm.DrudeNoseHooverIntegrator(333.0 * u.kelvin, 10.0 / u.picosecond, 1.0 * u.kelvin, 40.0 / u.picosecond, dt * u.picosecond)
+            integ.setMaxDrudeDistance(0.02)
+            kind = "DrudeNoseHooverIntegrator"
+        else:
+            integ = mm.NoseHooverIntegrator((300.0 if cfg == "C2" else 333.0) * u.kelvin, 10.0 / u.picosecond, dt * u.picosecond)
+            kind = "NoseHooverIntegrator"
+        ctx = mm.Context(system, integ, mm.Platform.getPlatformByName("CPU"))
+        ctx.setPositions(pos)
+        ctx.setVelocitiesToTemperature(333.0)
+        integ.step(5)
+        t0 = time.perf_counter(); integ.step(10); per = (time.perf_counter() - t0) / 10
+        n = max(10, min(5000, int(seconds / max(per, 1e-6))))
+        t0 = time.perf_counter(); integ.step(n); el = time.perf_counter() - t0
+        return {"value": round(n / el, 2), "unit": "steps/s", "integrator": kind, "platform": "CPU", "threads": os.cpu_count(),
+                "sample": f"{n} steps ({el:.1f} s) incl. OpenMM's own force evaluation of the tether + Drude-spring terms", "openmm_version": mm.version.version}
+    except Exception as e:                                       # noqa: BLE001
+        return f"installed, but the CPU-platform run failed ({type(e).__name__}: {e})"
+
+
+def traffic_record(path, cfg, precision):
+    """HBM bytes per launch from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the builder, NOT counters
+    of this run -- the JSON says so in roofline.traffic_source) if it is for this configuration and precision."""
+    try:
+        rec = json.load(open(path))
+    except Exception:
+        return None, None
+    if rec.get("config") != cfg or rec.get("precision") != precision:
+        return None, None
+    src = {"file": os.path.relpath(path, ROOT), "round": rec.get("round"), "commit": rec.get("commit"),
+           "what": "separate rocprofv3 --pmc passes on the builder's GPU box, not counters of this run"}
+    return rec, src
+
+
+def rocprof_reference(key, algo, n_local):
+    """Cross-check from the committed rocprofv3 --kernel-trace --stats summary of the same workload (profiles/kernel_stats_latest.json,
+    written by tools/stamp_profiles.py): average duration of the most-launched variant of kernel A / kernel B, and the fractions they
+    give.  In a graph replay rocprofv3's duration of a kernel runs from its predecessor's end to its own end (profiles/r03a_trace_timeline_*)."""
+    try:
+        st = json.load(open(os.path.join(ROOT, "profiles", "kernel_stats_latest.json")))[key]
+    except Exception:
+        return None
+    out = {"file": st.get("file"), "round": st.get("round"), "commit": st.get("commit"), "avg_launch_us": {}, "frac": {}}
+    for k in "AB":
+        cand = {n: v for n, v in st["kernels"].items() if n.startswith(f"vv_kernel_{k.lower()}<")}
+        if not cand:
+            continue
+        name = max(cand, key=lambda n: cand[n]["calls"])
+        us = cand[name]["avg_ns"] * 1e-3
+        out["avg_launch_us"][k] = round(us, 3)
+        out["frac"][k] = round(algo[k] * n_local / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+    return out
+
+
+def roofline_block(ctx, n_local, times, rec=None, src=None, note=None, ref_key=None):
+    """roofline objects of kernel A, kernel B and the dominant one for context `ctx` (in-sequence clock)."""
+    algo = dict(zip("AB", ctx.algorithmic_bytes()))
+    per = {}
+    for k in "AB":
+        by = algo[k] * n_local
+        ach = by / (times[k] * 1e-3) / 1e9
+        per[k] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                  "traffic": rec.get(f"hbm_bytes_per_launch_{k}") if rec else None, "algorithmic_bytes_per_launch": by,
+                  "avg_launch_us": round(times[k] * 1e3, 3), "avg_launch_us_back_to_back": round(times[k + "_back_to_back"] * 1e3, 3)}
+    dom = "B" if times["B"] >= times["A"] else "A"
+    out = dict(per[dom])
+    out.update({"kernel": f"vv_kernel_{dom.lower()}", "traffic_source": src, "algorithmic_bytes_per_particle": algo,
+                "avg_launch_us": {"A": per["A"]["avg_launch_us"], "B": per["B"]["avg_launch_us"]},
+                "avg_launch_us_back_to_back": {"A": per["A"]["avg_launch_us_back_to_back"], "B": per["B"]["avg_launch_us_back_to_back"]},
+                "launch_timing": times["how"], "per_kernel": {"vv_kernel_a": per["A"], "vv_kernel_b": per["B"]}})
+    if ref_key:
+        out["rocprofv3_cross_check"] = rocprof_reference(ref_key, algo, n_local)
+    if note:
+        out["note"] = note
+    return out
 
 
 def main():
@@ -377,12 +490,18 @@ def main():
             ts.append(time.perf_counter() - t0)
         return n / statistics.median(ts)
 
-    # ---- the integrator path alone: forces resident in HBM (static buffer), no provider kernel in the loop
+    # ---- the integrator path alone: forces resident in HBM (static buffer, zeroed: thermostatted free flight -- the same loads, stores
+    # and arithmetic as with any other force values, and nothing that can run away), no provider kernel in the loop.  The physical
+    # state is saved and put back: the particles leave their tether sites meanwhile.
     if world == 1 and rank == 0 and not use_dist and args.forces == "tether" and not args.eager:
+        snap = (ctx.getPosq(), ctx.getPosqCorrection(), ctx.getVelm(), ctx.getNHState())
         prov = ctx.force_provider
+        ctx.force.upload(np.zeros(3 * ctx.padded, dtype=np.int64))
         ctx.force_provider = "static"
         out["config"]["integrator_only_steps_per_s"] = round(secondary(ctx), 1)
         ctx.force_provider = prov
+        ctx.synchronize()
+        ctx.posq.upload(snap[0]); ctx.posq_corr.upload(snap[1]); ctx.velm.upload(snap[2]); ctx.setNHState(snap[3])
 
     # ---- the same box with the constraints the reference's example scripts put on it (HBonds: examples/ommhelper/oplspsffile.py:952-955;
     # rigid water for C2), solved inside the fused kernels: a secondary figure, the headline stays the workload BASELINE.json names
@@ -394,42 +513,37 @@ def main():
         it_c.setMirrorLocation(it.getMirrorLocation())
         it_c.setElectricField(it.getElectricField())
         ctx_c = I.Context(spec_c, it_c, precision=args.precision, force_provider="tether", device=local_rank)
-        out["config"]["with_constraints"] = {"steps_per_s": round(secondary(ctx_c), 1), "constraints": int(len(spec_c.constraints)),
-                                             "shake_clusters": int(ctx_c.info.num_shake_clusters), "settle_molecules": int(ctx_c.info.num_settle_clusters)}
+        sps_c = secondary(ctx_c)
+        blk_c = {"steps_per_s": round(sps_c, 1), "constraints": int(len(spec_c.constraints)),
+                 "shake_clusters": int(ctx_c.info.num_shake_clusters), "settle_molecules": int(ctx_c.info.num_settle_clusters),
+                 "solver": "all constraints of a cluster at once: direct solve (velocities), coupled Newton (positions)" if os.environ.get("VVHIP_SHAKE_MODE", "1") != "0" else "Gauss-Seidel sweeps (VVHIP_SHAKE_MODE=0)"}
+        # the same two clocks for the constrained stage sets, and the whole step against the roofline
+        rec_c, src_c = traffic_record(os.path.join(ROOT, "profiles", "pmc_latest_hbonds.json"), cfg, args.precision)
+        t_c = kernel_times(ctx_c, 100, 5)
+        blk_c["roofline"] = roofline_block(ctx_c, spec_c.num_atoms, t_c, rec_c, src_c, ref_key=cfg + "_hbonds")
+        ab_c = sum(ctx_c.algorithmic_bytes()) * spec_c.num_atoms
+        blk_c["step"] = {"algorithmic_bytes_per_step": ab_c, "achieved": round(ab_c * sps_c / 1e9, 1), "unit": "GB/s", "frac": round(ab_c * sps_c / 1e9 / HBM_PEAK_GBS, 4)}
+        out["config"]["with_constraints"] = blk_c
         ctx_c.close()
 
-    # ---- roofline of the dominant kernel, measured live with HIP events on the plan's stream.  At N > 1 every rank runs the same
-    # launches (the mailbox exchange inside kernel B needs its peers), rank 0 reports its own shard; PMC traffic is a N = 1 figure.
+    # ---- roofline of the dominant kernel, measured live on the plan's stream (kernel_times: in-sequence clock).  At N > 1 every
+    # rank runs the same launches (the mailbox exchange inside kernel B needs its peers), rank 0 reports its own shard; PMC traffic
+    # is a N = 1 figure taken from the committed summary (traffic_source says which).  Runs after the headline measurement: the
+    # back-to-back batches scramble the physical state.
     if (world == 1 and rank == 0 and not use_dist) or (use_dist and stepper is None):
-        # two HIP events around 100 back-to-back launches (x5 batches) of each stage kernel with the fused step's stage bits
-        # (per-launch events in an eager stream starve the GPU and read ~2x high; the rocprofv3 averages under
-        # profiles/ are the cross-check).  Runs after the headline measurement: it scrambles the physical state.
-        import statistics
-        ms_a, ms_b, how = kernel_times(ctx, 100, 5)
-        dom = "B" if ms_b >= ms_a else "A"
-        ms = ms_b if dom == "B" else ms_a
+        times = kernel_times(ctx, 100, 5)
         n_local = bounds[rank][1] - bounds[rank][0]
-        algo = dict(zip("AB", ctx.algorithmic_bytes()))
-        bytes_per_launch = algo[dom] * n_local
-        achieved = bytes_per_launch / (ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc) and world == 1:
-            try:
-                rec = json.load(open(pmc))
-                if rec.get("config") == cfg and rec.get("precision") == args.precision:
-                    traffic = rec.get(f"hbm_bytes_per_launch_{dom}")
-            except Exception:
-                traffic = None
+        rec, src = traffic_record(os.path.join(ROOT, "profiles", "pmc_latest_hbonds.json" if args.hbonds else "pmc_latest.json"), cfg, args.precision) if world == 1 else (None, None)
         if rank == 0:
-            out["roofline"] = {"bound": "hbm", "kernel": f"vv_kernel_{dom.lower()}", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                               "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_bytes_per_particle": algo,
-                               "avg_launch_us": {"A": round(ms_a * 1e3, 3), "B": round(ms_b * 1e3, 3)}, "launch_timing": how,
-                               "note": (("working set (%.0f MB) is L2 / Infinity-Cache resident at this size: the launch is latency bound, "
-                                         "see config.large_n for the bandwidth-bound regime" % (228e-6 * n_local)) if n_local < 2_000_000 else
-                                        "bandwidth-bound regime (working set far beyond the 256 MB Infinity Cache)")
-                                       + ("" if world == 1 else f"; rank 0's shard of {n_local} particles")}
+            out["roofline"] = roofline_block(ctx, n_local, times, rec, src, ref_key=(cfg + ("_hbonds" if args.hbonds else "")) if world == 1 else None,
+                                             note=(("working set (%.0f MB) is L2 / Infinity-Cache resident at this size: the launch is latency and VALU-issue bound "
+                                                    "(two waves per SIMD), see config.large_n for the bandwidth-bound regime" % (228e-6 * n_local)) if n_local < 2_000_000 else
+                                                   "bandwidth-bound regime (working set far beyond the 256 MB Infinity Cache)")
+                                                  + ("" if world == 1 else f"; rank 0's shard of {n_local} particles"))
+            ab = sum(ctx.algorithmic_bytes()) * n_local
+            # the whole step (force provider + A + B) against the same roofline: algorithmic bytes of the integrator path / step time
+            out["step"] = {"algorithmic_bytes_per_step": ab, "achieved": round(ab * steps_per_s / 1e9, 1), "unit": "GB/s",
+                           "frac": round(ab * steps_per_s / 1e9 / HBM_PEAK_GBS, 4), "ms_per_step": round(1e3 * elapsed / args.steps, 6)}
 
     # ---- the bandwidth-bound regime of the same kernels: the C3 cell tiled 80x along z (8.88 M particles, ~2 GB working set), where
     # the HBM roofline is the real bound.  Secondary block (config.large_n); the headline stays the workload BASELINE.json names.
@@ -440,26 +554,15 @@ def main():
             it_l.setMaxDrudeDistance(0.02)
             ctx_l = I.Context(spec_l, it_l, precision=args.precision, force_provider="tether", device=local_rank)
             sps_l = secondary(ctx_l, 40)
-            la, lb, how_l = kernel_times(ctx_l, 20, 3)
+            t_l = kernel_times(ctx_l, 20, 3)
             nl = spec_l.num_atoms
+            rec_l, src_l = traffic_record(os.path.join(ROOT, "profiles", f"pmc_latest_{args.large_n}.json"), args.large_n, args.precision)
+            rb = roofline_block(ctx_l, nl, t_l, rec_l, src_l, ref_key=args.large_n)
             blk = {"workload": f"{args.large_n}: {nl} particles, {spec_l.num_molecules} molecules (the C3 cell tiled along z)",
-                   "steps_per_s": round(sps_l, 1), "atom_steps_per_s": round(sps_l * nl, 1), "launch_timing": how_l, "roofline": {}}
-            algo_l = dict(zip("AB", ctx_l.algorithmic_bytes()))
-            for k, ms in (("A", la), ("B", lb)):
-                by = algo_l[k] * nl
-                ach = by / (ms * 1e-3) / 1e9
-                tr = None
-                pmc_l = os.path.join(ROOT, "profiles", f"pmc_latest_{args.large_n}.json")
-                if os.path.exists(pmc_l):
-                    try:
-                        rec = json.load(open(pmc_l))
-                        if rec.get("precision") == args.precision:
-                            tr = rec.get(f"hbm_bytes_per_launch_{k}")
-                    except Exception:
-                        tr = None
-                blk["roofline"][f"vv_kernel_{k.lower()}"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": tr,
-                                                            "algorithmic_bytes_per_launch": by, "avg_launch_us": round(ms * 1e3, 2)}
+                   "steps_per_s": round(sps_l, 1), "atom_steps_per_s": round(sps_l * nl, 1), "launch_timing": t_l["how"],
+                   "roofline": rb["per_kernel"], "traffic_source": src_l, "rocprofv3_cross_check": rb.get("rocprofv3_cross_check"), "algorithmic_bytes_per_particle": rb["algorithmic_bytes_per_particle"]}
+            ab_l = sum(ctx_l.algorithmic_bytes()) * nl
+            blk["step"] = {"algorithmic_bytes_per_step": ab_l, "achieved": round(ab_l * sps_l / 1e9, 1), "unit": "GB/s", "frac": round(ab_l * sps_l / 1e9 / HBM_PEAK_GBS, 4)}
             out["config"]["large_n"] = blk
             ctx_l.close()
             del spec_l
@@ -494,7 +597,9 @@ def main():
         cpu_elapsed = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": round(nsteps / cpu_elapsed, 2), "unit": "steps/s", "cores": cores, "kind": "port",
                                "sample": f"{nsteps} steps of the same {cfg} workload ({cpu_elapsed:.1f} s), oracle/vv_oracle.c with OpenMP, "
-                                         f"fastest of 1..{min(ncpu, 128)} threads on a {ncpu}-CPU host"}
+                                         f"fastest of 1..{min(ncpu, 128)} threads on a {ncpu}-CPU host",
+                               # BASELINE.json names OpenMM's CPU platform as the baseline: tried here, and said so when it is absent
+                               "openmm": openmm_cpu_baseline(spec, cfg, dt, args.cpu_seconds)}
     # ---- still the baseline leg (the only part of this file that touches oracle/): the reference's own kernel sequence on this GPU
     # (oracle/_ref GPU build; present only if built where /root/reference exists), reported inside the cpu_baseline object
     if world == 1 and rank == 0 and not use_dist and not args.no_cpu_baseline and cfg in ("C2", "C3", "C4") and args.precision == "mixed" and args.forces == "tether" and not args.hbonds:

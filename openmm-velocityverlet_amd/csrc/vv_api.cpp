@@ -779,13 +779,21 @@ static bool use_rekick(const vvhip_plan* p) {
 }
 
 // Algorithmic bytes per particle that kernel A / kernel B of the fused middle step must move (SURVEY section 8d's accounting: particle
-// arrays + 6 bytes of index per pass): what bench.py prices the launches with.
+// arrays + 6 bytes of index per pass): what bench.py prices the launches with.  Where a kernel takes the arithmetic work-item layout
+// it loads no slot words, so no index bytes are counted for it; with the cos perturbation kernel A also reads posq (16 / 32 bytes; the
+// per-lane cos(kz) cache between the kernels is an implementation choice and is NOT counted, nor are the positions the in-kernel
+// velocity constraints read for cluster members: the figure stays a lower bound of what must move).
 int vvhip_algorithmic_bytes(const vvhip_plan* p, int32_t* bytes_a, int32_t* bytes_b) {
     if (!p || !bytes_a || !bytes_b) return VVHIP_ERR_INVALID;
     const int v = p->hp.precision == VVHIP_SINGLE ? 16 : 32;                       // velm: mixed4
     const int x = p->hp.precision == VVHIP_SINGLE ? 16 : 32;                       // posq (+ posqCorrection in mixed mode; double4 in double mode)
-    if (use_rekick(p)) { *bytes_a = v + 24 + 6; *bytes_b = v + 24 + x + v + x + 6; }    // A: R velm, R force;  B: R velm, R force, R pos, W velm, W pos
-    else { *bytes_a = v + 24 + v + 6; *bytes_b = v + x + v + x + 6; }                   // A: R velm, R force, W velm;  B: R velm, R pos, W velm, W pos
+    const int xr = p->hp.precision == VVHIP_DOUBLE ? 32 : 16;                      // posq alone
+    const bool per = p->hp.per.enabled && p->periodic_kernels;
+    const bool per_a = per && (p->periodic_a || shake_on(p)), per_b = per && !use_mailbox(p);      // as run_a / run_b decide
+    const int ia = per_a ? 0 : 6, ib = per_b ? 0 : 6;
+    if (use_rekick(p)) { *bytes_a = v + 24 + ia; *bytes_b = v + 24 + x + v + x + ib; }    // A: R velm, R force;  B: R velm, R force, R pos, W velm, W pos
+    else { *bytes_a = v + 24 + v + ia; *bytes_b = v + x + v + x + ib; }                   // A: R velm, R force, W velm;  B: R velm, R pos, W velm, W pos
+    if (cos_on(p)) *bytes_a += xr;
     return VVHIP_OK;
 }
 
