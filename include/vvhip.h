@@ -319,8 +319,10 @@ int vvhip_timing_read(vvhip_plan* plan, double* ms_pass_a, double* ms_pass_b, do
  *   VVHIP_PERIODIC=1|0        arithmetic work-item layout (vv_host.hpp: PeriodicLayout) always / never; default: from 0.2 M lanes, when the
  *                             system is runs of identical molecules (vvhip_plan_info.periodic_layout tells)
  *   VVHIP_PERIODIC_DEBUG=1    the decomposition into regions and why the layout was (not) enabled, on stderr
- *   VVHIP_PERIODIC_K=0        keep that layout but let kernel B load its slot words (comparison runs);  VVHIP_PERIODIC_A=1: kernel A
- *                             computes its particle indices too (no gain measured)
+ *   VVHIP_PERIODIC_K=0        keep that layout but let the kernels load their slot words (comparison runs);  VVHIP_PERIODIC_A=0: kernel A alone
+ *                             loads them (it computes its particle indices by default and keeps the next tile's loads in flight)
+ *   VVHIP_SHAKE_MODE=0        hydrogen-type constraint clusters by Gauss-Seidel sweeps of the central lane (OpenMM's iteration; generic
+ *                             kernels) instead of the direct velocity solve / coupled Newton iteration of all lanes of a cluster
  *   VVHIP_REKICK=0            kernel A stores the kicked velocities, kernel B does not repeat the kick
  *   VVHIP_MTAB_A=1 / VVHIP_MTAB_B=0   static mass tables in kernel A (off) / kernel B (on)
  *   VVHIP_NO_MOMENTS=1        cos perturbation as three launches (bias, sums, scale) instead of two

@@ -86,9 +86,11 @@ struct vvhip_plan {
     bool fextra_external = false;  // the host asked for the pointer (vvhip_force_extra) and may write to it: never assume zeros
     bool no_moments = false;       // VVHIP_NO_MOMENTS=1: keep the three-launch cos sequence (comparison runs)
     bool wt_stores = false;        // write-through stores in the fused kernels (VVHIP_WT=1; tuning experiment)
-    // with an arithmetic work-item layout (HostPlan::per) kernel B computes particle indices instead of loading slot words (VVHIP_PERIODIC_K=0: comparison runs);
-    // kernel A has the same path (VVHIP_PERIODIC_A=1) but does not gain from it: 113.6 vs 115.7 us at 8.9 M particles
-    bool periodic_kernels = true, periodic_a = false;
+    // with an arithmetic work-item layout (HostPlan::per) the kernels compute particle indices instead of loading slot words (VVHIP_PERIODIC_K=0:
+    // comparison runs).  Kernel A: no slot traffic (1.13 -> 1.0 x the algorithmic bytes) and the next tile's loads in flight during this tile's
+    // arithmetic: 133 vs 138 us in sequence at 8.9 M particles (round 2 without the second tile in flight: 113.6 vs 115.7 back to back);
+    // VVHIP_PERIODIC_A=0 switches it off
+    bool periodic_kernels = true, periodic_a = true;
     int shake_mode = 1;            // hydrogen-type constraint clusters: 1 = all constraints of a cluster at once (direct velocity solve, coupled Newton
                                    // for positions), 0 = Gauss-Seidel sweeps by the central lane (OpenMM's iteration; generic kernels) -- VVHIP_SHAKE_MODE
     bool rekick = true;            // fused middle step: kick repeated in kernel B instead of a velm store in kernel A (use_rekick)

@@ -770,7 +770,23 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const int2* __restrict__ pre_
         }
         __syncthreads();
     }
-    for (int wave = blockIdx.x * pre_wpb + (threadIdx.x >> 6); wave < pre_nwaves; wave += gridDim.x * pre_wpb) {
+    // Arithmetic layout: a tile's particle addresses follow from the wave index alone, so the NEXT tile's velocity and force loads are
+    // issued before this tile's arithmetic (two tiles in flight per wave; with loaded slot words the same was tried one tile ahead and
+    // did not pay, see above).  pw_n / v_n / f*_n carry the next tile; the first tile is loaded in front of the loop.
+    PeriodicWave pw_n = {0, 0, 0, 0};
+    mixed4 v_n = {0, 0, 0, 0};
+    long long fx_n = 0, fy_n = 0, fz_n = 0;
+    const int wave_first = blockIdx.x * pre_wpb + (threadIdx.x >> 6), wave_stride = gridDim.x * pre_wpb;
+    auto request_tile = [&](int w) {
+        pw_n = periodic_wave(a.per, w);
+        const bool in = lane < pw_n.count;
+        const int at = pw_n.atom0 + lane;
+        v_n = mixed4{0, 0, 0, 0}; fx_n = fy_n = fz_n = 0;
+        if (in) v_n = ((const mixed4*) pre_velm)[at];
+        if ((F & (A_KICK_FULL | A_KICK_HALF)) && in) { fx_n = pre_force[at]; fy_n = pre_force[at + pre_padded]; fz_n = pre_force[at + 2 * pre_padded]; }
+    };
+    if ((F & A_PERIODIC) && wave_first < pre_nwaves) request_tile(wave_first);
+    for (int wave = wave_first; wave < pre_nwaves; wave += wave_stride) {
         int atom;
         unsigned meta;
         PeriodicWave pw = {0, 0, 0, 0};
@@ -778,12 +794,11 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const int2* __restrict__ pre_
         mixed4 v = {0, 0, 0, 0};
         long long fx = 0, fy = 0, fz = 0;
         if (F & A_PERIODIC) {
-            // the particle index is arithmetic: velocity and force are requested at once, no slot word in front of them
-            pw = periodic_wave(a.per, wave);
+            // the particle index is arithmetic: velocity and force were requested a tile ago, no slot word in front of them
+            pw = pw_n; v = v_n; fx = fx_n; fy = fy_n; fz = fz_n;
+            if (wave + wave_stride < pre_nwaves) request_tile(wave + wave_stride);
             const bool in = lane < pw.count;
             atom = in ? pw.atom0 + lane : -1;
-            if (in) v = ((const mixed4*) pre_velm)[atom];
-            if ((F & (A_KICK_FULL | A_KICK_HALF)) && in) { fx = pre_force[atom]; fy = pre_force[atom + pre_padded]; fz = pre_force[atom + 2 * pre_padded]; }
             meta = in ? sh_pat_meta[pw.region][lane] : 0u;
         } else {
             const int2 slot = pre_slots[(size_t) wave * 64 + lane];
