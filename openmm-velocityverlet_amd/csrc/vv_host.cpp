@@ -626,7 +626,9 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
             }
         }
         hp.seg_base[nwaves] = (int32_t) (dense.size() / 2);
-        if (dense.empty()) dense.assign(2, 0.0);
+        // one spare entry: the kernels load table[seg_base[wave] + leaders below the lane] unconditionally, and the lanes behind a
+        // wave's last leader point one entry past the wave's segments (the device COM tables are sized from this one)
+        dense.push_back(0.0); dense.push_back(0.0);
         hp.seg_mass.swap(dense);
     }
 

@@ -793,6 +793,7 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const int2* __restrict__ pre_
         mixed4* velm = (mixed4*) a.velm;
         mixed4 v = {0, 0, 0, 0};
         long long fx = 0, fy = 0, fz = 0;
+        int segb = 0;
         if (F & A_PERIODIC) {
             // the particle index is arithmetic: velocity and force were requested a tile ago, no slot word in front of them
             pw = pw_n; v = v_n; fx = fx_n; fy = fy_n; fz = fz_n;
@@ -801,6 +802,8 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const int2* __restrict__ pre_
             atom = in ? pw.atom0 + lane : -1;
             meta = in ? sh_pat_meta[pw.region][lane] : 0u;
         } else {
+            // (the wave's segment base is requested FIRST: it returns with the slot word, and everything below needs only these two)
+            if (F & A_KE) segb = a.seg_base[__builtin_amdgcn_readfirstlane(wave)];
             const int2 slot = pre_slots[(size_t) wave * 64 + lane];
             atom = slot.x;
             meta = (unsigned) slot.y;
@@ -808,39 +811,66 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const int2* __restrict__ pre_
         const unsigned role = meta & META_ROLE_MASK;
         const int partner = (meta >> META_PARTNER_SHIFT) & 63;
         const bool act = atom >= 0;
+        // ---- every load of the tile that needs nothing but the slot word, in ONE batch: unconditional loads from clamped indices
+        // (idle lanes read particle 0 / their own table entry and discard it), closed by a scheduling barrier.  Written as
+        // `if (act) x = array[atom]`, each load sits in a divergent block of its own, and the backend neither batches loads across
+        // blocks nor hoists them above the first use of an earlier one: kernel A went through FOUR dependent memory round trips per
+        // tile (slot -> velocity and force -> segment base -> segment mass), kernel B through six.
+        const int ai = act ? atom : 0;
+        const size_t li = (size_t) wave * 64 + lane;
         if (!(F & A_PERIODIC)) {
-            if (act) v = velm[atom];
-            // the forces are requested together with the velocity: waiting for velm.w to learn that the particle is massive would put a
-            // third dependent memory round trip in front of the kick (timeline: 0.6 us); the role word carries the same fact
-            if ((F & (A_KICK_FULL | A_KICK_HALF)) && act && (meta & META_MASSIVE)) {
-                fx = a.force[atom]; fy = a.force[atom + a.padded]; fz = a.force[atom + 2 * a.padded];
-            }
-        }
-        // Langevin lanes: slot of the normal deviates and the deviates themselves, requested with the particle data (keyed by the role
-        // word) instead of after velm.w has arrived
-        float4 rnd_a = make_float4(0, 0, 0, 0), rnd_b = make_float4(0, 0, 0, 0);
-        if ((F & A_LD) && act && (role == ROLE_LD_NORMAL || role == ROLE_LD_DRUDE || role == ROLE_LD_PARENT)) {
-            const unsigned ri = a.random_index + a.slot_rand[(size_t) wave * 64 + lane];
-            rnd_a = a.random[ri];
-            if (role != ROLE_LD_NORMAL) rnd_b = a.random[ri + 1];
+            v = velm[ai];
+            if (F & (A_KICK_FULL | A_KICK_HALF)) { fx = a.force[ai]; fy = a.force[ai + a.padded]; fz = a.force[ai + 2 * a.padded]; }
         }
         double2 seg_mw = {0, 0};                 // (mass, 1/mass) of this lane's COM segment, one 16-byte entry per segment
         // dense index of this lane's COM segment: segments are numbered wave by wave and, inside a wave, by the lane of their leader
-        // (= last) lane, so every lane of a segment counts the same leaders below itself (vv_host.cpp: seg_base)
+        // (= last) lane, so every lane of a segment counts the same leaders below itself (vv_host.cpp: seg_base; the tables end
+        // with one spare entry, which the lanes behind a wave's last leader read)
         int segi = 0;
         if (F & A_KE) {
             const int below = (int) lanes_below(__ballot((meta & META_COM_LEADER) != 0));
-            segi = ((F & A_PERIODIC) ? pw.seg0 : a.seg_base[__builtin_amdgcn_readfirstlane(wave)]) + below;
-            if (act && (meta & META_COM_LEADER)) seg_mw = (F & A_PERIODIC) ? sh_pat_segm[pw.region][lane] : ((const double2*) a.seg_mass)[segi];
+            segi = ((F & A_PERIODIC) ? pw.seg0 : segb) + below;
+            seg_mw = (F & A_PERIODIC) ? sh_pat_segm[pw.region][lane] : ((const double2*) a.seg_mass)[segi];
         }
         // Static per-lane masses (A_MTAB): m = RECIP(velm.w) and, for the members of a Drude pair, the mass fraction m / (m1 + m2), both
         // formed ONCE by vv_kernel_mass_table with the very operations the stages below used to repeat every step (IEEE quotients of the
         // mode's `mixed` type), so every value is bit-identical to the per-step one; velm.w never changes during a run.
         mixed tab_m = 0, tab_f = 0;
-        if ((F & A_MTAB) && (F & (A_KE | A_BIAS | A_COS | A_LD | A_KE_PLAIN | A_COMPART)) && act && (meta & META_MASSIVE)) {
-            tab_m = (mixed) a.slot_m[(size_t) wave * 64 + lane];
-            if ((F & A_KE) && (meta & META_PAIR)) tab_f = (mixed) a.slot_f[(size_t) wave * 64 + lane];
+        if ((F & A_MTAB) && (F & (A_KE | A_BIAS | A_COS | A_LD | A_KE_PLAIN | A_COMPART))) {
+            tab_m = (mixed) a.slot_m[li];
+            if (F & A_KE) tab_f = (mixed) a.slot_f[li];
         }
+        real4 pq = {0, 0, 0, 0};
+        const bool need_pos_any = ((F & (A_COS | A_BIAS | A_UNBIAS_ACC)) && !(F & A_CZ_LOAD)) || (F & A_EF);
+        if (need_pos_any) pq = ((const real4*) a.posq)[ai];
+        double czl = 0;          // cos(2 pi z / Lz): evaluated at most once per launch, cached across the launches of a step
+        if ((F & (A_COS | A_BIAS | A_UNBIAS_ACC)) && (F & A_CZ_LOAD)) czl = a.cosz[li];
+        real3 fe = {0, 0, 0};    // extra force (VVIntegrator.cpp:238-245), accumulated in `real` like forceExtra
+        if (F & A_FE_LOAD) fe = ((const real3*) a.fextra)[ai];
+        // in-kernel constraints: cluster word, parameters and position of every lane (members use them)
+        unsigned cons_word = 0;
+        float4 cons_prm = make_float4(0, 0, 0, 0);
+        real4 cons_p1 = {0, 0, 0, 0}, cons_p2 = {0, 0, 0, 0};
+        if (F & A_CONS) {
+            cons_word = (F & A_PERIODIC) ? sh_pat_shake[pw.region][lane] : (unsigned) a.slot_shake[li];
+            cons_prm = (F & A_PERIODIC) ? sh_pat_prm[pw.region][lane] : a.slot_shake_param[li];
+            cons_p1 = ((const real4*) a.posq)[ai];
+            if (PosIO<real, mixed>::kMixed) cons_p2 = ((const real4*) a.corr)[ai];
+        }
+        // Langevin lanes: slot of the normal deviates with the batch, the deviates themselves behind it (keyed by the role word)
+        int rand_slot = 0;
+        if (F & A_LD) rand_slot = a.slot_rand[li];
+        __builtin_amdgcn_sched_barrier(0);
+        float4 rnd_a = make_float4(0, 0, 0, 0), rnd_b = make_float4(0, 0, 0, 0);
+        if ((F & A_LD) && act && (role == ROLE_LD_NORMAL || role == ROLE_LD_DRUDE || role == ROLE_LD_PARENT)) {
+            const unsigned ri = a.random_index + (unsigned) rand_slot;
+            rnd_a = a.random[ri];
+            if (role != ROLE_LD_NORMAL) rnd_b = a.random[ri + 1];
+        }
+        if (!act) { v = mixed4{0, 0, 0, 0}; fe = real3{0, 0, 0}; }
+        if (!(act && (meta & META_COM_LEADER))) seg_mw = double2{0, 0};
+        if (!(act && (meta & META_MASSIVE))) { tab_m = 0; tab_f = 0; }
+        if (!(meta & META_PAIR)) tab_f = 0;
         const bool massive = act && v.w != 0;
         const mixed stepSize = (mixed) a.dt;
         // own mass: bit-exact form (feeds element-wise results) and the form for quantities that only feed reductions
@@ -853,19 +883,11 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const int2* __restrict__ pre_
             k_atom += t0; continue;
         }
 #endif
-        real4 pq = {0, 0, 0, 0};
-        const bool need_pos = ((F & (A_COS | A_BIAS | A_UNBIAS_ACC)) && !(F & A_CZ_LOAD)) || ((F & A_EF) && (meta & META_EFIELD));
-        if (act && need_pos) pq = ((const real4*) a.posq)[atom];
-
-        double czl = 0;          // cos(2 pi z / Lz): evaluated at most once per launch, cached across the launches of a step
         if (F & (A_COS | A_BIAS | A_UNBIAS_ACC)) {
-            if (F & A_CZ_LOAD) czl = a.cosz[(size_t) wave * 64 + lane];
-            else czl = cos_kz<real>(pq.z, (real) a.inv_box_z);
-            if (F & A_CZ_STORE) a.cosz[(size_t) wave * 64 + lane] = czl;
+            if (!(F & A_CZ_LOAD)) czl = cos_kz<real>(pq.z, (real) a.inv_box_z);
+            if (F & A_CZ_STORE) a.cosz[li] = czl;
         }
         // ---------------- extra force (VVIntegrator.cpp:238-245), accumulated in `real` like forceExtra
-        real3 fe = {0, 0, 0};
-        if ((F & A_FE_LOAD) && act) fe = ((const real3*) a.fextra)[atom];
         if (F & A_LD) {
             const mixed pvx = shfl(v.x, partner), pvy = shfl(v.y, partner), pvz = shfl(v.z, partner), pvw = shfl(v.w, partner);
             const mixed dragFactor = (mixed) a.drag, randFactor = (mixed) a.randf;
@@ -941,14 +963,13 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const int2* __restrict__ pre_
             // one page per wave of the block, sized at launch (dynamic LDS): a static [8] cost 28 KB per block also where blocks have 4 waves
             extern __shared__ double vv_dyn_lds[];
             mixed* shake_page_a = (mixed*) vv_dyn_lds + (threadIdx.x >> 6) * (7 * 64);
-            // cluster word, parameters and position are requested together, keyed by the role word's META_SHAKE bit (not one after
-            // the other, keyed by the cluster word: that put two more dependent memory round trips into this kernel)
+            // cluster word, parameters and position came with the tile's load batch
             const bool member = act && (meta & META_SHAKE);
-            const unsigned word = !member ? 0u : ((F & A_PERIODIC) ? sh_pat_shake[pw.region][lane] : (unsigned) a.slot_shake[(size_t) wave * 64 + lane]);
-            const float4 prm = !member ? make_float4(0, 0, 0, 0) : ((F & A_PERIODIC) ? sh_pat_prm[pw.region][lane] : a.slot_shake_param[(size_t) wave * 64 + lane]);
-            mixed sx = 0, sy = 0, sz = 0, sq = 0;
-            real sraw = 0;
-            if (member) PosIO<real, mixed>::load(a.posq, a.corr, atom, sx, sy, sz, sq, sraw);
+            const unsigned word = member ? cons_word : 0u;
+            const float4 prm = cons_prm;
+            mixed sx, sy, sz;
+            if (PosIO<real, mixed>::kMixed) { sx = cons_p1.x + (mixed) cons_p2.x; sy = cons_p1.y + (mixed) cons_p2.y; sz = cons_p1.z + (mixed) cons_p2.z; }
+            else { sx = cons_p1.x; sy = cons_p1.y; sz = cons_p1.z; }
             shake_velocities<mixed>(lane, word, prm, (mixed) a.shake_tol, sx, sy, sz, v.w, v.x, v.y, v.z, shake_page_a,
                                     (F & A_SHAKE_V) != 0, (F & A_SETTLE) != 0, (F & A_SHAKE_GS) != 0);
             if (massive) store_vec(velm, atom, v, (F & A_WT_STORES) != 0);
@@ -1455,55 +1476,94 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const int2* __restrict__ pre_
         PeriodicWave pw = {0, 0, 0, 0};
         mixed4* velm = (mixed4*) a.velm;
         mixed4 v = {0, 0, 0, 0};
+        int segb = 0;
         if (F & B_PERIODIC) {
             if (valid) {          // (uniform) particle index from the wave index: the particle loads do not wait for a slot word
                 pw = periodic_wave(a.per, wave);
                 const bool in = lane < pw.count;
                 atom = in ? pw.atom0 + lane : -1;
-                if (in) v = velm[atom];
                 meta = in ? sh_pat_meta[pw.region][lane] : 0u;
+                segb = pw.seg0;
             }
         } else if (valid) {
+            // (pre_seg_base: a preloaded argument; requested FIRST, it returns with the slot word)
+            if (F & B_SCALE) segb = pre_seg_base[__builtin_amdgcn_readfirstlane(wave)];
             const int2 slot = pre_slots[(size_t) wave * 64 + lane]; atom = slot.x; meta = (unsigned) slot.y;
         }
         const unsigned role = meta & META_ROLE_MASK;
         const int partner = (meta >> META_PARTNER_SHIFT) & 63;
         const bool act = atom >= 0;
-        if (!(F & B_PERIODIC) && act) v = velm[atom];
-        const bool massive = act && v.w != 0;
         const mixed stepSize = (mixed) a.dt;
         const bool touches_pos = F & (B_DRIFT_MIDDLE | B_POS3 | B_VV_POS | B_VV_KICK | B_HARDWALL | B_IMAGE | B_UNBIAS | B_BIAS_REMOVE | B_BIAS_RESTORE);
-        mixed x = 0, y = 0, z = 0, q = 0;
-        real zraw = 0;
-        if (act && touches_pos) IO::load(a.posq, a.corr, atom, x, y, z, q, zraw);
-        // cluster word and parameters of the in-kernel SHAKE: requested here, with the particle data and in front of the thermostat
-        // barrier (they used to be read where they are needed, behind it: two exposed memory round trips per tile)
+        // ---- every load of the tile that needs nothing but the slot word (or nothing at all, with the arithmetic layout), in ONE
+        // batch of unconditional loads from clamped indices closed by a scheduling barrier (see kernel A): velocity, position and
+        // correction, force, the molecule's COM velocity, the pair's mass fraction, the constraint cluster words.  Six dependent
+        // memory round trips per tile became two.
+        const int ai = act ? atom : 0;
+        const size_t li = valid ? (size_t) wave * 64 + lane : (size_t) lane;
+        v = velm[ai];
+        real4 p1 = {0, 0, 0, 0}, p2 = {0, 0, 0, 0};
+        if (touches_pos) {
+            p1 = ((const real4*) a.posq)[ai];
+            if (IO::kMixed) p2 = ((const real4*) a.corr)[ai];
+        }
+        long long kfx = 0, kfy = 0, kfz = 0;
+        if (F & B_KICK) { kfx = a.force[ai]; kfy = a.force[ai + a.padded]; kfz = a.force[ai + 2 * a.padded]; }
+        const unsigned long long leaders = (F & B_SCALE) ? __ballot((meta & META_COM_LEADER) != 0) : 0ull;     // in every lane: a wave-wide vote
+        // COM velocity of this lane's molecule as kernel A's KE stage left it (of the bias-free velocities when a bias is
+        // removed): one 32-byte entry per molecule, the same address for every lane of the segment (lanes behind the wave's last
+        // leader read the tables' spare entry)
+        mixed4 cv = {0, 0, 0, 0};
+        double cw_raw = 0;
+        if (F & B_SCALE) {
+            const int segi = segb + (int) lanes_below(leaders);
+            cv = ((const mixed4*) a.comv)[segi];
+            if (F & B_KE_MOM) cw_raw = a.comw[segi];
+        }
+        // B_MTAB: the pair's mass fractions are static (vv_kernel_mass_table formed them with the operations of K/drudeNoseHoover.cu:173-180
+        // on the same inverse masses, so they are the per-step values bit for bit): one 8-byte load per lane, requested with the
+        // particle data, instead of two IEEE fp64 divisions per pair lane and step
+        mixed tab_f = 0;
+        if ((F & B_MTAB) && (F & B_SCALE)) tab_f = (F & B_PERIODIC) ? (mixed) sh_pat_f[pw.region][lane] : (mixed) a.slot_f[li];
+        // cluster word and parameters of the in-kernel constraints
         unsigned shake_word = 0;
         float4 shake_prm = make_float4(0, 0, 0, 0);
-        if ((F & B_CONS) && act && (meta & META_SHAKE)) {
-            shake_word = (F & B_PERIODIC) ? sh_pat_shake[pw.region][lane] : (unsigned) a.slot_shake[(size_t) wave * 64 + lane];
-            shake_prm = (F & B_PERIODIC) ? sh_pat_prm[pw.region][lane] : a.slot_shake_param[(size_t) wave * 64 + lane];
+        if (F & B_CONS) {
+            shake_word = (F & B_PERIODIC) ? sh_pat_shake[pw.region][lane] : (unsigned) a.slot_shake[li];
+            shake_prm = (F & B_PERIODIC) ? sh_pat_prm[pw.region][lane] : a.slot_shake_param[li];
         }
-        // image particle of this lane's particle: its index and its present content (the charge and the correction's w survive the
-        // mirror update) are requested now, so that nothing has to be read after the position store at the end of the tile
+        // cos(2 pi z / Lz) of this lane, cached by kernel A (A_CZ_STORE)
+        double cz_early = 0;
+        if (F & B_CZ_LOAD) cz_early = a.cosz[li];
         int img = -1;
+        if (F & B_IMAGE) img = a.slot_image[li];
+        __builtin_amdgcn_sched_barrier(0);
+        if (!act) v = mixed4{0, 0, 0, 0};
+        if (!(act && (meta & META_SHAKE))) shake_word = 0;
+        const bool massive = act && v.w != 0;
+        mixed x = 0, y = 0, z = 0, q = 0;
+        real zraw = 0;
+        if (act && touches_pos) {          // K/middle.cu:81-96: positions are posq (+ posqCorrection in mixed mode)
+            zraw = p1.z;
+            if (IO::kMixed) { x = p1.x + (mixed) p2.x; y = p1.y + (mixed) p2.y; z = p1.z + (mixed) p2.z; q = p1.w; }
+            else { x = p1.x; y = p1.y; z = p1.z; q = p1.w; }
+        }
+        // image particle of this lane's particle: its present content (the charge and the correction's w survive the mirror update)
+        // is requested now, so that nothing has to be read after the position store at the end of the tile
         real4 img_p = {0, 0, 0, 0}, img_c = {0, 0, 0, 0};
-        if ((F & B_IMAGE) && act && (meta & META_HAS_IMAGE)) {
-            img = a.slot_image[(size_t) wave * 64 + lane];
+        if (!((F & B_IMAGE) && act && (meta & META_HAS_IMAGE))) img = -1;
+        if ((F & B_IMAGE) && img >= 0) {
             img_p = ((const real4*) a.posq)[img];
             if (IO::kMixed) img_c = ((const real4*) a.corr)[img];
         }
-        // B_KICK: kernel A kept its kicked velocities in registers (A_NOSTORE); the same kick again here, from the same velm and force
-        // bits with the same expression (K/middle.cu:11-21; forceExtra is zero on this path), gives the same velocities bit for bit.
-        // cos(2 pi z / Lz) of this lane, cached by kernel A (A_CZ_STORE): requested with the particle data
-        double cz_early = 0;
-        if ((F & B_CZ_LOAD) && valid) cz_early = a.cosz[(size_t) wave * 64 + lane];
 #ifdef VV_EXP_B_LOADSTORE
         const mixed4 v_in = v;
 #endif
-        // (periodic: the force loads must not wait for the role word; a massless particle's force is read and not used)
-        if ((F & B_KICK) && act && ((F & B_PERIODIC) || (meta & META_MASSIVE))) {
-            const long long fx = a.force[atom], fy = a.force[atom + a.padded], fz = a.force[atom + 2 * a.padded];
+        // B_KICK: kernel A kept its kicked velocities in registers (A_NOSTORE); the same kick again here, from the same velm and force
+        // bits with the same expression (K/middle.cu:11-21; forceExtra is zero on this path), gives the same velocities bit for bit.
+        // (a massless particle's force is read and not used)
+        if ((F & B_KICK) && act) {
+            const long long fx = kfx, fy = kfy, fz = kfz;
             real3 fe = {0, 0, 0};
             if (F & B_UNBIAS) fe.x += (real) a.cos_accel * cz_early * P::RECIP(v.w);      // K/cosineAccelerate.cu:9, kernel A's A_COS term to the bit
             const mixed fscale = stepSize / (mixed) 0x100000000;
@@ -1519,26 +1579,16 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const int2* __restrict__ pre_
         const bool nh = role == ROLE_NH_NORMAL || role == ROLE_NH_DRUDE || role == ROLE_NH_PARENT;
         const bool use_com = ((meta >> META_SEGFIRST_SHIFT) & 63) != ((meta >> META_SEGLAST_SHIFT) & 63) || (meta & META_COM_LEADER);
         mixed Vx = 0, Vy = 0, Vz = 0, Vw = 0, com_w = 0;
-        // COM velocity of this lane's molecule as kernel A's KE stage left it (of the bias-free velocities when a bias is
-        // removed): one 32-byte entry per molecule, the same address for every lane of the segment
-        const unsigned long long leaders = (F & B_SCALE) ? __ballot((meta & META_COM_LEADER) != 0) : 0ull;     // in every lane: a wave-wide vote
         if ((F & B_SCALE) && nh && use_com) {
-            // (pre_seg_base: a preloaded argument, so that this scalar load does not queue behind the loads of the argument block)
-            const int segi = ((F & B_PERIODIC) ? pw.seg0 : pre_seg_base[__builtin_amdgcn_readfirstlane(wave)]) + (int) lanes_below(leaders);
-            const mixed4 cv = ((const mixed4*) a.comv)[segi];
             Vx = cv.x; Vy = cv.y; Vz = cv.z; Vw = cv.w;
-            if (F & B_KE_MOM) com_w = (mixed) a.comw[segi];
+            if (F & B_KE_MOM) com_w = (mixed) cw_raw;
         }
 
         // Factor-independent half of the scaling: velocities relative to the molecular COM, the Drude partner's over the shuffle
         // network, mass fractions, COM / relative split of the pair.  Without a bias to remove first it runs here, i.e. while
         // the tile waves of the first iteration wait for the thermostat wave.
         mixed ux = 0, uy = 0, uz = 0, cmx = 0, cmy = 0, cmz = 0, rx = 0, ry = 0, rz = 0, mass1fract = 0, mass2fract = 0;
-        // B_MTAB: the pair's mass fractions are static (vv_kernel_mass_table formed them with the operations of K/drudeNoseHoover.cu:173-180
-        // on the same inverse masses, so they are the per-step values bit for bit): one 8-byte load per pair lane, requested with the
-        // particle data, instead of two IEEE fp64 divisions per lane and step
-        mixed tab_f = 0;
-        if ((F & B_MTAB) && (F & B_SCALE) && act && (role == ROLE_NH_DRUDE || role == ROLE_NH_PARENT)) tab_f = (F & B_PERIODIC) ? (mixed) sh_pat_f[pw.region][lane] : (mixed) a.slot_f[(size_t) wave * 64 + lane];
+        if (!(act && (role == ROLE_NH_DRUDE || role == ROLE_NH_PARENT))) tab_f = 0;
         auto scale_prep = [&]() {
             ux = v.x; uy = v.y; uz = v.z;
             if (nh) { ux -= Vx; uy -= Vy; uz -= Vz; }
