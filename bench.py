@@ -48,6 +48,43 @@ def kernel_times(ctx, reps, batches):
                    "back to back: two HIP events around %d launches of the same kernel, median of %d" % (reps, reps, batches)}
 
 
+def rocprof_child(args, extra, seconds=240):
+    """Kernel durations of this workload as rocprofv3 reports them, measured live: a child process
+        rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py <same workload> --child
+    (graph replay, no secondary blocks) started BEFORE this process touches the GPU; its kernel_stats.csv is parsed.  This is the very
+    command behind profiles/r*_rocprofv3_kernel_stats_*.csv, so roofline.frac can be recomputed from profiles/ with the same tool.
+    In a serialised graph replay rocprofv3's duration of a kernel runs from its predecessor's end to its own end
+    (profiles/r03a_trace_timeline_graph_vs_eager.txt).  Returns {kernel name: {"calls", "avg_ns"}} or a string saying why not."""
+    import csv, glob, re, shutil, subprocess, tempfile
+    if os.environ.get("VVHIP_BENCH_CHILD"):
+        return "child"
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or args.gpus != 1:
+        return "multi-GPU run"
+    if shutil.which("rocprofv3") is None:
+        return "rocprofv3 not on PATH"
+    if "rocprof" in os.environ.get("LD_PRELOAD", "") or os.environ.get("ROCPROFILER_REGISTER_FORCE_LOAD") or os.environ.get("ROCP_TOOL_LIBRARIES"):
+        return "this process already runs under a profiler"
+    tmp = tempfile.mkdtemp(prefix="vvbench_", dir="/tmp")
+    try:
+        cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", tmp, "-o", "run", "--", sys.executable, os.path.join(ROOT, "bench.py"),
+               "--child", "--precision", args.precision, "--forces", args.forces, "--steps-per-graph", str(args.steps_per_graph)] + extra
+        env = dict(os.environ, VVHIP_BENCH_CHILD="1", TMPDIR="/tmp")
+        r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=seconds)
+        files = glob.glob(os.path.join(tmp, "**", "*kernel_stats.csv"), recursive=True)
+        if not files:
+            return "rocprofv3 child wrote no kernel_stats.csv (exit code %d)" % r.returncode
+        out = {}
+        for row in csv.DictReader(open(files[0])):
+            m = re.match(r"void vv::(vv_kernel_\w+)<([^>]*)>", row["Name"])
+            if m:
+                out[f"{m.group(1)}<{m.group(2)}>"] = {"calls": int(row["Calls"]), "avg_ns": round(float(row["AverageNs"]), 1)}
+        return out or "no vv kernels in the child's kernel_stats.csv"
+    except Exception as e:                                       # noqa: BLE001 -- a cross-check must never break the bench line
+        return f"rocprofv3 child failed ({type(e).__name__}: {e})"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def openmm_cpu_baseline(spec, cfg, dt, seconds):
     """BASELINE.json's named (non-target) baseline: OpenMM's own CPU platform with its built-in NoseHooverIntegrator (no Drude pairs) /
     DrudeNoseHooverIntegrator on this host's cores, same particles, same synthetic tether + Drude-spring forces.  Returns a dict, or a
@@ -133,22 +170,37 @@ def rocprof_reference(key, algo, n_local):
     return out
 
 
-def roofline_block(ctx, n_local, times, rec=None, src=None, note=None, ref_key=None):
-    """roofline objects of kernel A, kernel B and the dominant one for context `ctx` (in-sequence clock)."""
+def roofline_block(ctx, n_local, times, rec=None, src=None, note=None, ref_key=None, live=None):
+    """roofline objects of kernel A, kernel B and the dominant one for context `ctx`.  Clock of `achieved` / `frac`: the rocprofv3 child
+    run of this very workload when there is one (`live` = its kernel_stats; the average duration of the most-launched variant of each
+    kernel, i.e. the kernel in its place in the replayed step), else the dispatch-timestamp clock of kernel_times.  All clocks are printed."""
     algo = dict(zip("AB", ctx.algorithmic_bytes()))
+    prof_ms = {}
+    if isinstance(live, dict):
+        for k in "AB":
+            cand = {n: v for n, v in live.items() if n.startswith(f"vv_kernel_{k.lower()}<")}
+            if cand:
+                prof_ms[k] = cand[max(cand, key=lambda n: cand[n]["calls"])]["avg_ns"] * 1e-6
+    clock = prof_ms if len(prof_ms) == 2 else times
     per = {}
     for k in "AB":
         by = algo[k] * n_local
-        ach = by / (times[k] * 1e-3) / 1e9
+        ach = by / (clock[k] * 1e-3) / 1e9
         per[k] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                   "traffic": rec.get(f"hbm_bytes_per_launch_{k}") if rec else None, "algorithmic_bytes_per_launch": by,
-                  "avg_launch_us": round(times[k] * 1e3, 3), "avg_launch_us_back_to_back": round(times[k + "_back_to_back"] * 1e3, 3)}
-    dom = "B" if times["B"] >= times["A"] else "A"
+                  "avg_launch_us": round(clock[k] * 1e3, 3), "avg_launch_us_dispatch_timestamps": round(times[k] * 1e3, 3),
+                  "avg_launch_us_back_to_back": round(times[k + "_back_to_back"] * 1e3, 3)}
+    dom = "B" if clock["B"] >= clock["A"] else "A"
     out = dict(per[dom])
     out.update({"kernel": f"vv_kernel_{dom.lower()}", "traffic_source": src, "algorithmic_bytes_per_particle": algo,
                 "avg_launch_us": {"A": per["A"]["avg_launch_us"], "B": per["B"]["avg_launch_us"]},
+                "avg_launch_us_dispatch_timestamps": {"A": per["A"]["avg_launch_us_dispatch_timestamps"], "B": per["B"]["avg_launch_us_dispatch_timestamps"]},
                 "avg_launch_us_back_to_back": {"A": per["A"]["avg_launch_us_back_to_back"], "B": per["B"]["avg_launch_us_back_to_back"]},
-                "launch_timing": times["how"], "per_kernel": {"vv_kernel_a": per["A"], "vv_kernel_b": per["B"]}})
+                "launch_timing": ("avg_launch_us / achieved / frac: rocprofv3 --kernel-trace --stats of a child run of this workload (graph replay), started by "
+                                  "this bench run before it touched the GPU -- the kernel from its predecessor's end to its own end; " if len(prof_ms) == 2 else
+                                  "avg_launch_us / achieved / frac: dispatch timestamps (no rocprofv3 child run: %s); " % (live if isinstance(live, str) else "not requested"))
+                                 + times["how"],
+                "per_kernel": {"vv_kernel_a": per["A"], "vv_kernel_b": per["B"]}})
     if ref_key:
         out["rocprofv3_cross_check"] = rocprof_reference(ref_key, algo, n_local)
     if note:
@@ -177,8 +229,21 @@ def main():
     ap.add_argument("--large-n", default="C3x80", choices=["C3x8", "C3x80", "none"],
                     help="secondary block (N = 1, config C3): the same kernels on the tiled box, where HBM bandwidth is the bound")
     ap.add_argument("--synthetic", action="store_true", help="procedural look-alike systems instead of the reference's example models (C3 / C4 / C5)")
+    ap.add_argument("--child", action="store_true", help="(internal) the run rocprofv3 wraps: headline measurement only, no secondary blocks")
+    ap.add_argument("--no-rocprof", action="store_true", help="do not spawn the rocprofv3 child runs; roofline.frac then comes from the dispatch-timestamp clock")
     ap.add_argument("--hbonds", action="store_true", help="constraints solved in-kernel: HBonds (SHAKE) for the ionic liquids, rigid water (SETTLE) for C2; not the headline workload")
     args = ap.parse_args()
+
+    # ---- rocprofv3 child runs, BEFORE this process initialises the GPU (kernel durations as the profiler reports them, measured live)
+    prof = {}
+    if not args.child and not args.no_rocprof and args.gpus == 1 and not args.eager and not args.force_dist:
+        base = ["--config", args.config] + (["--synthetic"] if args.synthetic else [])
+        short = ["--steps", "200", "--warmup", "40"] if args.config.startswith("C3x") else ["--steps", "4000", "--warmup", "400"]
+        prof["main"] = rocprof_child(args, base + short + (["--hbonds"] if args.hbonds else []))
+        if not args.hbonds and args.config in ("C2", "C3", "C4", "C5"):
+            prof["hbonds"] = rocprof_child(args, base + short + ["--hbonds"])
+        if args.config == "C3" and args.large_n != "none" and not args.hbonds:
+            prof["large_n"] = rocprof_child(args, ["--config", args.large_n, "--steps", "100", "--warmup", "20"] + (["--synthetic"] if args.synthetic else []))
 
     import numpy as np
     import torch
@@ -493,6 +558,10 @@ def main():
     # ---- the integrator path alone: forces resident in HBM (static buffer, zeroed: thermostatted free flight -- the same loads, stores
     # and arithmetic as with any other force values, and nothing that can run away), no provider kernel in the loop.  The physical
     # state is saved and put back: the particles leave their tether sites meanwhile.
+    if args.child:          # the run rocprofv3 wraps: the headline loop is all it needs
+        ctx.close()
+        print(json.dumps(out), flush=True)
+        return
     if world == 1 and rank == 0 and not use_dist and args.forces == "tether" and not args.eager:
         snap = (ctx.getPosq(), ctx.getPosqCorrection(), ctx.getVelm(), ctx.getNHState())
         prov = ctx.force_provider
@@ -520,7 +589,7 @@ def main():
         # the same two clocks for the constrained stage sets, and the whole step against the roofline
         rec_c, src_c = traffic_record(os.path.join(ROOT, "profiles", "pmc_latest_hbonds.json"), cfg, args.precision)
         t_c = kernel_times(ctx_c, 100, 5)
-        blk_c["roofline"] = roofline_block(ctx_c, spec_c.num_atoms, t_c, rec_c, src_c, ref_key=cfg + "_hbonds")
+        blk_c["roofline"] = roofline_block(ctx_c, spec_c.num_atoms, t_c, rec_c, src_c, ref_key=cfg + "_hbonds", live=prof.get("hbonds"))
         ab_c = sum(ctx_c.algorithmic_bytes()) * spec_c.num_atoms
         blk_c["step"] = {"algorithmic_bytes_per_step": ab_c, "achieved": round(ab_c * sps_c / 1e9, 1), "unit": "GB/s", "frac": round(ab_c * sps_c / 1e9 / HBM_PEAK_GBS, 4)}
         out["config"]["with_constraints"] = blk_c
@@ -535,7 +604,7 @@ def main():
         n_local = bounds[rank][1] - bounds[rank][0]
         rec, src = traffic_record(os.path.join(ROOT, "profiles", "pmc_latest_hbonds.json" if args.hbonds else "pmc_latest.json"), cfg, args.precision) if world == 1 else (None, None)
         if rank == 0:
-            out["roofline"] = roofline_block(ctx, n_local, times, rec, src, ref_key=(cfg + ("_hbonds" if args.hbonds else "")) if world == 1 else None,
+            out["roofline"] = roofline_block(ctx, n_local, times, rec, src, ref_key=(cfg + ("_hbonds" if args.hbonds else "")) if world == 1 else None, live=prof.get("main"),
                                              note=(("working set (%.0f MB) is L2 / Infinity-Cache resident at this size: the launch is latency and VALU-issue bound "
                                                     "(two waves per SIMD), see config.large_n for the bandwidth-bound regime" % (228e-6 * n_local)) if n_local < 2_000_000 else
                                                    "bandwidth-bound regime (working set far beyond the 256 MB Infinity Cache)")
@@ -557,10 +626,10 @@ def main():
             t_l = kernel_times(ctx_l, 20, 3)
             nl = spec_l.num_atoms
             rec_l, src_l = traffic_record(os.path.join(ROOT, "profiles", f"pmc_latest_{args.large_n}.json"), args.large_n, args.precision)
-            rb = roofline_block(ctx_l, nl, t_l, rec_l, src_l, ref_key=args.large_n)
+            rb = roofline_block(ctx_l, nl, t_l, rec_l, src_l, ref_key=args.large_n, live=prof.get("large_n"))
             blk = {"workload": f"{args.large_n}: {nl} particles, {spec_l.num_molecules} molecules (the C3 cell tiled along z)",
-                   "steps_per_s": round(sps_l, 1), "atom_steps_per_s": round(sps_l * nl, 1), "launch_timing": t_l["how"],
-                   "roofline": rb["per_kernel"], "traffic_source": src_l, "rocprofv3_cross_check": rb.get("rocprofv3_cross_check"), "algorithmic_bytes_per_particle": rb["algorithmic_bytes_per_particle"]}
+                   "steps_per_s": round(sps_l, 1), "atom_steps_per_s": round(sps_l * nl, 1),
+                   "roofline": rb["per_kernel"], "launch_timing": rb["launch_timing"], "traffic_source": src_l, "rocprofv3_cross_check": rb.get("rocprofv3_cross_check"), "algorithmic_bytes_per_particle": rb["algorithmic_bytes_per_particle"]}
             ab_l = sum(ctx_l.algorithmic_bytes()) * nl
             blk["step"] = {"algorithmic_bytes_per_step": ab_l, "achieved": round(ab_l * sps_l / 1e9, 1), "unit": "GB/s", "frac": round(ab_l * sps_l / 1e9 / HBM_PEAK_GBS, 4)}
             out["config"]["large_n"] = blk
