@@ -209,10 +209,21 @@ __device__ __forceinline__ long long dpp_fetch_i64(long long x) {
     const int hi = dpp_fetch32<CTRL, ROW_MASK>((int) (x >> 32));
     return ((long long) hi << 32) | (unsigned int) lo;
 }
+__device__ __forceinline__ long long acc_reduce_lane_sum(long long s);
+// ... of values the caller has already loaded (kernel B's thermostat wave issues all its loads first)
+__device__ __forceinline__ long long acc_reduce(const long long (&raw)[ACC_SLOTS / 64]) {
+    long long s = 0;
+#pragma unroll
+    for (int j = 0; j < ACC_SLOTS / 64; j++) s += raw[j];
+    return acc_reduce_lane_sum(s);
+}
 __device__ __forceinline__ long long acc_total(const unsigned long long* acc, int k, int lane) {
     long long s = 0;
 #pragma unroll
     for (int j = 0; j < ACC_SLOTS / 64; j++) s += (long long) acc[k * ACC_SLOTS + lane + 64 * j];
+    return acc_reduce_lane_sum(s);
+}
+__device__ __forceinline__ long long acc_reduce_lane_sum(long long s) {
     s += dpp_fetch_i64<0x111, 0xF>(s);
     s += dpp_fetch_i64<0x112, 0xF>(s);
     s += dpp_fetch_i64<0x114, 0xF>(s);
@@ -1386,16 +1397,28 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const int2* __restrict__ pre_
         __builtin_amdgcn_s_setprio(3);            // the block waits for this wave: let it win the issue arbitration on its SIMD
         VV_STAMP(7, 0);
         const int cg = lane < VVHIP_NUM_TG ? lane : VVHIP_NUM_TG - 1;
+        // every load of this wave -- thermostat state, chain constants, the accumulator slots of all rows in use -- is issued here, in
+        // front of a scheduling barrier: left to itself the backend sank part of the state loads BEHIND the first row's reduction
+        // (register pressure), i.e. behind a wait for the cold accumulator loads, and the chain started a second memory round trip late
+        long long raw[NUM_ACC][ACC_SLOTS / 64];
+#pragma unroll
+        for (int k = 0; k < NUM_ACC; k++) {
+            const bool wanted = (k < 3 || (k == 3 && (F & B_UNBIAS)) || (k > 3 && (F & B_KE_MOM))) && !(F & B_DBG_NOFOLD);
+#pragma unroll
+            for (int j = 0; j < ACC_SLOTS / 64; j++) raw[k][j] = wanted ? (long long) pre_acc[k * ACC_SLOTS + lane + 64 * j] : 0ll;
+        }
         ChainRegs cr;
 #pragma unroll
         for (int i = 0; i < 4; i++) { cr.eta[i] = pre_nh->s.eta[cg][i]; cr.eta_dot[i] = pre_nh->s.eta_dot[cg][i]; cr.eta_dotdot[i] = pre_nh->s.eta_dotdot[cg][i]; }
         cr.eta_dot[4] = pre_nh->s.eta_dot[cg][4];
         const ChainLaneBlock lc = pre_lane_const[cg];
+        const double bias_carried = pre_nh->scales[3];
+        __builtin_amdgcn_sched_barrier(0);
         long long tot[NUM_ACC];
 #pragma unroll
         for (int k = 0; k < NUM_ACC; k++) {
-            const bool wanted = k < 3 || (k == 3 && (F & B_UNBIAS)) || (k > 3 && (F & B_KE_MOM));
-            tot[k] = (!wanted || (F & B_DBG_NOFOLD)) ? 0 : acc_total(pre_acc, k, lane);
+            const bool wanted = (k < 3 || (k == 3 && (F & B_UNBIAS)) || (k > 3 && (F & B_KE_MOM))) && !(F & B_DBG_NOFOLD);
+            tot[k] = wanted ? acc_reduce(raw[k]) : 0ll;
         }
         if (F & B_MAILBOX) {                      // multi-GPU: block 0 publishes this rank's totals, every block collects all ranks'
             __shared__ unsigned int mb_words[MB_MAX_RANKS * MB_WORDS];
@@ -1417,7 +1440,7 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const int2* __restrict__ pre_
         double factor = 1.0;
         // the bias is requested before the chain starts (when it is carried over it is a load from the state)
         const double bias = (F & B_UNBIAS) ? (double) tot[3] * a.chain.acc_inv_scale[3] * a.chain.inv_mass_total   // K/cosineAccelerate.cu:57-59
-                                           : pre_nh->scales[3];                                               // carried over unchanged
+                                           : bias_carried;                                                    // carried over unchanged
         VV_STAMP_AFTER(7, 4, ke2);
         // Hands the scale factors to the block's tile waves the moment they are final -- in the MIDDLE of the chain update (see
         // propagate_preloaded): this wave's only barrier.  The second half of the chain runs while the tile waves scale and drift.
