@@ -93,6 +93,7 @@ struct vvhip_plan {
     bool periodic_kernels = true, periodic_a = true;
     int shake_mode = 1;            // hydrogen-type constraint clusters: 1 = all constraints of a cluster at once (direct velocity solve, coupled Newton
                                    // for positions), 0 = Gauss-Seidel sweeps by the central lane (OpenMM's iteration; generic kernels) -- VVHIP_SHAKE_MODE
+    bool acc_store = true;         // kernel A launches of <= 256 blocks store old + new into their accumulator slots instead of atomics (VVHIP_ACC_STORE=0: atomics)
     bool rekick = true;            // fused middle step: kick repeated in kernel B instead of a velm store in kernel A (use_rekick)
     // plan-owned device state
     int2* d_slots = nullptr;
@@ -322,6 +323,7 @@ vv::KArgs make_args(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
     a.padded = p->hp.padded_num_atoms;
     a.nwaves = p->hp.info.num_waves;
     a.acc_rows = p->hp.params.cos_acceleration != 0 ? vv::NUM_ACC : 4;
+    a.acc_exclusive = p->acc_store ? 1 : 0;
     a.flags = flags;
     a.random_index = random_index;
     a.per = vv::periodic_args(p->hp.per);
@@ -552,6 +554,7 @@ int vvhip_plan_create(const vvhip_system_desc* system, const vvhip_params* param
         if (const char* e = std::getenv("VVHIP_WT")) p->wt_stores = std::atoi(e) != 0;
         if (const char* e = std::getenv("VVHIP_NO_MOMENTS")) p->no_moments = std::atoi(e) != 0;
         if (const char* e = std::getenv("VVHIP_REKICK")) p->rekick = std::atoi(e) != 0;
+        if (const char* e = std::getenv("VVHIP_ACC_STORE")) p->acc_store = std::atoi(e) != 0;
         if (const char* e = std::getenv("VVHIP_SHAKE_MODE")) p->shake_mode = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("VVHIP_PERIODIC_K")) p->periodic_kernels = std::atoi(e) != 0;
         if (const char* e = std::getenv("VVHIP_PERIODIC_A")) p->periodic_a = std::atoi(e) != 0;

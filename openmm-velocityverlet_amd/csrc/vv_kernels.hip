@@ -160,7 +160,7 @@ __device__ __forceinline__ T segment_total(T x, int lane, int first, int last) {
 // Block partials -> fixed-point atomics.  vals[k] is the calling thread's contribution.
 template <int NV>
 __device__ __forceinline__ void block_accumulate(const double (&vals)[NV], const bool (&enabled)[NV],
-                                                 unsigned long long* acc, const double* scale, unsigned int* status) {
+                                                 unsigned long long* acc, const double* scale, unsigned int* status, bool exclusive, unsigned long long acc_old) {
     __shared__ double red[16][NV];
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -197,7 +197,11 @@ __device__ __forceinline__ void block_accumulate(const double (&vals)[NV], const
         if (__builtin_expect(!(fabs(scaled) * (double) gridDim.x < 4611686018427387904.0), 0) && status)
             __hip_atomic_store(&status[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         const long long q = __double2ll_rn(scaled);
-        if (q != 0) atomicAdd(&acc[threadIdx.x * ACC_SLOTS + (blockIdx.x & (ACC_SLOTS - 1))], (unsigned long long) q);
+        // `exclusive`: the launch has at most ACC_SLOTS blocks, so this block is the only one that touches its slot: the slot's old
+        // content (requested at the kernel's top) plus q goes back as a plain store.  An agent-scope atomic of this multi-XCD part is
+        // executed at the memory side, and the kernel cannot end before it has come back.
+        if (exclusive) { if (q != 0) acc[threadIdx.x * ACC_SLOTS + (blockIdx.x & (ACC_SLOTS - 1))] = acc_old + (unsigned long long) q; }
+        else if (q != 0) atomicAdd(&acc[threadIdx.x * ACC_SLOTS + (blockIdx.x & (ACC_SLOTS - 1))], (unsigned long long) q);
     }
 }
 
@@ -751,6 +755,9 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const int2* __restrict__ pre_
     // s_load in front of the first slot load
     VV_STAMP(threadIdx.x >> 6, 0);
     VV_SPAN_BEGIN;
+    // this block's accumulator slots as they are now (block_accumulate: exclusive slots take a plain store of old + new at the end)
+    unsigned long long acc_old = 0;
+    if ((F & (A_KE | A_BIAS | A_KE_PLAIN)) && a.acc_exclusive && threadIdx.x < NUM_ACC) acc_old = a.acc[threadIdx.x * ACC_SLOTS + (blockIdx.x & (ACC_SLOTS - 1))];
     // (Requesting the NEXT tile's slot words one tile ahead in this grid-stride loop was measured, same box, three alternating runs:
     // 8.9 M particles A 237.7 -> 236.1 us, B 264.1 -> 267.7 us; 111 k particles A 5.27 -> 5.47 us.  Not kept.)
     // Periodic layout: the role words and segment masses of a region's waves are those of its pattern wave (the region's first wave of
@@ -1111,7 +1118,7 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const int2* __restrict__ pre_
                                       m_bb[0] - m_bb[2] - m_bb[1], m_bb[1], m_bb[2]};
         const bool mom = (F & A_KE_MOM) != 0;
         const bool en[NUM_ACC] = {(F & (A_KE | A_KE_PLAIN)) != 0, (F & A_KE) != 0, (F & A_KE) != 0, (F & A_BIAS) != 0, mom, mom, mom, mom, mom, mom};
-        block_accumulate<NUM_ACC>(vals, en, a.acc, a.acc_scale, a.status);
+        block_accumulate<NUM_ACC>(vals, en, a.acc, a.acc_scale, a.status, a.acc_exclusive != 0, acc_old);
     }
     VV_STAMP(threadIdx.x >> 6, 4);
     VV_STAMP_DUMP(threadIdx.x >> 6);
@@ -2154,10 +2161,12 @@ static void note_generic(const char* kernel, uint32_t flags) {
     std::fprintf(stderr, "vvhip: kernel %s runs stage set 0x%x on the generic kernel (no compiled specialisation)\n", kernel, flags);
 }
 
-hipError_t launch_a(int precision, const KArgs& a, int block_threads, int grid_cap, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+hipError_t launch_a(int precision, const KArgs& a_in, int block_threads, int grid_cap, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    KArgs a = a_in;
     dim3 g = grid_for(a.nwaves, block_threads);
     if ((int) g.x > grid_cap) g.x = (unsigned) grid_cap;          // beyond that the kernel strides over tiles
     vv_last_grid_value = g.x;
+    if (g.x > (unsigned) ACC_SLOTS) a.acc_exclusive = 0;          // several blocks per accumulator slot: atomics (block_accumulate)
     const dim3 b(block_threads);
     // per-wave LDS page of the in-kernel constraint solver (7 values of the mode's `mixed` type per lane)
     const unsigned lds = (a.flags & A_CONS) ? (unsigned) (block_threads / 64) * 64u * 7u * (precision == VVHIP_SINGLE ? 4u : 8u) : 0u;

@@ -197,7 +197,8 @@ struct KArgs {
     const float4* random;
     unsigned long long* acc_next;   // other parity: zeroed by B when it runs the chain inline
     NHDevState* nh_next;            // where an inline chain writes the advanced state
-    int32_t acc_rows, acc_rows_pad_;   // accumulator rows in use (4, or NUM_ACC with the cos moments): what kernel B has to clear
+    int32_t acc_rows;                  // accumulator rows in use (4, or NUM_ACC with the cos moments): what kernel B has to clear
+    int32_t acc_exclusive;             // kernel A: 1 = a launch of <= ACC_SLOTS blocks stores into its slots instead of adding atomically (launch_a clears it for larger grids)
     double fscale_vv;          // 0.5*dt/2^32 computed in double on the host (HOST:306)
     double drag, randf, drag_drude, randf_drude;   // HOST:835-839
     double efscale;            // E * AVOGADRO (HOST:978)
