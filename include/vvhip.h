@@ -328,7 +328,6 @@ int vvhip_timing_read(vvhip_plan* plan, double* ms_pass_a, double* ms_pass_b, do
  *   VVHIP_NO_MOMENTS=1        cos perturbation as three launches (bias, sums, scale) instead of two
  *   VVHIP_SPLIT_CHAIN_WAVES=n the thermostat chain becomes its own 1-wave launch from n waves on (default 12288)
  *   VVHIP_BLOCK=t, VVHIP_CAP_A=b, VVHIP_CAP_B=b   launch shape: threads per block (multiple of 64), most blocks per launch of kernel A / B
- *   VVHIP_WT=1                write-through stores in the fused kernels (tuning experiment)
  *   VVHIP_ROCTX=1             roctx ranges (see vvhip_set_trace)
  *   VVHIP_WARN_GENERIC=1      one line on stderr per stage set that runs on the generic kernel (no compiled specialisation: 15-20 % slower)
  * and in the OpenMM adapters (platforms/hip): VVHIP_PLUGIN_DEFER=0 -- run every KernelImpl call as its own launch(es) instead of answering a

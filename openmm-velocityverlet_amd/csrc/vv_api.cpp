@@ -85,7 +85,6 @@ struct vvhip_plan {
     bool fextra_dirty = false;     // forceExtra holds something since the last reset (split entry points)
     bool fextra_external = false;  // the host asked for the pointer (vvhip_force_extra) and may write to it: never assume zeros
     bool no_moments = false;       // VVHIP_NO_MOMENTS=1: keep the three-launch cos sequence (comparison runs)
-    bool wt_stores = false;        // write-through stores in the fused kernels (VVHIP_WT=1; tuning experiment)
     // with an arithmetic work-item layout (HostPlan::per) the kernels compute particle indices instead of loading slot words (VVHIP_PERIODIC_K=0:
     // comparison runs).  Kernel A: no slot traffic (1.13 -> 1.0 x the algorithmic bytes) and the next tile's loads in flight during this tile's
     // arithmetic: 133 vs 138 us in sequence at 8.9 M particles (round 2 without the second tile in flight: 113.6 vs 115.7 back to back);
@@ -446,7 +445,6 @@ int run_a(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
     if (p->mass_tab_a) { flags |= vv::A_MTAB; TRY(ensure_mass_table(p)); }
     // (kernel A takes the arithmetic path where it also saves the 20 bytes per lane of constraint tables; else it does not gain, see periodic_a)
     if (p->hp.per.enabled && p->periodic_kernels && (p->periodic_a || (flags & vv::A_CONS))) flags |= vv::A_PERIODIC;
-    if (p->wt_stores && (flags & (vv::A_KICK_FULL | vv::A_KICK_HALF))) flags |= vv::A_WT_STORES;
     if ((flags & vv::A_SHAKE_V) && p->shake_mode == 0) flags |= vv::A_SHAKE_GS;
     ScopedTimer t(p, T_A, true);
     HIP_TRY(p, vv::launch_a(p->hp.precision, make_args(p, flags, random_index), p->block_threads, p->grid_cap_a, p->stream, t.e0, t.e1));
@@ -456,7 +454,6 @@ int run_b(vvhip_plan* p, uint32_t flags) {
     if (p->mass_tab_b) { flags |= vv::B_MTAB; TRY(ensure_mass_table(p)); }
     // (not next to the mailbox exchange: that combination timed out when two ranks shared one GPU, the only multi-rank set-up at hand)
     if (p->hp.per.enabled && p->periodic_kernels && !(flags & vv::B_MAILBOX)) flags |= vv::B_PERIODIC;
-    if (p->wt_stores) flags |= vv::B_WT_STORES;
     if ((flags & vv::B_SHAKE) && p->shake_mode == 0) flags |= vv::B_SHAKE_GS;
     ScopedTimer t(p, T_B, true);
     HIP_TRY(p, vv::launch_b(p->hp.precision, make_args(p, flags, 0), p->block_threads, p->grid_cap_b, p->stream, t.e0, t.e1));
@@ -551,7 +548,6 @@ int vvhip_plan_create(const vvhip_system_desc* system, const vvhip_params* param
         vvhip_plan* p = new vvhip_plan();
         p->hp = vv::analyze(*system, *params, precision);
         fill_scales(p);
-        if (const char* e = std::getenv("VVHIP_WT")) p->wt_stores = std::atoi(e) != 0;
         if (const char* e = std::getenv("VVHIP_NO_MOMENTS")) p->no_moments = std::atoi(e) != 0;
         if (const char* e = std::getenv("VVHIP_REKICK")) p->rekick = std::atoi(e) != 0;
         if (const char* e = std::getenv("VVHIP_ACC_STORE")) p->acc_store = std::atoi(e) != 0;
@@ -780,7 +776,7 @@ int vvhip_step_middle_phases(const vvhip_plan* p) {
 static bool use_rekick(const vvhip_plan* p) {
     const uint32_t ex = extra_flags(p);
     const bool extra_ok = ex == 0 || (ex == vv::A_COS && use_moments(p));
-    return p->rekick && p->hp.has_nh && extra_ok && !shake_on(p) && p->hp.num_big == 0 && !p->wt_stores;
+    return p->rekick && p->hp.has_nh && extra_ok && !shake_on(p) && p->hp.num_big == 0;
 }
 
 // Algorithmic bytes per particle that kernel A / kernel B of the fused middle step must move (SURVEY section 8d's accounting: particle

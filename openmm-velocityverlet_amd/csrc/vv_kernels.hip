@@ -48,26 +48,8 @@ template <> struct Prec<double> {
     static __device__ __forceinline__ double RECIP_SUM(double x) { double r = __builtin_amdgcn_rcp(x); r = fma(fma(-x, r, 1.0), r, r); return fma(fma(-x, r, 1.0), r, r); }
 };
 
-// 16-byte write-through store (buffer_store_dwordx4 ... sc1): the line goes to memory now instead of staying dirty in the
-// XCD's L2 until the end-of-kernel write-back (MI355X_MICROARCH.md "publish-large").  `base` must be wave-uniform.
-#ifndef VV_WT_AUX
-#define VV_WT_AUX 16      // cache-policy bits of the experiment: 16 = sc1 (write-through), 2 = nt (streaming)
-#endif
-typedef unsigned int vv_u4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store16_wt(void* base, unsigned byte_offset, const void* src) {
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0xFFFFFFFF, 0x00020000);
-    __builtin_amdgcn_raw_buffer_store_b128(*(const vv_u4*) src, rsrc, (int) byte_offset, 0, VV_WT_AUX);
-}
-
 template <class V>
-__device__ __forceinline__ void store_vec(V* base, int index, const V& val, bool write_through) {
-    if (write_through) {
-#pragma unroll
-        for (unsigned o = 0; o < sizeof(V); o += 16) store16_wt((void*) base, (unsigned) index * (unsigned) sizeof(V) + o, (const char*) &val + o);
-    } else {
-        base[index] = val;
-    }
-}
+__device__ __forceinline__ void store_vec(V* base, int index, const V& val) { base[index] = val; }
 
 __device__ __forceinline__ float shfl(float x, int src) { return __shfl(x, src, 64); }
 __device__ __forceinline__ double shfl(double x, int src) { return __shfl(x, src, 64); }
@@ -258,12 +240,12 @@ struct PosIO {
             x = p1.x; y = p1.y; z = p1.z; w = p1.w;
         }
     }
-    static __device__ __forceinline__ void store(void* posq, void* corr, int i, mixed x, mixed y, mixed z, mixed w, bool wt = false) {
+    static __device__ __forceinline__ void store(void* posq, void* corr, int i, mixed x, mixed y, mixed z, mixed w) {
         real4 p = {(real) x, (real) y, (real) z, (real) w};
-        store_vec((real4*) posq, i, p, wt);
+        store_vec((real4*) posq, i, p);
         if (kMixed) {
             real4 c = {(real) (x - (real) x), (real) (y - (real) y), (real) (z - (real) z), 0};
-            store_vec((real4*) corr, i, c, wt);
+            store_vec((real4*) corr, i, c);
         }
     }
 };
@@ -705,30 +687,8 @@ __device__ __forceinline__ void mailbox_exchange(const KArgs& a, int lane, unsig
     }
 }
 
-// Instrumented build only (-DVV_KERNEL_TIMESTAMPS, tools/probes): wave `w` of block a.dbg_block records the shader clock at point k.
-// Stamps go to LDS and are copied out when the wave ends: a global store per stamp would sit in the same vmcnt queue as the loads
-// whose arrival the next stamp waits for (the first version of this did exactly that and inflated every interval by ~0.7 us).
-#ifdef VV_KERNEL_TIMESTAMPS
-__shared__ long long vv_stamps[8][16];
-#define VV_STAMP_ON (a.dbg && (int) blockIdx.x == a.dbg_block && (threadIdx.x & 63) == 0)
-#define VV_STAMP(w, k) do { if (VV_STAMP_ON) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); vv_stamps[w][k] = (long long) __builtin_readcyclecounter(); } } while (0)
-#define VV_STAMP_NOWAIT(w, k) do { if (VV_STAMP_ON) { vv_stamps[w][k] = (long long) __builtin_readcyclecounter(); } } while (0)
-// stamp that cannot be taken before `val` has been computed (pure arithmetic is free to move across the other forms)
-#define VV_STAMP_AFTER(w, k, val) do { asm volatile("" :: "v"(val) : "memory"); if (VV_STAMP_ON) { vv_stamps[w][k] = (long long) __builtin_readcyclecounter(); } asm volatile("" ::: "memory"); } while (0)
-#define VV_STAMP_DUMP(w) do { if (VV_STAMP_ON) { for (int k_ = 0; k_ < 16; k_++) a.dbg[(w) * 16 + k_] = vv_stamps[w][k_]; } } while (0)
-// entry time stays in a register; both stamps are stored when the wave ends (after its memory operations have drained)
-#define VV_SPAN_BEGIN const long long vv_span_t0 = a.dbg_span ? (long long) wall_clock64() : 0
-#define VV_SPAN_END do { if (a.dbg_span && (threadIdx.x & 63) == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
-    long long* row_ = a.dbg_span + (((size_t) a.dbg_parity * gridDim.x + blockIdx.x) * 8 + (threadIdx.x >> 6)) * 2; \
-    row_[1] = (long long) wall_clock64(); row_[0] = vv_span_t0; } } while (0)
-#else
-#define VV_STAMP(w, k) do { } while (0)
-#define VV_STAMP_NOWAIT(w, k) do { } while (0)
-#define VV_STAMP_AFTER(w, k, val) do { } while (0)
-#define VV_STAMP_DUMP(w) do { } while (0)
-#define VV_SPAN_BEGIN do { } while (0)
-#define VV_SPAN_END do { } while (0)
-#endif
+// Shader-clock stamps of the instrumented build (-DVV_KERNEL_TIMESTAMPS, tools/probes): empty macros otherwise
+#include "vv_probes.inc"
 
 // ================================================================================ kernel A
 // Kernel-argument preload (gfx950: up to 16 user SGPRs are filled from the head of the kernarg segment by the packet processor
@@ -895,12 +855,6 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const int2* __restrict__ pre_
         auto mass_exact = [&]() -> mixed { return (F & A_MTAB) ? tab_m : P::RECIP(v.w); };
         auto mass_sum = [&]() -> mixed { return (F & A_MTAB) ? tab_m : P::RECIP_SUM(v.w); };
 
-#ifdef VV_EXP_A_LOADONLY     // probe: the loads of a tile and nothing else (what the memory system alone allows for this access pattern)
-        if (SF != 0) {
-            double t0 = ((double) v.x + (double) v.w + (double) ((fx ^ fy ^ fz) & 1) + seg_mw.x) * 1e-30;
-            k_atom += t0; continue;
-        }
-#endif
         if (F & (A_COS | A_BIAS | A_UNBIAS_ACC)) {
             if (!(F & A_CZ_LOAD)) czl = cos_kz<real>(pq.z, (real) a.inv_box_z);
             if (F & A_CZ_STORE) a.cosz[li] = czl;
@@ -970,7 +924,7 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const int2* __restrict__ pre_
                     v.y += 0.5 * stepSize * v.w * fe.y + fscale * v.w * fy;
                     v.z += 0.5 * stepSize * v.w * fe.z + fscale * v.w * fz;
                 }
-                if (!(F & (A_CONS | A_NOSTORE))) store_vec(velm, atom, v, (F & A_WT_STORES) != 0);
+                if (!(F & (A_CONS | A_NOSTORE))) store_vec(velm, atom, v);
                 if (F & A_POSDELTA_VV) {                                    // K/velocityVerlet.cu:24-26
                     mixed4 d = {stepSize * v.x, stepSize * v.y, stepSize * v.z, 0};
                     ((mixed4*) a.pos_delta)[atom] = d;
@@ -990,7 +944,7 @@ __global__ void __launch_bounds__(512) vv_kernel_a(const int2* __restrict__ pre_
             else { sx = cons_p1.x; sy = cons_p1.y; sz = cons_p1.z; }
             shake_velocities<mixed>(lane, word, prm, (mixed) a.shake_tol, sx, sy, sz, v.w, v.x, v.y, v.z, shake_page_a,
                                     (F & A_SHAKE_V) != 0, (F & A_SETTLE) != 0, (F & A_SHAKE_GS) != 0);
-            if (massive) store_vec(velm, atom, v, (F & A_WT_STORES) != 0);
+            if (massive) store_vec(velm, atom, v);
         }
         if ((F & A_POS1) && massive) {                                      // K/middle.cu:33-40
             const mixed halfdt = 0.5f * stepSize;
@@ -1410,7 +1364,7 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const int2* __restrict__ pre_
         long long raw[NUM_ACC][ACC_SLOTS / 64];
 #pragma unroll
         for (int k = 0; k < NUM_ACC; k++) {
-            const bool wanted = (k < 3 || (k == 3 && (F & B_UNBIAS)) || (k > 3 && (F & B_KE_MOM))) && !(F & B_DBG_NOFOLD);
+            const bool wanted = (k < 3 || (k == 3 && (F & B_UNBIAS)) || (k > 3 && (F & B_KE_MOM)));
 #pragma unroll
             for (int j = 0; j < ACC_SLOTS / 64; j++) raw[k][j] = wanted ? (long long) pre_acc[k * ACC_SLOTS + lane + 64 * j] : 0ll;
         }
@@ -1424,7 +1378,7 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const int2* __restrict__ pre_
         long long tot[NUM_ACC];
 #pragma unroll
         for (int k = 0; k < NUM_ACC; k++) {
-            const bool wanted = (k < 3 || (k == 3 && (F & B_UNBIAS)) || (k > 3 && (F & B_KE_MOM))) && !(F & B_DBG_NOFOLD);
+            const bool wanted = (k < 3 || (k == 3 && (F & B_UNBIAS)) || (k > 3 && (F & B_KE_MOM)));
             tot[k] = wanted ? acc_reduce(raw[k]) : 0ll;
         }
         if (F & B_MAILBOX) {                      // multi-GPU: block 0 publishes this rank's totals, every block collects all ranks'
@@ -1457,23 +1411,7 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const int2* __restrict__ pre_
             VV_STAMP_AFTER(7, 5, f);
             __syncthreads();
         };
-#ifdef VV_CHAIN_LOOP       // probe (instrumented builds): the SAME chain code executed twice in a real loop (first pass on a scratch copy,
-        {                      // no publish) to tell cold instruction fetch from arithmetic latency; stamp 6 = end of the first pass
-            const ChainRegs keep = cr;
-            const int passes = a.dbg ? 2 : 1;
-#pragma nounroll
-            for (int pass = 0; pass < passes; pass++) {
-                const bool last = pass == passes - 1;
-                if (!last) cr = keep;
-                auto maybe = [&](double f) { if (last) release_tiles(f); };
-                factor = propagate_group_small<(SF != 0 ? 3 : 0)>(a.chain, lc, ke2, cr, maybe);
-                if (!last) { VV_STAMP_AFTER(7, 6, factor); cr = keep; }
-            }
-        }
-#else
-        if (!(F & B_DBG_NOMATH)) factor = propagate_group_small<(SF != 0 ? 3 : 0)>(a.chain, lc, ke2, cr, release_tiles);
-        else release_tiles(1.0);
-#endif
+        factor = propagate_group_small<(SF != 0 ? 3 : 0)>(a.chain, lc, ke2, cr, release_tiles);
         VV_STAMP_AFTER(7, 2, factor);
         if (blockIdx.x == 0) {                    // one block records the advanced thermostat and clears the idle accumulator copy
             NHDevState* out = a.nh_next;
@@ -1586,9 +1524,6 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const int2* __restrict__ pre_
             img_p = ((const real4*) a.posq)[img];
             if (IO::kMixed) img_c = ((const real4*) a.corr)[img];
         }
-#ifdef VV_EXP_B_LOADSTORE
-        const mixed4 v_in = v;
-#endif
         // B_KICK: kernel A kept its kicked velocities in registers (A_NOSTORE); the same kick again here, from the same velm and force
         // bits with the same expression (K/middle.cu:11-21; forceExtra is zero on this path), gives the same velocities bit for bit.
         // (a massless particle's force is read and not used)
@@ -1644,22 +1579,6 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const int2* __restrict__ pre_
                 rx = a2x - a1x; ry = a2y - a1y; rz = a2z - a1z;
             }
         };
-#ifdef VV_EXP_B_LOADSTORE    // probe: the loads and stores of a tile and nothing else
-        if (SF != 0) {
-            if (need_scales) { need_scales = false; if (has_cw) __syncthreads(); if (!valid) break; }
-            mixed4 vo = v_in;
-            vo.x += (tab_f + Vx + Vw + v.x + v.y + v.z) * (mixed) 0.0;
-#ifndef VV_EXP_B_NOSTORE
-            if (act) store_vec(velm, atom, vo, false);
-#endif
-#ifndef VV_EXP_B_NOSTORE
-            if (act) IO::store(a.posq, a.corr, atom, x, y, z, q, false);
-#else
-            if (act && vo.x + x + y + z == (mixed) 1e300) store_vec(velm, atom, vo, false);
-#endif
-            continue;
-        }
-#endif
         const bool prep_early = (F & B_SCALE) && !(F & (B_UNBIAS | B_BIAS_REMOVE));
         VV_STAMP(wib, 1);
         if (prep_early) scale_prep();
@@ -1860,8 +1779,8 @@ __global__ void __launch_bounds__(512) vv_kernel_b(const int2* __restrict__ pre_
 
         // ---------------- write back
         VV_STAMP(wib, 4);
-        if (act && vel_dirty) store_vec(velm, atom, v, (F & B_WT_STORES) != 0);
-        if (act && pos_dirty) IO::store(a.posq, a.corr, atom, x, y, z, q, (F & B_WT_STORES) != 0);
+        if (act && vel_dirty) store_vec(velm, atom, v);
+        if (act && pos_dirty) IO::store(a.posq, a.corr, atom, x, y, z, q);
         if ((F & B_VV_KICK) && massive) {
             mixed4 d = {dx, dy, dz, 0};
             if (a.pos_delta) ((mixed4*) a.pos_delta)[atom] = d;
@@ -2049,12 +1968,10 @@ static inline void vv_launch(F kernel, dim3 g, dim3 b, unsigned lds, hipStream_t
 // Stage-bit sets with their own compiled kernel: the fused middle step of a Drude system with / without hard wall
 // (BASELINE configs C3 / C2).  Everything else runs the generic kernel with run-time bits.
 constexpr uint32_t SF_A_MIDDLE = A_KICK_FULL | A_KE;
-constexpr uint32_t SF_A_MIDDLE_WT = SF_A_MIDDLE | A_WT_STORES;
 constexpr uint32_t SF_A_COS1 = A_KICK_FULL | A_COS | A_BIAS | A_CZ_STORE;          // cos acceleration (BASELINE C4): kick + bias moment
 constexpr uint32_t SF_A_COS2 = A_KE | A_UNBIAS_ACC | A_CZ_LOAD;                     // ... kinetic energies of the bias-free velocities
 constexpr uint32_t SF_B_COS_HW = B_CHAIN | B_SCALE | B_UNBIAS | B_CZ_LOAD | B_DRIFT_MIDDLE | B_HARDWALL;
 constexpr uint32_t SF_B_MIDDLE_HW = B_CHAIN | B_SCALE | B_DRIFT_MIDDLE | B_HARDWALL;
-constexpr uint32_t SF_B_MIDDLE_HW_WT = SF_B_MIDDLE_HW | B_WT_STORES;
 constexpr uint32_t SF_B_MIDDLE = B_CHAIN | B_SCALE | B_DRIFT_MIDDLE;
 constexpr uint32_t SF_A_EDL = A_KICK_FULL | A_LD | A_EF | A_KE;                                // electrode slab (BASELINE C5): Langevin subset + field
 constexpr uint32_t SF_B_EDL = SF_B_MIDDLE_HW | B_IMAGE;                                         // ... + image mirror
@@ -2177,7 +2094,6 @@ hipError_t launch_a(int precision, const KArgs& a_in, int block_threads, int gri
     VV_TRY_SF(vv_kernel_a, SF_A_MIDDLE_NS)
     VV_TRY_SF(vv_kernel_a, SF_A_COS_MOM_NS)
     VV_TRY_SF(vv_kernel_a, SF_A_MIDDLE)
-    VV_TRY_SF(vv_kernel_a, SF_A_MIDDLE_WT)
     VV_TRY_SF(vv_kernel_a, SF_A_COS1)
     VV_TRY_SF(vv_kernel_a, SF_A_COS2)
     VV_TRY_SF(vv_kernel_a, SF_A_COS_MOM)
@@ -2228,7 +2144,6 @@ hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_c
     VV_TRY_SF(vv_kernel_b, SF_B_COS_HW_MOM_K)
     VV_TRY_SF(vv_kernel_b, SF_B_COS_HW_MOM_MB_K)
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_HW)
-    VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_HW_WT)
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE)
     VV_TRY_SF(vv_kernel_b, SF_B_COS_HW)
     VV_TRY_SF(vv_kernel_b, SF_B_COS_HW_MOM)

@@ -40,7 +40,6 @@ enum : uint32_t {
                              // 3.5 MB less dirty data behind this launch at the headline size (the kernel boundary waits for it)
     A_SHAKE_GS = 1u << 21,   // hydrogen-type clusters by Gauss-Seidel sweeps of the central lane (OpenMM's iteration; VVHIP_SHAKE_MODE=0, generic
                              // kernel only) instead of the direct solve of the cluster's velocity constraints
-    A_WT_STORES = 1u << 27,  // write-through (sc1) store of the kicked velocities
     A_KE_PLAIN = 1u << 15,   // sum m v^2 over every massive particle into accumulator 0 (kinetic-energy query)
 };
 // ---- stage flags of kernel B ("consume": starts from the scale factors) -------------------------
@@ -67,9 +66,6 @@ enum : uint32_t {
     B_PERIODIC = 1u << 18,    // as A_PERIODIC
     B_MTAB = 1u << 16,        // Drude-pair mass fractions from the static per-lane table (slot_f) instead of two IEEE divisions per lane
     B_SHAKE_GS = 1u << 19,    // as A_SHAKE_GS, for the position constraints (instead of the coupled Newton iteration)
-    B_WT_STORES = 1u << 27,   // write-through (sc1) stores for the particle arrays: the dirty lines leave L2 during the kernel, not at its end
-    B_DBG_NOFOLD = 1u << 28,  // timing experiments only: skip the accumulator fold / the chain arithmetic
-    B_DBG_NOMATH = 1u << 29,
 };
 constexpr uint32_t A_CONS = A_SHAKE_V | A_SETTLE, B_CONS = B_SHAKE | B_SETTLE;      // in-kernel constraints of either kind
 // ---- chain kernel --------------------------------------------------------------------------------

@@ -8,7 +8,7 @@ spec = S.make_config("C3")
 it = I.VVIntegrator(333.0, 10, 1.0, 40, 0.001); it.setMaxDrudeDistance(0.02)
 ctx = I.Context(spec, it, precision="mixed", force_provider="tether")
 ctx.run_graph(200, 100); ctx.synchronize()
-B = dict(SCALE=1, DRIFT=16, POS3=64, HW=512, CHAIN=2048, NOFOLD=1 << 28, NOMATH=1 << 29)
+B = dict(SCALE=1, DRIFT=16, POS3=64, HW=512, CHAIN=2048)
 A = dict(KICK=32, KE=1024)
 def t(kernel, flags):
     vals = []
@@ -20,9 +20,6 @@ def t(kernel, flags):
 rows = [("B full (specialised)", 1, B["CHAIN"] | B["SCALE"] | B["DRIFT"] | B["HW"]),
         ("B no chain wave (scales from memory)", 1, B["SCALE"] | B["DRIFT"] | B["HW"]),
         ("B chain+scale+drift (no hard wall)", 1, B["CHAIN"] | B["SCALE"] | B["DRIFT"]),
-        ("B generic: full + NOFOLD", 1, B["CHAIN"] | B["SCALE"] | B["DRIFT"] | B["HW"] | B["NOFOLD"]),
-        ("B generic: full + NOMATH", 1, B["CHAIN"] | B["SCALE"] | B["DRIFT"] | B["HW"] | B["NOMATH"]),
-        ("B generic: full + NOFOLD + NOMATH", 1, B["CHAIN"] | B["SCALE"] | B["DRIFT"] | B["HW"] | B["NOFOLD"] | B["NOMATH"]),
         ("B drift only", 1, B["DRIFT"]),
         ("B pos3 only (load/store skeleton)", 1, B["POS3"]),
         ("A full (kick + KE)", 0, A["KICK"] | A["KE"]),
