@@ -306,6 +306,12 @@ int vvhip_time_kernel(vvhip_plan* plan, int kernel, uint32_t flags, int reps, do
  * VVIntegrator::setDebugEnabled and prints the reference's per-call lines itself (VVIntegrator.h:417-419, CudaVVKernels.cpp:57,120,...).
  * Also VVHIP_ROCTX=1 in the environment.  libroctx64 is resolved at run time. */
 int vvhip_set_trace(vvhip_plan* plan, int enable);
+/* Every stage set that a supported path launches has a kernel compiled for it (the reference compiles its kernels per System at run time,
+ * CudaVVKernels.cpp:98-101, 639-647; here the enumeration happens at build time, vv_kernels.hip: SF_*); a stage set outside that list
+ * runs the generic kernel with run-time stage bits, 15-20 % slower.  counts[0 / 1] = enqueued launches of kernel A / B of this plan that
+ * did (a launch captured into a graph counts once), stage_sets = the last stage bits that did.  tests/test_gpu_specialised.py asserts 0
+ * for every BASELINE configuration +- constraints, classic scheme, sharded.  VVHIP_WARN_GENERIC=1 prints them as they happen. */
+int vvhip_generic_launches(vvhip_plan* plan, int64_t counts[2], uint32_t stage_sets[2]);
 /* Per-launch timing of eager (not captured) launches, summed per class until vvhip_timing_read.  Kernels A and B: the dispatch's own
  * begin / end timestamps (hipExtLaunchKernel with start / stop events: nothing is added to the stream; what rocprofv3's kernel trace
  * reports).  enable = 1: everything else ("other": force provider, chain launch, collectives) bracketed by recorded events as well;

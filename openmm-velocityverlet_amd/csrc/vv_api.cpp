@@ -93,6 +93,8 @@ struct vvhip_plan {
     int shake_mode = 1;            // hydrogen-type constraint clusters: 1 = all constraints of a cluster at once (direct velocity solve, coupled Newton
                                    // for positions), 0 = Gauss-Seidel sweeps by the central lane (OpenMM's iteration; generic kernels) -- VVHIP_SHAKE_MODE
     bool acc_store = true;         // kernel A launches of <= 256 blocks store old + new into their accumulator slots instead of atomics (VVHIP_ACC_STORE=0: atomics)
+    long long generic_launches[2] = {0, 0};   // kernel A / B launches of this plan (captured ones count once) that ran the generic kernel
+    uint32_t generic_flags[2] = {0, 0};       // ... and the last stage set that did (vvhip_generic_launches)
     bool rekick = true;            // fused middle step: kick repeated in kernel B instead of a velm store in kernel A (use_rekick)
     // plan-owned device state
     int2* d_slots = nullptr;
@@ -447,7 +449,9 @@ int run_a(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
     if (p->hp.per.enabled && p->periodic_kernels && (p->periodic_a || (flags & vv::A_CONS))) flags |= vv::A_PERIODIC;
     if ((flags & vv::A_SHAKE_V) && p->shake_mode == 0) flags |= vv::A_SHAKE_GS;
     ScopedTimer t(p, T_A, true);
+    const unsigned long long g0 = vv::vv_generic_count[0];
     HIP_TRY(p, vv::launch_a(p->hp.precision, make_args(p, flags, random_index), p->block_threads, p->grid_cap_a, p->stream, t.e0, t.e1));
+    if (vv::vv_generic_count[0] != g0) { p->generic_launches[0]++; p->generic_flags[0] = vv::vv_generic_flags[0]; }
     return VVHIP_OK;
 }
 int run_b(vvhip_plan* p, uint32_t flags) {
@@ -456,7 +460,9 @@ int run_b(vvhip_plan* p, uint32_t flags) {
     if (p->hp.per.enabled && p->periodic_kernels && !(flags & vv::B_MAILBOX)) flags |= vv::B_PERIODIC;
     if ((flags & vv::B_SHAKE) && p->shake_mode == 0) flags |= vv::B_SHAKE_GS;
     ScopedTimer t(p, T_B, true);
+    const unsigned long long g0 = vv::vv_generic_count[1];
     HIP_TRY(p, vv::launch_b(p->hp.precision, make_args(p, flags, 0), p->block_threads, p->grid_cap_b, p->stream, t.e0, t.e1));
+    if (vv::vv_generic_count[1] != g0) { p->generic_launches[1]++; p->generic_flags[1] = vv::vv_generic_flags[1]; }
     if (flags & vv::B_CHAIN) p->parity ^= 1;     // the advanced thermostat state now lives in the other copy
     return VVHIP_OK;
 }
@@ -1407,6 +1413,11 @@ int vvhip_run_eager_unfused(vvhip_plan* p, int nsteps, const void* site, double 
 int vvhip_set_trace(vvhip_plan* p, int enable) {
     if (!p) return VVHIP_ERR_INVALID;
     p->trace = enable != 0;
+    return VVHIP_OK;
+}
+int vvhip_generic_launches(vvhip_plan* p, int64_t counts[2], uint32_t stage_sets[2]) {
+    if (!p || !counts) return VVHIP_ERR_INVALID;
+    for (int k = 0; k < 2; k++) { counts[k] = p->generic_launches[k]; if (stage_sets) stage_sets[k] = p->generic_flags[k]; }
     return VVHIP_OK;
 }
 int vvhip_timing_enable(vvhip_plan* p, int enable) {

@@ -2051,6 +2051,26 @@ constexpr uint32_t SF_B_VV1_HW_NC_P = SF_B_VV1_HW_NC | B_PERIODIC;
 constexpr uint32_t SF_B_SCALE_NC = B_SCALE;
 constexpr uint32_t SF_B_SCALE_NC_P = SF_B_SCALE_NC | B_PERIODIC;
 
+// The classic scheme (two thermostat applications per step) of every BASELINE configuration with what the example scripts add to it:
+// second half = half kick (+ extra forces kept for the next first half) + sums, first half = scale + half kick + positions.
+constexpr uint32_t SF_A_KE_P = A_KE | A_PERIODIC;                                              // large boxes
+constexpr uint32_t SF_A_VV2_P = SF_A_VV2 | A_PERIODIC;
+constexpr uint32_t SF_A_VV2_SHAKE = SF_A_VV2 | A_SHAKE_V;                                      // + HBonds
+constexpr uint32_t SF_A_VV2_SETTLE = SF_A_VV2 | A_SETTLE;                                      // rigid water
+constexpr uint32_t SF_A_VV2_EDL = SF_A_VV2 | A_FE_STORE | A_LD | A_EF;                         // electrode slab
+constexpr uint32_t SF_A_VV2_EDL_SHAKE = SF_A_VV2_EDL | A_SHAKE_V;
+constexpr uint32_t SF_A_COS_MOM_VV1 = A_BIAS | A_KE | A_CZ_STORE | A_KE_MOM;                   // cos perturbation: sums of the first half
+constexpr uint32_t SF_A_COS_MOM_VV2 = SF_A_COS_MOM_VV1 | A_FE_STORE | A_COS | A_KICK_HALF;     // ... half kick + sums of the second half
+constexpr uint32_t SF_A_COS_MOM_VV2_SHAKE = SF_A_COS_MOM_VV2 | A_SHAKE_V;
+constexpr uint32_t SF_B_VV1_HW_SHAKE = SF_B_VV1_HW | B_SHAKE;
+constexpr uint32_t SF_B_VV1_SETTLE = SF_B_VV1 | B_SETTLE;
+constexpr uint32_t SF_B_VV1_EDL = SF_B_VV1_HW | B_IMAGE;
+constexpr uint32_t SF_B_VV1_EDL_SHAKE = SF_B_VV1_EDL | B_SHAKE;
+constexpr uint32_t SF_B_COS_SCALE_MOM = B_CHAIN | B_SCALE | B_UNBIAS | B_CZ_LOAD | B_KE_MOM;   // cos perturbation: second half's scaling
+constexpr uint32_t SF_B_COS_VV1_HW_MOM = SF_B_COS_SCALE_MOM | B_VV_KICK | B_HARDWALL;          // ... first half
+constexpr uint32_t SF_B_COS_VV1_HW_MOM_SHAKE = SF_B_COS_VV1_HW_MOM | B_SHAKE;
+constexpr uint32_t SF_B_MIDDLE_SETTLE_P = SF_B_MIDDLE_SETTLE | B_PERIODIC;                      // rigid water between 0.2 M and 0.8 M particles
+
 // Which specialised kernels are compiled with the static mass tables; a launch whose flags disagree with the build falls through to
 // the generic kernel.  Measured on MI355X (gpurun_out/r02c-e): kernel B gains at every size (two IEEE fp64 divisions per pair lane
 // gone, 140 -> 101 VGPRs; C3 5.74 -> 5.29 us with the chain fix, 8.9 M particles unchanged), kernel A does not -- with the Koenig
@@ -2066,8 +2086,14 @@ constexpr uint32_t SF_AM = VV_SF_MTAB_A ? A_MTAB : 0u, SF_BM = VV_SF_MTAB_B ? B_
 bool sf_kernels_use_mass_table(int kernel) { return kernel == 0 ? VV_SF_MTAB_A != 0 : VV_SF_MTAB_B != 0; }
 #define VV_TRY_SF(KERNEL, SFV) if (a.flags == ((SFV) | XM)) { VV_DISPATCH_SF(KERNEL, ((SFV) | XM), g, b, lds, s, ev0, ev1, VV_PRE_ARGS, a); return hipGetLastError(); }
 
-// VVHIP_WARN_GENERIC=1: one line on stderr per stage set that has no compiled kernel of its own and runs the generic one (15-20 % slower)
+// Launches that found no compiled specialisation of their stage set and ran the generic kernel with run-time stage bits (15-20 % slower):
+// counted per kernel with the last such stage set (vvhip_generic_launches reads them); VVHIP_WARN_GENERIC=1 also prints one line on
+// stderr per stage set.
+unsigned long long vv_generic_count[2] = {0, 0};
+uint32_t vv_generic_flags[2] = {0, 0};
 static void note_generic(const char* kernel, uint32_t flags) {
+    vv_generic_count[kernel[0] == 'A' ? 0 : 1]++;
+    vv_generic_flags[kernel[0] == 'A' ? 0 : 1] = flags;
     static const bool on = std::getenv("VVHIP_WARN_GENERIC") != nullptr;
     if (!on) return;
     static uint32_t seen[2][16];
@@ -2113,6 +2139,15 @@ hipError_t launch_a(int precision, const KArgs& a_in, int block_threads, int gri
     VV_TRY_SF(vv_kernel_a, SF_A_KICK)
     VV_TRY_SF(vv_kernel_a, SF_A_KICK_FE)
     VV_TRY_SF(vv_kernel_a, SF_A_POS1)
+    VV_TRY_SF(vv_kernel_a, SF_A_KE_P)
+    VV_TRY_SF(vv_kernel_a, SF_A_VV2_P)
+    VV_TRY_SF(vv_kernel_a, SF_A_VV2_SHAKE)
+    VV_TRY_SF(vv_kernel_a, SF_A_VV2_SETTLE)
+    VV_TRY_SF(vv_kernel_a, SF_A_VV2_EDL)
+    VV_TRY_SF(vv_kernel_a, SF_A_VV2_EDL_SHAKE)
+    VV_TRY_SF(vv_kernel_a, SF_A_COS_MOM_VV1)
+    VV_TRY_SF(vv_kernel_a, SF_A_COS_MOM_VV2)
+    VV_TRY_SF(vv_kernel_a, SF_A_COS_MOM_VV2_SHAKE)
     note_generic("A", a.flags);
     VV_DISPATCH_SF(vv_kernel_a, 0u, g, b, lds, s, ev0, ev1, VV_PRE_ARGS, a);
     return hipGetLastError();
@@ -2129,6 +2164,7 @@ hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_c
     constexpr uint32_t XM = SF_BM;
 #define VV_PRE_ARGS a.slots, a.nwaves, (int) (b.x >> 6), (const unsigned long long*) a.acc, a.nh, a.lane_const, a.seg_base
     if ((a.flags & B_CHAIN) && a.chain.num_chains != 3) {       // the specialised kernels carry the three-link chain only
+        note_generic("B", a.flags);
         VV_DISPATCH_SF(vv_kernel_b, 0u, g, b, lds, s, ev0, ev1, VV_PRE_ARGS, a);
         return hipGetLastError();
     }
@@ -2179,6 +2215,14 @@ hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_c
     VV_TRY_SF(vv_kernel_b, SF_B_POS2)
     VV_TRY_SF(vv_kernel_b, SF_B_POS3_HW)
     VV_TRY_SF(vv_kernel_b, SF_B_POS3)
+    VV_TRY_SF(vv_kernel_b, SF_B_VV1_HW_SHAKE)
+    VV_TRY_SF(vv_kernel_b, SF_B_VV1_SETTLE)
+    VV_TRY_SF(vv_kernel_b, SF_B_VV1_EDL)
+    VV_TRY_SF(vv_kernel_b, SF_B_VV1_EDL_SHAKE)
+    VV_TRY_SF(vv_kernel_b, SF_B_COS_SCALE_MOM)
+    VV_TRY_SF(vv_kernel_b, SF_B_COS_VV1_HW_MOM)
+    VV_TRY_SF(vv_kernel_b, SF_B_COS_VV1_HW_MOM_SHAKE)
+    VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_SETTLE_P)
     note_generic("B", a.flags);
     VV_DISPATCH_SF(vv_kernel_b, 0u, g, b, lds, s, ev0, ev1, VV_PRE_ARGS, a);
     return hipGetLastError();

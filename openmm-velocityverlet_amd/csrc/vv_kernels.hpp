@@ -227,6 +227,9 @@ struct TetherArgs {
 // ev0 / ev1 (optional): events that receive the dispatch's own begin / end timestamps (timing runs; never inside a graph capture)
 hipError_t launch_a(int precision, const KArgs& a, int block_threads, int grid_cap, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_cap, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+// launches of kernel A / B (index 0 / 1) that ran the generic kernel, process-wide, and the last stage set that did
+extern unsigned long long vv_generic_count[2];
+extern uint32_t vv_generic_flags[2];
 hipError_t launch_chain(const NHConst& c, NHDevState* st, unsigned long long* acc, hipStream_t s);
 hipError_t launch_tether(int precision, const TetherArgs& t, int block_threads, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 // Fills the static per-lane mass tables from the inverse masses in velm.w (once per binding; see A_MTAB / B_MTAB).

@@ -438,6 +438,13 @@ class Context:
         H.check(H.lib.vvhip_calc_viscosity(self.plan, C.byref(v), C.byref(inv)), self.plan)
         return (v.value, inv.value)
 
+    def generic_launches(self):
+        """((count_A, count_B), (stage_set_A, stage_set_B)): launches of this plan that found no compiled specialisation of their stage
+        set and ran the generic kernel (vvhip_generic_launches)."""
+        n, f = (C.c_int64 * 2)(), (C.c_uint32 * 2)()
+        H.check(H.lib.vvhip_generic_launches(self.plan, C.byref(n), C.byref(f)), self.plan)
+        return (int(n[0]), int(n[1])), (int(f[0]), int(f[1]))
+
     def timing(self, enable):
         """0 / False off; 1 / True every launch group; 2 kernels A and B only (dispatch timestamps, nothing added to the stream);
         n > 2 as 2 with n events prepared beforehand (vvhip_timing_enable)."""
