@@ -1118,6 +1118,12 @@ __device__ __forceinline__ double chain_exp_small(double x, unsigned& max_hi) {
 constexpr unsigned CHAIN_EXP_SMALL_HI = 0x3FC00000u;      // high word of 2^-3
 __device__ __forceinline__ double chain_exp_wide(double x) { return exp(x); }
 
+// CHAIN INVARIANT, stated once for both implementations below (propagate_regs: the stand-alone chain kernel; propagate_preloaded:
+// kernel B's thermostat wave): eta_dot[NC], the element behind the chain's last link, is 0.  The reference sizes etaDot numChains + 1,
+// initialises it to 0 and never writes the last element (API:340-376); here the plan's chain length is fixed at creation
+// (vvhip_set_params keeps num_nh_chains), vvhip_bind starts both state copies from zeros and vvhip_set_nh_state zeroes everything from
+// index NC on.  exp(-dt/8 * 0) is exactly 1, so BOTH implementations drop the two evaluations that take it as argument -- they cannot
+// drift apart over it, whatever size regime or chain length selects between them.
 // One temperature group, chain length NC known at compile time so the chain lives in registers.
 // Differences from the host routine, both below 1 ulp per operation: chain_exp for exp, and multiplication by
 // the reciprocal thermostat mass instead of a division.
@@ -1142,7 +1148,7 @@ __device__ __forceinline__ double propagate_regs(const NHConst& c, int g, double
         for (int iloop = 0; iloop < c.loops_per_step; iloop++) {
 #pragma unroll
             for (int ich = NC - 1; ich >= 0; ich--) {
-                expfac = chain_exp(-dt8 * eta_dot[ich + 1]);
+                expfac = ich == NC - 1 ? 1.0 : chain_exp(-dt8 * eta_dot[ich + 1]);     // CHAIN INVARIANT (below): eta_dot[NC] == 0
                 eta_dot[ich] *= expfac;
                 eta_dot[ich] += eta_dotdot[ich] * dt4;
                 eta_dot[ich] *= expfac;
@@ -1156,7 +1162,7 @@ __device__ __forceinline__ double propagate_regs(const NHConst& c, int g, double
             eta_dot[0] *= expfac;
 #pragma unroll
             for (int ich = 1; ich < NC; ich++) {
-                expfac = chain_exp(-dt8 * eta_dot[ich + 1]);
+                expfac = ich == NC - 1 ? 1.0 : chain_exp(-dt8 * eta_dot[ich + 1]);
                 eta_dot[ich] *= expfac;
                 eta_dotdot[ich] = (eta_mass[ich - 1] * eta_dot[ich - 1] * eta_dot[ich - 1] - kT) * inv_mass[ich];
                 eta_dot[ich] += eta_dotdot[ich] * dt4;
@@ -1186,9 +1192,7 @@ struct ChainRegs { double eta[4], eta_dot[5], eta_dotdot[4]; };
 template <int NC, bool FAST, class Pub>
 __device__ __forceinline__ double propagate_preloaded(const NHConst& c, const ChainLaneBlock& lc, double ke2, ChainRegs& r, unsigned& max_hi, Pub&& publish) {
     auto ex = [&](double x) { return FAST ? chain_exp_small(x, max_hi) : chain_exp_wide(x); };
-    // eta_dot[NC] is the chain's closing zero: the reference sizes etaDot numChains + 1, initialises it to 0 and never writes the last
-    // element (API:340-376), and vvhip_set_nh_state keeps it 0 here.  exp(-dt8 * 0) is exactly 1, so the two evaluations that take
-    // it as argument are dropped at compile time (two of the six serial exps for NC = 3).
+    // eta_dot[NC] == 0 (CHAIN INVARIANT above): the two exps that take it as argument are dropped (two of the six serial ones for NC = 3)
     constexpr bool tail_zero = true;
     // Runs in the block's thermostat wave only (lanes 0..2 = the three temperature groups).  Lanes of a group that is not
     // thermostatted (HOST:729) run the same instructions on harmless values (their reciprocal masses are 0) so that `publish` is

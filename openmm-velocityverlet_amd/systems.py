@@ -350,6 +350,39 @@ def bulk_Im21(cells=(2, 2, 3), pairs_per_cell=250, hbonds=False, T=333.0, T_drud
     return spec
 
 
+def nondrude_Im21(num_pairs=83, hbonds=False, T=333.0, seed=SEED) -> SystemSpec:
+    """C1 as SURVEY.md section 8d defines it: the first `num_pairs` ion pairs of examples/models/bulk_Im21 with the Drude particles
+    stripped -- every Drude's mass and charge go back to its parent -- : 83 pairs = 1 992 particles (19-atom c2c1im+, 5-atom dca-), 166
+    molecules, no Drude pairs, so the plain Nose-Hoover thermostat with one temperature group (VVIntegrator.cpp:106-108)."""
+    z = np.load(os.path.join(_TOPO_DIR, "topo_bulk_Im21.npz"))
+    mol0 = z["mol_id"]
+    k = int(num_pairs)
+    assert 1 <= k <= 250
+    masses0, charges0 = z["masses"].astype(np.float64).copy(), z["charges"].astype(np.float64).copy()
+    drudes, parents = z["drude_pairs"][:, 0], z["drude_pairs"][:, 1]
+    np.add.at(masses0, parents, masses0[drudes])
+    np.add.at(charges0, parents, charges0[drudes])
+    is_drude = np.zeros(mol0.size, dtype=bool)
+    is_drude[drudes] = True
+    keep = np.nonzero(((mol0 < k) | ((mol0 >= 250) & (mol0 < 250 + k))) & ~is_drude)[0]      # conf.gro: 250 cations, then 250 anions
+    renum = -np.ones(mol0.size, dtype=np.int64)
+    renum[keep] = np.arange(keep.size)
+    _, mol = np.unique(mol0[keep], return_inverse=True)
+    masses = masses0[keep]
+    rng = np.random.default_rng(seed)
+    none = np.zeros(masses.size, dtype=bool)
+    vel = _maxwell_boltzmann(rng, masses, none, np.arange(masses.size) - 1, T, 1.0)
+    spec = SystemSpec(name=f"bulk_Im21_nondrude_{k}", masses=masses, charges=charges0[keep], positions=z["positions"][keep].astype(np.float64),
+                      velocities=vel, box=z["box"].astype(np.float64), mol_id=mol.astype(np.int32), drude_pairs=np.zeros((0, 2), np.int32),
+                      constraints=np.zeros((0, 2), np.int32))
+    if hbonds:
+        sel = np.isin(z["constraints"][:, 0], keep) & np.isin(z["constraints"][:, 1], keep)
+        cons, dist = renum[z["constraints"][sel]].astype(np.int32), z["constraint_distances"][sel]
+        _on_constraint_manifold(spec.positions, spec.velocities, cons, dist)
+        spec.constraints, spec.constraint_distances = cons, dist
+    return spec
+
+
 def edl_Im21(hbonds=False, T=333.0, T_drude=1.0, seed=SEED) -> SystemSpec:
     """C5 as SURVEY.md section 8 defines it: examples/models/edl_Im21/conf.gro -- 2 496 MoS2 atoms (Langevin subset), 511 ion pairs =
     18 907 ionic-liquid particles (Nose-Hoover, electrolyte for the field), 18 907 massless images; mirror at Lz / 2 = 8 nm."""
@@ -373,12 +406,16 @@ def edl_Im21(hbonds=False, T=333.0, T_drude=1.0, seed=SEED) -> SystemSpec:
 
 
 def make_config(name: str, scale: float = 1.0, hbonds: bool = False, synthetic: bool = False) -> SystemSpec:
-    """BASELINE.json configs by id.  C3 / C4 / C5 are built from the reference's own example models (bulk_Im21 tiled 2 x 2 x 3; edl_Im21);
+    """BASELINE.json configs by id.  C1 / C3 / C4 / C5 are built from the reference's own example models (C1: the first 83 ion pairs of
+    bulk_Im21 with the Drude particles merged into their parents; C3 / C4: bulk_Im21 tiled 2 x 2 x 3; C5: edl_Im21);
     `synthetic=True` (or missing fixtures) gives the procedural look-alikes instead.  `scale` > 1 tiles C3 further along z, `scale` < 1
     gives a reduced copy for fast parity tests.  hbonds: with the HBonds constraints of the example scripts (rigid water for C2)."""
     real = have_reference_topologies() and not synthetic
     if name == "C1":
-        return nondrude_il(max(2, int(round(83 * scale))))
+        if real:
+            return nondrude_Im21(max(1, min(250, int(round(83 * scale)))), hbonds=hbonds)
+        spec = nondrude_il(max(2, int(round(83 * scale))))
+        return constrain_hydrogens(spec) if hbonds else spec
     if name == "C2":
         spec = spce_water(max(4, int(round(3333 * scale))))
         return rigid_water(spec) if hbonds else spec
