@@ -301,6 +301,7 @@ def main():
     dist_mode = None
     ctx = None
     candidates = {}
+    exchange_log = {}          # why each exchange mechanism was (not) usable: goes into config.exchange
 
     def agree(ok):
         flag = torch.tensor([1 if ok else 0], device="cuda")
@@ -342,11 +343,28 @@ def main():
             ok = True
         except Exception as e:                                   # noqa: BLE001
             sys.stderr.write(f"[rank {rank}] in-core RCCL unavailable ({e})\n")
+            exchange_log["rccl"] = f"unavailable on rank {rank}: {e}"
             ok = False
-        return agree(ok)
+        ok = agree(ok)
+        exchange_log.setdefault("rccl", "communicator up on every rank" if ok else "unavailable on another rank")
+        return ok
 
     def setup_mailbox():
         ok = True
+        if world > 1 and not args.share_device:          # the peers' boxes are mapped through hipIpc and written by device stores: needs P2P access
+            try:
+                H = pkg.vvhip
+                denied = []
+                for peer in range(world):
+                    can = H.C.c_int32(0)
+                    if peer != local_rank and (H.lib.vvhip_peer_access(local_rank, peer, H.C.byref(can)) != 0 or not can.value):
+                        denied.append(peer)
+                exchange_log["peer_access"] = "all peers" if not denied else f"rank {rank}: no peer access to device(s) {denied}"
+                if not agree(not denied):
+                    exchange_log["mailbox"] = "not tried: hipDeviceCanAccessPeer denies a pair of devices"
+                    return False
+            except Exception as e:                               # noqa: BLE001
+                exchange_log["peer_access"] = f"check failed ({e})"
         try:
             mine = torch.frombuffer(bytearray(ctx.mailbox_create(world, rank)), dtype=torch.uint8).cuda()
             allh = [torch.empty_like(mine) for _ in range(world)]
@@ -354,8 +372,10 @@ def main():
             ctx.mailbox_connect(b"".join(bytes(h.cpu().numpy().tobytes()) for h in allh))
         except Exception as e:                                   # noqa: BLE001
             sys.stderr.write(f"[rank {rank}] mailbox exchange unavailable ({e})\n")
+            exchange_log["mailbox"] = f"set-up failed on rank {rank}: {e}"
             ok = False
         if not agree(ok):
+            exchange_log.setdefault("mailbox", "set-up failed on another rank")
             return False
         try:                                                     # trial: eager steps, then a replayed graph; all ranks must end up
             it.step(4)                                           # with the very same thermostat bits and no wait may have run out
@@ -369,10 +389,16 @@ def main():
             dist.all_gather(every, mine)
             ok = active and not timed_out and all(torch.equal(e.view(torch.int64), mine.view(torch.int64)) for e in every) \
                 and bool(torch.isfinite(mine).all())
+            if not ok:
+                exchange_log["mailbox"] = ("trial run: a wait on the peers' words ran out" if timed_out else
+                                           "trial run: the ranks' thermostat bits differ" if active else "trial run: mailbox not active")
         except Exception as e:                                   # noqa: BLE001
             sys.stderr.write(f"[rank {rank}] mailbox trial failed ({e})\n")
+            exchange_log["mailbox"] = f"trial run failed on rank {rank}: {e}"
             ok = False
-        return agree(ok)
+        ok = agree(ok)
+        exchange_log.setdefault("mailbox", "trial run passed on every rank" if ok else "trial run failed on another rank")
+        return ok
 
     if use_dist and args.dist_mode != "python":
         want = args.dist_mode
@@ -539,6 +565,17 @@ def main():
         }
         if candidates:
             out["config"]["exchange_candidates"] = candidates
+        if use_dist:
+            rccl_ranks = 0
+            try:
+                rccl_ranks = ctx.comm_count()
+            except Exception:                                    # noqa: BLE001
+                pass
+            chosen = {"mailbox": "xGMI mailbox: kernel B's thermostat waves store / poll the int64 totals in the peers' boxes (no collective launch)",
+                      "graph": "ncclAllReduce(int64) captured inside the step graph", "eager": "ncclAllReduce(int64) enqueued from C between kernel A and kernel B",
+                      "python": "torch.distributed all-reduce per step (last resort)"}.get(dist_mode, str(dist_mode))
+            out["config"]["exchange"] = {"chosen": dist_mode, "what": chosen, "rccl_ranks": rccl_ranks, "process_group_ranks": world,
+                                         "candidates_us_per_step": candidates, "log": exchange_log}
 
     def secondary(c, n=None):
         """steps/s of context c from replays of a --steps-per-graph graph: graph prepared and warmed outside the timed region,

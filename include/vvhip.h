@@ -209,6 +209,11 @@ int vvhip_accumulators(vvhip_plan* plan, int phase, void** device_ptr, int32_t* 
 int vvhip_comm_unique_id(void* id128);
 int vvhip_comm_init(vvhip_plan* plan, const void* id128, int nranks, int rank);
 int vvhip_comm_destroy(vvhip_plan* plan);
+/* Ranks of the plan's communicator as RCCL itself reports them (ncclCommCount; 0 without a communicator): what bench.py prints as
+ * config.exchange.rccl_ranks, so that a scaling line says how many ranks the collective really spanned. */
+int vvhip_comm_count(vvhip_plan* plan, int32_t* ranks);
+/* hipDeviceCanAccessPeer(device, peer_device): whether the mailbox's hipIpc mappings of a peer's box can be direct (xGMI / PCIe P2P). */
+int vvhip_peer_access(int device, int peer_device, int32_t* can_access);
 
 /* Exchange without a collective launch, for the ranks of ONE node ("mailbox" over xGMI peer mappings).  Every rank calls
  * vvhip_mailbox_create (allocates its uncached box, returns a 64-byte hipIpc handle), the host gathers all handles in rank

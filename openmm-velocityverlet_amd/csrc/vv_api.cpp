@@ -25,6 +25,7 @@ struct RcclApi {
     decltype(&ncclCommInitRank) commInitRank = nullptr;
     decltype(&ncclAllReduce) allReduce = nullptr;
     decltype(&ncclCommDestroy) commDestroy = nullptr;
+    decltype(&ncclCommCount) commCount = nullptr;
     decltype(&ncclGetErrorString) getErrorString = nullptr;
     bool ok = false;
 };
@@ -39,6 +40,7 @@ RcclApi& rccl_api() {
     r.commInitRank = (decltype(r.commInitRank)) dlsym(r.handle, "ncclCommInitRank");
     r.allReduce = (decltype(r.allReduce)) dlsym(r.handle, "ncclAllReduce");
     r.commDestroy = (decltype(r.commDestroy)) dlsym(r.handle, "ncclCommDestroy");
+    r.commCount = (decltype(r.commCount)) dlsym(r.handle, "ncclCommCount");
     r.getErrorString = (decltype(r.getErrorString)) dlsym(r.handle, "ncclGetErrorString");
     r.ok = r.getUniqueId && r.commInitRank && r.allReduce && r.commDestroy;
     return r;
@@ -1294,6 +1296,24 @@ int vvhip_comm_init(vvhip_plan* p, const void* id128, int nranks, int rank) {
     if (e != ncclSuccess) { p->comm = nullptr; return fail(p, VVHIP_ERR_HIP, std::string("ncclCommInitRank: ") + (r.getErrorString ? r.getErrorString(e) : "error")); }
     p->comm_ranks = nranks;
     drop_graphs(p);
+    return VVHIP_OK;
+}
+int vvhip_comm_count(vvhip_plan* p, int32_t* ranks) {
+    if (!p || !ranks) return VVHIP_ERR_INVALID;
+    *ranks = 0;
+    if (!p->comm) return VVHIP_OK;                   // no communicator: 0
+    RcclApi& r = rccl_api();
+    int n = p->comm_ranks;
+    if (r.commCount && r.commCount(p->comm, &n) != ncclSuccess) return fail(p, VVHIP_ERR_HIP, "ncclCommCount failed");
+    *ranks = n;
+    return VVHIP_OK;
+}
+int vvhip_peer_access(int device, int peer_device, int32_t* can_access) {
+    if (!can_access) return VVHIP_ERR_INVALID;
+    int can = 0;
+    if (device == peer_device) { *can_access = 1; return VVHIP_OK; }
+    if (hipDeviceCanAccessPeer(&can, device, peer_device) != hipSuccess) return VVHIP_ERR_HIP;
+    *can_access = can;
     return VVHIP_OK;
 }
 // ---- xGMI mailbox (include/vvhip.h): create -> exchange the 64-byte handles by any means -> connect

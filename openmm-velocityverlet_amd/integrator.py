@@ -407,6 +407,12 @@ class Context:
         buf = C.create_string_buffer(bytes(unique_id), 128)
         H.check(H.lib.vvhip_comm_init(self.plan, buf, int(nranks), int(rank)), self.plan)
 
+    def comm_count(self) -> int:
+        """Ranks of the plan's RCCL communicator as ncclCommCount reports them (0: none)."""
+        n = C.c_int32(0)
+        H.check(H.lib.vvhip_comm_count(self.plan, C.byref(n)), self.plan)
+        return n.value
+
     def mailbox_create(self, nranks: int, rank: int) -> bytes:
         """xGMI mailbox exchange (vvhip_mailbox_*): returns this rank's 64-byte IPC handle; gather all ranks' handles in rank
         order and pass them to mailbox_connect()."""

@@ -123,6 +123,7 @@ def _load():
         "vvhip_run_eager": [vp, C.c_int, vp, dbl, dbl],
         "vvhip_run_eager_unfused": [vp, C.c_int, vp, dbl, dbl],
         "vvhip_set_random_seed": [vp, C.c_uint64], "vvhip_fill_random": [vp],
+        "vvhip_comm_count": [vp, P(i32)], "vvhip_peer_access": [C.c_int, C.c_int, P(i32)],
         "vvhip_comm_unique_id": [vp], "vvhip_comm_init": [vp, vp, C.c_int, C.c_int], "vvhip_comm_destroy": [vp],
         "vvhip_mailbox_create": [vp, C.c_int, C.c_int, vp], "vvhip_mailbox_connect": [vp, vp],
         "vvhip_mailbox_status": [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)], "vvhip_mailbox_destroy": [vp],

@@ -121,3 +121,41 @@ def test_bench_rank_counts_of_the_scaling_run_on_one_gpu(world, cfg):
     # several processes time-slicing one GPU may lose the mailbox trial (its waits are bounded); then the run falls back to the
     # per-step collective -- either way every rank finished with identical thermostat bits (bench.py checks that itself)
     assert any(k in line["config"]["parallelism"] for k in ("mailbox", "python", "eager"))
+
+
+@pytest.mark.gpu
+def test_distributed_code_path_costs_nothing_at_one_rank():
+    """`bench.py --force-dist` at N = 1 (process group, exchange set up and chosen as at N > 1, sharded plan of the whole box) against
+    the plain N = 1 run on the same GPU: the day a scaling curve is measured its N = 1 point must be the headline figure, not a slower
+    code path.  Also checks what the line says about the exchange (config.exchange: chosen mechanism, RCCL's own rank count)."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29561", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    vals = {}
+    for label, extra in (("plain", []), ("dist", ["--force-dist"]), ("plain2", []), ("dist2", ["--force-dist"])):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4000", "--warmup", "400", "--no-cpu-baseline",
+                            "--no-rocprof", "--large-n", "none"] + extra, capture_output=True, text=True, env=env, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        line = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+        vals[label] = line["value"]
+        if extra:
+            ex = line["config"]["exchange"]
+            assert ex["chosen"] in ("mailbox", "eager", "graph", "python") and ex["process_group_ranks"] == 1
+            assert ex["rccl_ranks"] in (0, 1) and isinstance(ex["log"], dict)
+    plain, distv = max(vals["plain"], vals["plain2"]), max(vals["dist"], vals["dist2"])
+    assert distv > 0.95 * plain, vals
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_large_box_on_one_gpu():
+    """The regime in which sharding pays (0.9 M particles: arithmetic work-item layout, capped grids, stand-alone chain launch) through
+    bench.py's N = 2 logic with both ranks on GPU 0 -- a dry run of `--gpus N --config C3x8` for the scaling curve's second series."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29563", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-device", "--config", "C3x8",
+           "--steps", "60", "--warmup", "20", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 1 and "x2" in line["config"]["parallelism"]
+    assert line["config"]["exchange"]["chosen"] in ("mailbox", "python", "eager")
