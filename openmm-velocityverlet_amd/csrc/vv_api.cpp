@@ -85,6 +85,13 @@ struct vvhip_plan {
     int split_chain_waves = 12288;   // systems with at least this many waves (~0.8 M particles; measured +3 % at 0.9 M, +5 % at 8.9 M) run the chain as its own launch (VVHIP_SPLIT_CHAIN_WAVES)
     bool trace = false;            // roctx range + one stderr line per launch group (the reference's setDebugEnabled, VVIntegrator.h:417-419)
     bool fextra_dirty = false;     // forceExtra holds something since the last reset (split entry points)
+    // The reference's kick kernels add forceExtra ALWAYS (K/middle.cu:11-21, K/velocityVerlet.cu:20-22) and the array is only reset in
+    // steps that have a source of extra forces (API:238-240, 316-318): once the cos acceleration is set to 0 in a run without Langevin
+    // particles or a field, the last cos force stays in forceExtra and every later kick keeps adding it.  The fused middle step computes
+    // extra forces on the fly and leaves the array alone; `fextra_virtual` says the array SHOULD hold the cos force of the last fused
+    // step.  vvhip_set_params materialises it (kernel A from the cached cos(kz)) when the acceleration goes to 0, and a fused kick
+    // without sources loads the array whenever it is dirty -- the reference's behaviour to the bit, quirk included.
+    bool fextra_virtual = false;
     bool fextra_external = false;  // the host asked for the pointer (vvhip_force_extra) and may write to it: never assume zeros
     bool no_moments = false;       // VVHIP_NO_MOMENTS=1: keep the three-launch cos sequence (comparison runs)
     // with an arithmetic work-item layout (HostPlan::per) the kernels compute particle indices instead of loading slot words (VVHIP_PERIODIC_K=0:
@@ -729,6 +736,13 @@ int vvhip_set_params(vvhip_plan* p, const vvhip_params* q) {
     if ((q->cos_acceleration != 0) && p->hp.has_ld)
         return fail(p, VVHIP_ERR_TOPOLOGY, "Langevin thermostat and periodic perturbation shouldn't be used together");
     const bool cos_switch = (p->hp.params.cos_acceleration != 0) != (n.cos_acceleration != 0);
+    if (cos_switch && n.cos_acceleration == 0 && p->bound && p->fextra_virtual && !p->hp.has_ld && !p->hp.has_ef) {
+        // forceExtra as the reference would have left it: the cos force of the last step, with the old acceleration (still in hp.params)
+        // and the cos(kz) that step cached (K/cosineAccelerate.cu:9)
+        TRY(run_a(p, vv::A_COS | vv::A_CZ_LOAD | vv::A_FE_STORE, 0));
+        p->fextra_dirty = true;
+    }
+    if (cos_switch) p->fextra_virtual = false;
     p->hp.params = n;
     drop_graphs(p);
     if (cos_switch && p->bound) {        // the accumulator copies are laid out by the rows in use: start the new layout from zeros
@@ -784,7 +798,8 @@ int vvhip_step_middle_phases(const vvhip_plan* p) {
 static bool use_rekick(const vvhip_plan* p) {
     const uint32_t ex = extra_flags(p);
     const bool extra_ok = ex == 0 || (ex == vv::A_COS && use_moments(p));
-    return p->rekick && p->hp.has_nh && extra_ok && !shake_on(p) && p->hp.num_big == 0;
+    const bool stale_extra = ex == 0 && (p->fextra_dirty || p->fextra_external);      // the kick must add what forceExtra holds
+    return p->rekick && p->hp.has_nh && extra_ok && !stale_extra && !shake_on(p) && p->hp.num_big == 0;
 }
 
 // Algorithmic bytes per particle that kernel A / kernel B of the fused middle step must move (SURVEY section 8d's accounting: particle
@@ -810,7 +825,11 @@ int vvhip_step_middle_phase(vvhip_plan* p, int phase, uint32_t random_index) {
     NEED_BOUND(p);
     NEED_FUSABLE(p);
     const bool rk = use_rekick(p);
-    const uint32_t kick = vv::A_KICK_FULL | extra_flags(p) | cons_a(p) | (rk ? vv::A_NOSTORE : 0);
+    // no source of extra forces in this step: the kick adds whatever forceExtra still holds (see fextra_virtual); with sources the
+    // forces are formed on the fly and the array is out of date from here on
+    const uint32_t stale = (extra_flags(p) == 0 && (p->fextra_dirty || p->fextra_external)) ? vv::A_FE_LOAD : 0u;
+    if (phase == 0 && cos_on(p) && !p->hp.has_ld && !p->hp.has_ef) p->fextra_virtual = true;
+    const uint32_t kick = vv::A_KICK_FULL | extra_flags(p) | stale | cons_a(p) | (rk ? vv::A_NOSTORE : 0);
     const uint32_t drift = vv::B_DRIFT_MIDDLE | tail_flags(p) | cons_b(p) | (rk ? vv::B_KICK : 0);
     if (!p->hp.has_nh) {                                   // API:251: no NH particles, nothing to reduce
         if (phase != 0) return fail(p, VVHIP_ERR_INVALID, "phase out of range");
@@ -901,6 +920,7 @@ int vvhip_step_vv_second(vvhip_plan* p, uint32_t random_index) {   // API:316-33
     NEED_BOUND(p);
     uint32_t ex = extra_flags(p);
     if (ex) { ex |= vv::A_FE_STORE; p->fextra_dirty = true; }   // the first half of the NEXT step kicks with these (API:316-323)
+    else if (p->fextra_dirty || p->fextra_external) ex = vv::A_FE_LOAD;      // no source: the kick adds what the array still holds (see fextra_virtual)
     NEED_FUSABLE(p);
     return nh_half(p, vv::A_KICK_HALF | ex | cons_a(p), random_index, 0);
 }
@@ -955,6 +975,7 @@ int vvhip_apply_electric_force(vvhip_plan* p) {
 int vvhip_apply_cosine_force(vvhip_plan* p) {
     NEED_BOUND(p);
     p->fextra_dirty = true;
+    p->fextra_virtual = false;      // the array holds this step's cos force itself
     return run_a(p, vv::A_FE_LOAD | vv::A_COS | vv::A_FE_STORE, 0);
 }
 int vvhip_calc_velocity_bias(vvhip_plan* p) {              // HOST:1061-1082

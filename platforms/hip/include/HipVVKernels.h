@@ -23,6 +23,7 @@ public:
     ~HipVVPlan();
     vvhip_plan* get() const { return plan; }
     void syncParameters(const VVIntegrator& integrator);      // the reference reads the getters at every call
+    double stepSizeOf(const VVIntegrator& integrator) const;   // integrator.getStepSize(), or the recorded one while recorded stages are replayed
     void check(int rc) const;                                  // vvhip error -> OpenMMException
     int numLangevinRandoms() const { return ldRandoms; }
     bool constraintFree() const { return noConstraints; }
@@ -33,8 +34,10 @@ public:
     // kernels stage by stage (VVIntegrator.cpp:232-338), with nothing read back in between.  The adapters therefore only RECORD a stage
     // while the calls follow the sequence the reference's stepMiddle / stepVV produce for the integrator's configuration, and the stage
     // that completes the sequence launches the fused step (2 launches instead of 8).  Any other call order runs what was recorded through
-    // the stage-by-stage entry points first, in order, and then the new stage: same results either way.  Off with constraints OpenMM's
-    // solver must interleave, or VVHIP_PLUGIN_DEFER=0.
+    // the stage-by-stage entry points first, in order, and then the new stage: same results either way.  A recorded stage belongs to the
+    // parameters and the box of the moment it was CALLED (the reference reads the getters at every call): the first recorded stage takes
+    // a snapshot, a later call that finds the integrator or the box changed runs the recorded stages with the snapshot before anything
+    // else, and a replay never reads the integrator again.  Off with constraints OpenMM's solver must interleave, or VVHIP_PLUGIN_DEFER=0.
     enum Stage { ST_RESET, ST_LD, ST_EF, ST_COS, ST_FIRST, ST_CALCBIAS, ST_RMBIAS, ST_SCALE, ST_RESTORE, ST_SECOND };
     // true: recorded, or the sequence is complete and the fused step has been launched -- the caller is done; false: the caller runs its stage now
     bool defer(Stage stage, const VVIntegrator& integrator, std::function<void()> stageByStage);
@@ -46,6 +49,9 @@ public:
 private:
     std::vector<Stage> pattern;
     std::vector<std::function<void()> > pending;
+    vvhip_params pendingParams;                                // parameters and box when the first pending stage was recorded
+    double pendingBox[3] = {0, 0, 0};
+    bool replaying = false;                                    // flush() in progress: syncParameters / stepSizeOf answer from the snapshot
     int classicHalf = 0;
     bool deferEnabled = true;
     HipContext& cu;

@@ -117,10 +117,11 @@ void HipVVPlan::syncParameters(const VVIntegrator& it) {
         debug = it.getDebugEnabled();
         check(vvhip_set_trace(plan, debug ? 1 : 0));
     }
-    vvhip_params now = paramsOf(it);
+    vvhip_params now = replaying ? pendingParams : paramsOf(it);
     if (!sameParams(now, last)) { check(vvhip_set_params(plan, &now)); last = now; }
     double box[3];
-    boxOf(cu, box);
+    if (replaying) { box[0] = pendingBox[0]; box[1] = pendingBox[1]; box[2] = pendingBox[2]; }
+    else boxOf(cu, box);
     if (box[0] != lastBox[0] || box[1] != lastBox[1] || box[2] != lastBox[2]) {      // a barostat move: the box is read live (HOST:1057, 1129)
         check(vvhip_set_box(plan, box));
         lastBox[0] = box[0]; lastBox[1] = box[1]; lastBox[2] = box[2];
@@ -140,11 +141,14 @@ std::shared_ptr<HipVVPlan> HipVVPlan::find(HipContext& cu) {
 }
 
 // ------------------------------------------------------------------------------------------ deferred fusion
+double HipVVPlan::stepSizeOf(const VVIntegrator& it) const { return replaying ? pendingParams.step_size : it.getStepSize(); }
 void HipVVPlan::flush() {
     std::vector<std::function<void()> > run;
     run.swap(pending);
     pattern.clear();
-    for (auto& f : run) { f(); stagedCalls++; }
+    replaying = true;            // the recorded stages run with the parameters and the box of the moment they were called
+    try { for (auto& f : run) { f(); stagedCalls++; } } catch (...) { replaying = false; throw; }
+    replaying = false;
 }
 bool HipVVPlan::defer(Stage stage, const VVIntegrator& it, std::function<void()> stageByStage) {
     if (!deferEnabled || !noConstraints) return false;
@@ -172,8 +176,18 @@ bool HipVVPlan::defer(Stage stage, const VVIntegrator& it, std::function<void()>
             pattern = classicHalf == 0 ? first : second;
         }
     }
+    if (!pending.empty()) {      // parameters or box changed since the first recorded stage: that stage belongs to the old ones
+        double box[3];
+        boxOf(cu, box);
+        if (!sameParams(paramsOf(it), pendingParams) || box[0] != pendingBox[0] || box[1] != pendingBox[1] || box[2] != pendingBox[2]) {
+            flush();
+            imagesFresh = false;
+            stagedCalls++;
+            return false;
+        }
+    }
     if (pending.size() < pattern.size() && pattern[pending.size()] == stage) {
-        if (pending.empty()) imagesFresh = false;
+        if (pending.empty()) { imagesFresh = false; pendingParams = paramsOf(it); boxOf(cu, pendingBox); }
         pending.push_back(std::move(stageByStage));
         if (pending.size() == pattern.size()) {            // complete: one fused step instead of the recorded stages
             pending.clear();
@@ -203,7 +217,7 @@ void HipVVStepCommon::create(const System& system, const VVIntegrator& it, const
 // OpenMM's own kernels (constraint solvers, virtual sites) read the step size from integration.getStepSize(): the middle kernel
 // announces a change with setNextStepSize (HOST:136-141), the classic kernel uploads (0, dt) itself (HOST:307-319).
 void HipVVStepCommon::announceStepSize(const VVIntegrator& it, bool classic) {
-    const double stepSize = it.getStepSize();
+    const double stepSize = plan->stepSizeOf(it);
     if (stepSize == prevStepSize) return;
     HipIntegrationUtilities& integration = cu.getIntegrationUtilities();
     if (!classic) integration.setNextStepSize(stepSize);
@@ -212,7 +226,7 @@ void HipVVStepCommon::announceStepSize(const VVIntegrator& it, bool classic) {
     prevStepSize = stepSize;
 }
 void HipVVStepCommon::advanceClock(const VVIntegrator& it) {      // HOST:219-220, 430-431
-    cu.setTime(cu.getTime() + it.getStepSize());
+    cu.setTime(cu.getTime() + plan->stepSizeOf(it));
     cu.setStepCount(cu.getStepCount() + 1);
 }
 uint32_t HipVVStepCommon::nextRandomIndex() { return (uint32_t) cu.getIntegrationUtilities().prepareRandomNumbers(plan->numLangevinRandoms()); }
@@ -305,6 +319,7 @@ void HipIntegrateVVStepKernel::secondIntegrate(ContextImpl&, const VVIntegrator&
 }
 void HipIntegrateVVStepKernel::secondIntegrateNow(const VVIntegrator& it) {
     cu.setAsCurrent();
+    plan->syncParameters(it);
     plan->check(vvhip_vv_half_kick(plan->get(), 0));
     cu.getIntegrationUtilities().applyVelocityConstraints(it.getConstraintTolerance());
     advanceClock(it);
@@ -327,6 +342,7 @@ void HipIntegrateVVStepKernel::fusedVVSecondHalf(ContextImpl&, const VVIntegrato
 }
 void HipIntegrateVVStepKernel::fusedSecondWith(const VVIntegrator& it, uint32_t randomIndex) {
     cu.setAsCurrent();
+    plan->syncParameters(it);
     plan->check(vvhip_step_vv_second(plan->get(), randomIndex));
     advanceClock(it);
 }
@@ -377,17 +393,18 @@ void HipModifyCosineAccelerateKernel::applyCosineForce(ContextImpl&, const VVInt
     now();
 }
 void HipModifyCosineAccelerateKernel::calcVelocityBias(ContextImpl&, const VVIntegrator& it) {
-    auto now = [this] { cu.setAsCurrent(); plan->check(vvhip_calc_velocity_bias(plan->get())); };
+    // (the box is read live here: HOST:1057 -- in the classic scheme this is the first call of a step, right behind a barostat move)
+    auto now = [this, &it] { cu.setAsCurrent(); plan->syncParameters(it); plan->check(vvhip_calc_velocity_bias(plan->get())); };
     if (plan->defer(HipVVPlan::ST_CALCBIAS, it, now)) return;
     now();
 }
 void HipModifyCosineAccelerateKernel::removeVelocityBias(ContextImpl&, const VVIntegrator& it) {
-    auto now = [this] { cu.setAsCurrent(); plan->check(vvhip_remove_velocity_bias(plan->get())); };
+    auto now = [this, &it] { cu.setAsCurrent(); plan->syncParameters(it); plan->check(vvhip_remove_velocity_bias(plan->get())); };
     if (plan->defer(HipVVPlan::ST_RMBIAS, it, now)) return;
     now();
 }
 void HipModifyCosineAccelerateKernel::restoreVelocityBias(ContextImpl&, const VVIntegrator& it) {
-    auto now = [this] { cu.setAsCurrent(); plan->check(vvhip_restore_velocity_bias(plan->get())); };
+    auto now = [this, &it] { cu.setAsCurrent(); plan->syncParameters(it); plan->check(vvhip_restore_velocity_bias(plan->get())); };
     if (plan->defer(HipVVPlan::ST_RESTORE, it, now)) return;
     now();
 }

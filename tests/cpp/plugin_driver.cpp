@@ -4,6 +4,8 @@
 //   vv_plugin_driver registry                 (no GPU needed) checks registration, names and error behaviour
 //   vv_plugin_driver chain                    (no GPU needed) prints VVIntegrator::propagateNHChain on fixed inputs
 //   vv_plugin_driver run OUT middle cons cos N   (GPU) runs N steps on a small Drude system and dumps system + result
+//   vv_plugin_driver fuzz OUT middle cons cos NOPS SEED HAND   (GPU) a seeded random sequence of steps, parameter / box changes and queries
+//                                                               (HAND = 1: stages driven by hand, changes and queries BETWEEN the stages)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -26,10 +28,14 @@ static unsigned long long lcg_state = 88172645463325252ull;
 static double uniform() { lcg_state = lcg_state * 6364136223846793005ull + 1442695040888963407ull; return (double) (lcg_state >> 11) / 9007199254740992.0; }
 static double gauss() { double s = 0; for (int i = 0; i < 12; i++) s += uniform(); return s - 6.0; }
 
-struct ProbeIntegrator : VVIntegrator {       // exposes the protected kernel-name list
+struct ProbeIntegrator : VVIntegrator {       // exposes the protected kernel-name list and the kinetic-energy query
     using VVIntegrator::VVIntegrator;
     std::vector<std::string> names() { return getKernelNames(); }
+    double kineticEnergy() { return computeKineticEnergy(); }
 };
+// second random stream: the operations of the fuzz run (the first one lays out the system, the same for every seed)
+static unsigned long long op_state = 1;
+static unsigned op_next(unsigned n) { op_state = op_state * 6364136223846793005ull + 1442695040888963407ull; return (unsigned) ((op_state >> 33) % n); }
 
 static int registry() {
     registerPlatforms();
@@ -179,7 +185,7 @@ static int run(const char* out, bool middle, int consMode, double cosacc, int ns
             posq[4 * i + d] = (float) pos[3 * i + d];
             corr[4 * i + d] = (float) (pos[3 * i + d] - (double) posq[4 * i + d]);
         }
-        velm[4 * i + 3] = 1.0 / masses[i];
+        velm[4 * i + 3] = masses[i] != 0 ? 1.0 / masses[i] : 0.0;      // OpenMM: inverse mass 0 for massless particles
         posq[4 * i + 3] = (float) charges[i];
     }
     cu.getVelm().upload(velm.data()); cu.getPosq().upload(posq.data()); cu.getPosqCorrection().upload(corr.data());
@@ -194,7 +200,48 @@ static int run(const char* out, bool middle, int consMode, double cosacc, int ns
     (void) hipDeviceSynchronize();
     Kernel vv, nh;                             // hostMode 1 / 2: the hand-driven kernel objects (alive until the counters are printed)
     const auto t0 = std::chrono::steady_clock::now();
-    if (hostMode == 0) {
+    long stepsDone = 0, stepsInterrupted = 0;
+    if (hostMode == 10 || hostMode == 11) {
+        // Fuzz: `nsteps` random operations.  Between steps (both modes): another step size / temperature / cos acceleration (also 0: the
+        // cos stages then drop out of the sequence) / box, a kinetic-energy or viscosity query.  hostMode 11 drives the middle scheme's
+        // stages by hand (plain thermostat sequence) and puts the same changes and queries at a random place INSIDE a step as well:
+        // what has been recorded then belongs to the old parameters and must run before the change shows.
+        const double dts[3] = {0.0005, 0.001, 0.00125}, temps[3] = {300.0, 333.0, 350.0}, coss[3] = {cosacc, 0.5 * cosacc, 0.0}, boxes[2] = {3.0, 3.1};
+        const unsigned mask = std::getenv("VV_FUZZ_MASK") ? (unsigned) std::atoi(std::getenv("VV_FUZZ_MASK")) : 63u;      // bisecting: allowed kinds
+        auto change = [&](unsigned what) {
+            if (!((mask >> what) & 1u)) return;
+            switch (what) {
+                case 0: it.setStepSize(dts[op_next(3)]); break;
+                case 1: it.setTemperature(temps[op_next(3)]); break;
+                case 2: if (cosacc != 0 && hostMode == 10) it.setCosAcceleration(coss[op_next(3)]); break;
+                case 3: { const double b = boxes[op_next(2)]; cu.setPeriodicBoxSize(b, b, b); break; }
+                case 4: (void) it.kineticEnergy(); break;
+                default: if (cosacc != 0) (void) it.getViscosity(); break;
+            }
+        };
+        if (hostMode == 11) {
+            vv = hip.createKernel(IntegrateMiddleStepKernel::Name(), ctx.getImpl());
+            nh = hip.createKernel(ModifyDrudeNoseKernel::Name(), ctx.getImpl());
+            vv.getAs<IntegrateMiddleStepKernel>().initialize(system, it, drude);
+            nh.getAs<ModifyDrudeNoseKernel>().initialize(system, it, drude);
+        }
+        for (int op = 0; op < nsteps; op++) {
+            if (op_next(3) != 0) {                       // two operations in three are steps
+                if (hostMode == 10) { const int k = 1 + (int) op_next(3); it.step(k); stepsDone += k; continue; }
+                const unsigned where = op_next(6);       // 0..2: a change / query behind that stage; 3..5: none inside this step
+                ctx.getImpl().calcForcesAndEnergy(true, false);
+                vv.getAs<IntegrateMiddleStepKernel>().firstIntegrate(ctx.getImpl(), it);
+                if (where == 0) change(op_next(5));
+                nh.getAs<ModifyDrudeNoseKernel>().scaleVelocity(ctx.getImpl(), it);
+                if (where == 1) change(op_next(5));
+                vv.getAs<IntegrateMiddleStepKernel>().secondIntegrate(ctx.getImpl(), it);
+                stepsDone++;
+                if (where < 2) stepsInterrupted++;
+            } else {
+                change(op_next(6));
+            }
+        }
+    } else if (hostMode == 0) {
         it.step(nsteps);
     } else {
         // A host that is neither VVIntegrator: its own kernel objects, driven by hand through the KernelImpl virtuals (middle scheme, no
@@ -224,6 +271,7 @@ static int run(const char* out, bool middle, int consMode, double cosacc, int ns
     put(f, velm); put(f, posq); put(f, corr); put(f, vis); put(f, consDist);
     put(f, ldList); put(f, imgList); put(f, elList); put(f, normals);
     std::printf("RUN OK steps=%d time=%.6f stepCount=%lld vMax=%.9g\n", nsteps, cu.getTime(), cu.getStepCount(), vis[0]);
+    if (hostMode >= 10) std::printf("FUZZ steps=%ld interrupted=%ld\n", stepsDone, stepsInterrupted);
     // how the adapters used the context services (the reference's pattern: HOST:60-63, 136-141, 214-216, 307-319)
     double ss[2] = {-1, -1};
     cu.getIntegrationUtilities().getStepSize().download(ss);
@@ -244,6 +292,10 @@ int main(int argc, char** argv) {
         if (argc >= 2 && !std::strcmp(argv[1], "registry")) return registry();
         if (argc >= 2 && !std::strcmp(argv[1], "chain")) return chain();
         if (argc >= 7 && !std::strcmp(argv[1], "run")) return run(argv[2], std::atoi(argv[3]) != 0, std::atoi(argv[4]), std::atof(argv[5]), std::atoi(argv[6]), argc >= 8 ? std::atoi(argv[7]) : 0);
+        if (argc >= 9 && !std::strcmp(argv[1], "fuzz")) {
+            op_state = 0x9E3779B97F4A7C15ull ^ (unsigned long long) std::atoll(argv[7]);
+            return run(argv[2], std::atoi(argv[3]) != 0, std::atoi(argv[4]), std::atof(argv[5]), std::atoi(argv[6]), std::atoi(argv[8]) ? 11 : 10);
+        }
     } catch (const std::exception& e) {
         std::fprintf(stderr, "exception: %s\n", e.what());
         return 2;
