@@ -316,6 +316,11 @@ class Context:
         H.check(H.lib.vvhip_set_nh_state(self.plan, C.byref(s)), self.plan)
 
     # ---- stepping
+    def setPeriodicBoxSize(self, lx, ly, lz):
+        """A barostat move as the plugin sees it: cu.getPeriodicBoxSize() is read live by the cos kernels (HOST:1057, 1129)."""
+        box = (C.c_double * 3)(float(lx), float(ly), float(lz))
+        H.check(H.lib.vvhip_set_box(self.plan, C.byref(box)), self.plan)
+
     def _set_params(self):
         H.check(H.lib.vvhip_set_params(self.plan, C.byref(self.integrator._params())), self.plan)
 

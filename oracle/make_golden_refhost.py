@@ -150,5 +150,25 @@ def main():
         print(name, "ok", spec.num_atoms, "particles,", len(idx), "sampled")
 
 
+def switch_goldens():
+    """refhost_switch_<name>.npz: end state (mixed precision) of the reference pipeline run through tests/test_ref_host.py:SWITCH_SEQUENCE --
+    the cos acceleration switched off and on again, a box change, another step size."""
+    from oracle import refhost as RH
+    from tests.test_ref_host import SWITCH_SEQUENCE, run_switch_sequence
+    for name in ("bulk_middle_cos", "bulk_classic_cos"):
+        spec, params = make_spec(name)
+        rnd, force = inputs_for(spec, params, 12)
+        r = RH.RefHost(spec, params, "mixed", random=rnd, force=force)
+        assert r.h, r.error
+        run_switch_sequence(r.step, r.set)
+        np.savez_compressed(os.path.join(GOLDEN, f"refhost_switch_{name}.npz"), velm=r.velm.copy(), posq=r.posq.copy(), posq_corr=r.state["posq_corr"].copy())
+        r.close()
+        print("switch", name, "ok")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "switch":
+        switch_goldens()
+    else:
+        main()
+        switch_goldens()

@@ -120,6 +120,19 @@ void* vvrh_create(int n, const double* masses, int nmol, const int* mol_id, int 
     }
 }
 
+// Parameter changes between steps, through the reference's own setters: which = 0 cosAcceleration, 1 stepSize, 2 temperature; 3 = the periodic box (cubic edge)
+int vvrh_set(void* handle, int which, double value) {
+    Handle* h = (Handle*) handle;
+    VVIntegrator& it = *h->integrator;
+    switch (which) {
+        case 0: it.setCosAcceleration(value); return 0;
+        case 1: it.setStepSize(value); return 0;
+        case 2: it.setTemperature(value); return 0;
+        case 3: h->cu->setPeriodicBoxSize(value, value, value); return 0;
+        default: return -1;
+    }
+}
+
 // which: 0 velm, 1 posq, 2 posqCorrection, 3 force, 4 random (float4[count]: allocates the buffer on first upload)
 int vvrh_upload(void* handle, int which, const void* src, long long count) {
     Handle* h = (Handle*) handle;

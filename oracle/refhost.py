@@ -93,6 +93,11 @@ class RefHost:
         if self.prec == "mixed":
             self.L.vvrh_download(C.c_void_p(self.h), C.c_int(2), _ip(self.state["posq_corr"]))
 
+    def set(self, which: str, value: float):
+        """A parameter change between steps through the reference's own setters (cos_acceleration, step_size, temperature) / the box edge."""
+        code = {"cos_acceleration": 0, "step_size": 1, "temperature": 2, "box": 3}[which]
+        assert self.L.vvrh_set(C.c_void_p(self.h), C.c_int(code), C.c_double(float(value))) == 0
+
     @property
     def velm(self): return self.state["velm"]
     @property

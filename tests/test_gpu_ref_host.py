@@ -99,3 +99,34 @@ def test_product_reproduces_reference_pipeline_at_full_baseline_size(name):
         print(f"{name}: vs the reference's own pipeline at full size, rel err vel {ev:.2e} pos {ex:.2e}")
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("name", ["bulk_middle_cos", "bulk_classic_cos"])
+def test_product_follows_the_reference_through_parameter_changes(name):
+    """The cos acceleration switched off (the reference keeps applying the last extra force: its kick kernels add forceExtra always and
+    nothing resets the array any more, VVIntegrator.cpp:238-240 / kernels/middle.cu:11-21), on again with another value, a box change,
+    another step size -- recorded from the reference's own pipeline (tests/golden/refhost_switch_*.npz), replayed on the fused path."""
+    from tests.test_ref_host import run_switch_sequence
+    g = np.load(os.path.join(GOLDEN, f"refhost_switch_{name}.npz"))
+    spec, params = make_spec(name)
+    rnd, force = inputs_for(spec, params, 12)
+    it = _integrator(params)
+    ctx = I.Context(spec, it, precision="mixed", force_provider="static", random=rnd)
+    try:
+        ctx.force.upload(force)
+
+        def setter(what, val):
+            if what == "cos_acceleration": it.setCosAcceleration(val)
+            elif what == "step_size": it.setStepSize(val)
+            elif what == "box": ctx.setPeriodicBoxSize(val, val, val)
+        run_switch_sequence(it.step, setter)
+        velm, posq, corr = ctx.getVelm(), ctx.getPosq(), ctx.getPosqCorrection()
+        rv = g["velm"]
+        ev = np.abs(velm[:, :3] - rv[:, :3]).max() / np.abs(rv[:, :3]).max()
+        x = posq[:, :3].astype(np.float64) + corr[:, :3].astype(np.float64)
+        xr = g["posq"][:, :3].astype(np.float64) + g["posq_corr"][:, :3].astype(np.float64)
+        ex = np.abs(x - xr).max() / np.abs(xr).max()
+        assert ev < 1e-9 and ex < 1e-9, f"{name}: rel err vel {ev:.2e} pos {ex:.2e}"
+        print(f"{name}: through the parameter changes, rel err vel {ev:.2e} pos {ex:.2e}")
+    finally:
+        ctx.close()

@@ -62,6 +62,47 @@ def test_reference_pipeline_equals_oracle_bit_for_bit(name, prec):
     r.close()
 
 
+SWITCH_SEQUENCE = [("step", 3), ("cos_acceleration", 0.0), ("step", 3), ("cos_acceleration", 0.005), ("step", 2), ("box", 3.3), ("step", 2),
+                   ("cos_acceleration", 0.0), ("step_size", 0.0005), ("step", 2)]
+
+
+def run_switch_sequence(stepper, setter):
+    for what, val in SWITCH_SEQUENCE:
+        if what == "step":
+            stepper(int(val))
+        else:
+            setter(what, val)
+
+
+@have
+@pytest.mark.parametrize("prec", ["mixed", "double"])
+@pytest.mark.parametrize("name", ["bulk_middle_cos", "bulk_classic_cos"])
+def test_cos_acceleration_switched_off_keeps_the_last_extra_force(name, prec):
+    """A reference behaviour nobody would guess from the API: the kick kernels add forceExtra always (kernels/middle.cu:11-21,
+    velocityVerlet.cu:20-22) and VVIntegrator only resets the array in steps that have a source of extra forces
+    (VVIntegrator.cpp:238-240, 316-318) -- so after setCosAcceleration(0) the LAST cos force stays in the array and keeps acting on
+    every later step.  Executed here with the reference's own host classes and kernels; the oracle states the same (bit for bit), and
+    tests/test_gpu_ref_host.py holds the product to the recorded end state.  Also a box change and another step size on the way."""
+    spec, params, r, o = _pair(name, prec, 12)
+
+    def oset(what, val):
+        if what == "cos_acceleration": o.s.cos_accel = val
+        elif what == "step_size": o.s.dt = val
+        elif what == "box": o.s.box[0] = o.s.box[1] = o.s.box[2] = val
+    done = [0]
+
+    def both(n):
+        for _ in range(n):
+            r.step(1); o.step(1); done[0] += 1
+            assert np.array_equal(r.velm.view(np.uint8), o.velm.view(np.uint8)), f"{name}/{prec}: velocities differ at step {done[0]}"
+            assert np.array_equal(r.posq.view(np.uint8), o.posq.view(np.uint8)), f"{name}/{prec}: positions differ at step {done[0]}"
+    run_switch_sequence(both, lambda w, v: (r.set(w, v), oset(w, v)))
+    g = np.load(os.path.join(GOLDEN, f"refhost_switch_{name}.npz"))       # what tests/test_gpu_ref_host.py holds the product to
+    if prec == "mixed":
+        assert np.array_equal(g["velm"].view(np.uint8), r.velm.view(np.uint8)) and np.array_equal(g["posq"].view(np.uint8), r.posq.view(np.uint8))
+    r.close()
+
+
 @have
 @pytest.mark.parametrize("name", sorted(CONFIGS))
 def test_reference_host_constants_equal_oracle_tables(name):

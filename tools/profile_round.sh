@@ -21,10 +21,10 @@ else
     python3 "$ROOT/bench.py" --config "$CFG" $EXTRA --large-n none --steps 200 --warmup 40 --no-cpu-baseline 2>"$OUT/bench_$CFG.stderr" | tail -1 > "$OUT/bench_${CFG}${SUF}_mixed.json"
     STEPS="--steps 100 --warmup 20"; PSTEPS="--steps 40 --warmup 10"
 fi
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$CFG" -o run -- python3 "$ROOT/bench.py" --config "$CFG" $EXTRA --large-n none $STEPS --no-cpu-baseline > "$OUT/stats_$CFG.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$CFG" -o run -- python3 "$ROOT/bench.py" --config "$CFG" $EXTRA --large-n none $STEPS --no-cpu-baseline --no-rocprof > "$OUT/stats_$CFG.log" 2>&1
 cp "$OUT/stats_$CFG"/run_kernel_stats.csv "$OUT/kernel_stats_$CFG$SUF.csv" 2>/dev/null || find "$OUT/stats_$CFG" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_$CFG$SUF.csv" \;
 for C in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_$C" -o run -- python3 "$ROOT/bench.py" --config "$CFG" $EXTRA --large-n none $PSTEPS --no-cpu-baseline > "$OUT/pmc_${CFG}_$C.log" 2>&1
+    rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_$C" -o run -- python3 "$ROOT/bench.py" --config "$CFG" $EXTRA --large-n none $PSTEPS --no-cpu-baseline --no-rocprof > "$OUT/pmc_${CFG}_$C.log" 2>&1
 done
 python3 "$ROOT/tools/pmc_summary.py" "$OUT" "$TAG" "$CFG" > "$OUT/pmc_$CFG$SUF.json"
 rm -rf "$OUT/stats_$CFG" "$OUT"/pmc_FETCH_SIZE "$OUT"/pmc_WRITE_SIZE
