@@ -32,9 +32,22 @@ for short, d in raw.items():
     res["raw_kb"][short]["dispatches"] = max(v[1] for v in d.values())
     f = d.get("FETCH_SIZE", [0, 1]); w = d.get("WRITE_SIZE", [0, 1])
     res[f"hbm_bytes_per_launch_{short}"] = int(round((2 * f[0] / max(f[1], 1) + w[0] / max(w[1], 1)) * 1024))
-# mixed precision; C3 / C3xK run the register-kick path (kernel A keeps the kicked velocities, kernel B repeats the kick: 62 + 158 B),
-# configurations with extra forces the store path (94 + 134 B): vvhip_algorithmic_bytes
-per = {"A": 62, "B": 158} if cfg.startswith("C3") or cfg in ("C1", "C2") else {"A": 94, "B": 134}
+# algorithmic bytes per particle: what the plan itself reports (vvhip_algorithmic_bytes, printed by bench.py as
+# roofline.algorithmic_bytes_per_particle) for the same configuration -- taken from the bench line of this profiling round
+suf = os.environ.get("SUF", "")
+per, src = None, None
+for name in (f"bench_{cfg}{suf}_mixed.json", f"bench_{cfg}_mixed.json"):
+    try:
+        b = json.load(open(os.path.join(out_dir, name)))
+        blk = b["roofline"] if b["config"]["workload"].startswith(cfg + ":") or not cfg.startswith("C3x") else b["roofline"]
+        per, src = blk["algorithmic_bytes_per_particle"], name
+        break
+    except Exception:
+        continue
+if per is None:      # no bench line at hand: the headline path's figures (mixed precision, register-kick path / store path)
+    per, src = ({"A": 62, "B": 158} if cfg.startswith("C3") or cfg in ("C1", "C2") else {"A": 94, "B": 134}), "built-in default"
+res["algorithmic_bytes_per_particle"] = per
+res["algorithmic_bytes_source"] = src
 res["algorithmic_bytes_per_launch"] = {k: v * natoms for k, v in per.items()}
 for k in ("A", "B"):
     if f"hbm_bytes_per_launch_{k}" in res:
