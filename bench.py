@@ -239,11 +239,15 @@ def main():
     if not args.child and not args.no_rocprof and args.gpus == 1 and not args.eager and not args.force_dist:
         base = ["--config", args.config] + (["--synthetic"] if args.synthetic else [])
         short = ["--steps", "200", "--warmup", "40"] if args.config.startswith("C3x") else ["--steps", "4000", "--warmup", "400"]
-        prof["main"] = rocprof_child(args, base + short + (["--hbonds"] if args.hbonds else []))
-        if not args.hbonds and args.config in ("C2", "C3", "C4", "C5"):
-            prof["hbonds"] = rocprof_child(args, base + short + ["--hbonds"])
-        if args.config == "C3" and args.large_n != "none" and not args.hbonds:
-            prof["large_n"] = rocprof_child(args, ["--config", args.large_n, "--steps", "100", "--warmup", "20"] + (["--synthetic"] if args.synthetic else []))
+        # (bounded: a child normally takes 3-15 s; if the first one cannot run, the others are not tried -- same reason, same answer)
+        prof["main"] = rocprof_child(args, base + short + (["--hbonds"] if args.hbonds else []), seconds=150 if args.config.startswith("C3x") else 90)
+        if isinstance(prof["main"], dict):
+            if not args.hbonds and args.config in ("C2", "C3", "C4", "C5"):
+                prof["hbonds"] = rocprof_child(args, base + short + ["--hbonds"], seconds=90)
+            if args.config == "C3" and args.large_n != "none" and not args.hbonds:
+                prof["large_n"] = rocprof_child(args, ["--config", args.large_n, "--steps", "100", "--warmup", "20"] + (["--synthetic"] if args.synthetic else []), seconds=150)
+        else:
+            prof["hbonds"] = prof["large_n"] = prof["main"]
 
     import numpy as np
     import torch

@@ -32,7 +32,29 @@ def test_driver_flags_give_the_long_run_figure():
     # ms_per_step is the timed region divided by K
     assert abs(short["ms_per_step"] * short["value"] * 1e-3 - 1.0) < 1e-3
     for line in (short, long_):
-        assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(line["roofline"])
+        r = line["roofline"]
+        assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "avg_launch_us", "avg_launch_us_dispatch_timestamps",
+                "avg_launch_us_back_to_back", "launch_timing"} <= set(r)
+        # frac = algorithmic bytes of the dominant kernel / its launch duration / peak, by the clock launch_timing names
+        k = "B" if r["kernel"].endswith("_b") else "A"
+        assert abs(r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"][k] * 1e-6) / 1e9 / r["peak"] - r["frac"]) < 2e-3
+        assert r["traffic"] is None or (r["traffic_source"] and r["traffic_source"]["file"].startswith("profiles/"))
+        assert 0 < line["step"]["frac"] < r["frac"] < 1
+        wc = line["config"]["with_constraints"]
+        assert wc["roofline"]["kernel"] in ("vv_kernel_a", "vv_kernel_b") and 0 < wc["step"]["frac"] < 1
+    import shutil
+    if shutil.which("rocprofv3"):          # the live rocprofv3 child run is the clock of frac, and agrees with the dispatch timestamps of kernel B
+        r = short["roofline"]
+        assert r["launch_timing"].startswith("avg_launch_us / achieved / frac: rocprofv3"), r["launch_timing"]
+        assert abs(r["avg_launch_us"]["B"] / r["avg_launch_us_dispatch_timestamps"]["B"] - 1) < 0.15
+
+
+@pytest.mark.gpu
+def test_cpu_baseline_says_whether_openmm_was_there():
+    line = _bench("--gpus", "1", "--steps", "20", "--warmup", "5", "--large-n", "none", "--no-rocprof", "--cpu-seconds", "2")
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    assert isinstance(cb["openmm"], dict) or cb["openmm"].startswith(("not installed", "installed, but"))
 
 
 @pytest.mark.gpu
