@@ -731,6 +731,92 @@ def main():
                             "KE download / host chain / upload per step (oracle/ref_gpu_driver.cpp); same workload and force provider"}
         except Exception as e:                                   # noqa: BLE001 -- a baseline must never break the bench line
             sys.stderr.write(f"reference-kernel baseline skipped: {e}\n")
+    # ---- N > 1: the same sharding on the box where it pays (C3 tiled along z, config.large_n_sharded): at 111 000 particles a step is
+    # latency bound per rank and sharding cannot win; the second series shows the bandwidth-bound regime next to it.  Same exchange
+    # mechanism as the headline run; every stage is agreed between the ranks, a failure anywhere skips the block on all of them.
+    if use_dist and cfg == "C3" and args.large_n != "none" and not args.hbonds:
+        blk, ctx_l, ok = {"workload": None}, None, True
+        dbg = (lambda m: sys.stderr.write(f"[rank {rank}] large-N sharded block: {m}\n")) if os.environ.get("VVHIP_BENCH_DEBUG") else (lambda m: None)
+        try:
+            spec_l = S.make_config("C3", float(args.large_n[3:]), synthetic=args.synthetic)
+            bounds_l = D.shard_bounds(spec_l, world)
+            it_l = I.VVIntegrator(333.0, 10.0, 1.0, 40.0, dt)
+            it_l.setMaxDrudeDistance(0.02)
+            ctx_l = I.Context(spec_l, it_l, precision=args.precision, force_provider=args.forces, shard=bounds_l[rank], device=local_rank,
+                              stream=torch.cuda.current_stream().cuda_stream if dist_mode == "python" else None)
+        except Exception as e:                                   # noqa: BLE001
+            sys.stderr.write(f"[rank {rank}] large-N sharded block: set-up failed ({e})\n")
+            ok = False
+        dbg("context built")
+        ok = agree(ok)
+        mode_l = dist_mode
+        if ok and mode_l == "mailbox":
+            try:
+                mine = torch.frombuffer(bytearray(ctx_l.mailbox_create(world, rank)), dtype=torch.uint8).cuda()
+                allh = [torch.empty_like(mine) for _ in range(world)]
+                dist.all_gather(allh, mine)
+                ctx_l.mailbox_connect(b"".join(bytes(h.cpu().numpy().tobytes()) for h in allh))
+            except Exception as e:                               # noqa: BLE001
+                sys.stderr.write(f"[rank {rank}] large-N sharded block: mailbox set-up failed ({e})\n")
+                ok = False
+            ok = agree(ok)
+        elif ok and mode_l in ("eager", "graph"):
+            try:
+                idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+                if rank == 0:
+                    idt.copy_(torch.frombuffer(bytearray(ctx_l.comm_unique_id()), dtype=torch.uint8))
+                dist.broadcast(idt, src=0)
+                ctx_l.comm_init(bytes(idt.cpu().numpy().tobytes()), world, rank)
+            except Exception as e:                               # noqa: BLE001
+                sys.stderr.write(f"[rank {rank}] large-N sharded block: RCCL set-up failed ({e})\n")
+                ok = False
+            ok = agree(ok)
+        if ok:
+            try:
+                st_l = D.ShardedStepper(ctx_l) if mode_l == "python" else None
+                g_l = 10
+
+                def run_l(n):
+                    if st_l is not None:
+                        st_l.step(n)
+                    elif mode_l in ("mailbox", "graph"):
+                        ctx_l.run_graph(n, g_l)
+                    else:
+                        ctx_l.run_eager(n)
+                dbg(f"exchange {mode_l} set up, warm-up")
+                run_l(2 * g_l)
+                ctx_l.synchronize(); torch.cuda.synchronize()
+                if mode_l == "mailbox" and ctx_l.mailbox_status()[1]:
+                    raise RuntimeError("a mailbox wait ran out during the warm-up")
+                dbg("warm-up done")
+            except Exception as e:                               # noqa: BLE001
+                sys.stderr.write(f"[rank {rank}] large-N sharded block: warm-up failed ({e})\n")
+                ok = False
+            ok = agree(ok)                                       # (also the barrier in front of the timed run; no collective inside a try block)
+            el_l = 0.0
+            if ok:
+                try:
+                    t0 = time.perf_counter()
+                    run_l(4 * g_l)
+                    ctx_l.synchronize(); torch.cuda.synchronize()
+                    el_l = time.perf_counter() - t0
+                except Exception as e:                           # noqa: BLE001
+                    sys.stderr.write(f"[rank {rank}] large-N sharded block: run failed ({e})\n")
+                    ok = False
+            ok = agree(ok)
+            if ok:
+                el_l = slowest(el_l)
+                nl = spec_l.num_atoms
+                blk = {"workload": f"{args.large_n}: {nl} particles (the C3 cell tiled along z), {bounds_l[rank][1] - bounds_l[rank][0]} on rank 0",
+                       "steps_per_s": round(4 * g_l / el_l, 1), "atom_steps_per_s": round(4 * g_l / el_l * nl, 1), "n_gpus": world, "exchange": mode_l,
+                       "scaling": "strong", "note": "second series of a scaling run: the regime in which sharding pays; compare with config.large_n of the N = 1 line"}
+        if rank == 0:
+            out["config"]["large_n_sharded"] = blk if ok else "skipped (see stderr)"
+        if ctx_l is not None:
+            try:
+                ctx_l.close()
+            except Exception:                                    # noqa: BLE001
+                pass
     ctx.close()
     if use_dist:
         dist.destroy_process_group()

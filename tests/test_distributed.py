@@ -53,17 +53,39 @@ def test_nccl_code_path_world1(mode):
 @pytest.mark.gpu
 def test_bench_two_ranks_share_one_gpu_mailbox():
     """bench.py's own N = 2 logic (handle gather, trial run, agreement between ranks, graph replay) with two processes on GPU 0;
-    gloo carries the set-up traffic because RCCL refuses two ranks on one device."""
+    gloo carries the set-up traffic because RCCL refuses two ranks on one device.  Also the second series of a scaling run: the large box
+    (here C3x8) sharded over the same ranks with the same exchange (config.large_n_sharded)."""
     import json
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29545", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-device",
-           "--steps", "400", "--warmup", "100", "--no-cpu-baseline"]
+           "--steps", "400", "--warmup", "100", "--no-cpu-baseline", "--large-n", "C3x8"]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["value"] > 100
     assert "mailbox" in line["config"]["parallelism"], line["config"]["parallelism"] + r.stderr[-2000:]
+    # the large box's capped grid fills the ONE shared GPU with polling thermostat waves, the other process's kernels cannot be scheduled and
+    # the bounded waits run out: the block must then be skipped on both ranks (and say so), not hang or report a number
+    ls = line["config"]["large_n_sharded"]
+    assert (isinstance(ls, dict) and ls["n_gpus"] == 2 and ls["steps_per_s"] > 1) or ls == "skipped (see stderr)", (ls, r.stderr[-2000:])
+
+
+@pytest.mark.gpu
+def test_bench_second_series_large_box_sharded_two_ranks():
+    """config.large_n_sharded through the exchange that works with two ranks on one GPU (accumulators staged through the host, gloo):
+    the large box sharded over the ranks of the run, the second series of a scaling curve."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29565", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-device", "--dist-mode", "python",
+           "--steps", "100", "--warmup", "20", "--no-cpu-baseline", "--large-n", "C3x8"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    ls = line["config"]["large_n_sharded"]
+    assert isinstance(ls, dict) and ls["n_gpus"] == 2 and ls["steps_per_s"] > 1 and ls["exchange"] == "python", (ls, r.stderr[-2000:])
+    assert "888000 particles" in ls["workload"]
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])
