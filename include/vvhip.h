@@ -311,12 +311,22 @@ int vvhip_time_kernel(vvhip_plan* plan, int kernel, uint32_t flags, int reps, do
  * VVIntegrator::setDebugEnabled and prints the reference's per-call lines itself (VVIntegrator.h:417-419, CudaVVKernels.cpp:57,120,...).
  * Also VVHIP_ROCTX=1 in the environment.  libroctx64 is resolved at run time. */
 int vvhip_set_trace(vvhip_plan* plan, int enable);
-/* Every stage set that a supported path launches has a kernel compiled for it (the reference compiles its kernels per System at run time,
- * CudaVVKernels.cpp:98-101, 639-647; here the enumeration happens at build time, vv_kernels.hip: SF_*); a stage set outside that list
- * runs the generic kernel with run-time stage bits, 15-20 % slower.  counts[0 / 1] = enqueued launches of kernel A / B of this plan that
- * did (a launch captured into a graph counts once), stage_sets = the last stage bits that did.  tests/test_gpu_specialised.py asserts 0
- * for every BASELINE configuration +- constraints, classic scheme, sharded.  VVHIP_WARN_GENERIC=1 prints them as they happen. */
+/* Every stage set a plan launches runs a kernel compiled for exactly its stage bits.  The reference compiles its kernels per System at
+ * run time (CudaVVKernels.cpp:98-101, 639-647); here the stage sets of the BASELINE configurations (+- constraints, classic scheme,
+ * sharded, large boxes) are compiled into the library (vv_kernels.hip: SF_*), and a stage set outside that list -- or a thermostat chain
+ * of 1, 2 or 4 links instead of the integrator's default 3 -- is compiled by hipRTC from the same source with the same options the first
+ * time a plan launches it (csrc/vv_rtc.cpp; ~1 s per kernel, once per process; VVHIP_RTC below).  Only if that is switched off or fails
+ * (libhiprtc.so missing; one line on stderr) does the generic kernel with run-time stage bits run, 15-20 % slower:
+ * counts[0 / 1] = enqueued launches of kernel A / B of this plan that did (a launch captured into a graph counts once), stage_sets = the
+ * last stage bits that did.  tests/test_gpu_specialised.py asserts 0 for every BASELINE configuration +- constraints, classic scheme,
+ * sharded, and for stage sets outside the compiled list.  VVHIP_WARN_GENERIC=1 prints them as they happen. */
 int vvhip_generic_launches(vvhip_plan* plan, int64_t counts[2], uint32_t stage_sets[2]);
+/* Process-wide: counts[0] = kernels compiled at run time so far, counts[1 / 2] = enqueued launches of kernel A / B that ran one;
+ * compile_seconds (optional) = time spent in the compiler. */
+int vvhip_rtc_stats(int64_t counts[3], double* compile_seconds);
+/* Sets VVHIP_RTC's value for the launches that follow (process-wide; graphs captured earlier keep their kernels) and returns the previous
+ * one; mode < 0 only returns it. */
+int vvhip_rtc_mode(int mode);
 /* Per-launch timing of eager (not captured) launches, summed per class until vvhip_timing_read.  Kernels A and B: the dispatch's own
  * begin / end timestamps (hipExtLaunchKernel with start / stop events: nothing is added to the stream; what rocprofv3's kernel trace
  * reports).  enable = 1: everything else ("other": force provider, chain launch, collectives) bracketed by recorded events as well;
@@ -340,7 +350,9 @@ int vvhip_timing_read(vvhip_plan* plan, double* ms_pass_a, double* ms_pass_b, do
  *   VVHIP_SPLIT_CHAIN_WAVES=n the thermostat chain becomes its own 1-wave launch from n waves on (default 12288)
  *   VVHIP_BLOCK=t, VVHIP_CAP_A=b, VVHIP_CAP_B=b   launch shape: threads per block (multiple of 64), most blocks per launch of kernel A / B
  *   VVHIP_ROCTX=1             roctx ranges (see vvhip_set_trace)
- *   VVHIP_WARN_GENERIC=1      one line on stderr per stage set that runs on the generic kernel (no compiled specialisation: 15-20 % slower)
+ *   VVHIP_RTC=0|1|2           run-time compilation of kernels A / B (vvhip_generic_launches): never / for stage sets without a compiled
+ *                             kernel (default) / for every launch (tests: the run-time kernel against the compiled one, bit for bit)
+ *   VVHIP_WARN_GENERIC=1      one line on stderr per stage set that runs on the generic kernel (15-20 % slower)
  * and in the OpenMM adapters (platforms/hip): VVHIP_PLUGIN_DEFER=0 -- run every KernelImpl call as its own launch(es) instead of answering a
  * completed stage-by-stage sequence with the fused step. */
 

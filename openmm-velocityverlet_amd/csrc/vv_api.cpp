@@ -15,6 +15,7 @@
 
 #include "vv_host.hpp"
 #include "vv_kernels.hpp"
+#include "vv_rtc.hpp"
 
 namespace {
 // RCCL is looked up lazily so that single-GPU users never need it.  If the process already has a librccl (PyTorch
@@ -1459,6 +1460,13 @@ int vvhip_set_trace(vvhip_plan* p, int enable) {
 int vvhip_generic_launches(vvhip_plan* p, int64_t counts[2], uint32_t stage_sets[2]) {
     if (!p || !counts) return VVHIP_ERR_INVALID;
     for (int k = 0; k < 2; k++) { counts[k] = p->generic_launches[k]; if (stage_sets) stage_sets[k] = p->generic_flags[k]; }
+    return VVHIP_OK;
+}
+int vvhip_rtc_mode(int mode) { return vv::set_rtc_mode(mode); }
+int vvhip_rtc_stats(int64_t counts[3], double* compile_seconds) {
+    if (!counts) return VVHIP_ERR_INVALID;
+    counts[0] = (int64_t) vv::vv_rtc_compiled; counts[1] = (int64_t) vv::vv_rtc_launches[0]; counts[2] = (int64_t) vv::vv_rtc_launches[1];
+    if (compile_seconds) *compile_seconds = vv::vv_rtc_compile_seconds;
     return VVHIP_OK;
 }
 int vvhip_timing_enable(vvhip_plan* p, int enable) {

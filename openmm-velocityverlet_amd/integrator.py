@@ -456,6 +456,22 @@ class Context:
         H.check(H.lib.vvhip_generic_launches(self.plan, C.byref(n), C.byref(f)), self.plan)
         return (int(n[0]), int(n[1])), (int(f[0]), int(f[1]))
 
+    @staticmethod
+    def rtc_stats():
+        """(kernels compiled at run time, launches of kernel A that ran one, of kernel B, seconds spent compiling), process-wide
+        (vvhip_rtc_stats)."""
+        n, t = (C.c_int64 * 3)(), C.c_double()
+        rc = H.lib.vvhip_rtc_stats(C.byref(n), C.byref(t))
+        if rc != 0:
+            raise RuntimeError("vvhip_rtc_stats failed: %d" % rc)
+        return int(n[0]), int(n[1]), int(n[2]), float(t.value)
+
+    @staticmethod
+    def rtc_mode(mode=-1):
+        """Sets VVHIP_RTC's value for the launches that follow (0 never, 1 stage sets without a compiled kernel, 2 always) and returns
+        the previous one; -1 only reads it (vvhip_rtc_mode)."""
+        return int(H.lib.vvhip_rtc_mode(int(mode)))
+
     def timing(self, enable):
         """0 / False off; 1 / True every launch group; 2 kernels A and B only (dispatch timestamps, nothing added to the stream);
         n > 2 as 2 with n events prepared beforehand (vvhip_timing_enable)."""

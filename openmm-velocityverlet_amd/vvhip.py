@@ -129,6 +129,8 @@ def _load():
         "vvhip_mailbox_status": [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)], "vvhip_mailbox_destroy": [vp],
         "vvhip_time_kernel": [vp, C.c_int, u32, C.c_int, P(dbl)],
         "vvhip_generic_launches": [vp, P(C.c_int64 * 2), P(u32 * 2)],
+        "vvhip_rtc_stats": [P(C.c_int64 * 3), P(C.c_double)],
+        "vvhip_rtc_mode": [C.c_int],
         "vvhip_timing_enable": [vp, C.c_int], "vvhip_timing_read": [vp, P(dbl), P(dbl), P(dbl), P(i32 * 3)],
         "vvhip_debug_launch": [vp, C.c_int, u32, u32],
         "vvhip_debug_read_accumulators": [vp, P(dbl * 4), C.c_int],

@@ -1,0 +1,137 @@
+"""-m gpu: kernels compiled at run time (csrc/vv_rtc.cpp).
+
+The reference compiles its kernels per System when the integrator is created (CudaVVKernels.cpp:98-101, 639-647).  libvvhip carries the
+stage sets of the BASELINE configurations compiled ahead of time; a stage set outside that list, or a thermostat chain of 1, 2 or 4
+links, is compiled by hipRTC from the same source the first time a plan launches it.  Checked here:
+  * the run-time kernel IS the compiled kernel: with VVHIP_RTC=2 every launch of kernels A / B takes the run-time route, and the
+    trajectories equal those of the ahead-of-time kernels bit for bit (same source, same options, -ffp-contract=off above all);
+  * stage sets outside the compiled list run a run-time kernel, not the generic one (vvhip_generic_launches stays 0), against the oracle;
+  * a stage set met for the first time INSIDE a graph capture compiles and loads there;
+  * VVHIP_RTC=0 restores the generic kernel."""
+import importlib
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pkg = importlib.import_module("openmm-velocityverlet_amd")
+H, I, S = pkg.vvhip, pkg.integrator, pkg.systems
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _restore_mode():
+    old = I.Context.rtc_mode()
+    yield
+    I.Context.rtc_mode(old)
+
+
+def _integrator(cfg, middle, spec, chains=3):
+    it = I.VVIntegrator(300.0 if cfg == "C2" else 333.0, 10.0, 1.0, 40.0, 0.002 if cfg == "C2" else 0.001, chains, 1)
+    if cfg not in ("C1", "C2"):
+        it.setMaxDrudeDistance(0.02)
+    if cfg == "C4":
+        it.setCosAcceleration(0.02)
+    if cfg == "C5":
+        lz = float(spec.box[2])
+        it.setMirrorLocation(lz / 2)
+        it.setElectricField(2.0 / lz * 2 * 1.602176634e-22)
+    it.setUseMiddleScheme(middle)
+    return it
+
+
+def _trajectory(spec, cfg, middle, prec, mode, steps=6):
+    I.Context.rtc_mode(mode)
+    it = _integrator(cfg, middle, spec)
+    ctx = I.Context(spec, it, precision=prec, force_provider="tether")
+    try:
+        it.step(steps)
+        ctx.run_graph(4, 2)
+        ctx.synchronize()
+        st = ctx.getNHState()
+        chain = np.array([list(st.eta[g]) + list(st.eta_dot[g]) for g in range(3)])
+        return ctx.getPosq().copy(), ctx.getVelm().copy(), chain, ctx.generic_launches()[0]
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("cfg,hbonds,middle,prec", [
+    ("C3", False, True, "mixed"), ("C3", True, True, "mixed"), ("C3", False, False, "mixed"), ("C4", False, True, "mixed"),
+    ("C5", True, True, "mixed"), ("C2", True, True, "mixed"), ("C3", True, True, "single"), ("C3", False, True, "double"),
+])
+def test_run_time_kernel_equals_compiled_kernel(cfg, hbonds, middle, prec):
+    spec = S.make_config(cfg, 0.08 if cfg in ("C3", "C4") else 1.0, hbonds=hbonds)
+    before = I.Context.rtc_stats()
+    ref = _trajectory(spec, cfg, middle, prec, 0)
+    mid = I.Context.rtc_stats()
+    assert mid[1:3] == before[1:3], "VVHIP_RTC=0 must not launch run-time kernels"
+    rtc = _trajectory(spec, cfg, middle, prec, 2)
+    after = I.Context.rtc_stats()
+    assert after[1] > mid[1] and after[2] > mid[2], "VVHIP_RTC=2: kernels A and B take the run-time route"
+    assert ref[3] == (0, 0)
+    for a, b, what in zip(ref[:3], rtc[:3], ("posq", "velm", "chain")):
+        assert np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b).view(np.uint8)), f"{what} differs between the compiled and the run-time kernel"
+
+
+def _oracle_pair(spec, nsteps, chains, middle, ld=False, efield=0.0):
+    p = O.Params(temperature=333.0, drude_temperature=1.0, max_drude_distance=0.02, use_middle_scheme=middle, num_chains=chains, loops_per_step=1)
+    osys = O.OracleSystem(spec, p, "mixed", force_mode=1)
+    it = I.VVIntegrator(333.0, 10.0, 1.0, 40.0, 0.001, chains, 1)
+    it.setMaxDrudeDistance(0.02)
+    it.setUseMiddleScheme(middle)
+    ctx = I.Context(spec, it, precision="mixed", force_provider="tether")
+    osys.step(nsteps)
+    it.step(nsteps)
+    return osys, ctx
+
+
+@pytest.mark.parametrize("chains", [1, 2, 4])
+@pytest.mark.parametrize("middle", [True, False])
+def test_other_chain_lengths_get_their_own_kernel(chains, middle):
+    """The compiled kernels carry the three-link chain; 1, 2 and 4 links used to run the generic kernel."""
+    I.Context.rtc_mode(1)
+    spec = S.drude_il(cells=(1, 1, 1), pairs_per_cell=40, seed=31)
+    before = I.Context.rtc_stats()
+    osys, ctx = _oracle_pair(spec, 10, chains, middle)
+    try:
+        counts, sets = ctx.generic_launches()
+        assert counts == (0, 0), f"generic kernel ran {counts}, stage sets A 0x{sets[0]:x} B 0x{sets[1]:x}"
+        assert I.Context.rtc_stats()[2] > before[2]
+        x_o, x_g = osys.positions(), ctx.getPositions()
+        v_o, v_g = osys.velm[:, :3].astype(np.float64), ctx.getVelocities()
+        m = osys.velm[:, 3] != 0
+        assert np.abs(x_g - x_o).max() / np.abs(x_o).max() < 1e-9 and np.abs(v_g[m] - v_o[m]).max() / np.abs(v_o[m]).max() < 1e-9
+        st, ch = ctx.getNHState(), osys.chain_state()
+        for g in range(3):
+            assert np.allclose(list(st.eta[g])[:chains], ch["eta"][g][:chains], rtol=1e-8, atol=1e-14)
+            assert np.allclose(list(st.eta_dot[g])[:chains], ch["eta_dot"][g][:chains], rtol=1e-7, atol=1e-12)
+    finally:
+        ctx.close()
+
+
+def test_uncompiled_stage_set_inside_a_graph_capture_and_mode_zero():
+    """Chain length 2 met for the first time while the step is being captured: the kernel compiles and loads inside the capture, the
+    replay equals the eager run bit for bit; with VVHIP_RTC=0 the same plan counts generic launches."""
+    spec = S.drude_il(cells=(1, 1, 1), pairs_per_cell=50, seed=77)
+    outs = []
+    for how in ("graph", "eager", "generic"):
+        I.Context.rtc_mode(0 if how == "generic" else 1)
+        it = I.VVIntegrator(333.0, 10.0, 1.0, 40.0, 0.001, 2, 1)
+        it.setMaxDrudeDistance(0.02)
+        ctx = I.Context(spec, it, precision="double", force_provider="tether")
+        try:
+            if how == "graph":
+                ctx.run_graph(12, 4)
+            else:
+                it.step(12)
+            ctx.synchronize()
+            counts, _ = ctx.generic_launches()
+            assert (counts[1] > 0) == (how == "generic")
+            outs.append((ctx.getPosq().copy(), ctx.getVelm().copy()))
+        finally:
+            ctx.close()
+    assert np.array_equal(outs[0][0].view(np.uint8), outs[1][0].view(np.uint8)) and np.array_equal(outs[0][1].view(np.uint8), outs[1][1].view(np.uint8))
+    # generic vs specialised: the same arithmetic statements; the chain of a 2-link thermostat runs through the run-time switch instead of the
+    # templated body -- element-wise stages agree to rounding of the scale factors
+    assert np.allclose(outs[0][0], outs[2][0], rtol=0, atol=1e-11) and np.allclose(outs[0][1][:, :3], outs[2][1][:, :3], rtol=1e-10, atol=1e-12)

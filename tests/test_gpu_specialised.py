@@ -1,9 +1,9 @@
 """-m gpu: every stage set that the BASELINE configurations launch has a kernel compiled for it.
 
 The reference JIT-compiles its kernels per System (CudaVVKernels.cpp:98-101, 639-647: the defines carry the System's sizes and
-precision), so each System runs code specialised for it.  Here the specialisation happens at build time: vv_kernels.hip enumerates the
-stage sets of the supported paths (SF_*), and a launch whose stage set is not in the list falls back to the generic kernel with
-run-time stage bits, 15-20 % slower.  vvhip_generic_launches counts those; this test runs every BASELINE configuration -- plain, with
+precision), so each System runs code specialised for it.  Here the stage sets of the supported paths are compiled at build time (vv_kernels.hip:
+SF_*); a launch whose stage set is not in the list gets a kernel compiled at run time (tests/test_gpu_rtc.py) and, failing that, the
+generic kernel with run-time stage bits, 15-20 % slower.  vvhip_generic_launches counts those; this test runs every BASELINE configuration -- plain, with
 the constraints the example scripts put on it, in the classic scheme, sharded with the mailbox exchange, and at the size where the
 arithmetic layout and the stand-alone chain launch take over -- and requires the count to stay 0."""
 import importlib
@@ -13,6 +13,15 @@ import pytest
 pkg = importlib.import_module("openmm-velocityverlet_amd")
 I, S, D = pkg.integrator, pkg.systems, pkg.distributed
 pytestmark = pytest.mark.gpu
+
+@pytest.fixture
+def no_run_time_kernels():
+    """The compiled list itself covers the case: no launch took a kernel compiled at run time either."""
+    before = I.Context.rtc_stats()
+    yield
+    after = I.Context.rtc_stats()
+    assert after[1:3] == before[1:3], f"launches of run-time kernels: A {after[1] - before[1]}, B {after[2] - before[2]}"
+
 
 CASES = [(cfg, hb, middle) for cfg in ("C1", "C2", "C3", "C4", "C5") for hb in (False, True) for middle in (True, False)
          if not (cfg == "C1" and hb)]
@@ -35,7 +44,7 @@ def _edl(it, spec):
 
 
 @pytest.mark.parametrize("cfg,hbonds,middle", CASES)
-def test_baseline_configurations_run_compiled_stage_sets(cfg, hbonds, middle):
+def test_baseline_configurations_run_compiled_stage_sets(cfg, hbonds, middle, no_run_time_kernels):
     spec = S.make_config(cfg, hbonds=hbonds)
     it = _integrator(cfg, middle)
     if cfg == "C5":
@@ -52,7 +61,7 @@ def test_baseline_configurations_run_compiled_stage_sets(cfg, hbonds, middle):
 
 
 @pytest.mark.parametrize("cfg,hbonds", [("C3", False), ("C3", True), ("C4", False)])
-def test_sharded_plans_run_compiled_stage_sets(cfg, hbonds):
+def test_sharded_plans_run_compiled_stage_sets(cfg, hbonds, no_run_time_kernels):
     """One rank of a two-rank decomposition with the mailbox exchange set up (its own handle as the only peer is enough to take the
     B_MAILBOX stage sets; the numbers are not used)."""
     spec = S.make_config(cfg, hbonds=hbonds)
@@ -71,7 +80,7 @@ def test_sharded_plans_run_compiled_stage_sets(cfg, hbonds):
 
 
 @pytest.mark.parametrize("cfg,scale,hbonds,middle", [("C3", 8.0, False, True), ("C3", 8.0, True, True), ("C3", 8.0, False, False), ("C2", 30.0, False, True), ("C2", 30.0, True, True)])
-def test_large_boxes_run_compiled_stage_sets(cfg, scale, hbonds, middle):
+def test_large_boxes_run_compiled_stage_sets(cfg, scale, hbonds, middle, no_run_time_kernels):
     """0.9 M particles (C3x8) / 0.3 M (water x30): arithmetic layout, capped grids; C3x8 also the stand-alone chain launch."""
     spec = S.make_config(cfg, scale, hbonds=hbonds)
     it = _integrator(cfg, middle)
@@ -86,16 +95,22 @@ def test_large_boxes_run_compiled_stage_sets(cfg, scale, hbonds, middle):
 
 
 def test_an_unlisted_stage_set_is_reported():
-    """Four chain links instead of three: kernel B's compiled specialisations carry the three-link chain only, the generic kernel runs
-    and the plan says so."""
+    """Four chain links instead of three: kernel B's compiled specialisations carry the three-link chain only.  By default a kernel is
+    compiled at run time for the plan (tests/test_gpu_rtc.py); with that switched off (VVHIP_RTC=0) the generic kernel runs and the plan says so."""
     spec = S.drude_il(cells=(1, 1, 1), pairs_per_cell=20, seed=2)
-    it = I.VVIntegrator(333.0, 10.0, 1.0, 40.0, 0.001, numNHChains=4)
-    it.setMaxDrudeDistance(0.02)
-    ctx = I.Context(spec, it, precision="mixed", force_provider="tether")
+    old = I.Context.rtc_mode()
     try:
-        it.step(3)
-        ctx.synchronize()
-        counts, sets = ctx.generic_launches()
-        assert counts[1] == 3 and counts[0] == 0 and sets[1] != 0
+        for mode, expected in ((0, 3), (1, 0)):
+            I.Context.rtc_mode(mode)
+            it = I.VVIntegrator(333.0, 10.0, 1.0, 40.0, 0.001, numNHChains=4)
+            it.setMaxDrudeDistance(0.02)
+            ctx = I.Context(spec, it, precision="mixed", force_provider="tether")
+            try:
+                it.step(3)
+                ctx.synchronize()
+                counts, sets = ctx.generic_launches()
+                assert counts[1] == expected and counts[0] == 0 and (sets[1] != 0) == (expected != 0)
+            finally:
+                ctx.close()
     finally:
-        ctx.close()
+        I.Context.rtc_mode(old)
