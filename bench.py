@@ -410,7 +410,7 @@ def main():
         have_rccl = setup_rccl() if want in ("auto", "eager", "graph") else False
         if have_rccl and want == "auto":
             t_rccl = timed(ctx.run_eager, 100)                   # warm-up, and a first sign of life of the collective
-            t_rccl = timed(ctx.run_eager, 300) if t_rccl is not None else None
+            t_rccl = timed(ctx.run_eager, 1000) if t_rccl is not None else None
             if t_rccl is None:
                 have_rccl = False
             else:
@@ -433,8 +433,10 @@ def main():
                     pass
                 ctx = fresh_context()
                 have_rccl = setup_rccl() if want in ("auto", "eager", "graph") else False
+        # (the eager loop's short trial flatters it: over thousands of steps its 3-4 host launches per step become the bound, 14-15 us per
+        # step where the trial showed 12; a replayed graph has no such tail -- so the mailbox keeps the run unless it is clearly slower)
         if have_mb and (not have_rccl or want == "mailbox" or
-                        candidates.get("mailbox_graph_us_per_step", 0.0) <= candidates.get("rccl_eager_us_per_step", float("inf"))):
+                        candidates.get("mailbox_graph_us_per_step", 0.0) <= 1.15 * candidates.get("rccl_eager_us_per_step", float("inf"))):
             dist_mode = "mailbox"
         elif have_rccl:
             if ctx.mailbox_status()[0]:                          # set up but not chosen: the plan must stop using it

@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libvvhip.so")
+# VVHIP_LIB: another build of the same library (A/B runs of two builds on one GPU box, tools/probes); default: the in-tree one
+LIB_PATH = os.environ.get("VVHIP_LIB") or os.path.join(HERE, "lib", "libvvhip.so")
 
 MAX_CHAINS = 8
 SINGLE, MIXED, DOUBLE = 0, 1, 2
