@@ -510,11 +510,18 @@ def main():
         raise SystemExit("bench: the warm-up run is void (mailbox time-out or accumulator overflow on some rank)")
 
     def timed_k_steps():
+        # barrier + synchronize on both sides of the K steps; the clock is read between the closing synchronize and the closing barrier:
+        # every rank times its own K steps from the common start, the MAX over ranks is the job's time -- the collective that implements the
+        # barrier (50-200 us, as much as the 20 steps of the driver's flags take) is not part of the steps
         fence()
         t0 = time.perf_counter()
         run(args.steps)
-        fence()
+        ctx.synchronize()
+        torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        if use_dist:
+            dist.barrier()
+            torch.cuda.synchronize()
         if use_dist:
             t = torch.tensor([el], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

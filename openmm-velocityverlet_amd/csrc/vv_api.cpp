@@ -680,17 +680,20 @@ int vvhip_bind(vvhip_plan* p, const vvhip_buffers* b) {
         HIP_TRY(p, hipMalloc((void**) &p->d_slot_big, nslots * sizeof(int32_t)));
         HIP_TRY(p, hipMemcpy(p->d_slot_big, hp.slot_big.data(), nslots * sizeof(int32_t), hipMemcpyHostToDevice));
         HIP_TRY(p, hipMalloc((void**) &p->d_bigacc, (size_t) hp.num_big * 4 * sizeof(unsigned long long)));
-        HIP_TRY(p, hipMemset(p->d_bigacc, 0, (size_t) hp.num_big * 4 * sizeof(unsigned long long)));
+        HIP_TRY(p, hipMemsetAsync(p->d_bigacc, 0, (size_t) hp.num_big * 4 * sizeof(unsigned long long), p->stream));
     }
     HIP_TRY(p, hipMalloc(&p->d_fextra, nloc * 3 * rs));            // zero-initialised like HOST:79-89
-    HIP_TRY(p, hipMemset(p->d_fextra, 0, nloc * 3 * rs));
+    // (every fill of a plan buffer goes into the PLAN's stream: a plain hipMemset only enqueues on the null stream, which a non-blocking
+    // stream does not wait for -- the accumulator reset behind a kinetic-energy query could land after the next step's kernel A had added its
+    // sums; found by the adapter fuzz when a host stall changed the timing, tests/test_cpp_plugin.py)
+    HIP_TRY(p, hipMemsetAsync(p->d_fextra, 0, nloc * 3 * rs, p->stream));
     HIP_TRY(p, hipMalloc(&p->d_old_delta, nloc * 4 * ms));
-    HIP_TRY(p, hipMemset(p->d_old_delta, 0, nloc * 4 * ms));
+    HIP_TRY(p, hipMemsetAsync(p->d_old_delta, 0, nloc * 4 * ms, p->stream));
     HIP_TRY(p, hipMalloc((void**) &p->d_cosz, nslots * sizeof(double)));
-    HIP_TRY(p, hipMemset(p->d_cosz, 0, nslots * sizeof(double)));
+    HIP_TRY(p, hipMemsetAsync(p->d_cosz, 0, nslots * sizeof(double), p->stream));
     const size_t nseg = std::max<size_t>(hp.seg_mass.size() / 2, 1);
     HIP_TRY(p, hipMalloc(&p->d_comv, nseg * 4 * ms));
-    HIP_TRY(p, hipMemset(p->d_comv, 0, nseg * 4 * ms));
+    HIP_TRY(p, hipMemsetAsync(p->d_comv, 0, nseg * 4 * ms, p->stream));
     HIP_TRY(p, hipMalloc((void**) &p->d_seg_base, hp.seg_base.size() * sizeof(int32_t)));
     HIP_TRY(p, hipMemcpy(p->d_seg_base, hp.seg_base.data(), hp.seg_base.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     HIP_TRY(p, hipMalloc((void**) &p->d_seg_mass, hp.seg_mass.size() * sizeof(double)));
@@ -698,13 +701,13 @@ int vvhip_bind(vvhip_plan* p, const vvhip_buffers* b) {
     HIP_TRY(p, hipMalloc((void**) &p->d_slot_m, nslots * sizeof(double)));
     HIP_TRY(p, hipMalloc((void**) &p->d_slot_f, nslots * sizeof(double)));
     HIP_TRY(p, hipMalloc((void**) &p->d_comw, nseg * sizeof(double)));
-    HIP_TRY(p, hipMemset(p->d_comw, 0, nseg * sizeof(double)));
+    HIP_TRY(p, hipMemsetAsync(p->d_comw, 0, nseg * sizeof(double), p->stream));
     HIP_TRY(p, hipMalloc(&p->d_pos_delta, nloc * 4 * ms));
-    HIP_TRY(p, hipMemset(p->d_pos_delta, 0, nloc * 4 * ms));
+    HIP_TRY(p, hipMemsetAsync(p->d_pos_delta, 0, nloc * 4 * ms, p->stream));
     HIP_TRY(p, hipMalloc((void**) &p->d_epoch, sizeof(unsigned long long)));
-    HIP_TRY(p, hipMemset(p->d_epoch, 0, sizeof(unsigned long long)));
+    HIP_TRY(p, hipMemsetAsync(p->d_epoch, 0, sizeof(unsigned long long), p->stream));
     HIP_TRY(p, hipMalloc((void**) &p->d_acc, 2 * kAccN * sizeof(unsigned long long)));
-    HIP_TRY(p, hipMemset(p->d_acc, 0, 2 * kAccN * sizeof(unsigned long long)));
+    HIP_TRY(p, hipMemsetAsync(p->d_acc, 0, 2 * kAccN * sizeof(unsigned long long), p->stream));
     HIP_TRY(p, hipMalloc((void**) &p->d_nh, 2 * sizeof(vv::NHDevState)));
     vv::NHDevState init[2] = {};
     for (int c = 0; c < 2; c++)
@@ -748,7 +751,7 @@ int vvhip_set_params(vvhip_plan* p, const vvhip_params* q) {
     drop_graphs(p);
     if (cos_switch && p->bound) {        // the accumulator copies are laid out by the rows in use: start the new layout from zeros
         HIP_TRY(p, hipStreamSynchronize(p->stream));
-        HIP_TRY(p, hipMemset(p->d_acc, 0, 2 * kAccN * sizeof(unsigned long long)));
+        HIP_TRY(p, hipMemsetAsync(p->d_acc, 0, 2 * kAccN * sizeof(unsigned long long), p->stream));
     }
     return upload_lane_const(p);
 }
@@ -1038,7 +1041,9 @@ int vvhip_malloc(void** ptr, size_t bytes) { return hipMalloc(ptr, bytes ? bytes
 int vvhip_free(void* ptr) { return hipFree(ptr) == hipSuccess ? VVHIP_OK : VVHIP_ERR_HIP; }
 int vvhip_memcpy_h2d(void* dst, const void* src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess ? VVHIP_OK : VVHIP_ERR_HIP; }
 int vvhip_memcpy_d2h(void* dst, const void* src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? VVHIP_OK : VVHIP_ERR_HIP; }
-int vvhip_memset(void* dst, int value, size_t bytes) { return hipMemset(dst, value, bytes) == hipSuccess ? VVHIP_OK : VVHIP_ERR_HIP; }
+int vvhip_memset(void* dst, int value, size_t bytes) {      // complete on return (hipMemset alone only enqueues on the null stream, which the plans' streams do not wait for)
+    return hipMemset(dst, value, bytes) == hipSuccess && hipStreamSynchronize(nullptr) == hipSuccess ? VVHIP_OK : VVHIP_ERR_HIP;
+}
 int vvhip_synchronize(vvhip_plan* p) {
     NEED_BOUND(p);
     HIP_TRY(p, hipStreamSynchronize(p->stream));
@@ -1054,7 +1059,7 @@ int vvhip_status_clear(vvhip_plan* p) {
     NEED_BOUND(p);
     HIP_TRY(p, hipStreamSynchronize(p->stream));
     std::memset(p->h_status, 0, 4 * sizeof(unsigned int));
-    if (p->d_mb_ctl) HIP_TRY(p, hipMemset(p->d_mb_ctl, 0, 4 * sizeof(unsigned int)));
+    if (p->d_mb_ctl) HIP_TRY(p, hipMemsetAsync(p->d_mb_ctl, 0, 4 * sizeof(unsigned int), p->stream));
     return VVHIP_OK;
 }
 
@@ -1359,9 +1364,9 @@ int vvhip_mailbox_create(vvhip_plan* p, int nranks, int rank, void* handle64) {
     const size_t bytes = (size_t) 2 * nranks * vv::MB_WORDS * sizeof(unsigned long long);
     // uncached: peers' stores land in this GPU's memory over xGMI and must be seen by loads that would otherwise hit in L2
     HIP_TRY(p, hipExtMallocWithFlags((void**) &p->mb_local, std::max(bytes, (size_t) 4096), hipDeviceMallocUncached));
-    HIP_TRY(p, hipMemset(p->mb_local, 0, std::max(bytes, (size_t) 4096)));
+    HIP_TRY(p, hipMemsetAsync(p->mb_local, 0, std::max(bytes, (size_t) 4096), p->stream));
     HIP_TRY(p, hipMalloc((void**) &p->d_mb_ctl, 4 * sizeof(unsigned int)));
-    HIP_TRY(p, hipMemset(p->d_mb_ctl, 0, 4 * sizeof(unsigned int)));
+    HIP_TRY(p, hipMemsetAsync(p->d_mb_ctl, 0, 4 * sizeof(unsigned int), p->stream));
     HIP_TRY(p, hipDeviceSynchronize());
     hipIpcMemHandle_t h;
     HIP_TRY(p, hipIpcGetMemHandle(&h, p->mb_local));
@@ -1518,7 +1523,7 @@ int vvhip_debug_read_accumulators(vvhip_plan* p, double out[4], int zero_after) 
         for (int j = 0; j < vv::ACC_SLOTS; j++) s += raw[i * vv::ACC_SLOTS + j];
         out[i] = (double) s * p->acc_inv_scale[i];
     }
-    if (zero_after) HIP_TRY(p, hipMemset(p->d_acc + p->parity * acc_stride(p), 0, 4 * vv::ACC_SLOTS * sizeof(long long)));
+    if (zero_after) HIP_TRY(p, hipMemsetAsync(p->d_acc + p->parity * acc_stride(p), 0, 4 * vv::ACC_SLOTS * sizeof(long long), p->stream));
     return VVHIP_OK;
 }
 int vvhip_debug_set_scales(vvhip_plan* p, const double scales[4]) {

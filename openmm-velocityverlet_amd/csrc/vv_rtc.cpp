@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -125,6 +126,13 @@ hipFunction_t rtc_kernel(char kind, int precision, uint32_t flags, int num_chain
     const auto it = cache.find(key);
     if (it != cache.end()) return it->second;
     hipFunction_t fn = nullptr;
+    if (const char* deny = std::getenv("VVHIP_RTC_DENY")) {      // debugging: "A:0x13,B:0x10004,A:*" -- these stage sets stay on the generic kernel
+        char tag[32];
+        std::snprintf(tag, sizeof tag, "%c:0x%x", kind, flags);
+        char any[8];
+        std::snprintf(any, sizeof any, "%c:*", kind);
+        if (std::strstr(deny, tag) || std::strstr(deny, any)) { cache[key] = nullptr; return nullptr; }
+    }
     hipDeviceProp_t prop;
     std::string why;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
@@ -140,7 +148,11 @@ hipFunction_t rtc_kernel(char kind, int precision, uint32_t flags, int num_chain
             if (e == hipSuccess) e = hipModuleGetFunction(&fn, mod, name.c_str());
             (void) hipThreadExchangeStreamCaptureMode(&mode);
             if (e != hipSuccess) { fn = nullptr; why = std::string("loading the code object: ") + hipGetErrorString(e); }
-            else vv_rtc_compiled++;
+            else {
+                vv_rtc_compiled++;
+                static const bool verbose = std::getenv("VVHIP_RTC_VERBOSE") != nullptr;
+                if (verbose) std::fprintf(stderr, "vvhip: compiled kernel %c for stage set 0x%x (precision %d, %d chain links) at run time\n", kind, flags, precision, num_chains);
+            }
         } else {
             why = log;
         }

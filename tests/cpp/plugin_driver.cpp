@@ -225,7 +225,21 @@ static int run(const char* out, bool middle, int consMode, double cosacc, int ns
             vv.getAs<IntegrateMiddleStepKernel>().initialize(system, it, drude);
             nh.getAs<ModifyDrudeNoseKernel>().initialize(system, it, drude);
         }
+        // VV_FUZZ_TRACE=file: one line per operation with a checksum of the velocities after it (bisecting a divergence between two runs)
+        std::FILE* trace = std::getenv("VV_FUZZ_TRACE") ? std::fopen(std::getenv("VV_FUZZ_TRACE"), "w") : nullptr;
+        auto trace_op = [&](int op, const char* what) {
+            if (!trace) return;
+            (void) hipDeviceSynchronize();
+            cu.getVelm().download(velm.data());
+            double sum = 0, sq = 0;
+            const double* v = reinterpret_cast<const double*>(velm.data());
+            const size_t n = velm.size() * sizeof(velm[0]) / sizeof(double);
+            for (size_t i = 0; i < n; i++) { sum += v[i]; sq += v[i] * v[i]; }
+            std::fprintf(trace, "%d %s dt=%g cos=%g sum=%.17g sq=%.17g\n", op, what, it.getStepSize(), it.getCosAcceleration(), sum, sq);
+            std::fflush(trace);
+        };
         for (int op = 0; op < nsteps; op++) {
+            trace_op(op, "before");
             if (op_next(3) != 0) {                       // two operations in three are steps
                 if (hostMode == 10) { const int k = 1 + (int) op_next(3); it.step(k); stepsDone += k; continue; }
                 const unsigned where = op_next(6);       // 0..2: a change / query behind that stage; 3..5: none inside this step

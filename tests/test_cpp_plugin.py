@@ -200,11 +200,11 @@ def test_deferred_fusion_only_answers_the_reference_call_order(tmp_path):
         assert np.allclose(dumps[mode][8], dumps[0][8], rtol=0, atol=2e-7 * np.abs(dumps[0][8]).max())       # posq
 
 
-def _fuzz(driver, tmp_path, middle, cons, cos, nops, seed, hand, defer):
+def _fuzz(driver, tmp_path, middle, cons, cos, nops, seed, hand, defer, **extra_env):
     import re
     d = str(tmp_path / f"fz_{middle}{cons}{seed}{hand}{defer}.bin")
     r = subprocess.run([driver, "fuzz", d, str(middle), str(cons), str(cos), str(nops), str(seed), str(hand)], capture_output=True, text=True,
-                       env=dict(os.environ, VVHIP_PLUGIN_DEFER=str(defer)))
+                       env=dict(os.environ, VVHIP_PLUGIN_DEFER=str(defer), **extra_env))
     assert r.returncode == 0 and "RUN OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     fused, staged = map(int, re.search(r"DEFER fused=(\d+) staged=(\d+)", r.stdout).groups())
     steps, interrupted = map(int, re.search(r"FUZZ steps=(\d+) interrupted=(\d+)", r.stdout).groups())
@@ -239,6 +239,22 @@ def test_deferred_fusion_fuzz_under_the_reference_integrator(tmp_path, middle, c
             # (K/middle.cu:11-21, VVIntegrator.cpp:238-240) -- the fused path now does the same (vv_api.cpp: fextra_virtual).
             assert np.abs(a[k].astype(np.float64) - b[k].astype(np.float64)).max() <= 1e-12 * max(1.0, np.abs(b[k]).max()), (k, np.abs(a[k] - b[k]).max())
     assert np.isfinite(a[7]).all() and np.isfinite(a[8]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(REF_DRIVER), reason="oracle/_ref/refplugin not built (reference sources absent)")
+@pytest.mark.parametrize("seed", [4, 6])
+@pytest.mark.parametrize("rep", range(4))
+def test_fuzz_is_insensitive_to_host_stalls(tmp_path, seed, rep):
+    """The classic scheme with the cos perturbation again, every kernel compiled at run time (VVHIP_RTC=2): each first launch of a stage set
+    stalls the host for about a second while the GPU drains.  Found with exactly this: the accumulator reset behind a kinetic-energy query
+    was a plain hipMemset, i.e. enqueued on the null stream, which the plan's non-blocking stream does not wait for -- after a stall it
+    could land behind the next step's kernel A and wipe its sums (a third of the runs differed by 1e-3).  Every fill of a plan buffer is now
+    ordered in the plan's stream; fused and staged runs agree to rounding whatever the host's timing."""
+    a = _fuzz(REF_DRIVER, tmp_path, 0, 0, 0.02, 40, seed, 0, 1, VVHIP_RTC="2")[0]
+    b = _fuzz(REF_DRIVER, tmp_path, 0, 0, 0.02, 40, seed, 0, 0, VVHIP_RTC="2")[0]
+    for k in (7, 8, 9):
+        assert np.abs(a[k].astype(np.float64) - b[k].astype(np.float64)).max() <= 1e-12 * max(1.0, np.abs(b[k]).max()), (k, rep)
 
 
 @pytest.mark.gpu
