@@ -74,6 +74,30 @@ def test_run_time_kernel_equals_compiled_kernel(cfg, hbonds, middle, prec):
         assert np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b).view(np.uint8)), f"{what} differs between the compiled and the run-time kernel"
 
 
+@pytest.mark.parametrize("what", ["large", "sharded"])
+def test_run_time_kernel_equals_compiled_kernel_large_and_sharded(what):
+    """The arithmetic work-item layout with the stand-alone chain launch (C3x8, 0.9 M particles) and the mailbox stage sets of a sharded plan
+    (one rank of two, its own handle as the only peer): run-time kernels against the compiled ones, bit for bit."""
+    D = pkg.distributed
+    spec = S.make_config("C3", 8.0 if what == "large" else 0.08)
+    res = []
+    for mode in (0, 2):
+        I.Context.rtc_mode(mode)
+        it = _integrator("C3", True, spec)
+        kw = {"shard": D.shard_bounds(spec, 2)[0]} if what == "sharded" else {}
+        ctx = I.Context(spec, it, precision="mixed", force_provider="tether", **kw)
+        try:
+            if what == "sharded":
+                ctx.mailbox_connect(ctx.mailbox_create(1, 0))
+            it.step(4)
+            ctx.synchronize()
+            res.append((ctx.getPosq().copy(), ctx.getVelm().copy(), ctx.generic_launches()[0]))
+        finally:
+            ctx.close()
+    assert res[0][2] == (0, 0) and res[1][2] == (0, 0)
+    assert np.array_equal(res[0][0].view(np.uint8), res[1][0].view(np.uint8)) and np.array_equal(res[0][1].view(np.uint8), res[1][1].view(np.uint8))
+
+
 def _oracle_pair(spec, nsteps, chains, middle, ld=False, efield=0.0):
     p = O.Params(temperature=333.0, drude_temperature=1.0, max_drude_distance=0.02, use_middle_scheme=middle, num_chains=chains, loops_per_step=1)
     osys = O.OracleSystem(spec, p, "mixed", force_mode=1)
