@@ -11,6 +11,7 @@
 #include <vector>
 
 #include <dlfcn.h>
+#include <unistd.h>
 #include <rccl/rccl.h>      // types and prototypes only: the library is resolved at run time (see rccl_api)
 
 #include "vv_host.hpp"
@@ -102,6 +103,10 @@ struct vvhip_plan {
     bool periodic_kernels = true, periodic_a = true;
     int shake_mode = 1;            // hydrogen-type constraint clusters: 1 = all constraints of a cluster at once (direct velocity solve, coupled Newton
                                    // for positions), 0 = Gauss-Seidel sweeps by the central lane (OpenMM's iteration; generic kernels) -- VVHIP_SHAKE_MODE
+    // Race detection by timing (VVHIP_STALL=us[:period]): every period-th launch of this plan is preceded by a host sleep of `us` microseconds --
+    // the GPU drains, anything that was only ordered by the depth of the queue (a fill or copy on another stream, a host read without a
+    // synchronisation) lands differently, and the trajectory changes.  tests/test_gpu_stalls.py compares stalled and unstalled runs bit for bit.
+    long stall_us = 0, stall_period = 1, stall_count = 0;
     bool acc_store = true;         // kernel A launches of <= 256 blocks store old + new into their accumulator slots instead of atomics (VVHIP_ACC_STORE=0: atomics)
     long long generic_launches[2] = {0, 0};   // kernel A / B launches of this plan (captured ones count once) that ran the generic kernel
     uint32_t generic_flags[2] = {0, 0};       // ... and the last stage set that did (vvhip_generic_launches)
@@ -446,6 +451,9 @@ struct ScopedTimer {
 
 // The static mass tables are filled lazily, right in front of the first stage launch that reads them (by then velm.w is what the
 // host integrates with); inside a graph capture that would record the fill into every replay, so the capture entry points call this first.
+static inline void debug_stall(vvhip_plan* p) {
+    if (p->stall_us > 0 && !p->capturing && ++p->stall_count % p->stall_period == 0) usleep((useconds_t) p->stall_us);
+}
 int ensure_mass_table(vvhip_plan* p) {
     if (!(p->mass_tab_a || p->mass_tab_b) || p->mass_tab_valid) return VVHIP_OK;
     if (p->capturing) return fail(p, VVHIP_ERR_INVALID, "internal: mass tables must be filled before a graph capture starts");
@@ -458,6 +466,7 @@ int run_a(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
     // (kernel A takes the arithmetic path where it also saves the 20 bytes per lane of constraint tables; else it does not gain, see periodic_a)
     if (p->hp.per.enabled && p->periodic_kernels && (p->periodic_a || (flags & vv::A_CONS))) flags |= vv::A_PERIODIC;
     if ((flags & vv::A_SHAKE_V) && p->shake_mode == 0) flags |= vv::A_SHAKE_GS;
+    debug_stall(p);
     ScopedTimer t(p, T_A, true);
     const unsigned long long g0 = vv::vv_generic_count[0];
     HIP_TRY(p, vv::launch_a(p->hp.precision, make_args(p, flags, random_index), p->block_threads, p->grid_cap_a, p->stream, t.e0, t.e1));
@@ -469,6 +478,7 @@ int run_b(vvhip_plan* p, uint32_t flags) {
     // (not next to the mailbox exchange: that combination timed out when two ranks shared one GPU, the only multi-rank set-up at hand)
     if (p->hp.per.enabled && p->periodic_kernels && !(flags & vv::B_MAILBOX)) flags |= vv::B_PERIODIC;
     if ((flags & vv::B_SHAKE) && p->shake_mode == 0) flags |= vv::B_SHAKE_GS;
+    debug_stall(p);
     ScopedTimer t(p, T_B, true);
     const unsigned long long g0 = vv::vv_generic_count[1];
     HIP_TRY(p, vv::launch_b(p->hp.precision, make_args(p, flags, 0), p->block_threads, p->grid_cap_b, p->stream, t.e0, t.e1));
@@ -477,6 +487,7 @@ int run_b(vvhip_plan* p, uint32_t flags) {
     return VVHIP_OK;
 }
 int run_chain(vvhip_plan* p, uint32_t flags) {
+    debug_stall(p);
     ScopedTimer t(p, T_OTHER);
     HIP_TRY(p, vv::launch_chain(make_chain(p, flags), p->d_nh + p->parity, p->d_acc + p->parity * acc_stride(p), p->stream));
     return VVHIP_OK;
@@ -567,6 +578,10 @@ int vvhip_plan_create(const vvhip_system_desc* system, const vvhip_params* param
         if (const char* e = std::getenv("VVHIP_NO_MOMENTS")) p->no_moments = std::atoi(e) != 0;
         if (const char* e = std::getenv("VVHIP_REKICK")) p->rekick = std::atoi(e) != 0;
         if (const char* e = std::getenv("VVHIP_ACC_STORE")) p->acc_store = std::atoi(e) != 0;
+        if (const char* e = std::getenv("VVHIP_STALL")) {
+            p->stall_us = std::atol(e);
+            if (const char* c = std::strchr(e, ':')) p->stall_period = std::max(1L, std::atol(c + 1));
+        }
         if (const char* e = std::getenv("VVHIP_SHAKE_MODE")) p->shake_mode = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("VVHIP_PERIODIC_K")) p->periodic_kernels = std::atoi(e) != 0;
         if (const char* e = std::getenv("VVHIP_PERIODIC_A")) p->periodic_a = std::atoi(e) != 0;
@@ -684,8 +699,8 @@ int vvhip_bind(vvhip_plan* p, const vvhip_buffers* b) {
     }
     HIP_TRY(p, hipMalloc(&p->d_fextra, nloc * 3 * rs));            // zero-initialised like HOST:79-89
     // (every fill of a plan buffer goes into the PLAN's stream: a plain hipMemset only enqueues on the null stream, which a non-blocking
-    // stream does not wait for -- the accumulator reset behind a kinetic-energy query could land after the next step's kernel A had added its
-    // sums; found by the adapter fuzz when a host stall changed the timing, tests/test_cpp_plugin.py)
+    // stream does not wait for -- the reset of both accumulator copies at a switch of the cos perturbation (vvhip_set_params) could land a
+    // step later and wipe kernel A's sums; found by the adapter fuzz when a host stall changed the timing, tests/test_cpp_plugin.py)
     HIP_TRY(p, hipMemsetAsync(p->d_fextra, 0, nloc * 3 * rs, p->stream));
     HIP_TRY(p, hipMalloc(&p->d_old_delta, nloc * 4 * ms));
     HIP_TRY(p, hipMemsetAsync(p->d_old_delta, 0, nloc * 4 * ms, p->stream));

@@ -247,9 +247,10 @@ def test_deferred_fusion_fuzz_under_the_reference_integrator(tmp_path, middle, c
 @pytest.mark.parametrize("rep", range(4))
 def test_fuzz_is_insensitive_to_host_stalls(tmp_path, seed, rep):
     """The classic scheme with the cos perturbation again, every kernel compiled at run time (VVHIP_RTC=2): each first launch of a stage set
-    stalls the host for about a second while the GPU drains.  Found with exactly this: the accumulator reset behind a kinetic-energy query
-    was a plain hipMemset, i.e. enqueued on the null stream, which the plan's non-blocking stream does not wait for -- after a stall it
-    could land behind the next step's kernel A and wipe its sums (a third of the runs differed by 1e-3).  Every fill of a plan buffer is now
+    stalls the host for about a second while the GPU drains.  Found with exactly this: the reset of both accumulator copies at a switch
+    of the cos perturbation (vvhip_set_params) was a plain hipMemset, i.e. enqueued on the null stream, which the plan's non-blocking stream
+    does not wait for -- it could land a step later and wipe kernel A's sums (a third to a half of the runs differed by 1e-3; bisected to that one
+    fill with per-fill builds, tools/probes/fuzz_flaky.py).  Every fill of a plan buffer is now
     ordered in the plan's stream; fused and staged runs agree to rounding whatever the host's timing."""
     a = _fuzz(REF_DRIVER, tmp_path, 0, 0, 0.02, 40, seed, 0, 1, VVHIP_RTC="2")[0]
     b = _fuzz(REF_DRIVER, tmp_path, 0, 0, 0.02, 40, seed, 0, 0, VVHIP_RTC="2")[0]
