@@ -705,18 +705,25 @@ void vvo_shake_velocities(int nclusters, const int* atoms, const float* params, 
  *               off-diagonals imc r_k . r_m taken at the old bonds (they differ from imc b_k . r_m by the bond's rotation during one
  *               step, a few percent of an entry that is itself 3 % of the diagonal for C-H clusters): one corrective iteration
  *               where the sweeps need four.  Same convergence test as OpenMM's: |d^2 - |b_k|^2| < tol d^2 for every constraint.
- * Unused rows (np < 3) are identity rows.  Every product and sum in the order written: the device code repeats them verbatim. */
-#define DOT3(a, b) ((a)[0] * (b)[0] + (a)[1] * (b)[1] + (a)[2] * (b)[2])
+ * Unused rows (np < 3) are identity rows.  Every product, sum and fused multiply-add in the order written: the device code repeats them verbatim. */
+/* Explicit fused multiply-adds, the same calls in the same places as the device code (vv_device.inc: vfma): C's fma / fmaf is the one
+ * correctly rounded operation v_fma_f64 / v_fma_f32 is, so the two agree bit for bit although everything else is built without contraction. */
+#if defined(VVO_SINGLE)
+#define FMA(a, b, c) fmaf((a), (b), (c))
+#else
+#define FMA(a, b, c) fma((a), (b), (c))
+#endif
+#define DOT3(a, b) FMA((a)[2], (b)[2], FMA((a)[1], (b)[1], (a)[0] * (b)[0]))
 typedef struct { mixed c00, c01, c02, c11, c12, c22, inv; } sym3inv;
 static inline sym3inv sym3_cofactors(mixed A00, mixed A01, mixed A02, mixed A11, mixed A12, mixed A22) {
     sym3inv q;
-    q.c00 = A11 * A22 - A12 * A12;
-    q.c01 = A02 * A12 - A01 * A22;
-    q.c02 = A01 * A12 - A02 * A11;
-    q.c11 = A00 * A22 - A02 * A02;
-    q.c12 = A01 * A02 - A00 * A12;
-    q.c22 = A00 * A11 - A01 * A01;
-    const mixed det = A00 * q.c00 + A01 * q.c01 + A02 * q.c02;
+    q.c00 = FMA(A11, A22, -(A12 * A12));
+    q.c01 = FMA(A02, A12, -(A01 * A22));
+    q.c02 = FMA(A01, A12, -(A02 * A11));
+    q.c11 = FMA(A00, A22, -(A02 * A02));
+    q.c12 = FMA(A01, A02, -(A00 * A12));
+    q.c22 = FMA(A00, A11, -(A01 * A01));
+    const mixed det = FMA(A02, q.c02, FMA(A01, q.c01, A00 * q.c00));
     q.inv = 1 / det;
     return q;
 }
@@ -750,16 +757,16 @@ void vvo_cluster_velocities_direct(int nclusters, const int* atoms, const float*
         const mixed A01 = imc * DOT3(r[0], r[1]), A02 = imc * DOT3(r[0], r[2]), A12 = imc * DOT3(r[1], r[2]);
         const sym3inv q = sym3_cofactors(A00, A01, A02, A11, A12, A22);
         mixed l[3];
-        l[0] = -((q.c00 * b[0] + q.c01 * b[1] + q.c02 * b[2]) * q.inv);
-        l[1] = -((q.c01 * b[0] + q.c11 * b[1] + q.c12 * b[2]) * q.inv);
-        l[2] = -((q.c02 * b[0] + q.c12 * b[1] + q.c22 * b[2]) * q.inv);
+        l[0] = -(FMA(q.c02, b[2], FMA(q.c01, b[1], q.c00 * b[0])) * q.inv);
+        l[1] = -(FMA(q.c12, b[2], FMA(q.c11, b[1], q.c01 * b[0])) * q.inv);
+        l[2] = -(FMA(q.c22, b[2], FMA(q.c12, b[1], q.c02 * b[0])) * q.inv);
         mixed t[3];
-        for (int a = 0; a < 3; a++) t[a] = l[0] * r[0][a] + l[1] * r[1][a] + l[2] * r[2][a];
-        velm[ic].x += imc * t[0]; velm[ic].y += imc * t[1]; velm[ic].z += imc * t[2];
+        for (int a = 0; a < 3; a++) t[a] = FMA(l[2], r[2][a], FMA(l[1], r[1][a], l[0] * r[0][a]));
+        velm[ic].x = FMA(imc, t[0], velm[ic].x); velm[ic].y = FMA(imc, t[1], velm[ic].y); velm[ic].z = FMA(imc, t[2], velm[ic].z);
         for (int k = 0; k < np; k++) {
             const int j = atoms[4 * c + 1 + k];
             const mixed f = imp * l[k];
-            velm[j].x -= f * r[k][0]; velm[j].y -= f * r[k][1]; velm[j].z -= f * r[k][2];
+            velm[j].x = FMA(-f, r[k][0], velm[j].x); velm[j].y = FMA(-f, r[k][1], velm[j].y); velm[j].z = FMA(-f, r[k][2], velm[j].z);
         }
     }
 }
@@ -803,20 +810,20 @@ void vvo_cluster_positions_newton(int nclusters, const int* atoms, const float* 
             const mixed D2 = np > 2 ? ims * DOT3(b[2], r[2]) : (mixed) 1;
             const sym3inv q = sym3_cofactors(D0, O01, O02, D1, O12, D2);
             const mixed h0 = 0.5f * g[0], h1 = 0.5f * g[1], h2 = 0.5f * g[2];
-            l[0] -= (q.c00 * h0 + q.c01 * h1 + q.c02 * h2) * q.inv;
-            l[1] -= (q.c01 * h0 + q.c11 * h1 + q.c12 * h2) * q.inv;
-            l[2] -= (q.c02 * h0 + q.c12 * h1 + q.c22 * h2) * q.inv;
-            for (int a = 0; a < 3; a++) t[a] = imc * (l[0] * r[0][a] + l[1] * r[1][a] + l[2] * r[2][a]);
+            l[0] = FMA(-FMA(q.c02, h2, FMA(q.c01, h1, q.c00 * h0)), q.inv, l[0]);
+            l[1] = FMA(-FMA(q.c12, h2, FMA(q.c11, h1, q.c01 * h0)), q.inv, l[1]);
+            l[2] = FMA(-FMA(q.c22, h2, FMA(q.c12, h1, q.c02 * h0)), q.inv, l[2]);
+            for (int a = 0; a < 3; a++) t[a] = imc * FMA(l[2], r[2][a], FMA(l[1], r[1][a], l[0] * r[0][a]));
             for (int k = 0; k < np; k++) {
                 const mixed f = imp * l[k];
-                for (int a = 0; a < 3; a++) b[k][a] = (s[k][a] + t[a]) + f * r[k][a];
+                for (int a = 0; a < 3; a++) b[k][a] = FMA(f, r[k][a], s[k][a] + t[a]);
             }
         }
         pos_delta[ic].x = dc[0] + t[0]; pos_delta[ic].y = dc[1] + t[1]; pos_delta[ic].z = dc[2] + t[2];
         for (int k = 0; k < np; k++) {
             const int j = atoms[4 * c + 1 + k];
             const mixed f = imp * l[k];
-            pos_delta[j].x -= f * r[k][0]; pos_delta[j].y -= f * r[k][1]; pos_delta[j].z -= f * r[k][2];
+            pos_delta[j].x = FMA(-f, r[k][0], pos_delta[j].x); pos_delta[j].y = FMA(-f, r[k][1], pos_delta[j].y); pos_delta[j].z = FMA(-f, r[k][2], pos_delta[j].z);
         }
     }
 }
