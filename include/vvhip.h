@@ -362,7 +362,7 @@ int vvhip_timing_read(vvhip_plan* plan, double* ms_pass_a, double* ms_pass_b, do
 
 /* ---------------------------------------------------------------- test hooks
  * Used by tests/ to drive single stages against the oracle; not needed by an integrating host.
- * kernel: 0 = A (produce), 1 = B (consume), 2 = chain; flags are the stage bits of csrc/vv_kernels.hpp. */
+ * kernel: 0 = A (produce), 1 = B (consume), 2 = chain; flags are the stage bits of csrc/vv_args.hpp. */
 int vvhip_debug_launch(vvhip_plan* plan, int kernel, uint32_t flags, uint32_t random_index);
 int vvhip_debug_read_accumulators(vvhip_plan* plan, double out[4], int zero_after);  /* blocks */
 int vvhip_debug_set_scales(vvhip_plan* plan, const double scales[4]);                /* vscale[3], bias V; blocks */

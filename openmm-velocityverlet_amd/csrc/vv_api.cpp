@@ -124,7 +124,7 @@ struct vvhip_plan {
     void* d_old_delta = nullptr;
     void* d_pos_delta = nullptr;   // used when the caller does not supply one
     void* d_comv = nullptr;        // per-segment COM velocities handed from kernel A to kernel B
-    double* d_slot_m = nullptr;    // static per-lane RECIP(velm.w) (vv_kernels.hpp: A_MTAB), filled on the device from velm.w
+    double* d_slot_m = nullptr;    // static per-lane RECIP(velm.w) (vv_args.hpp: A_MTAB), filled on the device from velm.w
     double* d_slot_f = nullptr;    // static per-lane Drude-pair mass fraction (A_MTAB / B_MTAB)
     bool mass_tab_a = false, mass_tab_b = true;   // kernel A / B launches read the tables (defaults follow the build; VVHIP_MTAB_A / VVHIP_MTAB_B override: comparison runs)
     bool mass_tab_valid = false;   // tables match the bound velm.w (vvhip_bind / vvhip_masses_changed reset it)
@@ -159,7 +159,7 @@ struct vvhip_plan {
     // particle sharding over GPUs: RCCL communicator for the accumulator exchange (null = single GPU)
     ncclComm_t comm = nullptr;
     int comm_ranks = 1;
-    // ... or the xGMI mailbox (vv_kernels.hpp: Mailbox): no collective launch, works inside a captured graph
+    // ... or the xGMI mailbox (vv_args.hpp: Mailbox): no collective launch, works inside a captured graph
     unsigned long long* mb_local = nullptr;       // uncached, exported through hipIpc
     unsigned long long** d_mb_peers = nullptr;    // device array of the peers' mappings
     unsigned int* d_mb_ctl = nullptr;
@@ -494,7 +494,7 @@ int run_chain(vvhip_plan* p, uint32_t flags) {
 }
 
 // cos perturbation in two launches instead of three: kernel A accumulates the group sums as moments of the biased velocities next
-// to the bias moment itself, kernel B's inline chain finishes the algebra (vv_kernels.hpp: A_KE_MOM).  Not with molecules larger
+// to the bias moment itself, kernel B's inline chain finishes the algebra (vv_args.hpp: A_KE_MOM).  Not with molecules larger
 // than a wave or the stand-alone chain launch (long chains, very large systems), which keep the bias -> KE -> scale sequence.
 bool use_moments(const vvhip_plan* p) {
     return p->hp.params.cos_acceleration != 0 && p->hp.has_nh && p->hp.num_big == 0 && p->hp.params.num_nh_chains <= 4 &&
@@ -810,7 +810,7 @@ int vvhip_step_middle_phases(const vvhip_plan* p) {
 }
 
 // The fused middle step without a velm round trip between its kernels: kernel A keeps the kicked velocities in registers, kernel B
-// repeats the kick from velm + force (vv_kernels.hpp: A_NOSTORE / B_KICK).  Needs what A adds to the velocities beyond the plain
+// repeats the kick from velm + force (vv_args.hpp: A_NOSTORE / B_KICK).  Needs what A adds to the velocities beyond the plain
 // kick to be absent or cheap to repeat: no Langevin subset and no field (kernel B repeats the cos force from the cached cos(kz), in
 // the two-launch moment form only), no in-kernel velocity constraints; and a thermostat, i.e. the A -> B pair of one step
 // (VVHIP_REKICK=0 switches it off: comparison runs).

@@ -22,7 +22,7 @@ REAL = {"single": np.float32, "mixed": np.float32, "double": np.float64}
 MIXED_T = {"single": np.float32, "mixed": np.float64, "double": np.float64}
 OK, ERR_INVALID, ERR_TOPOLOGY, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE, ERR_EXCHANGE, ERR_OVERFLOW = 0, -1, -2, -3, -4, -5, -6, -7
 
-# stage bits of csrc/vv_kernels.hpp (only the test hooks need them)
+# stage bits of csrc/vv_args.hpp (only the test hooks need them)
 A_FE_LOAD, A_FE_STORE, A_LD, A_EF, A_COS, A_KICK_FULL, A_KICK_HALF, A_POSDELTA_VV, A_POS1, A_BIAS, A_KE, A_UNBIAS_ACC, A_COMPART, A_CZ_STORE, A_CZ_LOAD = \
     [1 << i for i in range(15)]
 B_SCALE, B_UNBIAS, B_BIAS_REMOVE, B_BIAS_RESTORE, B_DRIFT_MIDDLE, B_POS2, B_POS3, B_VV_KICK, B_VV_POS, B_HARDWALL, B_IMAGE, B_CHAIN, B_CZ_LOAD = \
