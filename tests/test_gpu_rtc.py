@@ -159,3 +159,88 @@ def test_uncompiled_stage_set_inside_a_graph_capture_and_mode_zero():
     # generic vs specialised: the same arithmetic statements; the chain of a 2-link thermostat runs through the run-time switch instead of the
     # templated body -- element-wise stages agree to rounding of the scale factors
     assert np.allclose(outs[0][0], outs[2][0], rtol=0, atol=1e-11) and np.allclose(outs[0][1][:, :3], outs[2][1][:, :3], rtol=1e-10, atol=1e-12)
+
+
+def _random_stage_sets(rng, n):
+    """Stage-bit combinations the launchers accept on a plain NH + Drude system (no Langevin, field, images, constraints, mailbox, big molecules),
+    sensible or not: the generic kernel takes any of them, so must a kernel compiled for exactly that set."""
+    A = {k: getattr(H, k) for k in ("A_FE_LOAD", "A_FE_STORE", "A_COS", "A_KICK_FULL", "A_KICK_HALF", "A_POSDELTA_VV", "A_POS1", "A_BIAS", "A_KE", "A_CZ_STORE", "A_CZ_LOAD")}
+    A.update(A_KE_MOM=1 << 17, A_KE_PLAIN=1 << 15, A_NOSTORE=1 << 19, A_UNBIAS_ACC=1 << 11)
+    B = {k: getattr(H, k) for k in ("B_SCALE", "B_UNBIAS", "B_BIAS_REMOVE", "B_BIAS_RESTORE", "B_DRIFT_MIDDLE", "B_POS2", "B_POS3", "B_VV_KICK", "B_VV_POS", "B_HARDWALL", "B_CHAIN", "B_CZ_LOAD")}
+    B.update(B_KE_MOM=1 << 15, B_KICK=1 << 17)
+    out = []
+    while len(out) < n:
+        if rng.random() < 0.5:
+            f = 0
+            for k, bit in A.items():
+                if rng.random() < 0.35:
+                    f |= bit
+            if (f & A["A_KICK_FULL"]) and (f & A["A_KICK_HALF"]):
+                f &= ~A["A_KICK_HALF"]
+            if (f & A["A_CZ_STORE"]) and (f & A["A_CZ_LOAD"]):
+                f &= ~A["A_CZ_LOAD"]
+            if f & A["A_KE_MOM"]:
+                f |= A["A_KE"] | A["A_BIAS"]
+                f &= ~A["A_UNBIAS_ACC"]
+            if (f & A["A_KE_PLAIN"]) and (f & A["A_KE"]):
+                f &= ~A["A_KE_PLAIN"]
+            if f & A["A_NOSTORE"] and not f & (A["A_KICK_FULL"] | A["A_KICK_HALF"]):
+                f &= ~A["A_NOSTORE"]
+            if f:
+                out.append((0, f))
+        else:
+            f = 0
+            for k, bit in B.items():
+                if rng.random() < 0.35:
+                    f |= bit
+            pos = [B["B_DRIFT_MIDDLE"], B["B_POS2"], B["B_POS3"], B["B_VV_KICK"], B["B_VV_POS"]]
+            chosen = [b for b in pos if f & b]
+            for b in chosen[1:]:
+                f &= ~b
+            if f & B["B_UNBIAS"]:
+                f &= ~(B["B_BIAS_REMOVE"] | B["B_BIAS_RESTORE"])
+            if (f & B["B_KE_MOM"]) and not (f & B["B_UNBIAS"] and f & B["B_CHAIN"]):
+                f &= ~B["B_KE_MOM"]
+            if (f & B["B_KICK"]) and (f & B["B_VV_KICK"]):
+                f &= ~B["B_KICK"]
+            if f:
+                out.append((1, f))
+    return out
+
+
+def test_random_stage_sets_specialised_kernel_equals_generic_kernel():
+    """A walk through the space of stage sets: 40 random combinations of stage bits, each launched on the same state once on the generic kernel
+    (run-time stage bits, VVHIP_RTC=0) and once on a kernel compiled at run time for exactly that set -- every particle array, the accumulators'
+    totals and the thermostat state must come out the same to the bit.  What specialisation removes from a kernel must be dead code, for every set."""
+    import ctypes as C
+    rng = np.random.default_rng(20260117)
+    spec = S.drude_il(cells=(1, 1, 1), pairs_per_cell=30, seed=9)
+    sets = _random_stage_sets(rng, 40)
+    results = []
+    compiled_before = I.Context.rtc_stats()[0]
+    for mode in (0, 1):
+        I.Context.rtc_mode(mode)
+        it = I.VVIntegrator(333.0, 10.0, 1.0, 40.0, 0.001)
+        it.setMaxDrudeDistance(0.02)
+        it.setCosAcceleration(0.02)
+        ctx = I.Context(spec, it, precision="mixed", force_provider="tether")
+        snap = []
+        try:
+            it.step(2)                                             # a physical state with forces, cos cache and thermostat history
+            ctx.synchronize()
+            for kernel, flags in sets:
+                H.check(H.lib.vvhip_debug_launch(ctx.plan, kernel, flags, 0), ctx.plan)
+                ctx.synchronize()
+                acc = (C.c_double * 4)()
+                H.check(H.lib.vvhip_debug_read_accumulators(ctx.plan, acc, 0), ctx.plan)
+                st = ctx.getNHState()
+                snap.append((ctx.getPosq().copy(), ctx.getVelm().copy(), np.array(list(acc) + [x for g in range(3) for x in list(st.eta[g]) + list(st.eta_dot[g])])))
+            results.append(snap)
+        finally:
+            ctx.close()
+    assert I.Context.rtc_stats()[0] - compiled_before >= 20, "most of these sets are outside the compiled list: they must have been compiled at run time"
+    for i, ((kernel, flags), a, b) in enumerate(zip(sets, results[0], results[1])):
+        for x, y, what in zip(a, b, ("posq", "velm", "accumulators and thermostat")):
+            assert np.array_equal(np.ascontiguousarray(x).view(np.uint8), np.ascontiguousarray(y).view(np.uint8)), \
+                f"launch {i}: kernel {'AB'[kernel]} stage set 0x{flags:x}: {what} differs between the generic and the specialised kernel"
+
