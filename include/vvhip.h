@@ -354,8 +354,6 @@ int vvhip_timing_read(vvhip_plan* plan, double* ms_pass_a, double* ms_pass_b, do
  *                             kernel (default) / for every launch (tests: the run-time kernel against the compiled one, bit for bit)
  *   VVHIP_STALL=us[:period]   race detection by timing: every period-th launch of a plan is preceded by a host sleep of `us` microseconds (the GPU
  *                             drains; whatever was only ordered by the depth of the queue lands differently); tests/test_gpu_stalls.py
- *   VVHIP_RTC_CACHE=<dir>     keep the kernels compiled at run time in that directory across processes (keyed by a hash of sources, options and
- *                             instantiation; the reference's kernels go through OpenMM's on-disk kernel cache the same way); default: none
  *   VVHIP_RTC_VERBOSE=1       one line on stderr per kernel compiled at run time;  VVHIP_RTC_DENY="A:0x441,B:*": these stage sets stay on the
  *                             generic kernel (bisecting)
  *   VVHIP_WARN_GENERIC=1      one line on stderr per stage set that runs on the generic kernel (15-20 % slower)

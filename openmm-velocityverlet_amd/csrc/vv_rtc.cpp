@@ -2,7 +2,6 @@
 #include "vv_rtc.hpp"
 
 #include <dlfcn.h>
-#include <unistd.h>
 #include <hip/hiprtc.h>
 
 #include <chrono>
@@ -91,50 +90,15 @@ bool rtc_compile(char kind, int precision, uint32_t flags, int num_chains, const
     const std::string h_vvhip = replaced(replaced(vv_src_vvhip, "#include <stddef.h>", ""), "#include <stdint.h>", "");
     const char* header_src[] = {h_args.c_str(), vv_src_layout, vv_src_device, vv_src_probes, h_vvhip.c_str()};
     const char* header_name[] = {"vv_args.hpp", "vv_layout.h", "vv_device.inc", "vv_probes.inc", "vvhip.h"};
+    hiprtcProgram prog = nullptr;
+    if (r.create(&prog, unit.c_str(), "vv_rtc_unit.hip", 5, header_src, header_name) != HIPRTC_SUCCESS) { log = "hiprtcCreateProgram failed"; return false; }
+    bool ok = r.add_name(prog, expr) == HIPRTC_SUCCESS;
     // the options of the ahead-of-time build (Makefile): contraction off (element-wise results equal the reference's operation for
     // operation), the leading scalar arguments preloaded into SGPRs
     const std::string arch_opt = "--offload-arch=" + arch;
     char links[40];
     std::snprintf(links, sizeof links, "-DVV_SF_CHAIN_LINKS=%d", num_chains >= 1 && num_chains <= 4 ? num_chains : 3);
     const char* opts[] = {arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-kernarg-preload-count=16", links};
-    // Optional cache across processes (VVHIP_RTC_CACHE=<directory>; the reference's kernels go through OpenMM's on-disk kernel cache the same
-    // way): the code object of a (sources, options, instantiation) triple under its 64-bit FNV-1a hash, with the lowered kernel name beside it.
-    std::string cache_base;
-    if (const char* dir = std::getenv("VVHIP_RTC_CACHE")) {
-        unsigned long long h = 1469598103934665603ull;
-        auto mix = [&](const char* t) { for (; *t; t++) { h ^= (unsigned char) *t; h *= 1099511628211ull; } h ^= 0xffu; h *= 1099511628211ull; };
-        mix(unit.c_str());
-        for (const char* t : header_src) mix(t);
-        for (const char* t : opts) mix(t);
-        mix(expr);
-        int ver[2] = {0, 0};
-        if (auto version = (decltype(&hiprtcVersion)) dlsym(r.lib, "hiprtcVersion")) (void) version(&ver[0], &ver[1]);
-        char tail[80];
-        std::snprintf(tail, sizeof tail, "/vvhip_%016llx_rtc%d.%d", h, ver[0], ver[1]);
-        cache_base = std::string(dir) + tail;
-        std::FILE* fc = std::fopen((cache_base + ".co").c_str(), "rb");
-        std::FILE* fn = std::fopen((cache_base + ".name").c_str(), "rb");
-        bool hit = false;
-        if (fc && fn) {
-            char name[512] = {0};
-            const size_t nn = std::fread(name, 1, sizeof name - 1, fn);
-            std::fseek(fc, 0, SEEK_END);
-            const long size = std::ftell(fc);
-            std::fseek(fc, 0, SEEK_SET);
-            if (nn > 0 && size > 0) {
-                code.resize((size_t) size);
-                hit = std::fread(code.data(), 1, (size_t) size, fc) == (size_t) size;
-                lowered_name.assign(name, nn);
-            }
-        }
-        if (fc) std::fclose(fc);
-        if (fn) std::fclose(fn);
-        if (hit) return true;
-        code.clear();
-    }
-    hiprtcProgram prog = nullptr;
-    if (r.create(&prog, unit.c_str(), "vv_rtc_unit.hip", 5, header_src, header_name) != HIPRTC_SUCCESS) { log = "hiprtcCreateProgram failed"; return false; }
-    bool ok = r.add_name(prog, expr) == HIPRTC_SUCCESS;
     const auto t0 = std::chrono::steady_clock::now();
     if (ok) ok = r.compile(prog, (int) (sizeof opts / sizeof opts[0]), opts) == HIPRTC_SUCCESS;
     vv_rtc_compile_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -148,17 +112,6 @@ bool rtc_compile(char kind, int precision, uint32_t flags, int num_chains, const
     if (ok) ok = r.code_size(prog, &n) == HIPRTC_SUCCESS && n > 0;
     if (ok) { code.resize(n); ok = r.code(prog, code.data()) == HIPRTC_SUCCESS; }
     (void) r.destroy(&prog);
-    if (ok && !cache_base.empty()) {      // written under a temporary name first: another process may be reading or writing the same entry
-        const std::string tmp = cache_base + ".tmp" + std::to_string((long) getpid());
-        std::FILE* f = std::fopen(tmp.c_str(), "wb");
-        if (f) {
-            const bool written = std::fwrite(code.data(), 1, code.size(), f) == code.size();
-            std::fclose(f);
-            std::FILE* fn = written ? std::fopen((cache_base + ".name").c_str(), "wb") : nullptr;
-            if (fn) { (void) std::fwrite(lowered_name.data(), 1, lowered_name.size(), fn); std::fclose(fn); (void) std::rename(tmp.c_str(), (cache_base + ".co").c_str()); }
-            else (void) std::remove(tmp.c_str());
-        }
-    }
     return ok;
 }
 

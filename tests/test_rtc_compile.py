@@ -31,15 +31,3 @@ def test_hiprtc_compiles_stage_sets_for_gfx950_without_a_gpu(checker, kind, prec
     r = subprocess.run([checker, kind, str(prec), str(flags), str(links)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout[-3000:] + r.stderr[-2000:]
     assert f"vv_kernel_{kind.lower()}" in r.stdout and f"Lj{flags}E" in r.stdout      # the instantiation asked for, by its mangled name
-
-
-def test_on_disk_cache_of_run_time_kernels(checker, tmp_path):
-    """VVHIP_RTC_CACHE=<dir>: the second process takes the code object from the directory (no compiler time), another instantiation is another entry."""
-    env = dict(os.environ, VVHIP_RTC_CACHE=str(tmp_path))
-    outs = [subprocess.run([checker, "B", "1", str(0x1 | 0x10 | 0x200 | 0x800), links], capture_output=True, text=True, timeout=300, env=env).stdout for links in ("2", "2", "4")]
-    assert all(o.startswith("OK") for o in outs), outs
-    seconds = [float(o.split("seconds=")[1].split()[0]) for o in outs]
-    size = [o.split("bytes=")[1].split()[0] for o in outs]
-    assert seconds[0] > 0.2 and seconds[1] < 0.05 and seconds[2] > 0.2, seconds
-    assert size[0] == size[1]
-    assert len([f for f in os.listdir(tmp_path) if f.endswith(".co")]) == 2
