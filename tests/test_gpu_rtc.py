@@ -59,6 +59,7 @@ def _trajectory(spec, cfg, middle, prec, mode, steps=6):
 @pytest.mark.parametrize("cfg,hbonds,middle,prec", [
     ("C3", False, True, "mixed"), ("C3", True, True, "mixed"), ("C3", False, False, "mixed"), ("C4", False, True, "mixed"),
     ("C5", True, True, "mixed"), ("C2", True, True, "mixed"), ("C3", True, True, "single"), ("C3", False, True, "double"),
+    ("C2", True, True, "single"), ("C2", True, False, "double"),      # SETTLE (its two solvers allow contraction: the same fusions in both builds)
 ])
 def test_run_time_kernel_equals_compiled_kernel(cfg, hbonds, middle, prec):
     spec = S.make_config(cfg, 0.08 if cfg in ("C3", "C4") else 1.0, hbonds=hbonds)
@@ -74,16 +75,17 @@ def test_run_time_kernel_equals_compiled_kernel(cfg, hbonds, middle, prec):
         assert np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b).view(np.uint8)), f"{what} differs between the compiled and the run-time kernel"
 
 
-@pytest.mark.parametrize("what", ["large", "sharded"])
+@pytest.mark.parametrize("what", ["large", "sharded", "large rigid water"])
 def test_run_time_kernel_equals_compiled_kernel_large_and_sharded(what):
     """The arithmetic work-item layout with the stand-alone chain launch (C3x8, 0.9 M particles) and the mailbox stage sets of a sharded plan
     (one rank of two, its own handle as the only peer): run-time kernels against the compiled ones, bit for bit."""
     D = pkg.distributed
-    spec = S.make_config("C3", 8.0 if what == "large" else 0.08)
+    cfg = "C2" if "water" in what else "C3"
+    spec = S.make_config("C2", 30.0, hbonds=True) if cfg == "C2" else S.make_config("C3", 8.0 if what == "large" else 0.08)
     res = []
     for mode in (0, 2):
         I.Context.rtc_mode(mode)
-        it = _integrator("C3", True, spec)
+        it = _integrator(cfg, True, spec)
         kw = {"shard": D.shard_bounds(spec, 2)[0]} if what == "sharded" else {}
         ctx = I.Context(spec, it, precision="mixed", force_provider="tether", **kw)
         try:
