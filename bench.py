@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- MD steps/s (ns/day) of the integrator hot path on the 100k-atom Drude ionic-liquid box.
 
-  python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W      (N > 1: one rank per GPU -- under torch.distributed.run, or plain: the
+                                                      command then starts `python -m torch.distributed.run ... bench.py` itself)
 
 A "step" is one VVIntegrator step of the whole box: synthetic force provider (plays OpenMM's calcForcesAndEnergy,
 IN the timed region) + the fused middle-scheme integrator path (TGNH thermostat, Drude hard wall).  State is
@@ -48,6 +49,46 @@ def kernel_times(ctx, reps, batches):
                    "back to back: two HIP events around %d launches of the same kernel, median of %d" % (reps, reps, batches)}
 
 
+def kill_group(child):
+    """End a child started with start_new_session=True together with everything it started, and reap it."""
+    import signal
+    for sig in (signal.SIGTERM, signal.SIGKILL):
+        try:
+            os.killpg(child.pid, sig)
+        except (ProcessLookupError, PermissionError):
+            break
+        try:
+            child.wait(timeout=10)
+            break
+        except Exception:                                        # noqa: BLE001
+            continue
+
+
+def launch_ranks(n, argv):
+    """`python3 bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, the way the driver's documented
+    command does (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`),
+    as a CHILD process -- this process has not imported torch or touched the GPU and never will (an exec from a process that has
+    initialised the GPU takes the box down; a child does not) -- pass its stdout / stderr through and return its exit code."""
+    import socket, subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.join(ROOT, "bench.py")] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL and the mailbox's hipIpc handles need on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    sys.stderr.write("bench.py: --gpus %d without a launcher: starting %s\n" % (n, " ".join(cmd[1:9])))
+    child = subprocess.Popen(cmd, env=env, stdin=subprocess.DEVNULL, start_new_session=True)
+    try:
+        return child.wait()
+    except BaseException:                                        # Ctrl-C / SIGTERM of the parent: take the ranks along
+        kill_group(child)
+        raise
+
+
 def rocprof_child(args, extra, seconds=240):
     """Kernel durations of this workload as rocprofv3 reports them, measured live: a child process
         rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py <same workload> --child
@@ -69,10 +110,18 @@ def rocprof_child(args, extra, seconds=240):
         cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", tmp, "-o", "run", "--", sys.executable, os.path.join(ROOT, "bench.py"),
                "--child", "--precision", args.precision, "--forces", args.forces, "--steps-per-graph", str(args.steps_per_graph)] + extra
         env = dict(os.environ, VVHIP_BENCH_CHILD="1", TMPDIR="/tmp")
-        r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=seconds)
+        # own session + output to a file: on a time-out the WHOLE group goes (rocprofv3 is a wrapper; its python grandchild would
+        # otherwise keep the pipes open and share the GPU with the timed region of this process)
+        with open(os.path.join(tmp, "child.log"), "wb") as log:
+            child = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=log, stderr=subprocess.STDOUT, stdin=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = child.wait(timeout=seconds)
+            except subprocess.TimeoutExpired:
+                kill_group(child)
+                return "rocprofv3 child timed out after %d s (its process group was killed)" % seconds
         files = glob.glob(os.path.join(tmp, "**", "*kernel_stats.csv"), recursive=True)
         if not files:
-            return "rocprofv3 child wrote no kernel_stats.csv (exit code %d)" % r.returncode
+            return "rocprofv3 child wrote no kernel_stats.csv (exit code %d)" % rc
         out = {}
         for row in csv.DictReader(open(files[0])):
             m = re.match(r"void vv::(vv_kernel_\w+)<([^>]*)>", row["Name"])
@@ -233,6 +282,10 @@ def main():
     ap.add_argument("--no-rocprof", action="store_true", help="do not spawn the rocprofv3 child runs; roofline.frac then comes from the dispatch-timestamp clock")
     ap.add_argument("--hbonds", action="store_true", help="constraints solved in-kernel: HBonds (SHAKE) for the ionic liquids, rigid water (SETTLE) for C2; not the headline workload")
     args = ap.parse_args()
+
+    # ---- N > 1 without a launcher: become the launcher (child process; nothing below runs in this process)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     # ---- rocprofv3 child runs, BEFORE this process initialises the GPU (kernel durations as the profiler reports them, measured live)
     prof = {}

@@ -64,3 +64,36 @@ def test_odd_step_counts_and_tails():
     line = _bench("--gpus", "1", "--steps", "21", "--warmup", "5", "--no-cpu-baseline", "--large-n", "none")
     assert "1 replay(s) of a 20-step hipGraph" in line["config"]["launch"] and "+ 1 host-launched" in line["config"]["launch"]
     assert line["value"] > 1000
+
+
+def test_plain_command_with_several_gpus_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2 ...` WITHOUT a launcher (how the driver's 1-GPU command looks, extended to N): bench.py must start
+    torch.distributed.run itself as a child process.  No GPU here: every rank stops at "needs a GPU" -- which proves that two ranks with
+    RANK / WORLD_SIZE set were started (under the old code the parent itself exited with a usage error) and that the exit code comes back."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["HIP_VISIBLE_DEVICES"] = ""          # also on a GPU box: this test is about the launcher only
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
+                        "--backend", "gloo", "--share-device"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode != 0
+    assert "launch with torch.distributed.run" not in r.stderr, r.stderr[-2000:]
+    assert "starting -m torch.distributed.run --nnodes=1 --nproc-per-node=2" in r.stderr, r.stderr[-2000:]
+    assert r.stderr.count("bench.py needs a GPU") >= 1, r.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_plain_command_two_ranks_one_gpu():
+    """The scaling tier's command as the driver would type it by hand -- no launcher -- with two ranks sharing this box's one GPU:
+    rc 0, one JSON line, n_gpus == 2, both ranks in the process group."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-device", "--steps", "20", "--warmup", "5",
+                        "--no-cpu-baseline", "--large-n", "none"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 20 and line["value"] > 10
+    assert line["config"]["exchange"]["process_group_ranks"] == 2
+    one = _bench("--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--large-n", "none", "--no-rocprof")
+    assert one["n_gpus"] == 1 and "exchange" not in one["config"]

@@ -7,7 +7,7 @@ EXTRA=${EXTRA:-}
 for mode in graph eager; do
   EX=""; [ $mode = eager ] && EX="--eager"
   rm -rf /tmp/tl_$mode
-  rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_$mode -o run -- python3 $R/bench.py $EXTRA --large-n none --steps 2000 --warmup 200 --no-cpu-baseline $EX > /tmp/tl_$mode.log 2>&1
+  rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_$mode -o run -- python3 $R/bench.py $EXTRA --large-n none --steps 2000 --warmup 200 --no-cpu-baseline --no-rocprof $EX > /tmp/tl_$mode.log 2>&1
   echo "== $mode: $(tail -1 /tmp/tl_$mode.log | cut -c1-120)"
   python3 - /tmp/tl_$mode <<'PY'
 import csv, glob, sys, re
