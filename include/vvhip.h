@@ -231,6 +231,10 @@ int vvhip_mailbox_create(vvhip_plan* plan, int nranks, int rank, void* handle64)
 int vvhip_mailbox_connect(vvhip_plan* plan, const void* handles);
 int vvhip_mailbox_status(vvhip_plan* plan, int32_t* active, int32_t* timed_out);
 int vvhip_mailbox_destroy(vvhip_plan* plan);
+/* After vvhip_mailbox_connect: *shared_device = 1 if a peer's box lives on this rank's own device (several ranks on one GPU: test
+ * set-ups) -- kernel B then keeps the explicit work-item layout next to the exchange; *arithmetic_layout = 1 if kernel B of this plan
+ * takes the arithmetic layout together with the mailbox exchange. */
+int vvhip_mailbox_layout(vvhip_plan* plan, int32_t* shared_device, int32_t* arithmetic_layout);
 
 /* ---------------------------------------------------------------- kernel-interface level
  * One entry per KernelImpl virtual, for use inside OpenMM where constraint solvers run between them. */

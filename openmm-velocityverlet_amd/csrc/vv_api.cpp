@@ -166,6 +166,11 @@ struct vvhip_plan {
     std::vector<void*> mb_opened;                 // hipIpcOpenMemHandle mappings to close
     int mb_ranks = 0, mb_rank = 0;
     bool mb_on = false;
+    // A peer's box lives on THIS device (several ranks sharing one GPU: test set-ups): found out by vvhip_mailbox_connect.  Such ranks'
+    // kernels compete for the same CUs, and a large capped grid of polling thermostat waves can keep the other process's kernels off
+    // the device until the bounded waits run out -- kernel B then keeps the explicit layout next to the mailbox.
+    bool mb_shared_device = false;
+    int periodic_mb = -1;          // arithmetic layout of kernel B next to the mailbox: -1 = unless a peer shares the device, 0 / 1 = VVHIP_PERIODIC_MB
     // Sticky health word in pinned host memory, written by the kernels with system-scope stores when something goes wrong and
     // read by the host without synchronising: [0] a mailbox wait on the peers ran out (the ranks have diverged), [1] a fixed-point
     // accumulator left its range (|sum| x scale >= 2^62: the thermostat would see garbage).  Checked at the entry of the run loops
@@ -473,10 +478,16 @@ int run_a(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
     if (vv::vv_generic_count[0] != g0) { p->generic_launches[0]++; p->generic_flags[0] = vv::vv_generic_flags[0]; }
     return VVHIP_OK;
 }
+// Kernel B takes the arithmetic layout whenever the plan has one -- next to the mailbox exchange only where every rank owns its device
+// (mb_shared_device)
+bool periodic_b(const vvhip_plan* p, bool mailbox) {
+    if (!(p->hp.per.enabled && p->periodic_kernels)) return false;
+    if (!mailbox) return true;
+    return p->periodic_mb >= 0 ? p->periodic_mb != 0 : !p->mb_shared_device;
+}
 int run_b(vvhip_plan* p, uint32_t flags) {
     if (p->mass_tab_b) { flags |= vv::B_MTAB; TRY(ensure_mass_table(p)); }
-    // (not next to the mailbox exchange: that combination timed out when two ranks shared one GPU, the only multi-rank set-up at hand)
-    if (p->hp.per.enabled && p->periodic_kernels && !(flags & vv::B_MAILBOX)) flags |= vv::B_PERIODIC;
+    if (periodic_b(p, (flags & vv::B_MAILBOX) != 0)) flags |= vv::B_PERIODIC;
     if ((flags & vv::B_SHAKE) && p->shake_mode == 0) flags |= vv::B_SHAKE_GS;
     debug_stall(p);
     ScopedTimer t(p, T_B, true);
@@ -585,6 +596,7 @@ int vvhip_plan_create(const vvhip_system_desc* system, const vvhip_params* param
         if (const char* e = std::getenv("VVHIP_SHAKE_MODE")) p->shake_mode = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("VVHIP_PERIODIC_K")) p->periodic_kernels = std::atoi(e) != 0;
         if (const char* e = std::getenv("VVHIP_PERIODIC_A")) p->periodic_a = std::atoi(e) != 0;
+        if (const char* e = std::getenv("VVHIP_PERIODIC_MB")) p->periodic_mb = std::atoi(e) != 0 ? 1 : 0;
         p->mass_tab_a = vv::sf_kernels_use_mass_table(0);
         p->mass_tab_b = vv::sf_kernels_use_mass_table(1);
         if (const char* e = std::getenv("VVHIP_MTAB_A")) p->mass_tab_a = std::atoi(e) != 0;
@@ -664,6 +676,9 @@ int vvhip_bind(vvhip_plan* p, const vvhip_buffers* b) {
         if (b->velm != o.velm) p->mass_tab_valid = false;
         if (!same) drop_graphs(p);
     }
+    // a re-bind that moves the plan to another stream: whatever the plan still has in flight on the old one (fills, steps) must be
+    // complete before work enqueued on the new one can touch the same buffers
+    if (p->bound && p->stream != (hipStream_t) b->stream) HIP_TRY(p, hipStreamSynchronize(p->stream));
     p->buf = *b;
     p->stream = (hipStream_t) b->stream;
     if (p->bound) return VVHIP_OK;      // re-binding only swaps the caller-owned pointers
@@ -742,7 +757,12 @@ int vvhip_bind(vvhip_plan* p, const vvhip_buffers* b) {
         }
     }
     p->bound = true;
-    return upload_lane_const(p);
+    TRY(upload_lane_const(p));
+    // The fills above are ordered in the plan's stream only.  A host may take vvhip_force_extra() / the plan's pos_delta pointer
+    // right after this call and write through a blocking copy or another stream: bind is not on the hot path, so it returns
+    // with every fill complete.
+    HIP_TRY(p, hipStreamSynchronize(p->stream));
+    return VVHIP_OK;
 }
 
 int vvhip_set_params(vvhip_plan* p, const vvhip_params* q) {
@@ -832,7 +852,7 @@ int vvhip_algorithmic_bytes(const vvhip_plan* p, int32_t* bytes_a, int32_t* byte
     const int x = p->hp.precision == VVHIP_SINGLE ? 16 : 32;                       // posq (+ posqCorrection in mixed mode; double4 in double mode)
     const int xr = p->hp.precision == VVHIP_DOUBLE ? 32 : 16;                      // posq alone
     const bool per = p->hp.per.enabled && p->periodic_kernels;
-    const bool per_a = per && (p->periodic_a || shake_on(p)), per_b = per && !use_mailbox(p);      // as run_a / run_b decide
+    const bool per_a = per && (p->periodic_a || shake_on(p)), per_b = periodic_b(p, use_mailbox(p));      // as run_a / run_b decide
     const int ia = per_a ? 0 : 6, ib = per_b ? 0 : 6;
     if (use_rekick(p)) { *bytes_a = v + 24 + ia; *bytes_b = v + 24 + x + v + x + ib; }    // A: R velm, R force;  B: R velm, R force, R pos, W velm, W pos
     else { *bytes_a = v + 24 + v + ia; *bytes_b = v + x + v + x + ib; }                   // A: R velm, R force, W velm;  B: R velm, R pos, W velm, W pos
@@ -852,7 +872,8 @@ int vvhip_step_middle_phase(vvhip_plan* p, int phase, uint32_t random_index) {
     const uint32_t drift = vv::B_DRIFT_MIDDLE | tail_flags(p) | cons_b(p) | (rk ? vv::B_KICK : 0);
     if (!p->hp.has_nh) {                                   // API:251: no NH particles, nothing to reduce
         if (phase != 0) return fail(p, VVHIP_ERR_INVALID, "phase out of range");
-        TRY(run_a(p, kick, random_index));
+        // (with the cos perturbation the kick caches cos(kz) here too: vvhip_set_params rebuilds the stale forceExtra from it)
+        TRY(run_a(p, kick | (cos_on(p) ? vv::A_CZ_STORE : 0u), random_index));
         return run_b(p, drift);
     }
     if (!cos_on(p)) {
@@ -1152,7 +1173,7 @@ static int prepare_slot(vvhip_plan* p, int q, int steps_per_graph, const void* s
     // afterwards, because nothing has run yet.  A replay moves them to the graph's end (vvhip_run_graph).
     const int parity0 = p->parity;
     const uint32_t random0 = p->random_pos;
-    const bool fextra_dirty0 = p->fextra_dirty;
+    const bool fextra_dirty0 = p->fextra_dirty, fextra_virtual0 = p->fextra_virtual;
     p->parity = q & 1;
     hipGraph_t graph = nullptr;
     hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
@@ -1164,7 +1185,7 @@ static int prepare_slot(vvhip_plan* p, int q, int steps_per_graph, const void* s
     p->capturing = false;
     e = hipStreamEndCapture(s, &graph);
     g.random_end = p->random_pos;
-    p->parity = parity0; p->random_pos = random0; p->fextra_dirty = fextra_dirty0;
+    p->parity = parity0; p->random_pos = random0; p->fextra_dirty = fextra_dirty0; p->fextra_virtual = fextra_virtual0;
     if (rc != VVHIP_OK) { if (graph) (void) hipGraphDestroy(graph); return rc; }
     if (e != hipSuccess) return hip_fail(p, e, "hipStreamEndCapture");
     e = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
@@ -1204,6 +1225,7 @@ int vvhip_run_graph(vvhip_plan* p, int nsteps, int steps_per_graph, const void* 
         for (; done + steps_per_graph <= nsteps; done += steps_per_graph) HIP_TRY(p, hipGraphLaunch(g.exec, s));
         p->random_pos = g.random_end;                // an even number of steps: the parity is where it was
         if (!middle && extra_flags(p)) p->fextra_dirty = true;
+        if (middle && cos_on(p) && !p->hp.has_ld && !p->hp.has_ef) p->fextra_virtual = true;    // what the replayed steps' phase 0 would have set
     }
     for (; done < nsteps; done++) TRY(plan_step(p, site, k_tether, k_drude, false));
     return VVHIP_OK;
@@ -1361,6 +1383,7 @@ int vvhip_peer_access(int device, int peer_device, int32_t* can_access) {
 // ---- xGMI mailbox (include/vvhip.h): create -> exchange the 64-byte handles by any means -> connect
 static void mailbox_release(vvhip_plan* p) {
     p->mb_on = false;
+    p->mb_shared_device = false;
     for (void* m : p->mb_opened) (void) hipIpcCloseMemHandle(m);
     p->mb_opened.clear();
     if (p->d_mb_peers) { (void) hipFree(p->d_mb_peers); p->d_mb_peers = nullptr; }
@@ -1402,6 +1425,11 @@ int vvhip_mailbox_connect(vvhip_plan* p, const void* handles) {
         HIP_TRY(p, hipIpcOpenMemHandle(&m, h, hipIpcMemLazyEnablePeerAccess));
         p->mb_opened.push_back(m);
         peers[r] = (unsigned long long*) m;
+        // whose memory is it?  A box on this very device means that rank shares the GPU with this one
+        hipPointerAttribute_t attr;
+        int dev = -1;
+        if (hipGetDevice(&dev) == hipSuccess && hipPointerGetAttributes(&attr, m) == hipSuccess && attr.device == dev) p->mb_shared_device = true;
+        else (void) hipGetLastError();
     }
     HIP_TRY(p, hipMalloc((void**) &p->d_mb_peers, peers.size() * sizeof(void*)));
     HIP_TRY(p, hipMemcpy(p->d_mb_peers, peers.data(), peers.size() * sizeof(void*), hipMemcpyHostToDevice));
@@ -1420,6 +1448,12 @@ int vvhip_mailbox_status(vvhip_plan* p, int32_t* active, int32_t* timed_out) {
             *timed_out = (int32_t) ctl[0];
         }
     }
+    return VVHIP_OK;
+}
+int vvhip_mailbox_layout(vvhip_plan* p, int32_t* shared_device, int32_t* arithmetic_layout) {
+    NEED_BOUND(p);
+    if (shared_device) *shared_device = p->mb_shared_device ? 1 : 0;
+    if (arithmetic_layout) *arithmetic_layout = (use_mailbox(p) && periodic_b(p, true)) ? 1 : 0;
     return VVHIP_OK;
 }
 int vvhip_mailbox_destroy(vvhip_plan* p) {

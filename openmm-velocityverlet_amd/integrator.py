@@ -435,6 +435,13 @@ class Context:
         H.check(H.lib.vvhip_mailbox_status(self.plan, C.byref(a), C.byref(t)), self.plan)
         return bool(a.value), bool(t.value)
 
+    def mailbox_layout(self):
+        """(shared_device, arithmetic_layout): whether a peer's box lives on this rank's own device, and whether kernel B takes the
+        arithmetic work-item layout next to the exchange."""
+        a, t = C.c_int32(0), C.c_int32(0)
+        H.check(H.lib.vvhip_mailbox_layout(self.plan, C.byref(a), C.byref(t)), self.plan)
+        return bool(a.value), bool(t.value)
+
     def mailbox_destroy(self):
         H.check(H.lib.vvhip_mailbox_destroy(self.plan), self.plan)
 

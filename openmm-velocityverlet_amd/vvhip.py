@@ -128,6 +128,7 @@ def _load():
         "vvhip_comm_unique_id": [vp], "vvhip_comm_init": [vp, vp, C.c_int, C.c_int], "vvhip_comm_destroy": [vp],
         "vvhip_mailbox_create": [vp, C.c_int, C.c_int, vp], "vvhip_mailbox_connect": [vp, vp],
         "vvhip_mailbox_status": [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)], "vvhip_mailbox_destroy": [vp],
+        "vvhip_mailbox_layout": [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
         "vvhip_time_kernel": [vp, C.c_int, u32, C.c_int, P(dbl)],
         "vvhip_generic_launches": [vp, P(C.c_int64 * 2), P(u32 * 2)],
         "vvhip_rtc_stats": [P(C.c_int64 * 3), P(C.c_double)],

@@ -159,9 +159,59 @@ def mailbox(rank, world):
         print("MAILBOX OK", flush=True)
 
 
+def mailbox_periodic(rank, world):
+    """Mailbox exchange NEXT TO the arithmetic work-item layout of kernel B (a box large enough to get one: C3x2 = 222 000 particles
+    per default, VV_MBP_CONFIG overrides), two processes on GPU 0, against one process.  The environment decides the variant:
+    VVHIP_PERIODIC_MB=1 forces the layout on although the ranks share the device, VVHIP_CAP_A / VVHIP_CAP_B cap both processes' grids so
+    that their kernels can be resident together."""
+    I = pkg.integrator
+    tiles = float(os.environ.get("VV_MBP_CONFIG", "2"))
+    spec = S.make_config("C3", tiles)
+    bounds = D.shard_bounds(spec, world)
+
+    def make(shard):
+        it = I.VVIntegrator(333.0, 10, 1.0, 40, 0.001)
+        it.setMaxDrudeDistance(0.02)
+        return it, I.Context(spec, it, precision="mixed", force_provider="tether", shard=shard, device=0)
+    it, ctx = make(bounds[rank])
+    handles = [None] * world
+    dist.all_gather_object(handles, ctx.mailbox_create(world, rank))
+    ctx.mailbox_connect(b"".join(handles))
+    shared, arith = ctx.mailbox_layout()
+    assert shared, "two ranks on GPU 0: vvhip_mailbox_connect must notice that the peer's box lives on this device"
+    want = os.environ.get("VVHIP_PERIODIC_MB")
+    assert arith == (want == "1"), (arith, want)
+    dist.barrier()
+    it.step(6)
+    ctx.run_graph(24, steps_per_graph=8)
+    x, v, nh = ctx.getPositions(), ctx.getVelocities(), ctx.getNHState()
+    active, timed_out = ctx.mailbox_status()
+    parts = [None] * world
+    dist.all_gather_object(parts, (x, v, list(nh.ke2), list(nh.vscale), bool(timed_out)))
+    dist.barrier()
+    ctx.mailbox_destroy()
+    ctx.close()
+    if rank == 0:
+        if any(p[4] for p in parts):
+            print(f"MAILBOX PERIODIC TIMEOUT (arithmetic layout {arith}, CAP_A={os.environ.get('VVHIP_CAP_A')}, CAP_B={os.environ.get('VVHIP_CAP_B')})", flush=True)
+            return
+        it1, ctx1 = make(None)
+        it1.step(30)
+        x1, v1, nh1 = ctx1.getPositions(), ctx1.getVelocities(), ctx1.getNHState()
+        ctx1.close()
+        xs = np.concatenate([p[0] for p in parts]); vs = np.concatenate([p[1] for p in parts])
+        ex = np.abs(xs - x1).max() / np.abs(x1).max(); ev = np.abs(vs - v1).max() / np.abs(v1).max()
+        assert ex < 1e-11 and ev < 1e-11, (ex, ev)
+        for p in parts:
+            assert p[2] == parts[0][2] and p[3] == parts[0][3]
+            assert np.allclose(p[2], list(nh1.ke2), rtol=1e-12) and np.allclose(p[3], list(nh1.vscale), rtol=0, atol=1e-13)
+        print(f"MAILBOX PERIODIC OK (arithmetic layout {arith}, {spec.num_atoms} particles, pos {ex:.1e}, vel {ev:.1e}, "
+              f"CAP_A={os.environ.get('VVHIP_CAP_A')}, CAP_B={os.environ.get('VVHIP_CAP_B')})", flush=True)
+
+
 if __name__ == "__main__":
     dist.init_process_group(backend="gloo")
     r, w = dist.get_rank(), dist.get_world_size()
-    {"protocol": protocol, "gpu": gpu, "mailbox": mailbox}[sys.argv[1]](r, w)
+    {"protocol": protocol, "gpu": gpu, "mailbox": mailbox, "mailbox_periodic": mailbox_periodic}[sys.argv[1]](r, w)
     dist.barrier()
     dist.destroy_process_group()

@@ -17,6 +17,10 @@ if [ "$CFG" = "C3" ]; then
     python3 "$ROOT/bench.py" $EXTRA 2>"$OUT/bench_$CFG.stderr" | tail -1 > "$OUT/bench_${CFG}${SUF}_mixed.json"
     python3 "$ROOT/bench.py" $EXTRA --gpus 1 --steps 20 --warmup 5 2>>"$OUT/bench_$CFG.stderr" | tail -1 > "$OUT/bench_${CFG}${SUF}_mixed_driver_flags.json"
     STEPS="--steps 4000 --warmup 400"; PSTEPS="--steps 400 --warmup 100"
+elif [[ "$CFG" != C3x* ]]; then          # the other BASELINE configurations (C1, C2, C4, C5): long run + the driver's flags
+    python3 "$ROOT/bench.py" --config "$CFG" $EXTRA --large-n none --no-cpu-baseline 2>"$OUT/bench_$CFG.stderr" | tail -1 > "$OUT/bench_${CFG}${SUF}_mixed.json"
+    python3 "$ROOT/bench.py" --config "$CFG" $EXTRA --large-n none --no-cpu-baseline --gpus 1 --steps 20 --warmup 5 2>>"$OUT/bench_$CFG.stderr" | tail -1 > "$OUT/bench_${CFG}${SUF}_mixed_driver_flags.json"
+    STEPS="--steps 4000 --warmup 400"; PSTEPS="--steps 400 --warmup 100"
 else
     python3 "$ROOT/bench.py" --config "$CFG" $EXTRA --large-n none --steps 200 --warmup 40 --no-cpu-baseline 2>"$OUT/bench_$CFG.stderr" | tail -1 > "$OUT/bench_${CFG}${SUF}_mixed.json"
     STEPS="--steps 100 --warmup 20"; PSTEPS="--steps 40 --warmup 10"
