@@ -880,6 +880,10 @@ int vvhip_step_middle_phase(vvhip_plan* p, int phase, uint32_t random_index) {
         if (phase == 0) return run_ke(p, kick, random_index, false);
         if (phase == 1) return run_chain_and_b(p, vv::B_SCALE | drift, false);
     } else if (use_moments(p)) {                           // bias moment and group moments in one launch
+#ifdef VV_EXP_B_OWN_COS
+        if (phase == 0) return run_a(p, kick | vv::A_BIAS | vv::A_KE | vv::A_KE_MOM, random_index);
+        if (phase == 1) return run_chain_and_b(p, vv::B_SCALE | vv::B_UNBIAS | vv::B_KE_MOM | drift, true);
+#endif
         if (phase == 0) return run_a(p, kick | vv::A_BIAS | vv::A_CZ_STORE | vv::A_KE | vv::A_KE_MOM, random_index);
         if (phase == 1) return run_chain_and_b(p, vv::B_SCALE | vv::B_UNBIAS | vv::B_CZ_LOAD | vv::B_KE_MOM | drift, true);
     } else {                                               // API:252-259: bias -> remove -> scale -> restore

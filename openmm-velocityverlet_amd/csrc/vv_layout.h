@@ -39,4 +39,48 @@ constexpr uint32_t META_BIG_FIRST = 1u << 29;  // leader of the FIRST chunk of s
 
 inline uint32_t meta_role(uint32_t m) { return m & META_ROLE_MASK; }
 
+// ---- cos(x) for the cos-acceleration stages (K/cosineAccelerate.cu:8, 26, 70, 82: `cos(2*3.1415926*z*invBoxZ)`, double in every mode)
+// The library cosine of the device (ocml) spends ~150 instructions per lane on an argument reduction that copes with |x| up to 1e308;
+// the argument here is 2 pi z / Lz, a few turns at most.  One Cody-Waite step with the tail kept (k pi/2 subtracted as a double-double:
+// product and rounding error of k * PIO2_1 by fma, the second part of pi/2 by another), then the two fdlibm kernels (k_sin.c / k_cos.c
+// polynomials, the tail passed as their `y`) and a select on k mod 4: ~45 instructions.  Only +, *, fma and rint, all correctly
+// rounded on gfx950 and on the host alike, so the host check (tests/cpp/cos_check.cpp: 2^22 arguments as the kernels form them, 2^22
+// spread over |x| <= 1024 with half of them pushed next to multiples of pi/2, against quad precision) holds for the device bit for bit:
+// worst error 0.79 ulp.  `ok` = false where the short reduction is not enough -- |x| > 1024, or the argument within 2^-36 of a multiple
+// of pi/2, where the third part of pi/2 starts to matter -- the caller then takes the library cosine (wave-uniform branch, practically
+// never taken: probability ~1e-11 per lane for positions that are not adversarial).
+#if defined(__HIP__) || defined(__HIPCC_RTC__)
+#define VV_HOST_DEVICE __host__ __device__
+#else
+#define VV_HOST_DEVICE
+#endif
+VV_HOST_DEVICE inline double cos_short_range(double x, bool& ok) {
+    const double INV_PIO2 = 6.36619772367581382433e-01;
+    const double PIO2_1 = 1.57079632679489655800e+00;    // the double next to pi/2
+    const double PIO2_1T = 6.12323399573676603587e-17;   // pi/2 - PIO2_1, rounded
+    const double k = __builtin_rint(x * INV_PIO2);
+    const double p = k * PIO2_1, pe = __builtin_fma(k, PIO2_1, -p);      // p + pe = k * PIO2_1 exactly
+    const double r0 = x - p;                                              // exact (x / p in [1/2, 2], or p = 0)
+    const double t = __builtin_fma(-k, PIO2_1T, -pe);
+    const double rh = r0 + t;
+    const double bb = rh - r0;
+    const double rl = (r0 - (rh - bb)) + (t - bb);                        // rh + rl = r0 + t (two-sum)
+    ok = __builtin_fabs(x) <= 1024.0 && __builtin_fabs(rh) >= 0x1p-36;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double z = rh * rh, w = z * z;
+    const double rs = __builtin_fma(z, __builtin_fma(z, S4, S3), S2) + z * w * __builtin_fma(z, S6, S5);
+    const double v = z * rh;
+    const double sn = rh - ((z * (0.5 * rl - v * rs) - rl) - v * S1);
+    const double rc = z * __builtin_fma(z, __builtin_fma(z, C3, C2), C1) + (w * w) * __builtin_fma(z, __builtin_fma(z, C6, C5), C4);
+    const double hz = 0.5 * z;
+    const double ww = 1.0 - hz;
+    const double cs = ww + (((1.0 - ww) - hz) + (z * rc - rh * rl));
+    const int n = (int) k & 3;                                            // cos(r + n pi/2): cos, -sin, -cos, sin
+    const double res = (n & 1) ? sn : cs;
+    return (n == 1 || n == 2) ? -res : res;
+}
+
 }  // namespace vv

@@ -98,9 +98,15 @@ bool rtc_compile(char kind, int precision, uint32_t flags, int num_chains, const
     const std::string arch_opt = "--offload-arch=" + arch;
     char links[40];
     std::snprintf(links, sizeof links, "-DVV_SF_CHAIN_LINKS=%d", num_chains >= 1 && num_chains <= 4 ? num_chains : 3);
-    const char* opts[] = {arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-kernarg-preload-count=16", links};
+    std::vector<const char*> opts = {arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-kernarg-preload-count=16", links};
+#ifdef VV_EXP_LIN_PREP
+    opts.push_back("-DVV_EXP_LIN_PREP");
+#endif
+#ifdef VV_EXP_LIBM_COS
+    opts.push_back("-DVV_EXP_LIBM_COS");
+#endif
     const auto t0 = std::chrono::steady_clock::now();
-    if (ok) ok = r.compile(prog, (int) (sizeof opts / sizeof opts[0]), opts) == HIPRTC_SUCCESS;
+    if (ok) ok = r.compile(prog, (int) opts.size(), opts.data()) == HIPRTC_SUCCESS;
     vv_rtc_compile_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     size_t n = 0;
     if (r.log_size(prog, &n) == HIPRTC_SUCCESS && n > 1) { log.resize(n); (void) r.log(prog, &log[0]); }
@@ -131,7 +137,15 @@ hipFunction_t rtc_kernel(char kind, int precision, uint32_t flags, int num_chain
         std::snprintf(tag, sizeof tag, "%c:0x%x", kind, flags);
         char any[8];
         std::snprintf(any, sizeof any, "%c:*", kind);
-        if (std::strstr(deny, tag) || std::strstr(deny, any)) { cache[key] = nullptr; return nullptr; }
+        // whole comma-separated entries only ("A:0x13" must not match inside "A:0x1300")
+        bool denied = false;
+        for (const char* q = deny; *q && !denied;) {
+            const char* e = std::strchr(q, ',');
+            const size_t len = e ? (size_t) (e - q) : std::strlen(q);
+            denied = (len == std::strlen(tag) && std::strncmp(q, tag, len) == 0) || (len == std::strlen(any) && std::strncmp(q, any, len) == 0);
+            q += len + (e ? 1 : 0);
+        }
+        if (denied) { cache[key] = nullptr; return nullptr; }
     }
     hipDeviceProp_t prop;
     std::string why;

@@ -325,12 +325,14 @@ class _System(C.Structure):
 _LIBS: Dict[Tuple[str, str], C.CDLL] = {}
 
 
-def lib(prec: str) -> C.CDLL:
-    key = ("oracle", prec)
+def lib(prec: str, fmad: bool = False) -> C.CDLL:
+    """fmad: the build with contracted multiply-adds (`make -C oracle fmad`, oracle/Makefile: OPT_FMAD) -- NVRTC's default for the
+    reference's kernels; only tests/test_fmad_gap.py asks for it."""
+    key = ("oracle" + ("_fmad" if fmad else ""), prec)
     if key not in _LIBS:
-        path = os.path.join(HERE, f"liboracle_{prec}.so")
+        path = os.path.join(HERE, f"liboracle_{prec}{'_fmad' if fmad else ''}.so")
         if not os.path.exists(path):
-            build("all")
+            build("fmad" if fmad else "all")
         L = C.CDLL(path)
         assert L.vvo_sizeof_system() == C.sizeof(_System), "ctypes _System out of sync with vv_oracle.h"
         L.vvo_calc_viscosity.restype = C.c_double
@@ -338,11 +340,21 @@ def lib(prec: str) -> C.CDLL:
     return _LIBS[key]
 
 
-def ref_lib(prec: str) -> C.CDLL:
-    key = ("ref", prec)
+def ref_lib(prec: str, fmad: bool = False) -> C.CDLL:
+    key = ("ref" + ("_fmad" if fmad else ""), prec)
     if key not in _LIBS:
-        _LIBS[key] = C.CDLL(os.path.join(HERE, "_ref", f"libvvref_{prec}.so"))
+        _LIBS[key] = C.CDLL(os.path.join(HERE, "_ref", f"libvvref_{prec}{'_fmad' if fmad else ''}.so"))
     return _LIBS[key]
+
+
+def have_fmad() -> bool:
+    """liboracle_*_fmad.so present (or buildable) and this CPU has FMA instructions."""
+    try:
+        if " fma " not in open("/proc/cpuinfo").read().replace("\n", " "):
+            return False
+    except OSError:
+        return False
+    return all(os.path.exists(os.path.join(HERE, f"liboracle_{p}_fmad.so")) for p in PRECISIONS)
 
 
 def _p(a):
@@ -360,11 +372,11 @@ class OracleSystem:
 
     def __init__(self, spec, params: Params, prec: str = "mixed", random: np.ndarray | None = None,
                  force_mode: int = 1, k_tether: float = 1000.0, k_drude: float = 209200.0, num_threads: int = 1,
-                 shake_mode: int | None = None):
+                 shake_mode: int | None = None, fmad: bool = False):
         """shake_mode: 0 = Gauss-Seidel sweeps over a constraint cluster, 1 = the cluster's constraints at once (vv_oracle.c:
-        vvo_cluster_*); None follows VVHIP_SHAKE_MODE like the product (default 1)."""
+        vvo_cluster_*); None follows VVHIP_SHAKE_MODE like the product (default 1).  fmad: the contracted build (lib())."""
         self.prec, self.spec = prec, spec
-        self.L = lib(prec)
+        self.L = lib(prec, fmad)
         R, M = REAL[prec], MIXED[prec]
         self.t = t = build_tables(spec, params)
         self.params = p = t["params"]
@@ -513,9 +525,9 @@ class Kernels:
 
     Every method takes numpy arrays in the reference's device layouts and updates them in place."""
 
-    def __init__(self, which: str, prec: str):
+    def __init__(self, which: str, prec: str, fmad: bool = False):
         self.which, self.prec = which, prec
-        self.L = lib(prec) if which == "oracle" else ref_lib(prec)
+        self.L = lib(prec, fmad) if which == "oracle" else ref_lib(prec, fmad)
         self.cr, self.cm = _ct(prec)
         self.M = MIXED[prec]
         self.R = REAL[prec]

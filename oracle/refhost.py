@@ -18,17 +18,21 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBS = {}
 
 
-def path(prec: str) -> str:
-    return os.path.join(HERE, "_ref", f"libvvref_host_{prec}.so")
+def path(prec: str, fmad: bool = False) -> str:
+    """fmad: the build with contracted multiply-adds (`make -C oracle reffmad`, oracle/Makefile: OPT_FMAD)."""
+    return os.path.join(HERE, "_ref", f"libvvref_host_{prec}{'_fmad' if fmad else ''}.so")
 
 
-def available(prec: str = "mixed") -> bool:
-    return os.path.exists(path(prec))
+def available(prec: str = "mixed", fmad: bool = False) -> bool:
+    return os.path.exists(path(prec, fmad))
 
 
-def load(prec: str) -> C.CDLL:
+def load(prec: str, fmad: bool = False) -> C.CDLL:
+    key = prec + ("_fmad" if fmad else "")
+    prec_ = prec
+    prec = key
     if prec not in _LIBS:
-        L = C.CDLL(path(prec))
+        L = C.CDLL(path(prec_, fmad))
         L.vvrh_create.restype = C.c_void_p
         L.vvrh_time.restype = C.c_double
         L.vvrh_time.argtypes = [C.c_void_p]
@@ -47,8 +51,9 @@ class RefHost:
 
     Forces are static (whatever ``force`` holds, int64 fixed point, 3 x padded atoms), normals are the injected ``random`` buffer."""
 
-    def __init__(self, spec, params: Params, prec: str = "mixed", random: np.ndarray | None = None, force: np.ndarray | None = None):
-        self.L, self.prec, self.spec = load(prec), prec, spec
+    def __init__(self, spec, params: Params, prec: str = "mixed", random: np.ndarray | None = None, force: np.ndarray | None = None,
+                 fmad: bool = False):
+        self.L, self.prec, self.spec = load(prec, fmad), prec, spec
         p = params
         m = np.ascontiguousarray(spec.masses, dtype=np.float64)
         mol = np.ascontiguousarray(spec.mol_id, dtype=np.int32)
