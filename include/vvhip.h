@@ -328,6 +328,9 @@ int vvhip_generic_launches(vvhip_plan* plan, int64_t counts[2], uint32_t stage_s
 /* Process-wide: counts[0] = kernels compiled at run time so far, counts[1 / 2] = enqueued launches of kernel A / B that ran one;
  * compile_seconds (optional) = time spent in the compiler. */
 int vvhip_rtc_stats(int64_t counts[3], double* compile_seconds);
+/* Process-wide: stage sets whose run-time compilation FAILED (no compiler library, a compile error); their launches run the generic
+ * kernel (15-20 % slower) for the rest of the process.  One line on stderr each; hosts that report performance should look here. */
+int vvhip_rtc_failures(int64_t* failed);
 /* Sets VVHIP_RTC's value for the launches that follow (process-wide; graphs captured earlier keep their kernels) and returns the previous
  * one; mode < 0 only returns it. */
 int vvhip_rtc_mode(int mode);
@@ -340,19 +343,13 @@ int vvhip_timing_enable(vvhip_plan* plan, int enable);
 int vvhip_timing_read(vvhip_plan* plan, double* ms_pass_a, double* ms_pass_b, double* ms_other, int32_t launches[3]);
 
 /* ---------------------------------------------------------------- environment (read once, at vvhip_plan_create)
- * Behaviour switches, all optional; defaults are what the measurements in DESIGN.md section 7 selected.
+ * Behaviour switches, all optional.  (The tuning switches of rounds 1-3 -- launch shape, mass tables, velocity round trip, cos moments --
+ * are closed experiments, TUNING_LOG.md; what tests still need of them is the per-plan hook vvhip_debug_tune below.)
  *   VVHIP_PERIODIC=1|0        arithmetic work-item layout (vv_host.hpp: PeriodicLayout) always / never; default: from 0.2 M lanes, when the
  *                             system is runs of identical molecules (vvhip_plan_info.periodic_layout tells)
  *   VVHIP_PERIODIC_DEBUG=1    the decomposition into regions and why the layout was (not) enabled, on stderr
- *   VVHIP_PERIODIC_K=0        keep that layout but let the kernels load their slot words (comparison runs);  VVHIP_PERIODIC_A=0: kernel A alone
- *                             loads them (it computes its particle indices by default and keeps the next tile's loads in flight)
  *   VVHIP_SHAKE_MODE=0        hydrogen-type constraint clusters by Gauss-Seidel sweeps of the central lane (OpenMM's iteration; generic
  *                             kernels) instead of the direct velocity solve / coupled Newton iteration of all lanes of a cluster
- *   VVHIP_REKICK=0            kernel A stores the kicked velocities, kernel B does not repeat the kick
- *   VVHIP_MTAB_A=1 / VVHIP_MTAB_B=0   static mass tables in kernel A (off) / kernel B (on)
- *   VVHIP_NO_MOMENTS=1        cos perturbation as three launches (bias, sums, scale) instead of two
- *   VVHIP_SPLIT_CHAIN_WAVES=n the thermostat chain becomes its own 1-wave launch from n waves on (default 12288)
- *   VVHIP_BLOCK=t, VVHIP_CAP_A=b, VVHIP_CAP_B=b   launch shape: threads per block (multiple of 64), most blocks per launch of kernel A / B
  *   VVHIP_ROCTX=1             roctx ranges (see vvhip_set_trace)
  *   VVHIP_RTC=0|1|2           run-time compilation of kernels A / B (vvhip_generic_launches): never / for stage sets without a compiled
  *                             kernel (default) / for every launch (tests: the run-time kernel against the compiled one, bit for bit)
@@ -368,6 +365,11 @@ int vvhip_timing_read(vvhip_plan* plan, double* ms_pass_a, double* ms_pass_b, do
  * Used by tests/ to drive single stages against the oracle; not needed by an integrating host.
  * kernel: 0 = A (produce), 1 = B (consume), 2 = chain; flags are the stage bits of csrc/vv_args.hpp. */
 int vvhip_debug_launch(vvhip_plan* plan, int kernel, uint32_t flags, uint32_t random_index);
+/* One of the plan's tuning choices by name (call between vvhip_plan_create and vvhip_bind; later calls drop the captured graphs):
+ * "grid_cap_a" / "grid_cap_b" (most blocks per launch), "block_threads", "split_chain_waves" (the chain becomes its own launch from n waves
+ * on), "periodic_kernels" / "periodic_a" (0: load slot words although the layout is arithmetic), "rekick", "no_moments", "mass_tab_a" /
+ * "mass_tab_b", "acc_store".  Tests use it to run large-system code paths at small sizes. */
+int vvhip_debug_tune(vvhip_plan* plan, const char* key, int value);
 int vvhip_debug_read_accumulators(vvhip_plan* plan, double out[4], int zero_after);  /* blocks */
 int vvhip_debug_set_scales(vvhip_plan* plan, const double scales[4]);                /* vscale[3], bias V; blocks */
 int vvhip_debug_timestamps(vvhip_plan* plan, uint32_t flags, int block, long long out[128]);  /* instrumented builds only (tools/probes) */

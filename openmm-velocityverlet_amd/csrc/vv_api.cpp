@@ -167,10 +167,10 @@ struct vvhip_plan {
     int mb_ranks = 0, mb_rank = 0;
     bool mb_on = false;
     // A peer's box lives on THIS device (several ranks sharing one GPU: test set-ups): found out by vvhip_mailbox_connect.  Such ranks'
-    // kernels compete for the same CUs, and a large capped grid of polling thermostat waves can keep the other process's kernels off
-    // the device until the bounded waits run out -- kernel B then keeps the explicit layout next to the mailbox.
+    // kernels compete for the same CUs, and device-filling grids of polling thermostat waves keep the other process's kernels off
+    // the device until the bounded waits run out: every rank then launches on its share of the CUs (shared_device_cap).
     bool mb_shared_device = false;
-    int periodic_mb = -1;          // arithmetic layout of kernel B next to the mailbox: -1 = unless a peer shares the device, 0 / 1 = VVHIP_PERIODIC_MB
+    int mb_device_ranks = 1;       // ranks whose boxes live on this device (this one included)
     // Sticky health word in pinned host memory, written by the kernels with system-scope stores when something goes wrong and
     // read by the host without synchronising: [0] a mailbox wait on the peers ran out (the ranks have diverged), [1] a fixed-point
     // accumulator left its range (|sum| x scale >= 2^62: the thermostat would see garbage).  Checked at the entry of the run loops
@@ -459,6 +459,24 @@ struct ScopedTimer {
 static inline void debug_stall(vvhip_plan* p) {
     if (p->stall_us > 0 && !p->capturing && ++p->stall_count % p->stall_period == 0) usleep((useconds_t) p->stall_us);
 }
+// Ranks that SHARE a device (test set-ups; found out by vvhip_mailbox_connect) exchange through kernel B's polling thermostat waves: the
+// ranks' kernels must be resident together, or the one that got the device first polls until its bounded waits run out while the
+// others' launches cannot start (measured round 4, two ranks on one MI355X, 0.44 M / 0.89 M particles: device-filling grids time out
+// with either work-item layout, grids of <= half the CUs per rank never do -- tools/probes/mailbox_periodic.sh).  Every rank then
+// takes its share of the CUs, one block per CU.  Ranks on devices of their own keep the plan's launch shape.
+// A launch that found neither a compiled nor a run-time kernel for its stage set and ran the generic one (15-20 % slower): counted per
+// plan (vvhip_generic_launches); VVHIP_WARN_GENERIC=1 also prints one line per plan, kernel and stage set.
+void note_generic_launch(vvhip_plan* p, int kernel, uint32_t flags) {
+    p->generic_launches[kernel]++;
+    const bool seen = p->generic_flags[kernel] == flags;
+    p->generic_flags[kernel] = flags;
+    static const bool warn = std::getenv("VVHIP_WARN_GENERIC") != nullptr;
+    if (warn && !seen) std::fprintf(stderr, "vvhip: kernel %c runs stage set 0x%x on the generic kernel (no compiled specialisation)\n", kernel == 0 ? 'A' : 'B', flags);
+}
+int shared_device_cap(const vvhip_plan* p, int cap) {
+    if (!(p->mb_on && p->mb_shared_device) || p->launch_shape_forced) return cap;
+    return std::max(1, std::min(cap, p->num_cus / std::max(1, p->mb_device_ranks)));
+}
 int ensure_mass_table(vvhip_plan* p) {
     if (!(p->mass_tab_a || p->mass_tab_b) || p->mass_tab_valid) return VVHIP_OK;
     if (p->capturing) return fail(p, VVHIP_ERR_INVALID, "internal: mass tables must be filled before a graph capture starts");
@@ -473,27 +491,23 @@ int run_a(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
     if ((flags & vv::A_SHAKE_V) && p->shake_mode == 0) flags |= vv::A_SHAKE_GS;
     debug_stall(p);
     ScopedTimer t(p, T_A, true);
-    const unsigned long long g0 = vv::vv_generic_count[0];
-    HIP_TRY(p, vv::launch_a(p->hp.precision, make_args(p, flags, random_index), p->block_threads, p->grid_cap_a, p->stream, t.e0, t.e1));
-    if (vv::vv_generic_count[0] != g0) { p->generic_launches[0]++; p->generic_flags[0] = vv::vv_generic_flags[0]; }
+    int route = vv::ROUTE_COMPILED;
+    HIP_TRY(p, vv::launch_a(p->hp.precision, make_args(p, flags, random_index), p->block_threads, shared_device_cap(p, p->grid_cap_a), p->stream, t.e0, t.e1, &route));
+    if (route == vv::ROUTE_GENERIC) note_generic_launch(p, 0, flags);
     return VVHIP_OK;
 }
-// Kernel B takes the arithmetic layout whenever the plan has one -- next to the mailbox exchange only where every rank owns its device
-// (mb_shared_device)
-bool periodic_b(const vvhip_plan* p, bool mailbox) {
-    if (!(p->hp.per.enabled && p->periodic_kernels)) return false;
-    if (!mailbox) return true;
-    return p->periodic_mb >= 0 ? p->periodic_mb != 0 : !p->mb_shared_device;
-}
+// Kernel B takes the arithmetic layout whenever the plan has one, also next to the mailbox exchange (round 3 kept them apart after time-outs
+// with two ranks on one GPU; round 4 found the cause in device-filling grids of polling waves, whatever the layout: shared_device_cap)
+bool periodic_b(const vvhip_plan* p) { return p->hp.per.enabled && p->periodic_kernels; }
 int run_b(vvhip_plan* p, uint32_t flags) {
     if (p->mass_tab_b) { flags |= vv::B_MTAB; TRY(ensure_mass_table(p)); }
-    if (periodic_b(p, (flags & vv::B_MAILBOX) != 0)) flags |= vv::B_PERIODIC;
+    if (periodic_b(p)) flags |= vv::B_PERIODIC;
     if ((flags & vv::B_SHAKE) && p->shake_mode == 0) flags |= vv::B_SHAKE_GS;
     debug_stall(p);
     ScopedTimer t(p, T_B, true);
-    const unsigned long long g0 = vv::vv_generic_count[1];
-    HIP_TRY(p, vv::launch_b(p->hp.precision, make_args(p, flags, 0), p->block_threads, p->grid_cap_b, p->stream, t.e0, t.e1));
-    if (vv::vv_generic_count[1] != g0) { p->generic_launches[1]++; p->generic_flags[1] = vv::vv_generic_flags[1]; }
+    int route = vv::ROUTE_COMPILED;
+    HIP_TRY(p, vv::launch_b(p->hp.precision, make_args(p, flags, 0), p->block_threads, shared_device_cap(p, p->grid_cap_b), p->stream, t.e0, t.e1, &route));
+    if (route == vv::ROUTE_GENERIC) note_generic_launch(p, 1, flags);
     if (flags & vv::B_CHAIN) p->parity ^= 1;     // the advanced thermostat state now lives in the other copy
     return VVHIP_OK;
 }
@@ -586,30 +600,15 @@ int vvhip_plan_create(const vvhip_system_desc* system, const vvhip_params* param
         vvhip_plan* p = new vvhip_plan();
         p->hp = vv::analyze(*system, *params, precision);
         fill_scales(p);
-        if (const char* e = std::getenv("VVHIP_NO_MOMENTS")) p->no_moments = std::atoi(e) != 0;
-        if (const char* e = std::getenv("VVHIP_REKICK")) p->rekick = std::atoi(e) != 0;
-        if (const char* e = std::getenv("VVHIP_ACC_STORE")) p->acc_store = std::atoi(e) != 0;
         if (const char* e = std::getenv("VVHIP_STALL")) {
             p->stall_us = std::atol(e);
             if (const char* c = std::strchr(e, ':')) p->stall_period = std::max(1L, std::atol(c + 1));
         }
         if (const char* e = std::getenv("VVHIP_SHAKE_MODE")) p->shake_mode = std::atoi(e) != 0 ? 1 : 0;
-        if (const char* e = std::getenv("VVHIP_PERIODIC_K")) p->periodic_kernels = std::atoi(e) != 0;
-        if (const char* e = std::getenv("VVHIP_PERIODIC_A")) p->periodic_a = std::atoi(e) != 0;
-        if (const char* e = std::getenv("VVHIP_PERIODIC_MB")) p->periodic_mb = std::atoi(e) != 0 ? 1 : 0;
         p->mass_tab_a = vv::sf_kernels_use_mass_table(0);
         p->mass_tab_b = vv::sf_kernels_use_mass_table(1);
-        if (const char* e = std::getenv("VVHIP_MTAB_A")) p->mass_tab_a = std::atoi(e) != 0;
-        if (const char* e = std::getenv("VVHIP_MTAB_B")) p->mass_tab_b = std::atoi(e) != 0;
         if (const char* e = std::getenv("VVHIP_ROCTX")) p->trace = std::atoi(e) != 0;
-        if (const char* e = std::getenv("VVHIP_SPLIT_CHAIN_WAVES")) p->split_chain_waves = std::atoi(e);
         pick_launch_shape(p);
-        if (const char* e = std::getenv("VVHIP_BLOCK")) {          // tuning experiments
-            const int b = std::atoi(e);
-            if (b >= 64 && b <= 448 && b % 64 == 0) { p->block_threads = b; p->grid_cap_a = 2048; p->grid_cap_b = 1024; p->launch_shape_forced = true; }
-        }
-        if (const char* e = std::getenv("VVHIP_CAP_A")) { const int c = std::atoi(e); if (c > 0) { p->grid_cap_a = c; p->launch_shape_forced = true; } }
-        if (const char* e = std::getenv("VVHIP_CAP_B")) { const int c = std::atoi(e); if (c > 0) { p->grid_cap_b = c; p->launch_shape_forced = true; } }
         *plan_out = p;
         return VVHIP_OK;
     } catch (const vv::Error& e) {
@@ -617,6 +616,33 @@ int vvhip_plan_create(const vvhip_system_desc* system, const vvhip_params* param
     } catch (const std::exception& e) {
         return report(VVHIP_ERR_INVALID, e.what());
     }
+}
+
+// Test / tuning hook (include/vvhip.h): the choices the measurements of TUNING_LOG.md settled, adjustable per plan so that tests can force
+// code paths at sizes they can afford (the large-system launch shape on 10 000 particles, loaded instead of computed slot words, ...).
+// The environment switches of rounds 1-3 (VVHIP_REKICK, VVHIP_CAP_A, ...) are gone: their experiments are closed.
+int vvhip_debug_tune(vvhip_plan* p, const char* key, int value) {
+    if (!p || !key) return VVHIP_ERR_INVALID;
+    if (p->bound) HIP_TRY(p, hipStreamSynchronize(p->stream));
+    const std::string k = key;
+    if (k == "periodic_kernels") p->periodic_kernels = value != 0;          // 0: keep the arithmetic layout's slot order but load the slot words
+    else if (k == "periodic_a") p->periodic_a = value != 0;                 // kernel A alone
+    else if (k == "rekick") p->rekick = value != 0;                         // 0: kernel A stores the kicked velocities, kernel B does not repeat the kick
+    else if (k == "no_moments") p->no_moments = value != 0;                 // 1: cos perturbation as three launches (bias, sums, scale)
+    else if (k == "mass_tab_a") p->mass_tab_a = value != 0;
+    else if (k == "mass_tab_b") p->mass_tab_b = value != 0;
+    else if (k == "acc_store") p->acc_store = value != 0;                   // 0: atomics also where a block owns its accumulator slot
+    else if (k == "split_chain_waves") { p->split_chain_waves = value; if (!p->launch_shape_forced) pick_launch_shape(p); }
+    else if (k == "block_threads") {
+        if (value < 64 || value > 448 || value % 64) return fail(p, VVHIP_ERR_INVALID, "block_threads: a multiple of 64 in [64, 448]");
+        p->block_threads = value; p->grid_cap_a = 2048; p->grid_cap_b = 1024; p->launch_shape_forced = true;
+    }
+    else if (k == "grid_cap_a") { if (value < 1) return VVHIP_ERR_INVALID; p->grid_cap_a = value; p->launch_shape_forced = true; }
+    else if (k == "grid_cap_b") { if (value < 1) return VVHIP_ERR_INVALID; p->grid_cap_b = value; p->launch_shape_forced = true; }
+    else return fail(p, VVHIP_ERR_INVALID, "vvhip_debug_tune: unknown key " + k);
+    if (k == "mass_tab_a" || k == "mass_tab_b") p->mass_tab_valid = false;
+    drop_graphs(p);
+    return VVHIP_OK;
 }
 
 void vvhip_plan_destroy(vvhip_plan* p) {
@@ -852,7 +878,7 @@ int vvhip_algorithmic_bytes(const vvhip_plan* p, int32_t* bytes_a, int32_t* byte
     const int x = p->hp.precision == VVHIP_SINGLE ? 16 : 32;                       // posq (+ posqCorrection in mixed mode; double4 in double mode)
     const int xr = p->hp.precision == VVHIP_DOUBLE ? 32 : 16;                      // posq alone
     const bool per = p->hp.per.enabled && p->periodic_kernels;
-    const bool per_a = per && (p->periodic_a || shake_on(p)), per_b = periodic_b(p, use_mailbox(p));      // as run_a / run_b decide
+    const bool per_a = per && (p->periodic_a || shake_on(p)), per_b = periodic_b(p);      // as run_a / run_b decide
     const int ia = per_a ? 0 : 6, ib = per_b ? 0 : 6;
     if (use_rekick(p)) { *bytes_a = v + 24 + ia; *bytes_b = v + 24 + x + v + x + ib; }    // A: R velm, R force;  B: R velm, R force, R pos, W velm, W pos
     else { *bytes_a = v + 24 + v + ia; *bytes_b = v + x + v + x + ib; }                   // A: R velm, R force, W velm;  B: R velm, R pos, W velm, W pos
@@ -1388,6 +1414,7 @@ int vvhip_peer_access(int device, int peer_device, int32_t* can_access) {
 static void mailbox_release(vvhip_plan* p) {
     p->mb_on = false;
     p->mb_shared_device = false;
+    p->mb_device_ranks = 1;
     for (void* m : p->mb_opened) (void) hipIpcCloseMemHandle(m);
     p->mb_opened.clear();
     if (p->d_mb_peers) { (void) hipFree(p->d_mb_peers); p->d_mb_peers = nullptr; }
@@ -1432,7 +1459,7 @@ int vvhip_mailbox_connect(vvhip_plan* p, const void* handles) {
         // whose memory is it?  A box on this very device means that rank shares the GPU with this one
         hipPointerAttribute_t attr;
         int dev = -1;
-        if (hipGetDevice(&dev) == hipSuccess && hipPointerGetAttributes(&attr, m) == hipSuccess && attr.device == dev) p->mb_shared_device = true;
+        if (hipGetDevice(&dev) == hipSuccess && hipPointerGetAttributes(&attr, m) == hipSuccess && attr.device == dev) { p->mb_shared_device = true; p->mb_device_ranks++; }
         else (void) hipGetLastError();
     }
     HIP_TRY(p, hipMalloc((void**) &p->d_mb_peers, peers.size() * sizeof(void*)));
@@ -1457,7 +1484,7 @@ int vvhip_mailbox_status(vvhip_plan* p, int32_t* active, int32_t* timed_out) {
 int vvhip_mailbox_layout(vvhip_plan* p, int32_t* shared_device, int32_t* arithmetic_layout) {
     NEED_BOUND(p);
     if (shared_device) *shared_device = p->mb_shared_device ? 1 : 0;
-    if (arithmetic_layout) *arithmetic_layout = (use_mailbox(p) && periodic_b(p, true)) ? 1 : 0;
+    if (arithmetic_layout) *arithmetic_layout = (use_mailbox(p) && periodic_b(p)) ? 1 : 0;
     return VVHIP_OK;
 }
 int vvhip_mailbox_destroy(vvhip_plan* p) {
@@ -1523,8 +1550,13 @@ int vvhip_generic_launches(vvhip_plan* p, int64_t counts[2], uint32_t stage_sets
 int vvhip_rtc_mode(int mode) { return vv::set_rtc_mode(mode); }
 int vvhip_rtc_stats(int64_t counts[3], double* compile_seconds) {
     if (!counts) return VVHIP_ERR_INVALID;
-    counts[0] = (int64_t) vv::vv_rtc_compiled; counts[1] = (int64_t) vv::vv_rtc_launches[0]; counts[2] = (int64_t) vv::vv_rtc_launches[1];
+    counts[0] = (int64_t) vv::vv_rtc_compiled.load(); counts[1] = (int64_t) vv::vv_rtc_launches[0].load(); counts[2] = (int64_t) vv::vv_rtc_launches[1].load();
     if (compile_seconds) *compile_seconds = vv::vv_rtc_compile_seconds;
+    return VVHIP_OK;
+}
+int vvhip_rtc_failures(int64_t* failed) {
+    if (!failed) return VVHIP_ERR_INVALID;
+    *failed = (int64_t) vv::vv_rtc_failed.load();
     return VVHIP_OK;
 }
 int vvhip_timing_enable(vvhip_plan* p, int enable) {

@@ -123,6 +123,10 @@ constexpr uint32_t SF_B_MIDDLE_HW_K_P = SF_B_MIDDLE_HW_K | B_PERIODIC;
 constexpr uint32_t SF_B_MIDDLE_K_P = SF_B_MIDDLE_K | B_PERIODIC;
 constexpr uint32_t SF_B_MIDDLE_HW_NC_K_P = SF_B_MIDDLE_HW_NC_K | B_PERIODIC;
 constexpr uint32_t SF_B_COS_HW_MOM_K_P = SF_B_COS_HW_MOM_K | B_PERIODIC;
+// ... next to the mailbox exchange of sharded runs (the chain stays in kernel B's head there, whatever the size)
+constexpr uint32_t SF_B_MIDDLE_HW_MB_K_P = SF_B_MIDDLE_HW_MB_K | B_PERIODIC;
+constexpr uint32_t SF_B_MIDDLE_MB_K_P = SF_B_MIDDLE_MB_K | B_PERIODIC;
+constexpr uint32_t SF_B_COS_HW_MOM_MB_K_P = SF_B_COS_HW_MOM_MB_K | B_PERIODIC;
 // large constrained boxes (the chain as its own launch): HBonds clusters solved in kernel B without the thermostat wave
 constexpr uint32_t SF_B_MIDDLE_HW_NC_SHAKE = SF_B_MIDDLE_HW_NC | B_SHAKE;
 constexpr uint32_t SF_B_MIDDLE_HW_NC_SHAKE_P = SF_B_MIDDLE_HW_NC_SHAKE | B_PERIODIC;
@@ -183,23 +187,15 @@ bool sf_kernels_use_mass_table(int kernel) { return kernel == 0 ? VV_SF_MTAB_A !
 // Launches that found no compiled specialisation of their stage set and ran the generic kernel with run-time stage bits (15-20 % slower):
 // counted per kernel with the last such stage set (vvhip_generic_launches reads them); VVHIP_WARN_GENERIC=1 also prints one line on
 // stderr per stage set.
-unsigned long long vv_generic_count[2] = {0, 0};
-uint32_t vv_generic_flags[2] = {0, 0};
-static void note_generic(const char* kernel, uint32_t flags) {
+std::atomic<unsigned long long> vv_generic_count[2];
+static void note_generic(const char* kernel, int* route) {
     vv_generic_count[kernel[0] == 'A' ? 0 : 1]++;
-    vv_generic_flags[kernel[0] == 'A' ? 0 : 1] = flags;
-    static const bool on = std::getenv("VVHIP_WARN_GENERIC") != nullptr;
-    if (!on) return;
-    static uint32_t seen[2][16];
-    static int nseen[2] = {0, 0};
-    const int k = kernel[0] == 'A' ? 0 : 1;
-    for (int i = 0; i < nseen[k]; i++) if (seen[k][i] == flags) return;
-    if (nseen[k] < 16) seen[k][nseen[k]++] = flags;
-    std::fprintf(stderr, "vvhip: kernel %s runs stage set 0x%x on the generic kernel (no compiled specialisation)\n", kernel, flags);
+    if (route) *route = ROUTE_GENERIC;
 }
 
-hipError_t launch_a(int precision, const KArgs& a_in, int block_threads, int grid_cap, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+hipError_t launch_a(int precision, const KArgs& a_in, int block_threads, int grid_cap, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int* route) {
     KArgs a = a_in;
+    if (route) *route = ROUTE_COMPILED;
     dim3 g = grid_for(a.nwaves, block_threads);
     if ((int) g.x > grid_cap) g.x = (unsigned) grid_cap;          // beyond that the kernel strides over tiles
     vv_last_grid_value = g.x;
@@ -219,6 +215,7 @@ hipError_t launch_a(int precision, const KArgs& a_in, int block_threads, int gri
         void* params[] = {&p_slots, &p_nwaves, &p_wpb, &p_velm, &p_force, &p_padded, &a};
         rtc_error = vv_launch_module(f, g, b, lds, s, ev0, ev1, params);
         vv_rtc_launches[0]++;
+        if (route) *route = ROUTE_RUNTIME;
         return true;
     };
     if (rtc_mode() >= 2 && run_time_kernel()) return rtc_error;
@@ -256,12 +253,13 @@ hipError_t launch_a(int precision, const KArgs& a_in, int block_threads, int gri
     VV_TRY_SF(vv_kernel_a, SF_A_COS_MOM_VV2)
     VV_TRY_SF(vv_kernel_a, SF_A_COS_MOM_VV2_SHAKE)
     if (rtc_mode() == 1 && run_time_kernel()) return rtc_error;
-    note_generic("A", a.flags);
+    note_generic("A", route);
     VV_DISPATCH_SF(vv_kernel_a, 0u, g, b, lds, s, ev0, ev1, VV_PRE_ARGS, a);
     return hipGetLastError();
 #undef VV_PRE_ARGS
 }
-hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_cap, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_cap, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int* route) {
+    if (route) *route = ROUTE_COMPILED;
     // block_threads counts the tile waves; B_CHAIN adds the block's thermostat wave.  Beyond grid_cap blocks the kernel strides
     // over tiles and the per-block thermostat work is amortised.
     dim3 g = grid_for(a.nwaves, block_threads);
@@ -281,12 +279,13 @@ hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_c
         void* params[] = {&p_slots, &p_nwaves, &p_wpb, &p_acc, &p_nh, &p_lc, &p_sb, &copy};
         rtc_error = vv_launch_module(f, g, b, lds, s, ev0, ev1, params);
         vv_rtc_launches[1]++;
+        if (route) *route = ROUTE_RUNTIME;
         return true;
     };
     if (rtc_mode() >= 2 && run_time_kernel()) return rtc_error;
     if ((a.flags & B_CHAIN) && a.chain.num_chains != 3) {       // the compiled kernels carry the three-link chain only
         if (rtc_mode() == 1 && run_time_kernel()) return rtc_error;
-        note_generic("B", a.flags);
+        note_generic("B", route);
         VV_DISPATCH_SF(vv_kernel_b, 0u, g, b, lds, s, ev0, ev1, VV_PRE_ARGS, a);
         return hipGetLastError();
     }
@@ -294,6 +293,9 @@ hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_c
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_K_P)
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_HW_NC_K_P)
     VV_TRY_SF(vv_kernel_b, SF_B_COS_HW_MOM_K_P)
+    VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_HW_MB_K_P)
+    VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_MB_K_P)
+    VV_TRY_SF(vv_kernel_b, SF_B_COS_HW_MOM_MB_K_P)
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_HW_K)
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_K)
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_HW_NC_K)
@@ -346,7 +348,7 @@ hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_c
     VV_TRY_SF(vv_kernel_b, SF_B_COS_VV1_HW_MOM_SHAKE)
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_SETTLE_P)
     if (rtc_mode() == 1 && run_time_kernel()) return rtc_error;
-    note_generic("B", a.flags);
+    note_generic("B", route);
     VV_DISPATCH_SF(vv_kernel_b, 0u, g, b, lds, s, ev0, ev1, VV_PRE_ARGS, a);
     return hipGetLastError();
 #undef VV_PRE_ARGS

@@ -1,6 +1,7 @@
 // vv_kernels.hpp -- launch entry points of the HIP kernels (gfx950).
 // Device code lives in vv_device.inc (compiled through vv_kernels.hip); the C ABI (vv_api.cpp) only sees this header.
 #pragma once
+#include <atomic>
 #include "vv_args.hpp"
 #include "vv_host.hpp"
 
@@ -22,11 +23,13 @@ inline PeriodicArgs periodic_args(const PeriodicLayout& q) {
 // launchers (precision = VVHIP_SINGLE / MIXED / DOUBLE); return hipError_t of the launch
 // block_threads = 64 x tile waves per block; grid_cap = most blocks to launch (the kernels stride over tiles beyond that)
 // ev0 / ev1 (optional): events that receive the dispatch's own begin / end timestamps (timing runs; never inside a graph capture)
-hipError_t launch_a(int precision, const KArgs& a, int block_threads, int grid_cap, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
-hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_cap, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
-// launches of kernel A / B (index 0 / 1) that ran the generic kernel, process-wide, and the last stage set that did
-extern unsigned long long vv_generic_count[2];
-extern uint32_t vv_generic_flags[2];
+// route (optional): which kernel the launch took -- ROUTE_COMPILED (a specialisation of the library), ROUTE_RUNTIME (hipRTC),
+// ROUTE_GENERIC (run-time stage bits) -- so that the caller can count per plan (several host threads may drive plans of their own)
+enum LaunchRoute { ROUTE_COMPILED = 0, ROUTE_RUNTIME = 1, ROUTE_GENERIC = 2 };
+hipError_t launch_a(int precision, const KArgs& a, int block_threads, int grid_cap, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, int* route = nullptr);
+hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_cap, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, int* route = nullptr);
+// launches of kernel A / B (index 0 / 1) that ran the generic kernel, process-wide (statistics only)
+extern std::atomic<unsigned long long> vv_generic_count[2];
 hipError_t launch_chain(const NHConst& c, NHDevState* st, unsigned long long* acc, hipStream_t s);
 hipError_t launch_tether(int precision, const TetherArgs& t, int block_threads, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 // Fills the static per-lane mass tables from the inverse masses in velm.w (once per binding; see A_MTAB / B_MTAB).

@@ -17,7 +17,7 @@
 
 namespace vv {
 
-unsigned long long vv_rtc_compiled = 0, vv_rtc_launches[2] = {0, 0};
+std::atomic<unsigned long long> vv_rtc_compiled{0}, vv_rtc_failed{0}, vv_rtc_launches[2];
 double vv_rtc_compile_seconds = 0;
 
 static int& rtc_mode_value() {
@@ -173,6 +173,7 @@ hipFunction_t rtc_kernel(char kind, int precision, uint32_t flags, int num_chain
     } else {
         why = "hipGetDeviceProperties failed";
     }
+    if (!fn) vv_rtc_failed++;
     if (!fn) std::fprintf(stderr, "vvhip: run-time compilation of kernel %c, stage set 0x%x failed (the generic kernel runs instead): %s\n", kind, flags, why.c_str());
     cache[key] = fn;
     return fn;

@@ -197,6 +197,9 @@ def plan_layout(system: SystemSpec, integrator: "VVIntegrator", precision: str =
     return info, slots
 
 
+DEFAULT_TUNE: dict = {}      # see Context(tune=...)
+
+
 class Context:
     """Device state + force provider around one VVIntegrator.
 
@@ -208,7 +211,9 @@ class Context:
     def __init__(self, system: SystemSpec, integrator: VVIntegrator, precision: str = "mixed",
                  force_provider="tether", k_tether: float = 1000.0, k_drude: float = 209200.0,
                  random: Optional[np.ndarray] = None, shard: Optional[Tuple[int, int]] = None, device: Optional[int] = None,
-                 stream: Optional[int] = None):
+                 stream: Optional[int] = None, tune: Optional[dict] = None):
+        """tune: {name: value} for vvhip_debug_tune (test hook: launch shape, loaded instead of computed slot words, ...), applied between
+        plan creation and binding, on top of the module's DEFAULT_TUNE (which tests patch to reach contexts created elsewhere)."""
         if integrator._context is not None:
             raise H.VVHipError(H.ERR_INVALID, "This Integrator is already bound to a context")   # VVIntegrator.cpp:93-94
         if H.device_count() == 0:
@@ -226,6 +231,8 @@ class Context:
         self.plan, self.info, self._keep = create_plan(system, integrator, precision, self.shard, self._particles_ld,
                                                        self._image_pairs, self._electrolyte)
         plan = self.plan
+        for key, value in {**DEFAULT_TUNE, **(tune or {})}.items():
+            H.check(H.lib.vvhip_debug_tune(plan, key.encode(), int(value)), plan)
 
         # ---- device arrays in OpenMM's layouts, shard-local
         R, M = H.REAL[precision], H.MIXED_T[precision]

@@ -131,10 +131,10 @@ def _load():
         "vvhip_mailbox_layout": [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
         "vvhip_time_kernel": [vp, C.c_int, u32, C.c_int, P(dbl)],
         "vvhip_generic_launches": [vp, P(C.c_int64 * 2), P(u32 * 2)],
-        "vvhip_rtc_stats": [P(C.c_int64 * 3), P(C.c_double)],
+        "vvhip_rtc_stats": [P(C.c_int64 * 3), P(C.c_double)], "vvhip_rtc_failures": [P(C.c_int64)],
         "vvhip_rtc_mode": [C.c_int],
         "vvhip_timing_enable": [vp, C.c_int], "vvhip_timing_read": [vp, P(dbl), P(dbl), P(dbl), P(i32 * 3)],
-        "vvhip_debug_launch": [vp, C.c_int, u32, u32],
+        "vvhip_debug_launch": [vp, C.c_int, u32, u32], "vvhip_debug_tune": [vp, C.c_char_p, C.c_int],
         "vvhip_debug_read_accumulators": [vp, P(dbl * 4), C.c_int],
         "vvhip_debug_set_scales": [vp, P(dbl * 4)],
         "vvhip_debug_old_delta": [vp, P(vp)],

@@ -15,15 +15,19 @@ pytestmark = pytest.mark.gpu
 
 
 def _run(spec, prec, nsteps, env, monkeypatch, cos=0.0, maxd=0.02, T=333.0, dt=0.001, graph=False, middle=True):
-    for k in ("VVHIP_PERIODIC", "VVHIP_PERIODIC_K", "VVHIP_PERIODIC_A"):
-        monkeypatch.delenv(k, raising=False)
+    # VVHIP_PERIODIC is the library's switch for the layout; "VVHIP_PERIODIC_K" / "VVHIP_PERIODIC_A" in `env` are this file's names for the
+    # per-plan hook vvhip_debug_tune("periodic_kernels" / "periodic_a"): slot words loaded instead of computed, on the same layout
+    monkeypatch.delenv("VVHIP_PERIODIC", raising=False)
+    tune = {}
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        if k == "VVHIP_PERIODIC_K": tune["periodic_kernels"] = int(v)
+        elif k == "VVHIP_PERIODIC_A": tune["periodic_a"] = int(v)
+        else: monkeypatch.setenv(k, v)
     it = I.VVIntegrator(T, 10.0, 1.0, 40.0, dt)
     it.setMaxDrudeDistance(maxd)
     it.setCosAcceleration(cos)
     it.setUseMiddleScheme(middle)
-    ctx = I.Context(spec, it, precision=prec, force_provider="tether")
+    ctx = I.Context(spec, it, precision=prec, force_provider="tether", tune=tune)
     try:
         if graph:
             ctx.run_graph(nsteps, nsteps)
@@ -80,9 +84,9 @@ def test_periodic_kernels_under_graph_replay(monkeypatch):
 @pytest.mark.parametrize("name", ["water", "nondrude"])
 def test_large_system_launch_shape_without_drude_pairs(name, monkeypatch):
     """The stage sets big water / plain ionic-liquid boxes run (kernel B without thermostat wave and without hard wall), forced at a testable size."""
-    monkeypatch.setenv("VVHIP_SPLIT_CHAIN_WAVES", "1")
-    monkeypatch.setenv("VVHIP_CAP_A", "8")
-    monkeypatch.setenv("VVHIP_CAP_B", "8")
+    monkeypatch.setitem(I.DEFAULT_TUNE, "split_chain_waves", 1)
+    monkeypatch.setitem(I.DEFAULT_TUNE, "grid_cap_a", 8)
+    monkeypatch.setitem(I.DEFAULT_TUNE, "grid_cap_b", 8)
     spec, kw = SYSTEMS[name]()
     for env in ({"VVHIP_PERIODIC": "1"}, {"VVHIP_PERIODIC": "0"}):
         _, v, x, c, ke = _run(spec, "mixed", 12, env, monkeypatch, **kw)
@@ -98,9 +102,9 @@ def test_large_system_launch_shape_without_drude_pairs(name, monkeypatch):
 def test_periodic_kernels_in_the_large_system_launch_shape(cos, monkeypatch):
     """What systems beyond ~0.7 M particles run -- the chain as its own launch, kernel B without a thermostat wave, 256-thread blocks
     striding over tiles -- forced at a testable size, with the periodic layout, against the oracle and against the explicit-slot kernels."""
-    monkeypatch.setenv("VVHIP_SPLIT_CHAIN_WAVES", "1")
-    monkeypatch.setenv("VVHIP_CAP_A", "8")           # few blocks: every wave strides over several tiles
-    monkeypatch.setenv("VVHIP_CAP_B", "8")
+    monkeypatch.setitem(I.DEFAULT_TUNE, "split_chain_waves", 1)
+    monkeypatch.setitem(I.DEFAULT_TUNE, "grid_cap_a", 8)           # few blocks: every wave strides over several tiles
+    monkeypatch.setitem(I.DEFAULT_TUNE, "grid_cap_b", 8)
     spec, kw = SYSTEMS["bulk_cells"]()
     _, v_p, p_p, c_p, ke_p = _run(spec, "mixed", 12, {"VVHIP_PERIODIC": "1", "VVHIP_PERIODIC_A": "1"}, monkeypatch, cos=cos, **kw)
     _, v_e, p_e, c_e, ke_e = _run(spec, "mixed", 12, {"VVHIP_PERIODIC": "1", "VVHIP_PERIODIC_K": "0"}, monkeypatch, cos=cos, **kw)
@@ -116,8 +120,7 @@ def test_periodic_kernels_in_the_large_system_launch_shape(cos, monkeypatch):
 
 def test_periodic_layout_switches_itself_on_and_matches_the_oracle_at_that_size(monkeypatch):
     """C3 tiled twice (222 000 particles): the first size at which the arithmetic layout is chosen without being asked for."""
-    for k in ("VVHIP_PERIODIC", "VVHIP_PERIODIC_K", "VVHIP_PERIODIC_A"):
-        monkeypatch.delenv(k, raising=False)
+    monkeypatch.delenv("VVHIP_PERIODIC", raising=False)
     spec = systems.make_config("C3", scale=2)
     flag, v, x, c, ke = _run(spec, "mixed", 6, {}, monkeypatch, maxd=0.02)
     assert flag == 1
@@ -236,9 +239,9 @@ def test_periodic_kernels_with_in_kernel_constraints(name, large_shape, monkeypa
     """Constraint cluster words and parameters come from the pattern wave as well (both kernels take the arithmetic path here): bit-equal with
     the loaded tables, constraint lengths kept, oracle within the constraint tolerance."""
     if large_shape:
-        monkeypatch.setenv("VVHIP_SPLIT_CHAIN_WAVES", "1")
-        monkeypatch.setenv("VVHIP_CAP_A", "8")
-        monkeypatch.setenv("VVHIP_CAP_B", "8")
+        monkeypatch.setitem(I.DEFAULT_TUNE, "split_chain_waves", 1)
+        monkeypatch.setitem(I.DEFAULT_TUNE, "grid_cap_a", 8)
+        monkeypatch.setitem(I.DEFAULT_TUNE, "grid_cap_b", 8)
     spec, kw = CONSTRAINED[name]()
     flag, v_p, p_p, c_p, ke_p = _run(spec, "mixed", 10, {"VVHIP_PERIODIC": "1"}, monkeypatch, **kw)
     assert flag == 1
@@ -261,9 +264,9 @@ def test_periodic_kernels_with_in_kernel_constraints(name, large_shape, monkeypa
 def test_classic_scheme_in_the_large_system_launch_shape(periodic, monkeypatch):
     """stepVV's two thermostat applications as big boxes run them (scale + half kick + positions + hard wall, and scale alone, kernel B without a
     thermostat wave), forced at a testable size, with computed and with loaded slot words."""
-    monkeypatch.setenv("VVHIP_SPLIT_CHAIN_WAVES", "1")
-    monkeypatch.setenv("VVHIP_CAP_A", "8")
-    monkeypatch.setenv("VVHIP_CAP_B", "8")
+    monkeypatch.setitem(I.DEFAULT_TUNE, "split_chain_waves", 1)
+    monkeypatch.setitem(I.DEFAULT_TUNE, "grid_cap_a", 8)
+    monkeypatch.setitem(I.DEFAULT_TUNE, "grid_cap_b", 8)
     spec, kw = SYSTEMS["bulk_cells"]()
     _, v, x, c, ke = _run(spec, "mixed", 12, {"VVHIP_PERIODIC": periodic}, monkeypatch, middle=False, **kw)
     p = O.Params(temperature=333.0, drude_temperature=1.0, step_size=0.001, max_drude_distance=kw["maxd"], use_middle_scheme=False)
