@@ -658,6 +658,20 @@ def main():
             ts.append(time.perf_counter() - t0)
         return n / statistics.median(ts)
 
+    def driver_protocol(c, k=20, regions=25):
+        """steps/s of context c under the driver's flags (--steps 20 --warmup 5): one replay of a k-step graph per timed region between two
+        synchronisations, median of `regions` regions -- the protocol of the headline `value` when K = 20."""
+        c.run_graph(k, k)
+        c.graph_prepare(k)
+        c.synchronize()
+        ts = []
+        for _ in range(regions):
+            t0 = time.perf_counter()
+            c.run_graph(k, k)
+            c.synchronize()
+            ts.append(time.perf_counter() - t0)
+        return k / statistics.median(ts)
+
     # ---- the integrator path alone: forces resident in HBM (static buffer, zeroed: thermostatted free flight -- the same loads, stores
     # and arithmetic as with any other force values, and nothing that can run away), no provider kernel in the loop.  The physical
     # state is saved and put back: the particles leave their tether sites meanwhile.
@@ -686,7 +700,12 @@ def main():
         it_c.setElectricField(it.getElectricField())
         ctx_c = I.Context(spec_c, it_c, precision=args.precision, force_provider="tether", device=local_rank)
         sps_c = secondary(ctx_c)
-        blk_c = {"steps_per_s": round(sps_c, 1), "constraints": int(len(spec_c.constraints)),
+        g_c = args.steps_per_graph + args.steps_per_graph % 2
+        blk_c = {"steps_per_s": round(sps_c, 1),
+                 "protocol": f"median of 3 timed regions of {max(args.steps // 4 // g_c * g_c, 10 * g_c)} steps each, replays of a {g_c}-step hipGraph prepared outside the region (the long-run protocol; not the driver's flags)",
+                 "steps_per_s_driver_flags": round(driver_protocol(ctx_c), 1),
+                 "protocol_driver_flags": "one replay of a 20-step hipGraph per timed region, median of 25 regions (what --steps 20 --warmup 5 measures for the headline)",
+                 "constraints": int(len(spec_c.constraints)),
                  "shake_clusters": int(ctx_c.info.num_shake_clusters), "settle_molecules": int(ctx_c.info.num_settle_clusters),
                  "solver": "all constraints of a cluster at once: direct solve (velocities), coupled Newton (positions)" if os.environ.get("VVHIP_SHAKE_MODE", "1") != "0" else "Gauss-Seidel sweeps (VVHIP_SHAKE_MODE=0)"}
         # the same two clocks for the constrained stage sets, and the whole step against the roofline

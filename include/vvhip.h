@@ -374,6 +374,8 @@ int vvhip_debug_read_accumulators(vvhip_plan* plan, double out[4], int zero_afte
 int vvhip_debug_set_scales(vvhip_plan* plan, const double scales[4]);                /* vscale[3], bias V; blocks */
 int vvhip_debug_timestamps(vvhip_plan* plan, uint32_t flags, int block, long long out[128]);  /* instrumented builds only (tools/probes) */
 int vvhip_debug_span(vvhip_plan* plan, int kernel, uint32_t flags, int reps, double out[8]);   /* instrumented builds only */
+int vvhip_debug_fused_flags(vvhip_plan* plan, int kernel, uint32_t* flags);          /* stage bits of the fused middle step's kernel A (0) / B (1) */
+int vvhip_debug_step_spans(vvhip_plan* plan, int nsteps, const void* site, double k_tether, double k_drude, double out[36]);   /* instrumented builds only */
 int vvhip_debug_old_delta(vvhip_plan* plan, void** device_ptr);                       /* plan-owned oldDelta (mixed4[n]) */
 
 #ifdef __cplusplus

@@ -170,6 +170,7 @@ struct vvhip_plan {
     // kernels compete for the same CUs, and device-filling grids of polling thermostat waves keep the other process's kernels off
     // the device until the bounded waits run out: every rank then launches on its share of the CUs (shared_device_cap).
     bool mb_shared_device = false;
+    int dbg_seq = -1;              // instrumented build: >= 0 while vvhip_debug_step_spans numbers the launches of its steps
     int mb_device_ranks = 1;       // ranks whose boxes live on this device (this one included)
     // Sticky health word in pinned host memory, written by the kernels with system-scope stores when something goes wrong and
     // read by the host without synchronising: [0] a mailbox wait on the peers ran out (the ranks have diverged), [1] a fixed-point
@@ -340,8 +341,15 @@ vv::KArgs make_args(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
     a.dbg = p->d_dbg;
     a.dbg_block = p->dbg_block;
     a.dbg_span = p->d_dbg_span;
-    a.dbg_parity = p->dbg_parity;
+    a.dbg_parity = p->dbg_seq >= 0 ? p->dbg_seq++ % 6 : p->dbg_parity;
     a.padded = p->hp.padded_num_atoms;
+    {   // posq / posqCorrection as a buffer resource (kernel A's member-only position fetch): 32-bit sizes and offsets
+        const unsigned long long bytes = (unsigned long long) (p->hp.shard_end - p->hp.shard_begin) * (p->hp.precision == VVHIP_DOUBLE ? 32ull : 16ull);
+        a.pos_bytes = bytes < 0xFFFFFFE0ull ? (uint32_t) bytes : 0u;
+#ifdef VV_EXP_PLAIN_CONS_LOADS
+        a.pos_bytes = 0;
+#endif
+    }
     a.nwaves = p->hp.info.num_waves;
     a.acc_rows = p->hp.params.cos_acceleration != 0 ? vv::NUM_ACC : 4;
     a.acc_exclusive = p->acc_store ? 1 : 0;
@@ -869,9 +877,11 @@ static bool use_rekick(const vvhip_plan* p) {
 
 // Algorithmic bytes per particle that kernel A / kernel B of the fused middle step must move (SURVEY section 8d's accounting: particle
 // arrays + 6 bytes of index per pass): what bench.py prices the launches with.  Where a kernel takes the arithmetic work-item layout
-// it loads no slot words, so no index bytes are counted for it; with the cos perturbation kernel A also reads posq (16 / 32 bytes; the
-// per-lane cos(kz) cache between the kernels is an implementation choice and is NOT counted, nor are the positions the in-kernel
-// velocity constraints read for cluster members: the figure stays a lower bound of what must move).
+// it loads no slot words, so no index bytes are counted for it; with the cos perturbation kernel A also reads posq (16 / 32 bytes) and
+// the per-lane cos(kz) handed from kernel A to kernel B is counted on both sides (8 + 8 bytes: the step's design moves them).  With
+// in-kernel constraints kernel A reads the positions of the cluster MEMBERS (their share of the particles, rounded to whole bytes) and
+// both kernels read the cluster word and parameters (4 + 16 bytes per lane) wherever those come from memory, i.e. not in the
+// arithmetic layout, where they are pattern rows in LDS.
 int vvhip_algorithmic_bytes(const vvhip_plan* p, int32_t* bytes_a, int32_t* bytes_b) {
     if (!p || !bytes_a || !bytes_b) return VVHIP_ERR_INVALID;
     const int v = p->hp.precision == VVHIP_SINGLE ? 16 : 32;                       // velm: mixed4
@@ -882,7 +892,16 @@ int vvhip_algorithmic_bytes(const vvhip_plan* p, int32_t* bytes_a, int32_t* byte
     const int ia = per_a ? 0 : 6, ib = per_b ? 0 : 6;
     if (use_rekick(p)) { *bytes_a = v + 24 + ia; *bytes_b = v + 24 + x + v + x + ib; }    // A: R velm, R force;  B: R velm, R force, R pos, W velm, W pos
     else { *bytes_a = v + 24 + v + ia; *bytes_b = v + x + v + x + ib; }                   // A: R velm, R force, W velm;  B: R velm, R pos, W velm, W pos
-    if (cos_on(p)) *bytes_a += xr;
+    if (cos_on(p)) { *bytes_a += xr; if (use_moments(p)) { *bytes_a += 8; *bytes_b += 8; } }
+    if (shake_on(p)) {
+        long members = 0;
+        for (size_t i = 0; i < p->hp.slots.size() / 2; i++)
+            if (p->hp.slots[2 * i] >= 0 && ((uint32_t) p->hp.slots[2 * i + 1] & vv::META_SHAKE)) members++;
+        const long n = std::max<long>(1, (long) (p->hp.shard_end - p->hp.shard_begin));
+        *bytes_a += (int32_t) ((x * members + n / 2) / n);
+        if (!per_a) *bytes_a += 20;
+        if (!per_b) *bytes_b += 20;
+    }
     return VVHIP_OK;
 }
 
@@ -906,10 +925,8 @@ int vvhip_step_middle_phase(vvhip_plan* p, int phase, uint32_t random_index) {
         if (phase == 0) return run_ke(p, kick, random_index, false);
         if (phase == 1) return run_chain_and_b(p, vv::B_SCALE | drift, false);
     } else if (use_moments(p)) {                           // bias moment and group moments in one launch
-#ifdef VV_EXP_B_OWN_COS
-        if (phase == 0) return run_a(p, kick | vv::A_BIAS | vv::A_KE | vv::A_KE_MOM, random_index);
-        if (phase == 1) return run_chain_and_b(p, vv::B_SCALE | vv::B_UNBIAS | vv::B_KE_MOM | drift, true);
-#endif
+        // (the per-lane cos(kz) travels from kernel A to kernel B: letting kernel B evaluate its own -- no 8-byte store / load per lane, ~45
+        // more instructions per wave in B -- measured 74.5 k against 74.9 k steps/s at C4, profiles/r04b_ab_C4_cos_variants.txt)
         if (phase == 0) return run_a(p, kick | vv::A_BIAS | vv::A_CZ_STORE | vv::A_KE | vv::A_KE_MOM, random_index);
         if (phase == 1) return run_chain_and_b(p, vv::B_SCALE | vv::B_UNBIAS | vv::B_CZ_LOAD | vv::B_KE_MOM | drift, true);
     } else {                                               // API:252-259: bias -> remove -> scale -> restore
@@ -1143,7 +1160,8 @@ int vvhip_synth_tether_force(vvhip_plan* p, const void* site, double k_tether, d
     if (!site) return VVHIP_ERR_INVALID;
     ScopedTimer t(p, T_OTHER, true);
     vv::TetherArgs ta{p->buf.posq, site, p->buf.velm, (long long*) p->buf.force, p->d_slots,
-                      p->hp.padded_num_atoms, p->hp.info.num_waves, k_tether, k_drude};
+                      p->hp.padded_num_atoms, p->hp.info.num_waves, k_tether, k_drude, p->d_dbg_span, p->dbg_parity, 0};
+    if (p->dbg_seq >= 0) ta.dbg_parity = p->dbg_seq++ % 6;       // vvhip_debug_step_spans: every launch of the sequence stamps rows of its own
     HIP_TRY(p, vv::launch_tether(p->hp.precision, ta, p->block_threads, p->stream, t.e0, t.e1));
     return VVHIP_OK;
 }
@@ -1261,16 +1279,21 @@ int vvhip_run_graph(vvhip_plan* p, int nsteps, int steps_per_graph, const void* 
     return VVHIP_OK;
 }
 
+// The stage bits vvhip_step_middle launches kernel A (kernel = 0) / kernel B with for this plan (timing and probe entry points)
+int vvhip_debug_fused_flags(vvhip_plan* p, int kernel, uint32_t* flags) {
+    NEED_BOUND(p);
+    if (!flags) return VVHIP_ERR_INVALID;
+    const uint32_t mom_a = use_moments(p) ? (vv::A_KE | vv::A_KE_MOM) : 0, mom_b = use_moments(p) ? vv::B_KE_MOM : 0;
+    const bool rk = use_rekick(p);
+    if (kernel == 0) *flags = vv::A_KICK_FULL | (rk ? vv::A_NOSTORE : 0) | extra_flags(p) | cons_a(p) | (p->hp.has_nh ? (cos_on(p) ? (vv::A_BIAS | vv::A_CZ_STORE | mom_a) : vv::A_KE) : 0);
+    const bool split = p->hp.info.num_waves >= p->split_chain_waves && !use_mailbox(p);    // as run_chain_and_b decides
+    if (kernel != 0) *flags = vv::B_DRIFT_MIDDLE | (rk ? vv::B_KICK : 0) | tail_flags(p) | cons_b(p) | (p->hp.has_nh ? (((p->hp.params.num_nh_chains <= 4 && !split) ? vv::B_CHAIN : 0) | vv::B_SCALE | (cos_on(p) ? (vv::B_UNBIAS | vv::B_CZ_LOAD | mom_b) : 0)) : 0);
+    return VVHIP_OK;
+}
 int vvhip_time_kernel(vvhip_plan* p, int kernel, uint32_t flags, int reps, double* ms_per_launch) {
     NEED_BOUND(p);
     if (reps < 1 || !ms_per_launch) return VVHIP_ERR_INVALID;
-    if (flags == 0xFFFFFFFFu) {     // the stage bits vvhip_step_middle uses for this plan
-        const uint32_t mom_a = use_moments(p) ? (vv::A_KE | vv::A_KE_MOM) : 0, mom_b = use_moments(p) ? vv::B_KE_MOM : 0;
-        const bool rk = use_rekick(p);
-        if (kernel == 0) flags = vv::A_KICK_FULL | (rk ? vv::A_NOSTORE : 0) | extra_flags(p) | cons_a(p) | (p->hp.has_nh ? (cos_on(p) ? (vv::A_BIAS | vv::A_CZ_STORE | mom_a) : vv::A_KE) : 0);
-        const bool split = p->hp.info.num_waves >= p->split_chain_waves && !use_mailbox(p);    // as run_chain_and_b decides
-        if (kernel != 0) flags = vv::B_DRIFT_MIDDLE | (rk ? vv::B_KICK : 0) | tail_flags(p) | cons_b(p) | (p->hp.has_nh ? (((p->hp.params.num_nh_chains <= 4 && !split) ? vv::B_CHAIN : 0) | vv::B_SCALE | (cos_on(p) ? (vv::B_UNBIAS | vv::B_CZ_LOAD | mom_b) : 0)) : 0);
-    }
+    if (flags == 0xFFFFFFFFu) TRY(vvhip_debug_fused_flags(p, kernel, &flags));     // the stage bits vvhip_step_middle uses for this plan
     hipEvent_t e0, e1;
     HIP_TRY(p, hipEventCreate(&e0));
     HIP_TRY(p, hipEventCreate(&e1));
@@ -1328,8 +1351,8 @@ int vvhip_debug_span(vvhip_plan* p, int kernel, uint32_t flags, int reps, double
     return fail(p, VVHIP_ERR_UNSUPPORTED, "not an instrumented build");
 #else
     const size_t per = (size_t) 4096 * 8 * 2;
-    if (!p->d_dbg_span) HIP_TRY(p, hipMalloc((void**) &p->d_dbg_span, 2 * per * sizeof(long long)));
-    HIP_TRY(p, hipMemsetAsync(p->d_dbg_span, 0, 2 * per * sizeof(long long), p->stream));
+    if (!p->d_dbg_span) HIP_TRY(p, hipMalloc((void**) &p->d_dbg_span, 6 * per * sizeof(long long)));
+    HIP_TRY(p, hipMemsetAsync(p->d_dbg_span, 0, 6 * per * sizeof(long long), p->stream));
     const int parity = p->parity;
     int rc = VVHIP_OK;
     for (int i = 0; i < reps && rc == VVHIP_OK; i++) { p->parity = parity; p->dbg_parity = i & 1; rc = kernel == 0 ? run_a(p, flags, 0) : run_b(p, flags); }
@@ -1349,7 +1372,7 @@ int vvhip_debug_span(vvhip_plan* p, int kernel, uint32_t flags, int reps, double
     const int grid = (int) vv_last_grid();
     for (int q = 0; q < 2; q++)
         for (size_t r = 0; r < (size_t) grid * 8; r++) {
-            const long long a0 = h[(((size_t) q * grid) * 8 + r) * 2], a1 = h[(((size_t) q * grid) * 8 + r) * 2 + 1];
+            const long long a0 = h[(((size_t) q * 4096) * 8 + r) * 2], a1 = h[(((size_t) q * 4096) * 8 + r) * 2 + 1];
             if (a0 && a1) { in[q].push_back(a0); ex[q].push_back(a1); if (q == ((reps - 1) & 1)) blk.push_back((int) (r / 8)); }
         }
     if (in[0].empty() || in[1].empty()) return fail(p, VVHIP_ERR_INVALID, "no stamps recorded");
@@ -1365,6 +1388,51 @@ int vvhip_debug_span(vvhip_plan* p, int kernel, uint32_t flags, int reps, double
     out[4] = (double) life[life.size() * 9 / 10] * 10.0; out[5] = (double) life.back() * 10.0;
     out[0] = (double) (last_out - first_in) * 10.0; out[1] = (double) (first_in - prev_out) * 10.0;
     out[2] = (double) rel[rel.size() / 2] * 10.0; out[3] = (double) life[life.size() / 2] * 10.0;
+    return VVHIP_OK;
+#endif
+}
+
+// Instrumented build: `nsteps` consecutive fused steps enqueued from here (force provider -> kernel A -> kernel B; middle scheme), every wave
+// of the LAST TWO steps stamping the 100 MHz wall clock at entry and (memory operations drained) at exit.  For the six launches
+// (provider, A, B of the step before the last; provider, A, B of the last) out[l*6 ..] = first wave in, median wave in, last wave in,
+// first wave out, median wave out, last wave out, in ns after the first entry of the first of them.  What a kernel costs IN ITS PLACE:
+// ramp, body, tail and the gap to its neighbours, none of which a profiler's per-kernel duration separates.
+int vvhip_debug_step_spans(vvhip_plan* p, int nsteps, const void* site, double k_tether, double k_drude, double out[36]) {
+    NEED_BOUND(p);
+#ifndef VV_KERNEL_TIMESTAMPS
+    (void) nsteps; (void) site; (void) k_tether; (void) k_drude; (void) out;
+    return fail(p, VVHIP_ERR_UNSUPPORTED, "not an instrumented build");
+#else
+    if (nsteps < 2 || !site || !out || !p->hp.params.use_middle_scheme || vvhip_step_middle_phases(p) != 2) return VVHIP_ERR_INVALID;
+    const size_t per = (size_t) 4096 * 8 * 2;
+    if (!p->d_dbg_span) HIP_TRY(p, hipMalloc((void**) &p->d_dbg_span, 6 * per * sizeof(long long)));
+    TRY(ensure_mass_table(p));
+    for (int i = 0; i < nsteps - 2; i++) TRY(plan_step(p, site, k_tether, k_drude, false));      // warm: same launches, rows overwritten below
+    HIP_TRY(p, hipMemsetAsync(p->d_dbg_span, 0, 6 * per * sizeof(long long), p->stream));
+    long long* keep = p->d_dbg_span;
+    p->dbg_seq = 0;
+    int rc = VVHIP_OK;
+    for (int i = 0; i < 2 && rc == VVHIP_OK; i++) rc = plan_step(p, site, k_tether, k_drude, false);
+    p->dbg_seq = -1;
+    p->d_dbg_span = nullptr;
+    if (rc != VVHIP_OK) { p->d_dbg_span = keep; return rc; }
+    HIP_TRY(p, hipStreamSynchronize(p->stream));
+    std::vector<long long> h(6 * per);
+    HIP_TRY(p, hipMemcpy(h.data(), keep, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    p->d_dbg_span = keep;
+    long long t0 = 0;
+    for (int l = 0; l < 6; l++) {
+        std::vector<long long> in, ex;
+        for (size_t r = 0; r < (size_t) 4096 * 8; r++) {
+            const long long a0 = h[((size_t) l * 4096 * 8 + r) * 2], a1 = h[((size_t) l * 4096 * 8 + r) * 2 + 1];
+            if (a0 && a1) { in.push_back(a0); ex.push_back(a1); }
+        }
+        if (in.empty()) return fail(p, VVHIP_ERR_INVALID, "no stamps recorded for one of the launches");
+        std::sort(in.begin(), in.end()); std::sort(ex.begin(), ex.end());
+        if (l == 0) t0 = in.front();
+        const long long v[6] = {in.front(), in[in.size() / 2], in.back(), ex.front(), ex[ex.size() / 2], ex.back()};
+        for (int k = 0; k < 6; k++) out[l * 6 + k] = (double) (v[k] - t0) * 10.0;
+    }
     return VVHIP_OK;
 #endif
 }

@@ -200,6 +200,8 @@ struct KArgs {
     int32_t dbg_block, dbg_pad_;
     long long* dbg_span;            // instrumented build: [2 launch parities][blocks*8 waves][2] entry / exit stamps of every wave (100 MHz wall clock)
     int32_t dbg_parity, dbg_pad2_;
+    uint32_t pos_bytes;             // size of the posq (= posqCorrection) array in bytes if below 4 GB, else 0: kernel A fetches the positions of
+    uint32_t pos_pad_;              // constraint-cluster members through a buffer resource (load_members below), other lanes fetch nothing
 };
 
 struct TetherArgs {
@@ -210,6 +212,8 @@ struct TetherArgs {
     const int2* slots;
     int32_t padded, nwaves;
     double k_tether, k_drude;
+    long long* dbg_span;            // instrumented build (as KArgs::dbg_span)
+    int32_t dbg_parity, dbg_pad_;
 };
 
 }  // namespace vv

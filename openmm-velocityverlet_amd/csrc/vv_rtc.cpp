@@ -99,12 +99,6 @@ bool rtc_compile(char kind, int precision, uint32_t flags, int num_chains, const
     char links[40];
     std::snprintf(links, sizeof links, "-DVV_SF_CHAIN_LINKS=%d", num_chains >= 1 && num_chains <= 4 ? num_chains : 3);
     std::vector<const char*> opts = {arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-kernarg-preload-count=16", links};
-#ifdef VV_EXP_LIN_PREP
-    opts.push_back("-DVV_EXP_LIN_PREP");
-#endif
-#ifdef VV_EXP_LIBM_COS
-    opts.push_back("-DVV_EXP_LIBM_COS");
-#endif
     const auto t0 = std::chrono::steady_clock::now();
     if (ok) ok = r.compile(prog, (int) opts.size(), opts.data()) == HIPRTC_SUCCESS;
     vv_rtc_compile_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -6,7 +6,9 @@ import csv, glob, json, os, re, shutil, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip() or None
-dirty = bool(subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "openmm-velocityverlet_amd", "bench.py"], capture_output=True, text=True).stdout.strip())
+if os.environ.get("STAMP_COMMIT"):      # the set was measured at an earlier commit than HEAD (say which)
+    commit = os.environ["STAMP_COMMIT"]
+dirty = not os.environ.get("STAMP_COMMIT") and bool(subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "openmm-velocityverlet_amd", "bench.py"], capture_output=True, text=True).stdout.strip())
 stats_path = os.path.join(ROOT, "profiles", "kernel_stats_latest.json")
 stats = json.load(open(stats_path)) if os.path.exists(stats_path) else {}
 for tag in sys.argv[1:]:
