@@ -346,9 +346,6 @@ vv::KArgs make_args(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
     {   // posq / posqCorrection as a buffer resource (kernel A's member-only position fetch): 32-bit sizes and offsets
         const unsigned long long bytes = (unsigned long long) (p->hp.shard_end - p->hp.shard_begin) * (p->hp.precision == VVHIP_DOUBLE ? 32ull : 16ull);
         a.pos_bytes = bytes < 0xFFFFFFE0ull ? (uint32_t) bytes : 0u;
-#ifdef VV_EXP_PLAIN_CONS_LOADS
-        a.pos_bytes = 0;
-#endif
     }
     a.nwaves = p->hp.info.num_waves;
     a.acc_rows = p->hp.params.cos_acceleration != 0 ? vv::NUM_ACC : 4;
