@@ -279,6 +279,7 @@ def main():
                     help="secondary block (N = 1, config C3): the same kernels on the tiled box, where HBM bandwidth is the bound")
     ap.add_argument("--synthetic", action="store_true", help="procedural look-alike systems instead of the reference's example models (C3 / C4 / C5)")
     ap.add_argument("--child", action="store_true", help="(internal) the run rocprofv3 wraps: headline measurement only, no secondary blocks")
+    ap.add_argument("--headline-only", action="store_true", help="headline measurement only, no secondary blocks (what the counter passes of tools/profile_round.sh wrap: one variant of each kernel per run)")
     ap.add_argument("--no-rocprof", action="store_true", help="do not spawn the rocprofv3 child runs; roofline.frac then comes from the dispatch-timestamp clock")
     ap.add_argument("--hbonds", action="store_true", help="constraints solved in-kernel: HBonds (SHAKE) for the ionic liquids, rigid water (SETTLE) for C2; not the headline workload")
     args = ap.parse_args()
@@ -289,7 +290,7 @@ def main():
 
     # ---- rocprofv3 child runs, BEFORE this process initialises the GPU (kernel durations as the profiler reports them, measured live)
     prof = {}
-    if not args.child and not args.no_rocprof and args.gpus == 1 and not args.eager and not args.force_dist:
+    if not args.child and not args.headline_only and not args.no_rocprof and args.gpus == 1 and not args.eager and not args.force_dist:
         base = ["--config", args.config] + (["--synthetic"] if args.synthetic else [])
         short = ["--steps", "200", "--warmup", "40"] if args.config.startswith("C3x") else ["--steps", "4000", "--warmup", "400"]
         # (bounded: a child normally takes 3-15 s; if the first one cannot run, the others are not tried -- same reason, same answer)
@@ -675,7 +676,7 @@ def main():
     # ---- the integrator path alone: forces resident in HBM (static buffer, zeroed: thermostatted free flight -- the same loads, stores
     # and arithmetic as with any other force values, and nothing that can run away), no provider kernel in the loop.  The physical
     # state is saved and put back: the particles leave their tether sites meanwhile.
-    if args.child:          # the run rocprofv3 wraps: the headline loop is all it needs
+    if args.child or args.headline_only:          # the run rocprofv3 wraps: the headline loop is all it needs
         ctx.close()
         print(json.dumps(out), flush=True)
         return

@@ -1,5 +1,6 @@
 """Host logic of the product (vvhip_plan_create: no GPU needed) against the numpy restatement of the
 reference's initialize() methods, the wave-layout invariants the kernels rely on, and the C-ABI export list."""
+import ctypes as C
 import importlib
 import os
 import re
@@ -237,3 +238,48 @@ def test_periodic_layout_units_must_repeat(monkeypatch):
     it.setMaxDrudeDistance(0.02)
     info, slots = I.plan_layout(spec, it)
     assert info.periodic_layout == 1 and info.num_waves == 3 * 4       # 3 cells x (9x7 | 13x4 | 20x3 | 30x1 atoms: one wave each)
+
+
+def _bytes(plan):
+    a, b = C.c_int32(0), C.c_int32(0)
+    assert H.lib.vvhip_algorithmic_bytes(plan, C.byref(a), C.byref(b)) == H.OK
+    return a.value, b.value
+
+
+def test_algorithmic_bytes_follow_what_the_kernels_read():
+    """vvhip_algorithmic_bytes (bench.py prices every launch with it) per configuration, no GPU needed: SURVEY section 8d's accounting for the
+    headline path, + posq and the per-lane cos(kz) hand-over with the cos perturbation, + the positions of cluster members (their
+    share of the particles) and the cluster word / parameters with in-kernel constraints."""
+    def plan_of(cfg, cos=0.0, **kw):
+        spec = systems.make_config(cfg, **kw)
+        it = I.VVIntegrator(333.0, 10.0, 1.0, 40.0, 0.001)
+        it.setMaxDrudeDistance(0.02)
+        it.setCosAcceleration(cos)
+        plan, info, keep = I.create_plan(spec, it, "mixed")
+        return spec, plan, keep
+    spec, plan, keep = plan_of("C3")
+    assert _bytes(plan) == (62, 158)                                  # R velm 32 + R force 24 + idx 6 | + R pos 32 + W velm 32 + W pos 32
+    H.lib.vvhip_plan_destroy(plan)
+    spec, plan, keep = plan_of("C3", cos=0.02)
+    assert _bytes(plan) == (62 + 16 + 8, 158 + 8)                     # + R posq, W cos(kz) | + R cos(kz)
+    H.lib.vvhip_plan_destroy(plan)
+    spec, plan, keep = plan_of("C3", hbonds=True)
+    members = len(set(np.asarray(spec.constraints).reshape(-1).tolist()))
+    share = (32 * members + spec.num_atoms // 2) // spec.num_atoms
+    assert 10 <= share <= 20                                          # 51 000 of 111 000 particles sit in a cluster
+    assert _bytes(plan) == (94 + share + 20, 134 + 20)                # A writes the velocities back, reads members' positions, both read cluster word + parameters
+    H.lib.vvhip_plan_destroy(plan)
+
+
+def test_tuning_hook_names():
+    """vvhip_debug_tune replaces the tuning environment switches of rounds 1-3: known names are accepted before binding, unknown ones refused."""
+    spec = systems.make_config("C2")
+    it = I.VVIntegrator(300.0, 10.0, 1.0, 40.0, 0.002)
+    plan, info, keep = I.create_plan(spec, it, "mixed")
+    for key, val in (("grid_cap_a", 8), ("grid_cap_b", 8), ("split_chain_waves", 1), ("periodic_kernels", 0), ("periodic_a", 1), ("rekick", 0),
+                     ("no_moments", 1), ("mass_tab_a", 1), ("mass_tab_b", 0), ("acc_store", 0), ("block_threads", 128)):
+        assert H.lib.vvhip_debug_tune(plan, key.encode(), val) == H.OK, key
+    assert H.lib.vvhip_debug_tune(plan, b"no_such_choice", 1) == H.ERR_INVALID
+    assert b"no_such_choice" in H.lib.vvhip_last_error(plan)
+    assert H.lib.vvhip_debug_tune(plan, b"block_threads", 100) == H.ERR_INVALID
+    H.lib.vvhip_plan_destroy(plan)

@@ -13,7 +13,7 @@ if [[ "$CFG" != C3x* ]]; then STEPS="--steps 400 --warmup 100"; else STEPS="--st
 P=0
 for SET in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" "SQ_WAVES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD"; do
     P=$((P+1))
-    rocprofv3 --pmc $SET --kernel-trace --output-format csv -d "$OUT/pmc_sq$P" -o run -- python3 "$ROOT/bench.py" --config "$CFG" $EXTRA --large-n none $STEPS --no-cpu-baseline --no-rocprof > "$OUT/pmc_sq_${CFG}_$P.log" 2>&1
+    rocprofv3 --pmc $SET --kernel-trace --output-format csv -d "$OUT/pmc_sq$P" -o run -- python3 "$ROOT/bench.py" --config "$CFG" $EXTRA --large-n none $STEPS --no-cpu-baseline --no-rocprof --headline-only > "$OUT/pmc_sq_${CFG}_$P.log" 2>&1
 done
 python3 - "$OUT" "$TAG" "$CFG" <<'PY' > "$OUT/pmc_sq_$CFG$SUF.json"
 import csv, glob, json, os, re, sys

@@ -5,7 +5,7 @@ import csv, glob, json, os, sys
 
 out_dir, tag = sys.argv[1], sys.argv[2]
 cfg = sys.argv[3] if len(sys.argv) > 3 else "C3"
-natoms = {"C3": 111000, "C4": 111000, "C5": 40310, "C3x8": 888000, "C3x80": 8880000}.get(cfg, 111000)
+natoms = {"C1": 1992, "C2": 9999, "C3": 111000, "C4": 111000, "C5": 40310, "C3x8": 888000, "C3x80": 8880000}.get(cfg, 111000)
 names = {"vv_kernel_a": "A", "vv_kernel_b": "B", "vv_kernel_tether": "tether"}
 raw, variants, chosen = {}, {}, {}
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):

@@ -14,7 +14,7 @@ for seed in range(1000, 1160):
     maxd = 0.02 if len(spec.drude_pairs) else 0.0
     cos = 0.02 if seed % 3 == 0 else 0.0
     middle = seed % 5 != 0
-    for env in ({"VVHIP_PERIODIC": "1", "VVHIP_PERIODIC_A": "1"}, {"VVHIP_PERIODIC": "0"}):
+    for env in ({"VVHIP_PERIODIC": "1"}, {"VVHIP_PERIODIC": "0"}):
         flag, v, x, c, ke = T._run(spec, "mixed", 4, env, mp, cos=cos, maxd=maxd, middle=middle)
         nper += flag
         p = O.Params(temperature=333.0, drude_temperature=1.0, max_drude_distance=maxd, cos_acceleration=cos, use_middle_scheme=middle)

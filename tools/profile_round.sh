@@ -13,7 +13,11 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-if [ "$CFG" = "C3" ]; then
+if [ -n "${ONLY_PMC:-}" ]; then          # counters again for an existing set (the bench lines and kernel stats of $OUT stay)
+    if [[ "$CFG" != C3x* ]]; then PSTEPS="--steps 400 --warmup 100"; BS="--steps 2000 --warmup 200"; else PSTEPS="--steps 40 --warmup 10"; BS="--steps 100 --warmup 20"; fi
+    # (a short bench line of its own: pmc_summary.py takes the algorithmic bytes from it)
+    python3 "$ROOT/bench.py" --config "$CFG" $EXTRA --large-n none $BS --no-cpu-baseline --no-rocprof 2>"$OUT/bench_$CFG.stderr" | tail -1 > "$OUT/bench_${CFG}${SUF}_mixed.json"
+elif [ "$CFG" = "C3" ]; then
     python3 "$ROOT/bench.py" $EXTRA 2>"$OUT/bench_$CFG.stderr" | tail -1 > "$OUT/bench_${CFG}${SUF}_mixed.json"
     python3 "$ROOT/bench.py" $EXTRA --gpus 1 --steps 20 --warmup 5 2>>"$OUT/bench_$CFG.stderr" | tail -1 > "$OUT/bench_${CFG}${SUF}_mixed_driver_flags.json"
     STEPS="--steps 4000 --warmup 400"; PSTEPS="--steps 400 --warmup 100"
@@ -25,10 +29,11 @@ else
     python3 "$ROOT/bench.py" --config "$CFG" $EXTRA --large-n none --steps 200 --warmup 40 --no-cpu-baseline 2>"$OUT/bench_$CFG.stderr" | tail -1 > "$OUT/bench_${CFG}${SUF}_mixed.json"
     STEPS="--steps 100 --warmup 20"; PSTEPS="--steps 40 --warmup 10"
 fi
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$CFG" -o run -- python3 "$ROOT/bench.py" --config "$CFG" $EXTRA --large-n none $STEPS --no-cpu-baseline --no-rocprof > "$OUT/stats_$CFG.log" 2>&1
-cp "$OUT/stats_$CFG"/run_kernel_stats.csv "$OUT/kernel_stats_$CFG$SUF.csv" 2>/dev/null || find "$OUT/stats_$CFG" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_$CFG$SUF.csv" \;
+[ -z "${ONLY_PMC:-}" ] && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$CFG" -o run -- python3 "$ROOT/bench.py" --config "$CFG" $EXTRA --large-n none $STEPS --no-cpu-baseline --no-rocprof > "$OUT/stats_$CFG.log" 2>&1
+[ -z "${ONLY_PMC:-}" ] && cp "$OUT/stats_$CFG"/run_kernel_stats.csv "$OUT/kernel_stats_$CFG$SUF.csv" 2>/dev/null || find "$OUT/stats_$CFG" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_$CFG$SUF.csv" \;
 for C in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_$C" -o run -- python3 "$ROOT/bench.py" --config "$CFG" $EXTRA --large-n none $PSTEPS --no-cpu-baseline --no-rocprof > "$OUT/pmc_${CFG}_$C.log" 2>&1
+    # (--headline-only: the secondary blocks launch OTHER variants of the kernels -- the constrained box's -- more often than the headline's)
+    rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_$C" -o run -- python3 "$ROOT/bench.py" --config "$CFG" $EXTRA --large-n none $PSTEPS --no-cpu-baseline --no-rocprof --headline-only > "$OUT/pmc_${CFG}_$C.log" 2>&1
 done
 python3 "$ROOT/tools/pmc_summary.py" "$OUT" "$TAG" "$CFG" > "$OUT/pmc_$CFG$SUF.json"
 rm -rf "$OUT/stats_$CFG" "$OUT"/pmc_FETCH_SIZE "$OUT"/pmc_WRITE_SIZE
