@@ -325,14 +325,16 @@ class _System(C.Structure):
 _LIBS: Dict[Tuple[str, str], C.CDLL] = {}
 
 
-def lib(prec: str, fmad: bool = False) -> C.CDLL:
-    """fmad: the build with contracted multiply-adds (`make -C oracle fmad`, oracle/Makefile: OPT_FMAD) -- NVRTC's default for the
-    reference's kernels; only tests/test_fmad_gap.py asks for it."""
-    key = ("oracle" + ("_fmad" if fmad else ""), prec)
+def lib(prec: str, fmad=False) -> C.CDLL:
+    """fmad: True = the build with contracted multiply-adds (`make -C oracle fmad`, oracle/Makefile: OPT_FMAD) -- NVRTC's default for the
+    reference's kernels; "altprelude" = SQRT / RECIP of `mixed` values in double (`make altprelude`, mixed mode).  Only
+    tests/test_fmad_gap.py asks for either."""
+    suffix = "_altprelude" if fmad == "altprelude" else ("_fmad" if fmad else "")
+    key = ("oracle" + suffix, prec)
     if key not in _LIBS:
-        path = os.path.join(HERE, f"liboracle_{prec}{'_fmad' if fmad else ''}.so")
+        path = os.path.join(HERE, f"liboracle_{prec}{suffix}.so")
         if not os.path.exists(path):
-            build("fmad" if fmad else "all")
+            build("altprelude" if fmad == "altprelude" else ("fmad" if fmad else "all"))
         L = C.CDLL(path)
         assert L.vvo_sizeof_system() == C.sizeof(_System), "ctypes _System out of sync with vv_oracle.h"
         L.vvo_calc_viscosity.restype = C.c_double

@@ -29,7 +29,10 @@ typedef vvo_mixed4 mixed4;
 typedef vvo_int2 int2;
 
 /* What OpenMM's CudaContext prepends (see ref_prelude.h for the stated assumption). */
-#if defined(VVO_DOUBLE)
+#if defined(VVO_DOUBLE) || defined(VVO_ALT_PRELUDE)
+/* VVO_ALT_PRELUDE (`make altprelude`, mixed mode only): the OTHER reading of what OpenMM 8.1.2 prepends in mixed precision -- SQRT and
+ * RECIP in double wherever their argument is `mixed` -- built to measure how much rests on the assumption stated in ref_prelude.h
+ * (tests/test_fmad_gap.py::test_the_prelude_assumption_is_worth_one_float_ulp). */
 #define SQRT sqrt
 #define RECIP(x) (1.0/(x))
 #else

@@ -168,3 +168,31 @@ def test_langevin_drude_pairs_are_the_one_place_where_contraction_shows():
     b = O.OracleSystem(spec, params, "mixed", random=rnd, force_mode=1, fmad=True)
     a.step(STEPS); b.step(STEPS)
     assert rel(b.velm[others, :3], a.velm[others, :3]) < 1e-11      # everything outside the Langevin pairs stays at double rounding
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(O.__file__), "vv_oracle.c")), reason="oracle sources absent")
+def test_the_prelude_assumption_is_worth_one_float_ulp_and_nothing_at_the_headline():
+    """The second thing this image cannot verify: what OpenMM 8.1.2's CudaContext prepends in MIXED precision.  Assumed (oracle/ref_prelude.h):
+    `SQRT = sqrtf`, `RECIP(x) = 1.0f/(x)`.  RECIP of a double argument is a double quotient either way; SQRT is what matters -- the Drude
+    separation of the hard wall and the mass roots of the Langevin stage would be float roots of double values.  `make -C oracle altprelude`
+    builds the restatement under the OTHER reading (double roots), and this test measures what rests on the assumption:
+      * C1-C4 as benchmarked: NOTHING -- no particle reaches the hard wall, no Langevin subset; every bit of 200 steps of the full C3 box is equal;
+      * C5 (Langevin electrode): 5e-9 of the velocity scale after 200 steps (float `forceExtra` swallows most of a double root's extra digits);
+      * systems built to hit the wall from the first step (the golden configurations): one float ulp per hit, amplified by the Drude spring
+        to 1e-7 (middle scheme) ... 1e-4 (classic) of the velocity scale after 200 steps -- the size any change of the last float bit has there."""
+    def both(spec, params, steps=STEPS):
+        rnd = normals_for(spec, params, steps)
+        a = O.OracleSystem(spec, params, "mixed", random=rnd, force_mode=1)
+        b = O.OracleSystem(spec, params, "mixed", random=rnd, force_mode=1, fmad="altprelude")
+        a.step(steps); b.step(steps)
+        return a, b
+    a, b = both(systems.make_config("C3"), O.Params(temperature=333.0, max_drude_distance=0.02))
+    assert np.array_equal(a.velm.view(np.uint8), b.velm.view(np.uint8)) and np.array_equal(a.posq.view(np.uint8), b.posq.view(np.uint8))
+    spec = systems.make_config("C5")
+    p5 = O.Params(temperature=333.0, max_drude_distance=0.02, mirror_location=float(spec.box[2]) / 2, electric_field=2.0 / float(spec.box[2]) * 2 * 1.602176634e-22)
+    a, b = both(spec, p5)
+    assert rel(b.velm[:, :3], a.velm[:, :3]) < 1e-7 and rel(b.positions(), a.positions()) < 1e-8
+    for name, bound in (("bulk_middle", 1e-5), ("bulk_classic", 1e-3)):
+        a, b = both(*make_spec(name))
+        ev = rel(b.velm[:, :3], a.velm[:, :3])
+        assert 0 < ev < bound, (name, ev)
