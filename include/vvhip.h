@@ -125,6 +125,9 @@ typedef struct {
     int32_t num_settle_clusters;                 /* rigid three-site molecules solved in-kernel (SETTLE) */
     int32_t periodic_layout;                     /* 1: the work-item layout is arithmetic (runs of identical molecules): the fused kernels compute
                                                     particle indices instead of loading them (vv_host.hpp: PeriodicLayout) */
+    int32_t num_general_constraints;             /* constraints outside the two rules above (AllBonds, HAngles: chains, rings, triangles) that the
+                                                    fused kernels relax by coloured Gauss-Seidel sweeps inside the wave of their molecule; 0 if the
+                                                    System has none, or if a component of the constraint graph does not fit one wave */
 } vvhip_plan_info;
 
 /* Nose-Hoover chain state + last reduction results (HOST: CudaVVKernels.h:206-215).  The reference

@@ -343,6 +343,7 @@ vv::KArgs make_args(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
     a.dbg_span = p->d_dbg_span;
     a.dbg_parity = p->dbg_seq >= 0 ? p->dbg_seq++ % 6 : p->dbg_parity;
     a.padded = p->hp.padded_num_atoms;
+    a.gc_colors = p->hp.gc_colors;
     {   // posq / posqCorrection as a buffer resource (kernel A's member-only position fetch): 32-bit sizes and offsets
         const unsigned long long bytes = (unsigned long long) (p->hp.shard_end - p->hp.shard_begin) * (p->hp.precision == VVHIP_DOUBLE ? 32ull : 16ull);
         a.pos_bytes = bytes < 0xFFFFFFE0ull ? (uint32_t) bytes : 0u;
@@ -579,8 +580,8 @@ uint32_t tail_flags(const vvhip_plan* p) {      // what follows every position u
 bool cos_on(const vvhip_plan* p) { return p->hp.params.cos_acceleration != 0; }
 bool shake_on(const vvhip_plan* p) { return !p->hp.slot_shake.empty(); }
 // stage bits of the in-kernel constraints the plan holds: hydrogen-type clusters and / or rigid three-site molecules
-uint32_t cons_a(const vvhip_plan* p) { return (p->hp.info.num_shake_clusters > 0 ? vv::A_SHAKE_V : 0u) | (p->hp.info.num_settle_clusters > 0 ? vv::A_SETTLE : 0u); }
-uint32_t cons_b(const vvhip_plan* p) { return (p->hp.info.num_shake_clusters > 0 ? vv::B_SHAKE : 0u) | (p->hp.info.num_settle_clusters > 0 ? vv::B_SETTLE : 0u); }
+uint32_t cons_a(const vvhip_plan* p) { return (p->hp.info.num_shake_clusters > 0 ? vv::A_SHAKE_V : 0u) | (p->hp.info.num_settle_clusters > 0 ? vv::A_SETTLE : 0u) | (p->hp.info.num_general_constraints > 0 ? vv::A_GCONS : 0u); }
+uint32_t cons_b(const vvhip_plan* p) { return (p->hp.info.num_shake_clusters > 0 ? vv::B_SHAKE : 0u) | (p->hp.info.num_settle_clusters > 0 ? vv::B_SETTLE : 0u) | (p->hp.info.num_general_constraints > 0 ? vv::B_GCONS : 0u); }
 #define NEED_FUSABLE(p)                                                                                                   \
     do {                                                                                                                \
         if (!(p)->hp.info.constraints_fused)                                                                            \

@@ -44,6 +44,7 @@ enum : uint32_t {
     A_SHAKE_GS = 1u << 21,   // hydrogen-type clusters by Gauss-Seidel sweeps of the central lane (OpenMM's iteration; VVHIP_SHAKE_MODE=0, generic
                              // kernel only) instead of the direct solve of the cluster's velocity constraints
     A_KE_PLAIN = 1u << 15,   // sum m v^2 over every massive particle into accumulator 0 (kinetic-energy query)
+    A_GCONS = 1u << 23,      // velocity constraints of general clusters (any topology inside a wave): coloured Gauss-Seidel sweeps over the wave's list
 };
 // ---- stage flags of kernel B ("consume": starts from the scale factors) -------------------------
 enum : uint32_t {
@@ -69,8 +70,9 @@ enum : uint32_t {
     B_PERIODIC = 1u << 18,    // as A_PERIODIC
     B_MTAB = 1u << 16,        // Drude-pair mass fractions from the static per-lane table (slot_f) instead of two IEEE divisions per lane
     B_SHAKE_GS = 1u << 19,    // as A_SHAKE_GS, for the position constraints (instead of the coupled Newton iteration)
+    B_GCONS = 1u << 21,       // as A_GCONS, for the position constraints
 };
-constexpr uint32_t A_CONS = A_SHAKE_V | A_SETTLE, B_CONS = B_SHAKE | B_SETTLE;      // in-kernel constraints of either kind
+constexpr uint32_t A_CONS = A_SHAKE_V | A_SETTLE | A_GCONS, B_CONS = B_SHAKE | B_SETTLE | B_GCONS;      // in-kernel constraints of any kind
 // ---- chain kernel --------------------------------------------------------------------------------
 enum : uint32_t { C_CHAIN = 1u << 0, C_BIAS = 1u << 1 };
 
@@ -201,7 +203,8 @@ struct KArgs {
     long long* dbg_span;            // instrumented build: [2 launch parities][blocks*8 waves][2] entry / exit stamps of every wave (100 MHz wall clock)
     int32_t dbg_parity, dbg_pad2_;
     uint32_t pos_bytes;             // size of the posq (= posqCorrection) array in bytes if below 4 GB, else 0: kernel A fetches the positions of
-    uint32_t pos_pad_;              // constraint-cluster members through a buffer resource (load_members below), other lanes fetch nothing
+    int32_t gc_colors;              // constraint-cluster members through a buffer resource (load_wanted), other lanes fetch nothing; gc_colors:
+                                    // colours of the general clusters' sweeps (A_GCONS / B_GCONS)
 };
 
 struct TetherArgs {

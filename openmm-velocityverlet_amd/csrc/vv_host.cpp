@@ -262,6 +262,26 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
         if (ok) constraints_fused = true;
         else { shakes.clear(); std::fill(shake_of.begin(), shake_of.end(), -1); }
     }
+    // ---- anything else (AllBonds, HAngles: chains, rings, triangles of constraints; examples/ommhelper/oplspsffile.py:948-951) becomes GENERAL
+    // clusters: every connected component of the constraint graph must sit in one wave with its particles, and the wave relaxes its constraints
+    // by coloured Gauss-Seidel sweeps (vv_device.inc: general_positions / general_velocities).  gc_adj = constraint partners of a particle.
+    std::vector<std::vector<int32_t> > gc_adj;
+    bool general = false;
+    if (sys.num_constraints > 0 && sys.constraint_distances && !constraints_fused) {
+        general = true;
+        for (int k = 0; k < sys.num_constraints && general; k++) {
+            const int a = sys.constraints[2 * k], b = sys.constraints[2 * k + 1];
+            if (a == b || sys.masses[a] == 0 || sys.masses[b] == 0 || !(sys.constraint_distances[k] > 0)) general = false;      // (OpenMM refuses massless ones too)
+        }
+        if (general) {
+            gc_adj.assign(n, {});
+            for (int k = 0; k < sys.num_constraints; k++) {
+                gc_adj[sys.constraints[2 * k]].push_back(sys.constraints[2 * k + 1]);
+                gc_adj[sys.constraints[2 * k + 1]].push_back(sys.constraints[2 * k]);
+            }
+            constraints_fused = true;          // withdrawn below if a component does not fit a wave
+        }
+    }
 
     // ---- which particles need a lane, and which must share a wave
     auto needs_lane = [&](int i) {
@@ -305,6 +325,7 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
                     visit(s.center);
                     for (int q : s.periph) visit(q);
                 }
+                if (general) for (int q : gc_adj[j]) visit(q);
             }
             std::sort(c.members.begin(), c.members.end());
             c.first = c.members[0];
@@ -346,6 +367,7 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
                     auto visit = [&](int q) { const size_t t = index_in(q); if (!taken[t]) { taken[t] = 1; todo.push_back(q); } };
                     if (in_pair[j]) visit(partner[j]);
                     if (shake_of[j] >= 0) { visit(shakes[shake_of[j]].center); for (int q : shakes[shake_of[j]].periph) visit(q); }
+                    if (general) for (int q : gc_adj[j]) visit(q);
                 }
                 std::sort(u.begin(), u.end());
                 units.push_back(u);
@@ -394,7 +416,7 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
         bool want = lanes >= 200000;
         if (const char* e = std::getenv("VVHIP_PERIODIC")) want = std::atoi(e) != 0;
         if (!want) return false;
-        if (hp.has_ld || hp.has_images || hp.num_big > 0 || clusters.empty()) return false;
+        if (hp.has_ld || hp.has_images || hp.num_big > 0 || clusters.empty() || general) return false;
         const size_t K = clusters.size();
         std::vector<uint64_t> sig(K);
         int expect = sb;
@@ -581,7 +603,7 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
             if (in_pair[i]) meta |= META_PAIR;
             if (is_drude[i]) meta |= META_IS_DRUDE;
             if (massive) meta |= META_MASSIVE;
-            if (shake_of[i] >= 0) meta |= META_SHAKE;
+            if (shake_of[i] >= 0 || (general && !gc_adj[i].empty())) meta |= META_SHAKE;
             if (c.big >= 0) meta |= META_BIGMOL;
             if (c.big >= 0 && c.big_first && (meta & META_COM_LEADER)) meta |= META_BIG_FIRST;
             slots[(size_t) wave * 128 + 2 * lane] = i - sb;
@@ -713,6 +735,56 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
                 const int lq = lane_of[s.periph[k]];
                 hp.slot_shake[(size_t) w * 64 + lq] = (int32_t) (common | 2u | ((uint32_t) k << vv::SHAKE_WORD_OWN_SHIFT));
                 std::memcpy(&hp.slot_shake_param[((size_t) w * 64 + lq) * 4], prm, sizeof(prm));
+            }
+        }
+    }
+    info.num_general_constraints = 0;
+    hp.gc_colors = 0;
+    if (general) {
+        // Per wave: its constraints, coloured greedily in System order (two constraints that share a particle get different colours: a
+        // colour's constraints are relaxed side by side, one per lane), sorted by colour and handed to lanes 0, 1, ... of the wave.
+        // Word: bit 31 valid | colour << 12 | lane of b << 6 | lane of a; parameters: d^2, 0.5 / (1/m_a + 1/m_b), 1/m_a, 1/m_b (float, as
+        // OpenMM keeps its SHAKE parameters).  A wave with more than 64 constraints, more than 16 colours, or a constraint across two waves
+        // (a molecule cut into chunks): not fused, the split entry points take over as before.
+        struct GC { int la, lb, colour; float prm[4]; };
+        std::vector<std::vector<GC> > per_wave((size_t) nwaves);
+        std::vector<uint32_t> used_colours((size_t) nwaves * 64, 0u);
+        bool fits = true;
+        for (int k = 0; k < sys.num_constraints && fits; k++) {
+            const int a = sys.constraints[2 * k], b = sys.constraints[2 * k + 1];
+            if (!in_shard(a) && !in_shard(b)) continue;
+            if (!in_shard(a) || !in_shard(b)) throw Error(VVHIP_ERR_INVALID, "particle shard cuts a Drude pair or a constraint cluster");
+            const int w = wave_of[a];
+            if (w < 0 || wave_of[b] != w) { fits = false; break; }
+            const int la = lane_of[a], lb = lane_of[b];
+            const uint32_t taken = used_colours[(size_t) w * 64 + la] | used_colours[(size_t) w * 64 + lb];
+            int colour = 0;
+            while (colour < 16 && ((taken >> colour) & 1u)) colour++;
+            if (colour >= 16) { fits = false; break; }
+            used_colours[(size_t) w * 64 + la] |= 1u << colour;
+            used_colours[(size_t) w * 64 + lb] |= 1u << colour;
+            const double ima = 1.0 / sys.masses[a], imb = 1.0 / sys.masses[b], d = sys.constraint_distances[k];
+            GC g{la, lb, colour, {(float) (d * d), (float) (0.5 / (ima + imb)), (float) ima, (float) imb}};
+            per_wave[(size_t) w].push_back(g);
+            if (per_wave[(size_t) w].size() > 64) fits = false;
+            hp.gc_colors = std::max(hp.gc_colors, colour + 1);
+        }
+        if (!fits) {
+            constraints_fused = false;
+            info.constraints_fused = 0;
+            hp.gc_colors = 0;
+        } else {
+            hp.slot_shake.assign((size_t) nwaves * 64, 0);
+            hp.slot_shake_param.assign((size_t) nwaves * 64 * 4, 0.0f);
+            for (int w = 0; w < nwaves; w++) {
+                auto& list = per_wave[(size_t) w];
+                std::stable_sort(list.begin(), list.end(), [](const GC& x, const GC& y) { return x.colour < y.colour; });
+                for (size_t l = 0; l < list.size(); l++) {
+                    const GC& g = list[l];
+                    hp.slot_shake[(size_t) w * 64 + l] = (int32_t) (vv::GC_WORD_VALID | ((uint32_t) g.colour << 12) | ((uint32_t) g.lb << 6) | (uint32_t) g.la);
+                    std::memcpy(&hp.slot_shake_param[((size_t) w * 64 + l) * 4], g.prm, sizeof(g.prm));
+                    info.num_general_constraints++;
+                }
             }
         }
     }

@@ -35,6 +35,10 @@ constexpr int SHAKE_WORD_OWN_SHIFT = 28;
 constexpr uint32_t SHAKE_WORD_SETTLE = 1u << 30;
 constexpr uint32_t META_SHAKE = 1u << 30;      // member of an in-kernel constraint cluster: the kernels fetch its cluster word, parameters and
                                                // position in the same round of loads as the velocity, not after reading the cluster word
+// General constraint clusters (any topology inside one wave): slot_shake then holds the WAVE's constraint list, constraint l in lane l:
+// bits 0-5 lane of particle a, 6-11 lane of particle b, 12-15 colour (constraints of one colour share no particle), bit 31 valid;
+// slot_shake_param: d^2, 0.5 / (1/m_a + 1/m_b), 1/m_a, 1/m_b
+constexpr uint32_t GC_WORD_VALID = 1u << 31;
 constexpr uint32_t META_BIG_FIRST = 1u << 29;  // leader of the FIRST chunk of such a molecule (adds M*V^2 once, clears bigacc)
 
 inline uint32_t meta_role(uint32_t m) { return m & META_ROLE_MASK; }

@@ -252,6 +252,52 @@ def constrain_hydrogens(spec: SystemSpec, distance: float = 0.109) -> SystemSpec
     return spec
 
 
+def constrain_all_bonds(spec: SystemSpec, cutoff: float = 0.165, hangles: bool = False) -> SystemSpec:
+    """constraints=AllBonds (and HAngles) as examples/ommhelper/oplspsffile.py:948-951 can ask of OpenMM: every bond becomes a distance constraint,
+    with HAngles also the H-X-H angles (as a distance between the two hydrogens).  The topology files' bond lists are not part of the
+    fixtures, so bonds are found from the geometry: two real (non-Drude, massive) particles of one molecule closer than `cutoff` nm in
+    the initial positions are bonded (C-H 0.109, C-C / C-N 0.13-0.15 nm in conf.gro), and the constraint length is their distance there, so
+    the start satisfies the position constraints.  Rings (the imidazolium ring) and chains (dicyanamide) give constraint graphs that are
+    neither hydrogen-type clusters nor rigid triangles: what OpenMM hands to CCMA and the fused kernels to their general solver."""
+    is_drude = np.zeros(spec.num_atoms, dtype=bool)
+    pairs = np.asarray(spec.drude_pairs).reshape(-1, 2)
+    if len(pairs):
+        is_drude[pairs[:, 0]] = True
+    real = (~is_drude) & (spec.masses > 0)
+    cons, dist = [], []
+    order = np.argsort(spec.mol_id, kind="stable")
+    bounds = np.flatnonzero(np.diff(spec.mol_id[order])) + 1
+    for grp in np.split(order, bounds):
+        idx = np.sort(grp[real[grp]])
+        if idx.size < 2:
+            continue
+        x = spec.positions[idx]
+        d = np.linalg.norm(x[:, None, :] - x[None, :, :], axis=2)
+        bonded = (d < cutoff) & np.triu(np.ones_like(d, dtype=bool), 1)
+        for i, j in zip(*np.nonzero(bonded)):
+            cons.append((int(idx[i]), int(idx[j]))); dist.append(float(d[i, j]))
+        if hangles:
+            light = spec.masses[idx] < 1.5
+            adj = (d < cutoff) & ~np.eye(idx.size, dtype=bool)
+            for c in range(idx.size):
+                hs = [h for h in np.nonzero(adj[c] & light)[0] if not light[c]]
+                for p in range(len(hs)):
+                    for q in range(p + 1, len(hs)):
+                        cons.append((int(idx[hs[p]]), int(idx[hs[q]]))); dist.append(float(d[hs[p], hs[q]]))
+    spec.constraints = np.array(cons, dtype=np.int32).reshape(-1, 2)
+    spec.constraint_distances = np.array(dist, dtype=np.float64)
+    # remove the bond-parallel relative velocities (a few Gauss-Seidel passes: the constraints are coupled) so that the start is near the velocity manifold
+    v, m = spec.velocities, spec.masses
+    for _ in range(50):
+        for (a, b) in spec.constraints:
+            r = spec.positions[a] - spec.positions[b]
+            rv = float(np.dot(v[a] - v[b], r)) / float(np.dot(r, r))
+            ima, imb = 1.0 / m[a], 1.0 / m[b]
+            v[a] -= r * rv * ima / (ima + imb)
+            v[b] += r * rv * imb / (ima + imb)
+    return spec
+
+
 def rigid_water(spec: SystemSpec, d_oh: float = 0.1, d_hh: float = 0.1633) -> SystemSpec:
     """Rigid three-site water as OpenMM's rigidWater=True asks for it: O-H, O-H and H-H constrained in every (O, H, H) molecule
     of `spec`; the hydrogens are put on the rigid geometry and the molecule's velocity is made rigid-body compatible (the

@@ -73,7 +73,7 @@ class PlanInfo(C.Structure):
                 ("dof", C.c_double * 3), ("nkbt", C.c_double * 3), ("eta_mass", (C.c_double * MAX_CHAINS) * 3),
                 ("inv_mass_total", C.c_double), ("num_waves", C.c_int32), ("num_slots_used", C.c_int32),
                 ("max_cluster", C.c_int32), ("num_shake_clusters", C.c_int32), ("constraints_fused", C.c_int32),
-                ("num_settle_clusters", C.c_int32), ("periodic_layout", C.c_int32)]
+                ("num_settle_clusters", C.c_int32), ("periodic_layout", C.c_int32), ("num_general_constraints", C.c_int32)]
 
 
 class NHState(C.Structure):

@@ -249,6 +249,35 @@ def build_constraint_clusters(spec):
                 settle_atoms=np.array(settle_atoms, dtype=np.int32).reshape(-1, 3), settle_params=np.array(settle_params, dtype=np.float32).reshape(-1, 2))
 
 
+def build_general_constraints(spec):
+    """Any other constraint topology (AllBonds, HAngles): every constraint goes to the coloured Gauss-Seidel solver (vvo_general_*), as
+    vv::analyze decides for the product.  Colours: greedy in System order, the smallest colour none of the constraints already placed at
+    either particle uses -- the rule of csrc/vv_host.cpp, so both sides sweep in the same order.  Returns atoms int32 [n,2] and params
+    float32 [n,4] (d^2, 0.5/(1/m_a + 1/m_b), 1/m_a, 1/m_b), sorted by colour, the number of colours and the colour of every row."""
+    cons = np.asarray(spec.constraints).reshape(-1, 2)
+    dist = np.asarray(spec.constraint_distances, dtype=np.float64)
+    m = spec.masses
+    used = {}
+    rows = []
+    for (a, b), d in zip(cons, dist):
+        a, b = int(a), int(b)
+        taken = used.get(a, 0) | used.get(b, 0)
+        colour = 0
+        while (taken >> colour) & 1:
+            colour += 1
+        if colour >= 16:
+            raise OracleError("more than 16 colours: the product does not fuse such a System either")
+        used[a] = used.get(a, 0) | (1 << colour)
+        used[b] = used.get(b, 0) | (1 << colour)
+        ima, imb = 1.0 / m[a], 1.0 / m[b]
+        rows.append((colour, a, b, d * d, 0.5 / (ima + imb), ima, imb))
+    rows.sort(key=lambda r: r[0])          # stable: System order inside a colour
+    atoms = np.array([[r[1], r[2]] for r in rows], dtype=np.int32).reshape(-1, 2)
+    params = np.array([[r[3], r[4], r[5], r[6]] for r in rows], dtype=np.float32).reshape(-1, 4)
+    colours = np.array([r[0] for r in rows], dtype=np.int32)
+    return atoms, params, (int(colours.max()) + 1 if rows else 0), colours
+
+
 def build_shake(spec):
     """(atoms, params) of the SHAKE clusters only; None without constraint distances."""
     c = build_constraint_clusters(spec)
@@ -319,6 +348,7 @@ class _System(C.Structure):
         ("num_shake", C.c_int), ("shake_atoms", C.c_void_p), ("shake_params", C.c_void_p), ("constraint_tolerance", C.c_double),
         ("num_settle", C.c_int), ("settle_atoms", C.c_void_p), ("settle_params", C.c_void_p),
         ("shake_mode", C.c_int),
+        ("num_general", C.c_int), ("general_atoms", C.c_void_p), ("general_params", C.c_void_p),
     ]
 
 
@@ -427,7 +457,13 @@ class OracleSystem:
         s.use_middle = int(p.use_middle_scheme)
         s.force_mode, s.site, s.k_tether, s.k_drude = force_mode, _p(self.site), k_tether, k_drude
         s.forces_valid, s.num_threads = 0, num_threads
-        self.clusters = build_constraint_clusters(spec)
+        self.general = None
+        try:
+            self.clusters = build_constraint_clusters(spec)
+        except OracleError:                      # neither rigid triangles nor hydrogen-type clusters: the general solver takes ALL constraints
+            self.clusters = None
+            self.general = build_general_constraints(spec)
+            s.num_general, s.general_atoms, s.general_params = len(self.general[0]), _p(self.general[0]), _p(self.general[1])
         s.constraint_tolerance = 1e-5
         s.shake_mode = int(os.environ.get("VVHIP_SHAKE_MODE", "1")) if shake_mode is None else int(shake_mode)
         if self.clusters is not None:

@@ -697,6 +697,63 @@ void vvo_shake_velocities(int nclusters, const int* atoms, const float* params, 
     }
 }
 
+/* ------------------------------------------------------------------ general constraint clusters (ours; the product: vv_device.inc general_*)
+ * Any constraint topology (AllBonds, HAngles: chains, rings, triangles -- what OpenMM hands to CCMA between the reference's launches,
+ * HOST:151,176,351,427).  Coloured Gauss-Seidel: the constraints arrive sorted by colour (constraints of one colour share no particle,
+ * so their order inside a colour does not matter -- the product relaxes them side by side); a sweep visits every constraint once with
+ * OpenMM's SHAKE update (as vvo_shake_positions / vvo_shake_velocities), a constraint inside its tolerance is left alone, and sweeps
+ * repeat until nothing moved (<= 150).  The product sweeps wave by wave until THAT wave's constraints rest: the same values, because a
+ * resting constraint is not touched by further sweeps. */
+void vvo_general_positions(int n, const int* atoms, const float* params, mixed tol, const real4* posq, const real4* posq_corr, mixed4* pos_delta) {
+    for (int iteration = 0; iteration < 150; iteration++) {
+        int moved = 0;
+        for (int k = 0; k < n; k++) {
+            const int a = atoms[2 * k], b = atoms[2 * k + 1];
+            const mixed d2 = params[4 * k], avgMass = params[4 * k + 1], ima = params[4 * k + 2], imb = params[4 * k + 3], d2tol = d2 * tol;
+            mixed ax, ay, az, aw, bx, by, bz, bw;
+            load_pos(posq, posq_corr, a, &ax, &ay, &az, &aw);
+            load_pos(posq, posq_corr, b, &bx, &by, &bz, &bw);
+            const mixed r0 = ax - bx, r1 = ay - by, r2 = az - bz;
+            const mixed rsq = r0 * r0 + r1 * r1 + r2 * r2, ld = d2 - rsq;
+            const mixed rp0 = pos_delta[a].x - pos_delta[b].x, rp1 = pos_delta[a].y - pos_delta[b].y, rp2 = pos_delta[a].z - pos_delta[b].z;
+            const mixed rpsq = rp0 * rp0 + rp1 * rp1 + rp2 * rp2;
+            const mixed rrpr = r0 * rp0 + r1 * rp1 + r2 * rp2;
+            const mixed num = ld - 2.0f * rrpr - rpsq;
+            if (fabs(num) >= d2tol) {
+                const mixed acor = num * avgMass / (rrpr + rsq);
+                const mixed e0 = r0 * acor, e1 = r1 * acor, e2 = r2 * acor;
+                pos_delta[a].x = pos_delta[a].x + e0 * ima; pos_delta[a].y = pos_delta[a].y + e1 * ima; pos_delta[a].z = pos_delta[a].z + e2 * ima;
+                pos_delta[b].x = pos_delta[b].x - e0 * imb; pos_delta[b].y = pos_delta[b].y - e1 * imb; pos_delta[b].z = pos_delta[b].z - e2 * imb;
+                moved = 1;
+            }
+        }
+        if (!moved) break;
+    }
+}
+void vvo_general_velocities(int n, const int* atoms, const float* params, mixed tol, const real4* posq, const real4* posq_corr, mixed4* velm) {
+    for (int iteration = 0; iteration < 150; iteration++) {
+        int moved = 0;
+        for (int k = 0; k < n; k++) {
+            const int a = atoms[2 * k], b = atoms[2 * k + 1];
+            const mixed avgMass = params[4 * k + 1], ima = params[4 * k + 2], imb = params[4 * k + 3];
+            mixed ax, ay, az, aw, bx, by, bz, bw;
+            load_pos(posq, posq_corr, a, &ax, &ay, &az, &aw);
+            load_pos(posq, posq_corr, b, &bx, &by, &bz, &bw);
+            const mixed r0 = ax - bx, r1 = ay - by, r2 = az - bz;
+            const mixed rinv = (mixed) 1 / (r0 * r0 + r1 * r1 + r2 * r2);
+            const mixed rrpr = (velm[a].x - velm[b].x) * r0 + (velm[a].y - velm[b].y) * r1 + (velm[a].z - velm[b].z) * r2;
+            const mixed delta = -2.0f * avgMass * rrpr * rinv;
+            if (fabs(delta) > tol) {
+                const mixed e0 = r0 * delta, e1 = r1 * delta, e2 = r2 * delta;
+                velm[a].x = velm[a].x + e0 * ima; velm[a].y = velm[a].y + e1 * ima; velm[a].z = velm[a].z + e2 * ima;
+                velm[b].x = velm[b].x - e0 * imb; velm[b].y = velm[b].y - e1 * imb; velm[b].z = velm[b].z - e2 * imb;
+                moved = 1;
+            }
+        }
+        if (!moved) break;
+    }
+}
+
 /* ------------------------------------------------------------------ the same clusters, all constraints of a cluster at once
  * (shake_mode 1, what the product runs by default; the Gauss-Seidel sweeps above stay as shake_mode 0).
  * Multipliers l_k, one per constraint: the central particle moves by imc * sum_m l_m r_m, peripheral k by -imp * l_k r_k, with
@@ -1098,12 +1155,14 @@ static void step_middle(vvo_system* s) {           /* API:232-270; constraints/v
     vvo_integrate_middle_vel(n, s->padded_num_atoms, s->velm, s->force, s->force_extra, (mixed) s->dt);  /* HOST:144-148 */
     if (s->num_shake > 0)   /* integration.applyVelocityConstraints, HOST:151 */
         shake_v(s);
+    if (s->num_general > 0) vvo_general_velocities(s->num_general, s->general_atoms, s->general_params, (mixed) s->constraint_tolerance, s->posq, s->posq_corr, s->velm);
     if (s->num_settle > 0) vvo_settle_velocities(s->num_settle, s->settle_atoms, s->posq, s->posq_corr, s->velm);
     vvo_integrate_middle_pos1(n, s->velm, s->pos_delta, s->old_delta, (mixed) s->dt);                     /* HOST:154-158 */
     nh_half(s);
     vvo_integrate_middle_pos2(n, s->velm, s->pos_delta, s->old_delta, (mixed) s->dt);                     /* HOST:169-173 */
     if (s->num_shake > 0)   /* integration.applyConstraints, HOST:176 */
         shake_x(s);
+    if (s->num_general > 0) vvo_general_positions(s->num_general, s->general_atoms, s->general_params, (mixed) s->constraint_tolerance, s->posq, s->posq_corr, s->pos_delta);
     if (s->num_settle > 0) vvo_settle_positions(s->num_settle, s->settle_atoms, s->settle_params, s->posq, s->posq_corr, s->velm, s->pos_delta);
     vvo_integrate_middle_pos3(n, s->posq, s->posq_corr, s->pos_delta, s->old_delta, s->velm, (mixed) s->dt); /* HOST:179-185 */
     hard_wall(s);
@@ -1122,6 +1181,7 @@ static void step_vv(vvo_system* s) {               /* API:272-338 */
                                 (mixed) s->dt, (mixed) fscale, 1);                                        /* HOST:341-348 */
     if (s->num_shake > 0)   /* HOST:351 */
         shake_x(s);
+    if (s->num_general > 0) vvo_general_positions(s->num_general, s->general_atoms, s->general_params, (mixed) s->constraint_tolerance, s->posq, s->posq_corr, s->pos_delta);
     if (s->num_settle > 0) vvo_settle_positions(s->num_settle, s->settle_atoms, s->settle_params, s->posq, s->posq_corr, s->velm, s->pos_delta);
     vvo_vv_integrate_positions(n, s->posq, s->posq_corr, s->pos_delta, s->velm, (mixed) s->dt);           /* HOST:355-360 */
     hard_wall(s);
@@ -1134,6 +1194,7 @@ static void step_vv(vvo_system* s) {               /* API:272-338 */
                                 (mixed) s->dt, (mixed) fscale, 0);                                        /* HOST:417-424 */
     if (s->num_shake > 0)   /* HOST:427 */
         shake_v(s);
+    if (s->num_general > 0) vvo_general_velocities(s->num_general, s->general_atoms, s->general_params, (mixed) s->constraint_tolerance, s->posq, s->posq_corr, s->velm);
     if (s->num_settle > 0) vvo_settle_velocities(s->num_settle, s->settle_atoms, s->posq, s->posq_corr, s->velm);
     nh_half(s);
 }

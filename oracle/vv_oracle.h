@@ -120,6 +120,10 @@ typedef struct {
     const float* settle_params;               /* [2*n]: apex-partner distance, partner-partner distance */
     int shake_mode;                           /* 0: Gauss-Seidel sweeps over the cluster (OpenMM's iteration); 1: the cluster's constraints
                                                  at once (direct solve for velocities, coupled Newton for positions), see vvo_cluster_* */
+    /* general constraint clusters (any topology: AllBonds, HAngles), see vvo_general_positions: constraints SORTED BY COLOUR, two
+     * constraints of one colour never share a particle */
+    int num_general; const int* general_atoms;     /* [2*n]: a, b */
+    const float* general_params;                   /* [4*n]: d^2, 0.5/(1/m_a + 1/m_b), 1/m_a, 1/m_b */
 } vvo_system;
 
 #ifdef __cplusplus

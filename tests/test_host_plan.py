@@ -283,3 +283,35 @@ def test_tuning_hook_names():
     assert b"no_such_choice" in H.lib.vvhip_last_error(plan)
     assert H.lib.vvhip_debug_tune(plan, b"block_threads", 100) == H.ERR_INVALID
     H.lib.vvhip_plan_destroy(plan)
+
+
+@pytest.mark.parametrize("hangles", [False, True])
+def test_general_constraint_clusters_are_coloured_lists_per_wave(hangles):
+    """constraints=AllBonds / HAngles: rings and chains are neither hydrogen-type clusters nor rigid triangles.  vv::analyze then keeps every
+    connected component of the constraint graph in one wave and writes the wave's constraint list into the per-lane constraint tables:
+    constraint l in lane l, sorted by colour, no two constraints of one colour sharing a particle (csrc/vv_layout.h: GC_WORD_*)."""
+    spec = systems.constrain_all_bonds(systems.bulk_Im21(cells=(1, 1, 1), pairs_per_cell=20), hangles=hangles)
+    it = I.VVIntegrator(333.0, 10.0, 1.0, 40.0, 0.001)
+    it.setMaxDrudeDistance(0.02)
+    plan, info, keep = I.create_plan(spec, it, "mixed")
+    try:
+        assert info.constraints_fused == 1 and info.num_shake_clusters == 0 and info.num_general_constraints == len(spec.constraints)
+        nslots = info.num_waves * 64
+        slots = np.zeros((nslots, 2), dtype=np.int32)
+        assert H.lib.vvhip_plan_get_slots(plan, slots.ctypes.data, nslots) == nslots
+        wave_of = {int(a): k // 64 for k, a in enumerate(slots[:, 0]) if a >= 0}
+        lane_of = {int(a): k % 64 for k, a in enumerate(slots[:, 0]) if a >= 0}
+        for a, b in spec.constraints:                      # both ends in one wave, both marked as constraint members
+            assert wave_of[int(a)] == wave_of[int(b)]
+            assert slots[wave_of[int(a)] * 64 + lane_of[int(a)], 1] & (1 << 30) and slots[wave_of[int(b)] * 64 + lane_of[int(b)], 1] & (1 << 30)
+        # DOF: every constraint leaves the atom group (HOST:505-509)
+        t = O.build_tables(spec, O.Params(temperature=333.0, max_drude_distance=0.02))
+        assert list(info.dof) == list(t["dof"])
+    finally:
+        H.lib.vvhip_plan_destroy(plan)
+    # the oracle colours in the same System order (greedy, smallest free colour): within a colour no particle appears twice
+    atoms, params, ncol, colours = O.build_general_constraints(spec)
+    assert len(atoms) == len(spec.constraints) and 2 <= ncol <= 16 and (np.diff(colours) >= 0).all()
+    for c in range(ncol):
+        ends = atoms[colours == c].reshape(-1)
+        assert len(set(ends.tolist())) == ends.size
