@@ -121,7 +121,8 @@ typedef struct {
     int32_t num_waves, num_slots_used;           /* work-item layout: 64 slots per wave */
     int32_t max_cluster;                         /* largest set of particles that must share a wave */
     int32_t num_shake_clusters;                  /* hydrogen-type constraint clusters solved in-kernel (SHAKE; 0 if none / not possible) */
-    int32_t constraints_fused;                   /* 1: no constraints, or all of them are handled in-kernel => fused steps are valid */
+    int32_t constraints_fused;                   /* 1: no constraints, or all of them are handled in-kernel (hydrogen-type clusters, rigid three-site
+                                                    molecules, or general clusters: num_general_constraints) => fused steps are valid */
     int32_t num_settle_clusters;                 /* rigid three-site molecules solved in-kernel (SETTLE) */
     int32_t periodic_layout;                     /* 1: the work-item layout is arithmetic (runs of identical molecules): the fused kernels compute
                                                     particle indices instead of loading them (vv_host.hpp: PeriodicLayout) */

@@ -288,13 +288,14 @@ def constrain_all_bonds(spec: SystemSpec, cutoff: float = 0.165, hangles: bool =
     spec.constraint_distances = np.array(dist, dtype=np.float64)
     # remove the bond-parallel relative velocities (a few Gauss-Seidel passes: the constraints are coupled) so that the start is near the velocity manifold
     v, m = spec.velocities, spec.masses
-    for _ in range(50):
-        for (a, b) in spec.constraints:
-            r = spec.positions[a] - spec.positions[b]
-            rv = float(np.dot(v[a] - v[b], r)) / float(np.dot(r, r))
-            ima, imb = 1.0 / m[a], 1.0 / m[b]
-            v[a] -= r * rv * ima / (ima + imb)
-            v[b] += r * rv * imb / (ima + imb)
+    ca, cb = spec.constraints[:, 0], spec.constraints[:, 1]
+    r = spec.positions[ca] - spec.positions[cb]
+    rr = (r * r).sum(1)
+    ima, imb = 1.0 / m[ca], 1.0 / m[cb]
+    for _ in range(60):                              # damped Jacobi passes over all constraints at once (vectorised: the full C3 box has 66 000 of them)
+        rv = ((v[ca] - v[cb]) * r).sum(1) / rr
+        np.subtract.at(v, ca, 0.5 * r * (rv * ima / (ima + imb))[:, None])
+        np.add.at(v, cb, 0.5 * r * (rv * imb / (ima + imb))[:, None])
     return spec
 
 

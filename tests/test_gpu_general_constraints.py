@@ -53,9 +53,13 @@ def _check(spec, osys, ctx, prec, middle, label):
     r2 = (r * r).sum(1)
     slack = 2.0 * TOL + (4e-5 if prec == "single" else 1e-9)
     assert np.abs(r2 - d * d).max() < slack * (d * d).max(), f"{label}: |r^2 - d^2| / d^2 = {np.abs(r2 - d * d).max() / (d * d).max():.2e}"
-    if not middle:          # the classic scheme ends with the velocity constraints
+    if not middle:
+        # The classic scheme's step ends: half kick -> velocity constraints -> thermostat (API:327-336).  The thermostat scales a Drude pair's
+        # centre-of-mass and relative motion with different factors, so a ring bond between a polarisable atom and its neighbour picks up
+        # ~3e-3 nm/ps of bond-parallel relative velocity again (1e-2 in single precision) -- the reference's order of operations, and the
+        # oracle's, held by the parity assertion above; thermal velocities are ~1 nm/ps.
         rel = ((v_g[c[:, 0]] - v_g[c[:, 1]]) * r).sum(1) / np.sqrt(r2)
-        assert np.abs(rel).max() < 1e-3, f"{label}: bond-parallel relative velocity {np.abs(rel).max():.2e} nm/ps"
+        assert np.abs(rel).max() < 5e-2, f"{label}: bond-parallel relative velocity {np.abs(rel).max():.2e} nm/ps"
     print(f"{label}: rel err pos {ex:.2e} vel {ev:.2e}, constraints within {np.abs(r2 - d * d).max() / (d * d).max():.1e}")
 
 
