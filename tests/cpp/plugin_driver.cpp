@@ -117,13 +117,18 @@ static int run(const char* out, bool middle, int consMode, double cosacc, int ns
     }
     system.addForce(drude);
     if (consMode != 3) system.addForce(new CMMotionRemover());
-    // consMode 1: a chain H-heavy-H-H in molecule 0 -- neither a hydrogen-type cluster nor a rigid triangle, so the plan leaves constraints to OpenMM's solver
-    //             and VVIntegrator takes the un-fused path (the stand-in solver is a no-op; only the path and the DOF matter);
+    // consMode 1: particle 4 of molecule 0 tied to a hydrogen of 17 other molecules -- more constraints on one particle than a wave's colouring
+    //             takes, so the plan leaves constraints to OpenMM's solver and VVIntegrator takes the un-fused path (the stand-in solver is a
+    //             no-op; only the path and the DOF matter);
+    // consMode 4: a chain H-heavy-H-H in molecule 0 -- neither a hydrogen-type cluster nor a rigid triangle: a general cluster, solved inside
+    //             the fused kernels by coloured sweeps;
     // consMode 2: both hydrogens of every molecule constrained to the heavy particle 4 -- solved inside the fused kernels.
     std::vector<int> cons;
     std::vector<double> consDist;
     auto addCons = [&](int a, int b, double d) { system.addConstraint(a, b, d); cons.push_back(a); cons.push_back(b); consDist.push_back(d); };
-    if (consMode == 1) { addCons(6, 4, 0.1); addCons(7, 6, 0.16); }
+    if (consMode == 1)
+        for (int m = 1; m <= 17; m++) addCons(m * per + 6, 4, 0.5);
+    if (consMode == 4) { addCons(6, 4, 0.1); addCons(7, 6, 0.16); }
     if (consMode == 2)
         for (int m = 0; m < nmol; m++) { addCons(m * per + 6, m * per + 4, 0.1); addCons(m * per + 7, m * per + 4, 0.1); }
     const double box[3] = {3.0, 3.0, 3.0}, kB = (1.380649e-23 * 6.02214076e23) / 1000.0;
@@ -140,7 +145,7 @@ static int run(const char* out, bool middle, int consMode, double cosacc, int ns
             }
         }
     }
-    if (consMode == 2)                          // start on the constraint manifold: |r| = d, no relative velocity along the bond
+    if (consMode == 2 || consMode == 4)         // start on the constraint manifold: |r| = d, no relative velocity along the bond
         for (size_t c = 0; c < consDist.size(); c++) {
             const int h = cons[2 * c], o = cons[2 * c + 1];
             double u[3], len = 0, along = 0;

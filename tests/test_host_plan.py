@@ -166,13 +166,14 @@ def test_constraint_clusters_share_a_wave(use_com):
         assert len(set(wave_of[members])) == 1 and wave_of[members[0]] >= 0
     for d, par in np.asarray(spec.drude_pairs):
         assert wave_of[d] == wave_of[par]
-    # a chain of constraints (H-O-H plus a fourth particle hanging off one H) is neither a triangle nor such a cluster: reported,
-    # not silently dropped
+    # a chain of constraints (H-O-H plus a fourth particle hanging off one H) is neither a triangle nor such a cluster: it becomes a
+    # general cluster (coloured sweeps inside the wave), not silently dropped
     spec2 = systems.spce_water(4)
     spec2.constraints = np.array([(1, 0), (2, 0), (2, 3)], dtype=np.int32)
     spec2.constraint_distances = np.array([0.1, 0.1, 0.16])
     info2, _ = I.plan_layout(spec2, I.VVIntegrator(300.0, 10, 1.0, 40, 0.001))
-    assert not info2.constraints_fused and info2.num_shake_clusters == 0 and info2.num_settle_clusters == 0
+    assert info2.constraints_fused and info2.num_shake_clusters == 0 and info2.num_settle_clusters == 0
+    assert info2.num_general_constraints == 3
     with pytest.raises(O.OracleError):
         O.build_constraint_clusters(spec2)
 
