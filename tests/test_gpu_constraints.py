@@ -202,15 +202,17 @@ def test_constraints_hold_over_a_long_run_and_graph_replay_is_identical():
 
 
 def test_unfusable_topology_is_left_to_the_host_solver():
-    """A chain O-H1-H2 with unequal ends is neither a rigid triangle nor a hydrogen-type cluster: the plan reports
-    constraints_fused = 0, refuses the fused step (so a caller cannot silently run unconstrained) and the split entry points stay
-    available."""
+    """One oxygen tied to the oxygens of 17 other waters: more constraints on one particle than a wave's colouring takes (16), so it is
+    not a general cluster either: the plan reports constraints_fused = 0, refuses the fused step (so a caller cannot silently run
+    unconstrained) and the split entry points stay available."""
     spec = systems.spce_water(50, seed=3)
-    cons, dist = [], []
-    for m in range(50):
-        o = 3 * m
-        cons += [(o + 1, o), (o + 1, o + 2)]
-        dist += [0.1, 0.1633]
+    cons = [(0, 3 * m) for m in range(1, 18)]
+    dist = [0.5] * len(cons)
+    for m in range(18, 50):
+        cons += [(3 * m + 1, 3 * m)]
+        dist += [0.1]
+    cons += [(3 * 49 + 2, 3 * 49)]
+    dist += [0.1]
     spec.constraints = np.array(cons, dtype=np.int32)
     spec.constraint_distances = np.array(dist)
     it = I.VVIntegrator(300.0, 10, 1.0, 40, 0.002)
@@ -218,7 +220,7 @@ def test_unfusable_topology_is_left_to_the_host_solver():
     ctx = I.Context(spec, it, precision="mixed", force_provider="tether")
     try:
         assert not ctx.info.constraints_fused and ctx.info.num_shake_clusters == 0
-        assert list(ctx.info.dof)[0] == 3 * 150 - 100 - 3
+        assert list(ctx.info.dof)[0] == 3 * 150 - 50 - 3
         ctx.calcForces()
         rc = H.lib.vvhip_step_middle(ctx.plan, 0)
         assert rc != 0 and b"constraint" in H.lib.vvhip_last_error(ctx.plan)
