@@ -72,12 +72,26 @@ typedef struct {
      * above; must not cut a molecule or a Drude pair.  Device arrays passed to vvhip_bind are indexed
      * from shard_begin.  0,0 = the whole system. */
     int32_t shard_begin, shard_end;
-    /* Optional.  System::getConstraintParameters distances [num_constraints] (nm).  When given and every constraint belongs to a
-     * SHAKE-able cluster (one central particle + up to three peripheral particles of equal mass and distance: what OpenMM's own
-     * SHAKE kernel takes, e.g. all X-H bonds), the fused steps solve the constraints inside kernels A and B.  NULL: constraints
-     * only enter the DOF count and the fused steps refuse to run if there are any (use the split entry points around the host's solver). */
+    /* Optional.  System::getConstraintParameters distances [num_constraints] (nm).  When given, the fused steps solve the constraints
+     * inside kernels A and B: hydrogen-type clusters (one central particle + up to three peripheral particles of equal mass and
+     * distance: what OpenMM's own SHAKE kernel takes, e.g. all X-H bonds), rigid three-site molecules (SETTLE), anything else as
+     * general clusters (vvhip_plan_info.num_general_constraints), as long as every connected set of constraints fits one 64-lane wave.
+     * NULL: constraints only enter the DOF count and the fused steps refuse to run if there are any (use the split entry points around
+     * the host's solver). */
     const double* constraint_distances;
+    /* Optional.  System::getVirtualSite for every massless site (OpenMM's TwoParticleAverageSite, ThreeParticleAverageSite,
+     * OutOfPlaneSite, LocalCoordinatesSite with three parents -- what examples/ommhelper/oplspsffile.py:982-991 creates for lone pairs).
+     * Kernel B then places the sites right after its position update, where the reference calls integration.computeVirtualSites()
+     * (HOST:214, 374), and vvhip_plan_info.num_virtual_sites says so; the caller need not launch OpenMM's kernel.
+     *   virtual_sites       [5*n]  site particle, kind (VVHIP_VSITE_*), parents 1, 2, 3 (parent 3 = -1 for a two-particle average)
+     *   virtual_site_params [12*n] AVERAGE2: w1 w2; AVERAGE3: w1 w2 w3; OUT_OF_PLANE: w12 w13 wCross;
+     *                              LOCAL_COORDS: origin weights[3], x weights[3], y weights[3], local position[3] */
+    int32_t num_virtual_sites;
+    const int32_t* virtual_sites;
+    const double* virtual_site_params;
 } vvhip_system_desc;
+
+enum { VVHIP_VSITE_AVERAGE2 = 0, VVHIP_VSITE_AVERAGE3 = 1, VVHIP_VSITE_OUT_OF_PLANE = 2, VVHIP_VSITE_LOCAL_COORDS = 3 };
 
 /* VVIntegrator's parameters (openmmapi/include/openmm/VVIntegrator.h:70-431).  The reference reads
  * them through getters at every kernel call; here they are re-read whenever vvhip_set_params is
@@ -129,6 +143,8 @@ typedef struct {
     int32_t num_general_constraints;             /* constraints outside the two rules above (AllBonds, HAngles: chains, rings, triangles) that the
                                                     fused kernels relax by coloured Gauss-Seidel sweeps inside the wave of their molecule; 0 if the
                                                     System has none, or if a component of the constraint graph does not fit one wave */
+    int32_t num_virtual_sites;                   /* virtual sites placed by kernel B itself (0: none given, or one of them cannot share a wave with
+                                                    its parents -- then the caller runs its own computeVirtualSites after every step, as before) */
 } vvhip_plan_info;
 
 /* Nose-Hoover chain state + last reduction results (HOST: CudaVVKernels.h:206-215).  The reference
@@ -172,8 +188,10 @@ int vvhip_get_nh_state(vvhip_plan* plan, vvhip_nh_state* out);
 int vvhip_set_nh_state(vvhip_plan* plan, const vvhip_nh_state* in);
 
 /* ---------------------------------------------------------------- fused path
- * One whole VVIntegrator step between two force evaluations, for systems without constraints /
- * virtual sites (those solvers are OpenMM's).  Forces for the step must already be in `force`.
+ * One whole VVIntegrator step between two force evaluations.  Constraints are solved inside the two kernels when
+ * vvhip_plan_info.constraints_fused says so (otherwise the fused steps refuse to run and the split entry points below go around the
+ * host's solver); virtual sites are placed by kernel B when described (vvhip_system_desc.virtual_sites), otherwise the caller's own
+ * computeVirtualSites follows the step as it follows the reference's.  Forces for the step must already be in `force`.
  *
  * Middle scheme (API:232-270 after calcForcesAndEnergy): 2 launches
  *   pass A: extra forces (Langevin, E-field, cos) + full kick (+ velocity constraints) + molecular COM + per-group

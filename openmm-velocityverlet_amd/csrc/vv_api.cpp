@@ -118,6 +118,8 @@ struct vvhip_plan {
     int32_t* d_slot_big = nullptr;
     int32_t* d_slot_shake = nullptr;
     float4* d_slot_shake_param = nullptr;
+    int2* d_slot_vsite = nullptr;
+    double* d_vsite_params = nullptr;
     unsigned long long* d_bigacc = nullptr;
     int2* d_image_pairs = nullptr;
     void* d_fextra = nullptr;
@@ -320,6 +322,8 @@ vv::KArgs make_args(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
     a.slot_rand = p->d_slot_rand;
     a.slot_shake = p->d_slot_shake;
     a.slot_shake_param = p->d_slot_shake_param;
+    a.slot_vsite = p->d_slot_vsite;
+    a.vsite_params = p->d_vsite_params;
     a.shake_tol = q.constraint_tolerance > 0 ? q.constraint_tolerance : 1e-5;
     a.slot_big = p->d_slot_big;
     a.bigacc = p->d_bigacc;
@@ -575,6 +579,7 @@ uint32_t tail_flags(const vvhip_plan* p) {      // what follows every position u
     uint32_t f = 0;
     if (p->hp.params.max_drude_distance > 0 && p->hp.has_pairs) f |= vv::B_HARDWALL;
     if (p->hp.has_images) f |= vv::B_IMAGE;
+    if (!p->hp.slot_vsite.empty()) f |= vv::B_VSITE;
     return f;
 }
 bool cos_on(const vvhip_plan* p) { return p->hp.params.cos_acceleration != 0; }
@@ -655,7 +660,7 @@ void vvhip_plan_destroy(vvhip_plan* p) {
     if (!p) return;
     if (p->bound) {
         (void) hipStreamSynchronize(p->stream);
-        for (void* ptr : {(void*) p->d_slots, (void*) p->d_slot_image, (void*) p->d_slot_rand, (void*) p->d_slot_shake, (void*) p->d_slot_shake_param, (void*) p->d_slot_big, (void*) p->d_bigacc, (void*) p->d_image_pairs,
+        for (void* ptr : {(void*) p->d_slots, (void*) p->d_slot_image, (void*) p->d_slot_rand, (void*) p->d_slot_shake, (void*) p->d_slot_shake_param, (void*) p->d_slot_vsite, (void*) p->d_vsite_params, (void*) p->d_slot_big, (void*) p->d_bigacc, (void*) p->d_image_pairs,
                           p->d_fextra, p->d_old_delta, p->d_pos_delta, p->d_comv, (void*) p->d_comw, (void*) p->d_seg_mass, (void*) p->d_seg_base, (void*) p->d_slot_m, (void*) p->d_slot_f, (void*) p->d_cosz, (void*) p->d_epoch, (void*) p->d_acc, (void*) p->d_nh, (void*) p->d_lane_const, (void*) p->d_dbg, (void*) p->d_dbg_span})
             if (ptr) (void) hipFree(ptr);
         drop_graphs(p);
@@ -737,6 +742,12 @@ int vvhip_bind(vvhip_plan* p, const vvhip_buffers* b) {
         HIP_TRY(p, hipMemcpy(p->d_slot_shake, hp.slot_shake.data(), nslots * sizeof(int32_t), hipMemcpyHostToDevice));
         HIP_TRY(p, hipMalloc((void**) &p->d_slot_shake_param, nslots * sizeof(float4)));
         HIP_TRY(p, hipMemcpy(p->d_slot_shake_param, hp.slot_shake_param.data(), nslots * sizeof(float4), hipMemcpyHostToDevice));
+    }
+    if (!hp.slot_vsite.empty()) {
+        HIP_TRY(p, hipMalloc((void**) &p->d_slot_vsite, nslots * sizeof(int2)));
+        HIP_TRY(p, hipMemcpy(p->d_slot_vsite, hp.slot_vsite.data(), nslots * sizeof(int2), hipMemcpyHostToDevice));
+        HIP_TRY(p, hipMalloc((void**) &p->d_vsite_params, hp.vsite_params.size() * sizeof(double)));
+        HIP_TRY(p, hipMemcpy(p->d_vsite_params, hp.vsite_params.data(), hp.vsite_params.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     if (!hp.slot_big.empty()) {
         HIP_TRY(p, hipMalloc((void**) &p->d_slot_big, nslots * sizeof(int32_t)));

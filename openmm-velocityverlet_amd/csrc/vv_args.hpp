@@ -71,6 +71,7 @@ enum : uint32_t {
     B_MTAB = 1u << 16,        // Drude-pair mass fractions from the static per-lane table (slot_f) instead of two IEEE divisions per lane
     B_SHAKE_GS = 1u << 19,    // as A_SHAKE_GS, for the position constraints (instead of the coupled Newton iteration)
     B_GCONS = 1u << 21,       // as A_GCONS, for the position constraints
+    B_VSITE = 1u << 22,       // place the plan's virtual sites after the position update (integration.computeVirtualSites(), HOST:214, 374)
 };
 constexpr uint32_t A_CONS = A_SHAKE_V | A_SETTLE | A_GCONS, B_CONS = B_SHAKE | B_SETTLE | B_GCONS;      // in-kernel constraints of any kind
 // ---- chain kernel --------------------------------------------------------------------------------
@@ -205,6 +206,8 @@ struct KArgs {
     uint32_t pos_bytes;             // size of the posq (= posqCorrection) array in bytes if below 4 GB, else 0: kernel A fetches the positions of
     int32_t gc_colors;              // constraint-cluster members through a buffer resource (load_wanted), other lanes fetch nothing; gc_colors:
                                     // colours of the general clusters' sweeps (A_GCONS / B_GCONS)
+    const int2* slot_vsite;         // B_VSITE: [64*waves] (site word, vv_layout.h: VS_WORD_*; record number) of the lane's particle
+    const double* vsite_params;     // B_VSITE: [12*records] weights / local position of each site (vvhip_system_desc.virtual_site_params)
 };
 
 struct TetherArgs {

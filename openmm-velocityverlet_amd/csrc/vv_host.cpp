@@ -283,9 +283,36 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
         }
     }
 
+    // ---- virtual sites (vvhip_system_desc.virtual_sites): a site gets a lane in the wave of its parents and kernel B places it there
+    // (vv_device.inc: place_virtual_site).  vs_adj = the particles a particle is tied to that way.
+    std::vector<int32_t> vs_of(n, -1);
+    std::vector<std::vector<int32_t> > vs_adj;
+    bool vsites = sys.num_virtual_sites > 0 && sys.virtual_sites && sys.virtual_site_params;
+    if (vsites) {
+        vs_adj.assign(n, {});
+        for (int k = 0; k < sys.num_virtual_sites; k++) {
+            const int32_t* rec = sys.virtual_sites + 5 * (size_t) k;
+            const int site = rec[0], kind = rec[1], np = kind == VVHIP_VSITE_AVERAGE2 ? 2 : 3;
+            check_index(site, "virtual site");
+            if (kind < VVHIP_VSITE_AVERAGE2 || kind > VVHIP_VSITE_LOCAL_COORDS) throw Error(VVHIP_ERR_INVALID, "unknown kind of virtual site");
+            if (sys.masses[site] != 0.0) throw Error(VVHIP_ERR_INVALID, "a virtual site must have mass 0");
+            if (vs_of[site] >= 0) throw Error(VVHIP_ERR_INVALID, "a particle is described as a virtual site twice");
+            vs_of[site] = k;
+            for (int q = 0; q < np; q++) {
+                check_index(rec[2 + q], "virtual site parent");
+                vs_adj[site].push_back(rec[2 + q]);
+                vs_adj[rec[2 + q]].push_back(site);
+            }
+        }
+        for (int k = 0; k < sys.num_virtual_sites && vsites; k++)       // a site that hangs on another site: left to the caller's own kernel
+            for (int q : vs_adj[sys.virtual_sites[5 * (size_t) k]])
+                if (vs_of[q] >= 0) vsites = false;
+    }
+
     // ---- which particles need a lane, and which must share a wave
     auto needs_lane = [&](int i) {
         if (sys.masses[i] != 0.0) return true;      // anything massive is integrated
+        if (vsites && vs_of[i] >= 0) return true;   // a virtual site: placed by its own lane
         if (in_pair[i]) return true;                // massless Drude parent (hard-wall branch K/middle.cu:151-173)
         if (image_of[i] >= 0) return true;          // massless image parent: only the mirror copy
         return false;
@@ -326,6 +353,7 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
                     for (int q : s.periph) visit(q);
                 }
                 if (general) for (int q : gc_adj[j]) visit(q);
+                if (vsites) for (int q : vs_adj[j]) if (needs_lane(q)) visit(q);
             }
             std::sort(c.members.begin(), c.members.end());
             c.first = c.members[0];
@@ -368,6 +396,7 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
                     if (in_pair[j]) visit(partner[j]);
                     if (shake_of[j] >= 0) { visit(shakes[shake_of[j]].center); for (int q : shakes[shake_of[j]].periph) visit(q); }
                     if (general) for (int q : gc_adj[j]) visit(q);
+                    if (vsites) for (int q : vs_adj[j]) if (needs_lane(q)) visit(q);
                 }
                 std::sort(u.begin(), u.end());
                 units.push_back(u);
@@ -416,7 +445,7 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
         bool want = lanes >= 200000;
         if (const char* e = std::getenv("VVHIP_PERIODIC")) want = std::atoi(e) != 0;
         if (!want) return false;
-        if (hp.has_ld || hp.has_images || hp.num_big > 0 || clusters.empty() || general) return false;
+        if (hp.has_ld || hp.has_images || hp.num_big > 0 || clusters.empty() || general || vsites) return false;
         const size_t K = clusters.size();
         std::vector<uint64_t> sig(K);
         int expect = sb;
@@ -736,6 +765,39 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
                 hp.slot_shake[(size_t) w * 64 + lq] = (int32_t) (common | 2u | ((uint32_t) k << vv::SHAKE_WORD_OWN_SHIFT));
                 std::memcpy(&hp.slot_shake_param[((size_t) w * 64 + lq) * 4], prm, sizeof(prm));
             }
+        }
+    }
+    // Virtual sites: word of the site's lane = lanes of its parents | kind, record = row of vsite_params.  A site whose parents sit in
+    // another wave (another molecule, a molecule cut into chunks) or have no lane at all: nothing is placed in-kernel, the caller keeps
+    // running its own computeVirtualSites.
+    info.num_virtual_sites = 0;
+    if (vsites) {
+        std::vector<int32_t> table((size_t) nwaves * 128, 0);
+        std::vector<double> prm;
+        bool fits = true;
+        int count = 0;
+        for (int k = 0; k < sys.num_virtual_sites && fits; k++) {
+            const int32_t* rec = sys.virtual_sites + 5 * (size_t) k;
+            const int site = rec[0], kind = rec[1], np = kind == VVHIP_VSITE_AVERAGE2 ? 2 : 3;
+            bool any = in_shard(site);
+            for (int q = 0; q < np; q++) any = any || in_shard(rec[2 + q]);
+            if (!any) continue;
+            const int w = in_shard(site) ? wave_of[site] : -1;
+            uint32_t word = vv::VS_WORD_VALID | ((uint32_t) kind << 18);
+            for (int q = 0; q < 3 && w >= 0; q++) {
+                const int par = rec[2 + (q < np ? q : 0)];
+                if (!in_shard(par) || wave_of[par] != w) { fits = false; break; }
+                word |= (uint32_t) lane_of[par] << (6 * q);
+            }
+            if (w < 0 || !fits) { fits = false; break; }
+            table[((size_t) w * 64 + lane_of[site]) * 2] = (int32_t) word;
+            table[((size_t) w * 64 + lane_of[site]) * 2 + 1] = count++;
+            prm.insert(prm.end(), sys.virtual_site_params + 12 * (size_t) k, sys.virtual_site_params + 12 * (size_t) k + 12);
+        }
+        if (fits && count > 0) {
+            hp.slot_vsite.swap(table);
+            hp.vsite_params.swap(prm);
+            info.num_virtual_sites = count;
         }
     }
     info.num_general_constraints = 0;

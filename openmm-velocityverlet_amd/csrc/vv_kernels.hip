@@ -266,7 +266,7 @@ hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_c
     if ((int) g.x > grid_cap) g.x = (unsigned) grid_cap;
     vv_last_grid_value = g.x;
     const dim3 b(block_threads + ((a.flags & B_CHAIN) ? 64 : 0));
-    const unsigned lds = (a.flags & B_CONS) ? (unsigned) (block_threads / 64) * 64u * 7u * (precision == VVHIP_SINGLE ? 4u : 8u) : 0u;      // one page per tile wave
+    const unsigned lds = (a.flags & (B_CONS | B_VSITE)) ? (unsigned) (block_threads / 64) * 64u * 7u * (precision == VVHIP_SINGLE ? 4u : 8u) : 0u;      // one page per tile wave
     constexpr uint32_t XM = SF_BM;
 #define VV_PRE_ARGS a.slots, a.nwaves, (int) (b.x >> 6), (const unsigned long long*) a.acc, a.nh, a.lane_const, a.seg_base
     hipError_t rtc_error = hipSuccess;

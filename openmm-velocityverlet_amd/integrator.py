@@ -169,11 +169,19 @@ def create_plan(system: SystemSpec, integrator: "VVIntegrator", precision: str =
         cdist=np.ascontiguousarray(getattr(system, "constraint_distances", None) if getattr(system, "constraint_distances", None) is not None else [], dtype=np.float64))
     if k["cdist"].size not in (0, k["cons"].size // 2):
         raise ValueError("constraint_distances must have one entry per constraint")
+    vsites = list(getattr(system, "virtual_sites", None) or [])      # (site, kind, (parents), (params)) per site: System::getVirtualSite
+    k["vs"] = np.full((len(vsites), 5), -1, dtype=np.int32)
+    k["vsp"] = np.zeros((len(vsites), 12), dtype=np.float64)
+    for i, (site, kind, parents, prm) in enumerate(vsites):
+        k["vs"][i, 0], k["vs"][i, 1] = site, kind
+        k["vs"][i, 2:2 + len(parents)] = parents
+        k["vsp"][i, :len(prm)] = prm
     ptr = lambda a: a.ctypes.data if a.size else None
     desc = H.SystemDesc(n, padded(n), ptr(k["masses"]), ptr(k["mol_id"]), system.num_molecules,
                         k["drude"].size // 2, ptr(k["drude"]), k["cons"].size // 2, ptr(k["cons"]),
                         int(system.has_cm_motion_remover), k["ld"].size, ptr(k["ld"]), k["img"].size // 2, ptr(k["img"]),
-                        k["el"].size, ptr(k["el"]), int(shard[0]), int(shard[1]), ptr(k["cdist"]))
+                        k["el"].size, ptr(k["el"]), int(shard[0]), int(shard[1]), ptr(k["cdist"]),
+                        len(vsites), ptr(k["vs"]), ptr(k["vsp"]))
     plan = C.c_void_p()
     err = C.create_string_buffer(512)
     rc = H.lib.vvhip_plan_create(C.byref(desc), C.byref(integrator._params()), H.PRECISION[precision], C.byref(plan), err, 512)

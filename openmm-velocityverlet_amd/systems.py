@@ -71,6 +71,9 @@ class SystemSpec:
     particles_ld: List[int] = field(default_factory=list)
     image_pairs: List[Tuple[int, int]] = field(default_factory=list)   # (image, parent)
     particles_electrolyte: List[int] = field(default_factory=list)
+    # System::getVirtualSite, one (site, kind, (parents...), (parameters...)) per massless site; kinds and parameter order as
+    # include/vvhip.h: VVHIP_VSITE_*
+    virtual_sites: List[tuple] = field(default_factory=list)
 
     @property
     def num_atoms(self) -> int:
@@ -334,6 +337,93 @@ def rigid_water(spec: SystemSpec, d_oh: float = 0.1, d_hh: float = 0.1633) -> Sy
 # inside the real ions differs from the procedural look-alike above (the hydrogens of c2c1im+ come after the ring, not next to their
 # carbon), which is what decides the wave packing and the SHAKE cluster shapes.
 _TOPO_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+VSITE_PARAMS = {       # kind -> (number of parents, parameters): include/vvhip.h VVHIP_VSITE_*
+    0: (2, (0.6, 0.4)),
+    1: (3, (0.786646558, 0.106676721, 0.106676721)),                              # TIP4P-Ew's M site
+    2: (3, (0.3, 0.25, -2.0)),                                                    # out of plane: w12, w13, wCross (1/nm)
+    3: (3, (1.0, 0.0, 0.0, 1.0, -1.0, 0.0, 0.0, -1.0, 1.0, 0.03, 0.02, -0.01)),   # a lone pair as examples/ommhelper/oplspsffile.py:991 builds it
+}
+
+
+def virtual_site_position(kind, prm, p1, p2, p3=None):
+    """The definitions OpenMM documents for its four site classes, in float64 (initial positions of the synthetic systems only)."""
+    if kind == 0:
+        return p1 * prm[0] + p2 * prm[1]
+    if kind == 1:
+        return p1 * prm[0] + p2 * prm[1] + p3 * prm[2]
+    if kind == 2:
+        a, b = p2 - p1, p3 - p1
+        return p1 + a * prm[0] + b * prm[1] + np.cross(a, b) * prm[2]
+    o = p1 * prm[0] + p2 * prm[1] + p3 * prm[2]
+    x = p1 * prm[3] + p2 * prm[4] + p3 * prm[5]
+    y = p1 * prm[6] + p2 * prm[7] + p3 * prm[8]
+    z = np.cross(x, y)
+    x, z = x / np.linalg.norm(x), z / np.linalg.norm(z)
+    y = np.cross(z, x)
+    return o + x * prm[9] + y * prm[10] + z * prm[11]
+
+
+def add_virtual_sites(spec: SystemSpec, kinds=(1,), interleaved: bool = True) -> SystemSpec:
+    """One massless virtual site per molecule and entry of `kinds` (molecules with fewer massive non-Drude particles than the site needs
+    parents get none), hanging on the molecule's first massive non-Drude particles.  interleaved: the sites follow their molecule's last
+    particle (a TIP4P-like O H H M layout, everything renumbered); else they are appended behind the last particle of the system, in
+    their parent's molecule (as run-edl.py's images are)."""
+    n = spec.num_atoms
+    mol = np.asarray(spec.mol_id)
+    drude = np.zeros(n, bool)
+    if len(spec.drude_pairs):
+        drude[np.asarray(spec.drude_pairs)[:, 0]] = True
+    order = np.argsort(mol, kind="stable")
+    bounds = np.nonzero(np.diff(mol[order], prepend=-1, append=mol.max() + 1))[0]
+    new_of_old = np.zeros(n, dtype=np.int64)
+    sites = []                                   # (position in the new numbering, molecule, kind, parents (old numbering))
+    nxt, tail = 0, []
+    contiguous = bool(np.all(np.diff(mol) >= 0))
+    assert contiguous or not interleaved, "interleaved sites need molecules stored one after the other"
+    for b in range(len(bounds) - 1):
+        members = order[bounds[b]:bounds[b + 1]]
+        for i in members:
+            new_of_old[i] = nxt
+            nxt += 1
+        heavy = [i for i in members if spec.masses[i] != 0 and not drude[i]]
+        for kind in kinds:
+            npar = VSITE_PARAMS[kind][0]
+            if len(heavy) < npar:
+                continue
+            if interleaved:
+                sites.append((nxt, int(mol[members[0]]), kind, heavy[:npar]))
+                nxt += 1
+            else:
+                tail.append((int(mol[members[0]]), kind, heavy[:npar]))
+    if not interleaved:
+        new_of_old = np.arange(n, dtype=np.int64)
+        sites = [(n + k, m, kind, par) for k, (m, kind, par) in enumerate(tail)]
+    ntot = n + len(sites)
+    def spread(a, fill):
+        out = np.full((ntot,) + a.shape[1:], fill, dtype=a.dtype)
+        out[new_of_old] = a
+        return out
+    masses, charges = spread(np.asarray(spec.masses, float), 0.0), spread(np.asarray(spec.charges, float), 0.0)
+    pos, vel = spread(np.asarray(spec.positions, float), 0.0), spread(np.asarray(spec.velocities, float), 0.0)
+    molid = spread(mol.astype(np.int32), 0)
+    vs = []
+    for at, m, kind, par in sites:
+        prm = VSITE_PARAMS[kind][1]
+        pp = [np.asarray(spec.positions[i], float) for i in par]
+        pos[at] = virtual_site_position(kind, prm, *pp)
+        molid[at] = m
+        charges[at] = -0.3
+        vs.append((int(at), int(kind), tuple(int(new_of_old[i]) for i in par), tuple(prm)))
+    ren = lambda a: new_of_old[np.asarray(a, dtype=np.int64)].astype(np.int32) if len(a) else np.asarray(a, dtype=np.int32)
+    out = SystemSpec(name=spec.name + "+vsites", masses=masses, charges=charges, positions=pos, velocities=vel, box=spec.box, mol_id=molid,
+                     drude_pairs=ren(spec.drude_pairs).reshape(-1, 2), constraints=ren(spec.constraints).reshape(-1, 2),
+                     constraint_distances=spec.constraint_distances, has_cm_motion_remover=spec.has_cm_motion_remover,
+                     particles_ld=[int(new_of_old[i]) for i in spec.particles_ld],
+                     image_pairs=[(int(new_of_old[a]), int(new_of_old[b])) for a, b in spec.image_pairs],
+                     particles_electrolyte=[int(new_of_old[i]) for i in spec.particles_electrolyte], virtual_sites=vs)
+    return out
 
 
 def have_reference_topologies() -> bool:

@@ -47,7 +47,11 @@ class SystemDesc(C.Structure):
                 ("num_particles_ld", C.c_int32), ("particles_ld", C.c_void_p),
                 ("num_image_pairs", C.c_int32), ("image_pairs", C.c_void_p),
                 ("num_electrolyte", C.c_int32), ("particles_electrolyte", C.c_void_p),
-                ("shard_begin", C.c_int32), ("shard_end", C.c_int32), ("constraint_distances", C.c_void_p)]
+                ("shard_begin", C.c_int32), ("shard_end", C.c_int32), ("constraint_distances", C.c_void_p),
+                ("num_virtual_sites", C.c_int32), ("virtual_sites", C.c_void_p), ("virtual_site_params", C.c_void_p)]
+
+
+VSITE_AVERAGE2, VSITE_AVERAGE3, VSITE_OUT_OF_PLANE, VSITE_LOCAL_COORDS = 0, 1, 2, 3
 
 
 class Params(C.Structure):
@@ -73,7 +77,8 @@ class PlanInfo(C.Structure):
                 ("dof", C.c_double * 3), ("nkbt", C.c_double * 3), ("eta_mass", (C.c_double * MAX_CHAINS) * 3),
                 ("inv_mass_total", C.c_double), ("num_waves", C.c_int32), ("num_slots_used", C.c_int32),
                 ("max_cluster", C.c_int32), ("num_shake_clusters", C.c_int32), ("constraints_fused", C.c_int32),
-                ("num_settle_clusters", C.c_int32), ("periodic_layout", C.c_int32), ("num_general_constraints", C.c_int32)]
+                ("num_settle_clusters", C.c_int32), ("periodic_layout", C.c_int32), ("num_general_constraints", C.c_int32),
+                ("num_virtual_sites", C.c_int32)]
 
 
 class NHState(C.Structure):

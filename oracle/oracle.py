@@ -349,6 +349,7 @@ class _System(C.Structure):
         ("num_settle", C.c_int), ("settle_atoms", C.c_void_p), ("settle_params", C.c_void_p),
         ("shake_mode", C.c_int),
         ("num_general", C.c_int), ("general_atoms", C.c_void_p), ("general_params", C.c_void_p),
+        ("num_vsites", C.c_int), ("vsite_atoms", C.c_void_p), ("vsite_params", C.c_void_p),
     ]
 
 
@@ -464,6 +465,15 @@ class OracleSystem:
             self.clusters = None
             self.general = build_general_constraints(spec)
             s.num_general, s.general_atoms, s.general_params = len(self.general[0]), _p(self.general[0]), _p(self.general[1])
+        vsites = list(getattr(spec, "virtual_sites", None) or [])
+        if vsites:                               # (site, kind, parents, parameters) as SystemSpec.virtual_sites
+            self.vsite_atoms = np.full((len(vsites), 5), -1, dtype=np.int32)
+            self.vsite_params = np.zeros((len(vsites), 12), dtype=np.float64)
+            for i, (site, kind, parents, prm) in enumerate(vsites):
+                self.vsite_atoms[i, 0], self.vsite_atoms[i, 1] = site, kind
+                self.vsite_atoms[i, 2:2 + len(parents)] = parents
+                self.vsite_params[i, :len(prm)] = prm
+            s.num_vsites, s.vsite_atoms, s.vsite_params = len(vsites), _p(self.vsite_atoms), _p(self.vsite_params)
         s.constraint_tolerance = 1e-5
         s.shake_mode = int(os.environ.get("VVHIP_SHAKE_MODE", "1")) if shake_mode is None else int(shake_mode)
         if self.clusters is not None:

@@ -754,6 +754,51 @@ void vvo_general_velocities(int n, const int* atoms, const float* params, mixed 
     }
 }
 
+/* ------------------------------------------------------------------ integration.computeVirtualSites(), HOST:214, 374
+ * OpenMM's kernel is not under /root/reference (third-party arithmetic on the path).  Restated from the definitions OpenMM
+ * documents for its four site classes -- TwoParticleAverageSite: w1 r1 + w2 r2; ThreeParticleAverageSite: w1 r1 + w2 r2 + w3 r3;
+ * OutOfPlaneSite: r1 + w12 r12 + w13 r13 + wCross (r12 x r13); LocalCoordinatesSite: origin and two directions as weighted sums of the
+ * parents, z = x cross y, x and z normalised, y = z cross x, site = origin + local position in that frame -- with the parents read
+ * back from posq (+ posqCorrection) as every OpenMM kernel reads positions, weights in `real`, arithmetic in `mixed`, the site's
+ * charge kept.  Parity with OpenMM's own kernel: unpinned. */
+void vvo_compute_virtual_sites(int n, const int* sites, const double* params, real4* posq, real4* posq_corr) {
+    for (int k = 0; k < n; k++) {
+        const int site = sites[5 * k], kind = sites[5 * k + 1], a1 = sites[5 * k + 2], a2 = sites[5 * k + 3], a3 = kind == 0 ? a1 : sites[5 * k + 4];
+        real w[12];
+        for (int j = 0; j < 12; j++) w[j] = (real) params[12 * k + j];
+        mixed x, y, z, q, p1x, p1y, p1z, p2x, p2y, p2z, p3x, p3y, p3z, unused;
+        load_pos(posq, posq_corr, site, &x, &y, &z, &q);
+        load_pos(posq, posq_corr, a1, &p1x, &p1y, &p1z, &unused);
+        load_pos(posq, posq_corr, a2, &p2x, &p2y, &p2z, &unused);
+        load_pos(posq, posq_corr, a3, &p3x, &p3y, &p3z, &unused);
+        if (kind == 0) {
+            x = p1x * w[0] + p2x * w[1]; y = p1y * w[0] + p2y * w[1]; z = p1z * w[0] + p2z * w[1];
+        } else if (kind == 1) {
+            x = p1x * w[0] + p2x * w[1] + p3x * w[2]; y = p1y * w[0] + p2y * w[1] + p3y * w[2]; z = p1z * w[0] + p2z * w[1] + p3z * w[2];
+        } else if (kind == 2) {
+            const mixed ax = p2x - p1x, ay = p2y - p1y, az = p2z - p1z, bx = p3x - p1x, by = p3y - p1y, bz = p3z - p1z;
+            const mixed cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
+            x = p1x + ax * w[0] + bx * w[1] + cx * w[2]; y = p1y + ay * w[0] + by * w[1] + cy * w[2]; z = p1z + az * w[0] + bz * w[1] + cz * w[2];
+        } else {
+            const mixed ox = p1x * w[0] + p2x * w[1] + p3x * w[2], oy = p1y * w[0] + p2y * w[1] + p3y * w[2], oz = p1z * w[0] + p2z * w[1] + p3z * w[2];
+            mixed xx = p1x * w[3] + p2x * w[4] + p3x * w[5], xy = p1y * w[3] + p2y * w[4] + p3y * w[5], xz = p1z * w[3] + p2z * w[4] + p3z * w[5];
+            mixed yx = p1x * w[6] + p2x * w[7] + p3x * w[8], yy = p1y * w[6] + p2y * w[7] + p3y * w[8], yz = p1z * w[6] + p2z * w[7] + p3z * w[8];
+            mixed zx = xy * yz - xz * yy, zy = xz * yx - xx * yz, zz = xx * yy - xy * yx;
+#ifdef VVO_SINGLE          /* the square root of the `mixed` type */
+            const mixed normX = sqrtf(xx * xx + xy * xy + xz * xz), normZ = sqrtf(zx * zx + zy * zy + zz * zz);
+#else
+            const mixed normX = sqrt(xx * xx + xy * xy + xz * xz), normZ = sqrt(zx * zx + zy * zy + zz * zz);
+#endif
+            const mixed invX = normX > 0 ? (mixed) 1 / normX : (mixed) 0, invZ = normZ > 0 ? (mixed) 1 / normZ : (mixed) 0;
+            xx *= invX; xy *= invX; xz *= invX;
+            zx *= invZ; zy *= invZ; zz *= invZ;
+            yx = zy * xz - zz * xy; yy = zz * xx - zx * xz; yz = zx * xy - zy * xx;
+            x = ox + xx * w[9] + yx * w[10] + zx * w[11]; y = oy + xy * w[9] + yy * w[10] + zy * w[11]; z = oz + xz * w[9] + yz * w[10] + zz * w[11];
+        }
+        store_pos(posq, posq_corr, site, x, y, z, q);
+    }
+}
+
 /* ------------------------------------------------------------------ the same clusters, all constraints of a cluster at once
  * (shake_mode 1, what the product runs by default; the Gauss-Seidel sweeps above stay as shake_mode 0).
  * Multipliers l_k, one per constraint: the central particle moves by imc * sum_m l_m r_m, peripheral k by -imp * l_k r_k, with
@@ -1166,6 +1211,7 @@ static void step_middle(vvo_system* s) {           /* API:232-270; constraints/v
     if (s->num_settle > 0) vvo_settle_positions(s->num_settle, s->settle_atoms, s->settle_params, s->posq, s->posq_corr, s->velm, s->pos_delta);
     vvo_integrate_middle_pos3(n, s->posq, s->posq_corr, s->pos_delta, s->old_delta, s->velm, (mixed) s->dt); /* HOST:179-185 */
     hard_wall(s);
+    if (s->num_vsites > 0) vvo_compute_virtual_sites(s->num_vsites, s->vsite_atoms, s->vsite_params, s->posq, s->posq_corr);   /* HOST:214, 374 */
     if (s->num_images > 0)
         vvo_update_image_positions(s->num_images, s->posq, s->posq_corr, s->image_pairs, (mixed) s->mirror);
 }
@@ -1185,6 +1231,7 @@ static void step_vv(vvo_system* s) {               /* API:272-338 */
     if (s->num_settle > 0) vvo_settle_positions(s->num_settle, s->settle_atoms, s->settle_params, s->posq, s->posq_corr, s->velm, s->pos_delta);
     vvo_vv_integrate_positions(n, s->posq, s->posq_corr, s->pos_delta, s->velm, (mixed) s->dt);           /* HOST:355-360 */
     hard_wall(s);
+    if (s->num_vsites > 0) vvo_compute_virtual_sites(s->num_vsites, s->vsite_atoms, s->vsite_params, s->posq, s->posq_corr);   /* HOST:214, 374 */
     if (s->num_images > 0)
         vvo_update_image_positions(s->num_images, s->posq, s->posq_corr, s->image_pairs, (mixed) s->mirror);
     calc_forces(s);

@@ -124,6 +124,10 @@ typedef struct {
      * constraints of one colour never share a particle */
     int num_general; const int* general_atoms;     /* [2*n]: a, b */
     const float* general_params;                   /* [4*n]: d^2, 0.5/(1/m_a + 1/m_b), 1/m_a, 1/m_b */
+    /* virtual sites, see vvo_compute_virtual_sites */
+    int num_vsites; const int* vsite_atoms;        /* [5*n]: site, kind (0 average of two, 1 average of three, 2 out of plane, 3 local
+                                                      coordinates), parents 1, 2, 3 */
+    const double* vsite_params;                    /* [12*n]: weights / local position, include/vvhip.h: virtual_site_params */
 } vvo_system;
 
 #ifdef __cplusplus
@@ -194,6 +198,7 @@ void vvo_cluster_positions_newton(int nclusters, const int* atoms, const float* 
 /* SETTLE (Miyamoto & Kollman 1992) for rigid three-site molecules, on the step displacement / on the velocities; masses from
  * velm.w.  Written independently of the device code (vector form, the velocity multipliers by Cramer's rule); same unpinned status
  * as vvo_shake_*: OpenMM's source is not under /root/reference. */
+void vvo_compute_virtual_sites(int n, const int* sites, const double* params, vvo_real4* posq, vvo_real4* posq_corr);
 void vvo_settle_positions(int n, const int* atoms, const float* params, const vvo_real4* posq, const vvo_real4* posq_corr,
                           const vvo_mixed4* velm, vvo_mixed4* pos_delta);
 void vvo_settle_velocities(int n, const int* atoms, const vvo_real4* posq, const vvo_real4* posq_corr, vvo_mixed4* velm);

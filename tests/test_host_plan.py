@@ -316,3 +316,42 @@ def test_general_constraint_clusters_are_coloured_lists_per_wave(hangles):
     for c in range(ncol):
         ends = atoms[colours == c].reshape(-1)
         assert len(set(ends.tolist())) == ends.size
+
+
+def test_virtual_sites_share_a_wave_with_their_parents():
+    """vvhip_system_desc.virtual_sites: a site gets a lane (massless particles otherwise have none) in the wave of its parents; what cannot
+    be placed in-kernel is reported (num_virtual_sites == 0: the caller keeps its own computeVirtualSites), what is malformed is refused."""
+    base = systems.drude_il(cells=(1, 1, 1), pairs_per_cell=20, seed=2)
+    for interleaved in (True, False):
+        spec = systems.add_virtual_sites(base, kinds=(3, 0), interleaved=interleaved)
+        for use_com in (True, False):
+            it = I.VVIntegrator(333.0, 10, 1.0, 40, 0.001)
+            it.setUseCOMTempGroup(use_com)
+            info, slots = I.plan_layout(spec, it)
+            assert info.num_virtual_sites == len(spec.virtual_sites) == 80
+            wave_of = np.full(spec.num_atoms, -1)
+            live = slots[:, 0] >= 0
+            wave_of[slots[live, 0]] = np.nonzero(live)[0] // 64
+            for site, kind, parents, prm in spec.virtual_sites:
+                assert wave_of[site] >= 0 and all(wave_of[q] == wave_of[site] for q in parents)
+            info0, _ = I.plan_layout(base, it)
+            assert list(info.dof) == list(info0.dof) and info.num_slots_used == info0.num_slots_used + 80
+    spec = systems.add_virtual_sites(systems.spce_water(8), kinds=(1,))
+    it = I.VVIntegrator(300.0, 10, 1.0, 40, 0.001)
+    # a site hanging on another site: left to the caller
+    s2 = systems.add_virtual_sites(systems.spce_water(8), kinds=(1,))
+    s2.virtual_sites[1] = (s2.virtual_sites[1][0], 0, (s2.virtual_sites[0][0], 4), (0.5, 0.5))
+    assert I.plan_layout(s2, it)[0].num_virtual_sites == 0
+    # parents in another molecule while molecules are kept together for the molecular temperature group: not in one wave, left to the caller
+    s3 = systems.add_virtual_sites(systems.drude_il(cells=(1, 1, 1), pairs_per_cell=40, seed=2), kinds=(0,), interleaved=False)
+    far = s3.virtual_sites[-1]
+    s3.virtual_sites[0] = (s3.virtual_sites[0][0], 0, far[2], far[3])
+    itc = I.VVIntegrator(333.0, 10, 1.0, 40, 0.001)
+    itc.setUseCOMTempGroup(True)
+    assert I.plan_layout(s3, itc)[0].num_virtual_sites == 0
+    # malformed: a massive site, an unknown kind, a site described twice
+    for bad, text in (((0, 1, (1, 2, 4), (0.3, 0.3, 0.4)), "mass 0"), ((3, 7, (0, 1, 2), (1.0,)), "kind"), (spec.virtual_sites[0], "twice")):
+        s4 = systems.add_virtual_sites(systems.spce_water(8), kinds=(1,))
+        s4.virtual_sites.append(bad)
+        with pytest.raises(H.VVHipError, match=text):
+            I.plan_layout(s4, it)
