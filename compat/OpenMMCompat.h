@@ -20,7 +20,10 @@ public:
     explicit OpenMMException(const std::string& m) : std::runtime_error(m) {}
 };
 
-struct Vec3 { double x, y, z; };
+struct Vec3 {
+    double x, y, z;
+    double operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); }      // (OpenMM's Vec3 is indexed, it has no named members)
+};
 class State { public: enum DataType { Positions = 1, Velocities = 2, Forces = 4, Energy = 8, Parameters = 16 }; };
 
 class Force { public: virtual ~Force() {} };
@@ -42,9 +45,59 @@ private:
     std::vector<Row> rows;
 };
 
+// OpenMM's virtual-site classes (openmm/VirtualSite.h), as far as the adapters read them
+class VirtualSite {
+public:
+    virtual ~VirtualSite() {}
+    int getNumParticles() const { return (int) particles.size(); }
+    int getParticle(int i) const { return particles.at(i); }
+protected:
+    void setParticles(const std::vector<int>& p) { particles = p; }
+private:
+    std::vector<int> particles;
+};
+class TwoParticleAverageSite : public VirtualSite {
+public:
+    TwoParticleAverageSite(int p1, int p2, double w1, double w2) : w{w1, w2} { setParticles({p1, p2}); }
+    double getWeight(int i) const { return w[i]; }
+private:
+    double w[2];
+};
+class ThreeParticleAverageSite : public VirtualSite {
+public:
+    ThreeParticleAverageSite(int p1, int p2, int p3, double w1, double w2, double w3) : w{w1, w2, w3} { setParticles({p1, p2, p3}); }
+    double getWeight(int i) const { return w[i]; }
+private:
+    double w[3];
+};
+class OutOfPlaneSite : public VirtualSite {
+public:
+    OutOfPlaneSite(int p1, int p2, int p3, double w12, double w13, double wc) : w12(w12), w13(w13), wc(wc) { setParticles({p1, p2, p3}); }
+    double getWeight12() const { return w12; }
+    double getWeight13() const { return w13; }
+    double getWeightCross() const { return wc; }
+private:
+    double w12, w13, wc;
+};
+class LocalCoordinatesSite : public VirtualSite {
+public:
+    LocalCoordinatesSite(int p1, int p2, int p3, const Vec3& ow, const Vec3& xw, const Vec3& yw, const Vec3& local)
+        : ow{ow.x, ow.y, ow.z}, xw{xw.x, xw.y, xw.z}, yw{yw.x, yw.y, yw.z}, local(local) { setParticles({p1, p2, p3}); }
+    void getOriginWeights(std::vector<double>& w) const { w = ow; }
+    void getXWeights(std::vector<double>& w) const { w = xw; }
+    void getYWeights(std::vector<double>& w) const { w = yw; }
+    const Vec3& getLocalPosition() const { return local; }
+private:
+    std::vector<double> ow, xw, yw;
+    Vec3 local;
+};
+
 class System {
 public:
-    ~System() { for (Force* f : forces) delete f; }
+    ~System() { for (Force* f : forces) delete f; for (auto& s : sites) delete s.second; }
+    void setVirtualSite(int index, VirtualSite* site) { delete sites[index]; sites[index] = site; }      // takes ownership, as OpenMM does
+    bool isVirtualSite(int index) const { return sites.count(index) != 0; }
+    const VirtualSite& getVirtualSite(int index) const { return *sites.at(index); }
     int addParticle(double mass) { masses.push_back(mass); return (int) masses.size() - 1; }
     int getNumParticles() const { return (int) masses.size(); }
     double getParticleMass(int i) const { return masses.at(i); }
@@ -59,6 +112,7 @@ private:
     std::vector<double> masses;
     std::vector<Con> cons;
     std::vector<Force*> forces;
+    std::map<int, VirtualSite*> sites;
 };
 
 class Platform;

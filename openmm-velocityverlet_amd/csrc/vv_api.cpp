@@ -911,6 +911,7 @@ int vvhip_algorithmic_bytes(const vvhip_plan* p, int32_t* bytes_a, int32_t* byte
         if (!per_a) *bytes_a += 20;
         if (!per_b) *bytes_b += 20;
     }
+    if (!p->hp.slot_vsite.empty()) *bytes_b += 8;      // the site word of every lane (the 96-byte record of a site lane itself: well below a byte per particle)
     return VVHIP_OK;
 }
 

@@ -27,6 +27,7 @@ public:
     void check(int rc) const;                                  // vvhip error -> OpenMMException
     int numLangevinRandoms() const { return ldRandoms; }
     bool constraintFree() const { return noConstraints; }
+    bool placesVirtualSites() const { return sitesInKernel; }      // the fused steps place the System's virtual sites (vvhip_plan_info.num_virtual_sites)
     static std::shared_ptr<HipVVPlan> find(HipContext& cu);    // the plan the step kernel created for this context
     static std::shared_ptr<HipVVPlan> create(HipContext& cu, const System&, const VVIntegrator&, const DrudeForce*);
 
@@ -60,6 +61,7 @@ private:
     double lastBox[3] = {0, 0, 0};
     int ldRandoms;
     bool noConstraints;
+    bool sitesInKernel;
     bool debug = false;      // last VVIntegrator::getDebugEnabled() handed to vvhip_set_trace
 };
 

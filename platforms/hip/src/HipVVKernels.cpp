@@ -68,6 +68,37 @@ HipVVPlan::HipVVPlan(HipContext& cu, const System& system, const VVIntegrator& i
         cons.push_back(a); cons.push_back(b);
         consDist.push_back(d);
     }
+    // Virtual sites of the four classes the fused step can place itself (include/vvhip.h: virtual_sites); any other kind, and the whole list
+    // stays with OpenMM's computeVirtualSites
+    std::vector<int32_t> sites;
+    std::vector<double> siteParams;
+    bool sitesDescribed = true;
+    for (int i = 0; i < n && sitesDescribed; i++) {
+        if (!system.isVirtualSite(i)) continue;
+        const VirtualSite& vs = system.getVirtualSite(i);
+        double w[12] = {0};
+        int kind = -1;
+        if (const TwoParticleAverageSite* s2 = dynamic_cast<const TwoParticleAverageSite*>(&vs)) {
+            kind = VVHIP_VSITE_AVERAGE2; w[0] = s2->getWeight(0); w[1] = s2->getWeight(1);
+        } else if (const ThreeParticleAverageSite* s3 = dynamic_cast<const ThreeParticleAverageSite*>(&vs)) {
+            kind = VVHIP_VSITE_AVERAGE3; w[0] = s3->getWeight(0); w[1] = s3->getWeight(1); w[2] = s3->getWeight(2);
+        } else if (const OutOfPlaneSite* so = dynamic_cast<const OutOfPlaneSite*>(&vs)) {
+            kind = VVHIP_VSITE_OUT_OF_PLANE; w[0] = so->getWeight12(); w[1] = so->getWeight13(); w[2] = so->getWeightCross();
+        } else if (const LocalCoordinatesSite* sl = dynamic_cast<const LocalCoordinatesSite*>(&vs)) {
+            std::vector<double> ow, xw, yw;
+            sl->getOriginWeights(ow); sl->getXWeights(xw); sl->getYWeights(yw);
+            if (vs.getNumParticles() == 3 && ow.size() == 3 && xw.size() == 3 && yw.size() == 3) {
+                kind = VVHIP_VSITE_LOCAL_COORDS;
+                for (int k = 0; k < 3; k++) { w[k] = ow[k]; w[3 + k] = xw[k]; w[6 + k] = yw[k]; }
+                const Vec3 lp = sl->getLocalPosition();
+                w[9] = lp[0]; w[10] = lp[1]; w[11] = lp[2];
+            }
+        }
+        if (kind < 0) { sitesDescribed = false; break; }
+        sites.push_back(i); sites.push_back(kind);
+        for (int k = 0; k < 3; k++) sites.push_back(k < vs.getNumParticles() ? vs.getParticle(k) : -1);
+        siteParams.insert(siteParams.end(), w, w + 12);
+    }
     bool cmm = false;
     for (int i = 0; i < system.getNumForces(); i++)                     // HOST:550-558
         if (dynamic_cast<const CMMotionRemover*>(&system.getForce(i)) != NULL) cmm = true;
@@ -81,6 +112,7 @@ HipVVPlan::HipVVPlan(HipContext& cu, const System& system, const VVIntegrator& i
     d.num_particles_ld = (int) ld.size(); d.particles_ld = ld.data();
     d.num_image_pairs = (int) img.size() / 2; d.image_pairs = img.data();
     d.num_electrolyte = (int) el.size(); d.particles_electrolyte = el.data();
+    if (sitesDescribed && !sites.empty()) { d.num_virtual_sites = (int) sites.size() / 5; d.virtual_sites = sites.data(); d.virtual_site_params = siteParams.data(); }
     last = paramsOf(it);
     const int precision = cu.getUseDoublePrecision() ? VVHIP_DOUBLE : (cu.getUseMixedPrecision() ? VVHIP_MIXED : VVHIP_SINGLE);
     char err[512] = "";
@@ -89,6 +121,7 @@ HipVVPlan::HipVVPlan(HipContext& cu, const System& system, const VVIntegrator& i
     vvhip_plan_get_info(plan, &info);
     ldRandoms = std::max(info.num_normal_ld, 1) + 2 * std::max(info.num_pairs_ld, 1);   // HOST:806-807,863: array sizes are max(n,1)
     noConstraints = info.constraints_fused != 0;      // no constraints at all, or all of them solved inside the kernels
+    sitesInKernel = info.num_virtual_sites > 0;       // the fused steps place the virtual sites themselves
     if (const char* e = std::getenv("VVHIP_PLUGIN_DEFER")) deferEnabled = std::atoi(e) != 0;
     HipIntegrationUtilities& integration = cu.getIntegrationUtilities();
     vvhip_buffers b = {};
@@ -282,7 +315,8 @@ void HipIntegrateMiddleStepKernel::fusedMiddleWith(const VVIntegrator& it, uint3
     announceStepSize(it, false);
     if (it.getDebugEnabled()) std::cout << "HipIntegrateMiddleStepKernel fusedMiddleStep" << std::endl;
     plan->check(vvhip_step_middle(plan->get(), randomIndex));
-    cu.getIntegrationUtilities().computeVirtualSites();      // as the un-fused path and the reference after every position update (HOST:214)
+    // as the un-fused path and the reference after every position update (HOST:214), unless kernel B has placed the sites already
+    if (!plan->placesVirtualSites()) cu.getIntegrationUtilities().computeVirtualSites();
     cu.reorderAtoms();
     advanceClock(it);
 }
@@ -333,7 +367,7 @@ void HipIntegrateVVStepKernel::fusedFirstNow(const VVIntegrator& it) {
     plan->syncParameters(it);
     announceStepSize(it, true);
     plan->check(vvhip_step_vv_first(plan->get()));
-    cu.getIntegrationUtilities().computeVirtualSites();      // HOST:374
+    if (!plan->placesVirtualSites()) cu.getIntegrationUtilities().computeVirtualSites();      // HOST:374
     cu.reorderAtoms();
 }
 void HipIntegrateVVStepKernel::fusedVVSecondHalf(ContextImpl&, const VVIntegrator& it) {

@@ -104,7 +104,10 @@ static int run(const char* out, bool middle, int consMode, double cosacc, int ns
         }
     // consMode 3 ("electrode"): 16 Langevin-thermostatted wall atoms (each its own molecule), a massless image of every liquid particle in its
     // parent's molecule, the liquid in the electrolyte set -- the machinery of examples/run-edl.py (Langevin force, field force, image mirror)
-    const int nLiquid = nLiq, nWall = consMode == 3 ? 16 : 0, nImages = consMode == 3 ? nLiquid : 0, nAll = nLiquid + nWall + nImages;
+    // consMode 5: one virtual site per molecule behind the liquid (a lone pair in local coordinates on even molecules, a three-particle average
+    // on odd ones, hanging on the three heavy particles), in its molecule: kernel B places them, OpenMM's computeVirtualSites is not called
+    const int nSites = consMode == 5 ? nmol : 0;
+    const int nLiquid = nLiq, nWall = consMode == 3 ? 16 : 0, nImages = consMode == 3 ? nLiquid : 0, nAll = nLiquid + nWall + nImages + nSites;
     for (int w = 0; w < nWall; w++) {
         system.addParticle(32.06);
         masses.push_back(32.06); charges.push_back(0.0); molId.push_back(nmol + w);
@@ -114,6 +117,25 @@ static int run(const char* out, bool middle, int consMode, double cosacc, int ns
         system.addParticle(0.0);
         masses.push_back(0.0); charges.push_back(-charges[k]); molId.push_back(molId[k]);
         molecules[molId[k]].push_back(nLiquid + nWall + k);
+    }
+    std::vector<int> siteList;
+    std::vector<double> siteParams;
+    for (int m = 0; m < nSites; m++) {
+        const int i = nLiquid + m, p1 = m * per, p2 = m * per + 2, p3 = m * per + 4;
+        system.addParticle(0.0);
+        masses.push_back(0.0); charges.push_back(-0.3); molId.push_back(m);
+        molecules[m].push_back(i);
+        double w[12] = {0};
+        if (m % 2 == 0) {
+            const double lone[12] = {1.0, 0.0, 0.0, 1.0, -1.0, 0.0, 0.0, -1.0, 1.0, 0.03, 0.02, -0.01};
+            std::copy(lone, lone + 12, w);
+            system.setVirtualSite(i, new LocalCoordinatesSite(p1, p2, p3, Vec3{w[0], w[1], w[2]}, Vec3{w[3], w[4], w[5]}, Vec3{w[6], w[7], w[8]}, Vec3{w[9], w[10], w[11]}));
+        } else {
+            w[0] = 0.5; w[1] = 0.3; w[2] = 0.2;
+            system.setVirtualSite(i, new ThreeParticleAverageSite(p1, p2, p3, w[0], w[1], w[2]));
+        }
+        siteList.push_back(i); siteList.push_back(m % 2 == 0 ? 3 : 1); siteList.push_back(p1); siteList.push_back(p2); siteList.push_back(p3);
+        siteParams.insert(siteParams.end(), w, w + 12);
     }
     system.addForce(drude);
     if (consMode != 3) system.addForce(new CMMotionRemover());
@@ -289,6 +311,7 @@ static int run(const char* out, bool middle, int consMode, double cosacc, int ns
     put(f, masses); put(f, charges); put(f, molId); put(f, pairs); put(f, cons); put(f, pos); put(f, vel);
     put(f, velm); put(f, posq); put(f, corr); put(f, vis); put(f, consDist);
     put(f, ldList); put(f, imgList); put(f, elList); put(f, normals);
+    put(f, siteList); put(f, siteParams);
     std::printf("RUN OK steps=%d time=%.6f stepCount=%lld vMax=%.9g\n", nsteps, cu.getTime(), cu.getStepCount(), vis[0]);
     if (hostMode >= 10) std::printf("FUZZ steps=%ld interrupted=%ld\n", stepsDone, stepsInterrupted);
     // how the adapters used the context services (the reference's pattern: HOST:60-63, 136-141, 214-216, 307-319)

@@ -46,7 +46,7 @@ def _read(path):
     raw = open(path, "rb").read()
     off = 0
     out = []
-    for dt in ("f8", "f8", "i4", "i4", "i4", "f8", "f8", "f8", "f4", "f4", "f8", "f8", "i4", "i4", "i4", "f4"):
+    for dt in ("f8", "f8", "i4", "i4", "i4", "f8", "f8", "f8", "f4", "f4", "f8", "f8", "i4", "i4", "i4", "f4", "i4", "f8"):
         if off >= len(raw):
             break
         (n,) = struct.unpack_from("<q", raw, off)
@@ -67,6 +67,9 @@ def _oracle_for(arrays, middle, cons, cos, nsteps):
                               constraints=cns.reshape(-1, 2), has_cm_motion_remover=cons != 3)
     if cons in (2, 4):  # hydrogen-type / general clusters: solved in the fused kernels, and by the oracle (cons == 1: see the driver)
         spec.constraint_distances = cdist
+    if cons == 5:       # virtual sites: placed by kernel B, and by the oracle's statement of OpenMM's definitions
+        vs, vp = arrays[16].reshape(-1, 5), arrays[17].reshape(-1, 12)
+        spec.virtual_sites = [(int(r[0]), int(r[1]), tuple(int(q) for q in r[2:5]), tuple(w)) for r, w in zip(vs, vp)]
     p = O.Params(temperature=333.0, drude_temperature=1.0, max_drude_distance=0.02, cos_acceleration=cos, use_middle_scheme=bool(middle))
     rnd = None
     if cons == 3:
@@ -83,7 +86,8 @@ def _oracle_for(arrays, middle, cons, cos, nsteps):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("middle,cons,cos", [(1, 0, 0.0), (1, 1, 0.0), (1, 0, 0.02), (1, 1, 0.02), (0, 0, 0.0), (0, 1, 0.02),
-                                             (1, 2, 0.0), (1, 2, 0.02), (0, 2, 0.0), (1, 3, 0.0), (0, 3, 0.0), (1, 4, 0.0), (0, 4, 0.02)])
+                                             (1, 2, 0.0), (1, 2, 0.02), (0, 2, 0.0), (1, 3, 0.0), (0, 3, 0.0), (1, 4, 0.0), (0, 4, 0.02),
+                                             (1, 5, 0.0), (0, 5, 0.02)])
 def test_cpp_integrator_through_plugin_matches_oracle(tmp_path, middle, cons, cos):
     nsteps = 12
     dump = str(tmp_path / "run.bin")
@@ -100,7 +104,8 @@ def test_cpp_integrator_through_plugin_matches_oracle(tmp_path, middle, cons, co
     assert int(sv["selector"]) == nkern and int(sv["depth"]) == 0 and int(sv["initializeContexts"]) == 1 and int(sv["initRandom"]) == 1
     assert int(sv["setNextStepSize"]) == (1 if middle else 0)
     assert sv["stepSize"] == "(0,0.001)"
-    assert int(sv["virtualSites"]) == nsteps and int(sv["reorder"]) == nsteps
+    # (cons == 5: the System's virtual sites are described to the plan and placed by kernel B; OpenMM's kernel is not launched)
+    assert int(sv["virtualSites"]) == (0 if cons == 5 else nsteps) and int(sv["reorder"]) == nsteps
     assert int(sv["setAsCurrent"]) >= nsteps
     if cons == 1:                                        # constraints the kernels cannot fuse: OpenMM's solver runs between the stages
         assert int(sv["applyConstraints"]) == nsteps and int(sv["applyVelocityConstraints"]) == nsteps
