@@ -1,7 +1,8 @@
 // tests/cpp/host_sanitize.cpp -- the host analysis (csrc/vv_host.cpp: tables, wave layout, arithmetic layout) under AddressSanitizer and
 // UndefinedBehaviorSanitizer on the CPU (tests/test_host_sanitizers.py builds and runs it with g++ -fsanitize=address,undefined; GPU
 // sanitizers are not available on this pool).  Random inventories of repeated molecules -- Drude pairs, hydrogen constraints, rigid water,
-// Langevin / image / electrolyte subsets, defects, shard cuts on molecule boundaries, molecules larger than a wave -- analysed with the
+// Langevin / image / electrolyte subsets, general constraint clusters, virtual sites, defects, shard cuts on molecule boundaries, molecules
+// larger than a wave -- analysed with the
 // arithmetic layout forced on and off; a few invariants are checked so that the optimiser cannot drop the work.
 #include <cstdio>
 #include <cstdlib>
@@ -14,7 +15,8 @@
 namespace {
 struct Sys {
     std::vector<double> masses, cdist;
-    std::vector<int32_t> mol, pairs, cons, ld, img, el;
+    std::vector<int32_t> mol, pairs, cons, ld, img, el, vs;
+    std::vector<double> vsp;
     int nmol = 0;
 };
 
@@ -55,10 +57,12 @@ Sys build(std::mt19937& rng, int flavour) {
             } else if (u == 1) {
                 s.masses.push_back(1.008); s.mol.push_back(s.nmol);
                 const int h = (int) s.masses.size() - 1;
-                if (flavour >= 1 && last_heavy >= 0 && hcount < 3) { s.cons.push_back(h); s.cons.push_back(last_heavy); s.cdist.push_back(flavour == 2 ? 0.1 : 0.109); hcount++; }
+                if (flavour >= 1 && flavour != 6 && last_heavy >= 0 && hcount < 3) { s.cons.push_back(h); s.cons.push_back(last_heavy); s.cdist.push_back(flavour == 2 ? 0.1 : 0.109); hcount++; }
             } else {
                 s.masses.push_back(m.heavy); s.mol.push_back(s.nmol);
-                last_heavy = (int) s.masses.size() - 1; hcount = 0;
+                const int h = (int) s.masses.size() - 1;
+                if (flavour == 5 && last_heavy >= first) { s.cons.push_back(h); s.cons.push_back(last_heavy); s.cdist.push_back(0.15); }      // heavy-heavy bonds: general clusters
+                last_heavy = h; hcount = 0;
             }
         }
         if (flavour == 2) { s.cons.push_back(first + 1); s.cons.push_back(first + 2); s.cdist.push_back(0.1633); }      // H-H: a rigid triangle
@@ -77,6 +81,24 @@ Sys build(std::mt19937& rng, int flavour) {
         for (int i = 0; i < n0 && s.mol[i] == 0; i++) m0++;
         for (int i = 0; i < m0; i++) { s.masses.push_back(0.0); s.mol.push_back(0); s.img.push_back((int) s.masses.size() - 1); s.img.push_back(i); s.el.push_back(i); }
     }
+    if (flavour == 6) {      // virtual sites behind the last particle, each in the molecule of its first parent; now and then a parent from the next molecule
+        const int n0 = (int) s.masses.size();
+        for (int i = 0; i + 3 < n0; i += U(1, 9)) {
+            if (s.masses[i] == 0) continue;
+            const int kind = U(0, 3), np = kind == 0 ? 2 : 3;
+            int par[3] = {i, -1, -1};
+            bool ok = true;
+            for (int q = 1; q < np; q++) {
+                par[q] = i + q;
+                if (s.mol[par[q]] != s.mol[i] && U(0, 3) != 0) ok = false;
+            }
+            if (!ok) continue;
+            s.masses.push_back(0.0); s.mol.push_back(s.mol[i]);
+            s.vs.push_back((int) s.masses.size() - 1); s.vs.push_back(kind);
+            for (int q = 0; q < 3; q++) s.vs.push_back(par[q]);
+            for (int q = 0; q < 12; q++) s.vsp.push_back(0.1 * (q + 1));
+        }
+    }
     return s;
 }
 
@@ -92,6 +114,7 @@ long analyse(const Sys& s, int use_com, int shard_parts, int part) {
     d.num_particles_ld = (int) s.ld.size(); d.particles_ld = s.ld.data();
     d.num_image_pairs = (int) s.img.size() / 2; d.image_pairs = s.img.data();
     d.num_electrolyte = (int) s.el.size(); d.particles_electrolyte = s.el.data();
+    d.num_virtual_sites = (int) s.vs.size() / 5; d.virtual_sites = s.vs.data(); d.virtual_site_params = s.vsp.data();
     if (shard_parts > 1) {      // cut on molecule boundaries
         std::vector<int> starts;
         for (int i = 0; i < n; i++) if (i == 0 || s.mol[i] != s.mol[i - 1]) starts.push_back(i);
@@ -120,7 +143,17 @@ long analyse(const Sys& s, int use_com, int shard_parts, int part) {
         }
         if (hp.seg_base.size() != (size_t) hp.info.num_waves + 1 || hp.seg_mass.size() < 2 * (size_t) hp.seg_base.back()) { std::fprintf(stderr, "segment tables\n"); std::exit(2); }
         if (!hp.slot_shake.empty() && (hp.slot_shake.size() != nslots || hp.slot_shake_param.size() != 4 * nslots)) { std::fprintf(stderr, "shake tables\n"); std::exit(2); }
-        check += hp.info.periodic_layout * 1000003L + hp.info.num_waves;
+        if (!hp.slot_vsite.empty()) {
+            if (hp.slot_vsite.size() != 2 * nslots || hp.vsite_params.size() != 12 * (size_t) hp.info.num_virtual_sites) { std::fprintf(stderr, "site tables\n"); std::exit(2); }
+            for (size_t i = 0; i < nslots; i++)
+                if ((uint32_t) hp.slot_vsite[2 * i] >> 31) {
+                    if (hp.slots[2 * i] < 0 || hp.slot_vsite[2 * i + 1] < 0 || hp.slot_vsite[2 * i + 1] >= hp.info.num_virtual_sites) { std::fprintf(stderr, "site record\n"); std::exit(2); }
+                    for (int q = 0; q < 3; q++)
+                        if (hp.slots[2 * ((i & ~(size_t) 63) + (((uint32_t) hp.slot_vsite[2 * i] >> (6 * q)) & 63u))] < 0) { std::fprintf(stderr, "site parent lane is empty\n"); std::exit(2); }
+                    check += hp.slot_vsite[2 * i + 1];
+                }
+        }
+        check += hp.info.num_general_constraints + hp.info.periodic_layout * 1000003L + hp.info.num_waves;
     } catch (const vv::Error&) {
         check += 7;            // refused inventories (a Drude pair across molecules, ...) are fine: the point is that nothing reads out of bounds
     }
@@ -134,7 +167,8 @@ int main(int argc, char** argv) {
     long total = 0;
     int periodic = 0, plans = 0;
     for (int r = 0; r < rounds; r++) {
-        const int flavour = r % 5;                 // 0 plain, 1 hydrogen constraints, 2 rigid water, 3 big molecules, 4 Langevin + images
+        const int flavour = r % 7;                 // 0 plain, 1 hydrogen constraints, 2 rigid water, 3 big molecules, 4 Langevin + images,
+                                                   // 5 bonds between heavy particles as well (general clusters), 6 virtual sites
         const Sys s = build(rng, flavour);
         for (int per = 0; per < 2; per++) {
             setenv("VVHIP_PERIODIC", per ? "1" : "0", 1);
