@@ -100,7 +100,7 @@ struct vvhip_plan {
     // comparison runs).  Kernel A: no slot traffic (1.13 -> 1.0 x the algorithmic bytes) and the next tile's loads in flight during this tile's
     // arithmetic: 133 vs 138 us in sequence at 8.9 M particles (round 2 without the second tile in flight: 113.6 vs 115.7 back to back);
     // VVHIP_PERIODIC_A=0 switches it off
-    bool periodic_kernels = true, periodic_a = true;
+    bool periodic_kernels = true, periodic_a = true, periodic_b = true;
     int shake_mode = 1;            // hydrogen-type constraint clusters: 1 = all constraints of a cluster at once (direct velocity solve, coupled Newton
                                    // for positions), 0 = Gauss-Seidel sweeps by the central lane (OpenMM's iteration; generic kernels) -- VVHIP_SHAKE_MODE
     // Race detection by timing (VVHIP_STALL=us[:period]): every period-th launch of this plan is preceded by a host sleep of `us` microseconds --
@@ -508,7 +508,7 @@ int run_a(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
 }
 // Kernel B takes the arithmetic layout whenever the plan has one, also next to the mailbox exchange (round 3 kept them apart after time-outs
 // with two ranks on one GPU; round 4 found the cause in device-filling grids of polling waves, whatever the layout: shared_device_cap)
-bool periodic_b(const vvhip_plan* p) { return p->hp.per.enabled && p->periodic_kernels; }
+bool periodic_b(const vvhip_plan* p) { return p->hp.per.enabled && p->periodic_kernels && p->periodic_b; }
 int run_b(vvhip_plan* p, uint32_t flags) {
     if (p->mass_tab_b) { flags |= vv::B_MTAB; TRY(ensure_mass_table(p)); }
     if (periodic_b(p)) flags |= vv::B_PERIODIC;
@@ -638,6 +638,7 @@ int vvhip_debug_tune(vvhip_plan* p, const char* key, int value) {
     const std::string k = key;
     if (k == "periodic_kernels") p->periodic_kernels = value != 0;          // 0: keep the arithmetic layout's slot order but load the slot words
     else if (k == "periodic_a") p->periodic_a = value != 0;                 // kernel A alone
+    else if (k == "periodic_b") p->periodic_b = value != 0;                 // kernel B alone
     else if (k == "rekick") p->rekick = value != 0;                         // 0: kernel A stores the kicked velocities, kernel B does not repeat the kick
     else if (k == "no_moments") p->no_moments = value != 0;                 // 1: cos perturbation as three launches (bias, sums, scale)
     else if (k == "mass_tab_a") p->mass_tab_a = value != 0;
