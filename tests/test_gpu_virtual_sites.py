@@ -154,3 +154,43 @@ def test_images_mirror_the_sites_new_position():
             assert abs((lz - x[extra[j], 2]) - x[n0 + j, 2]) < 1e-6 and np.allclose(x[extra[j], :2], x[n0 + j, :2], atol=1e-7)
     finally:
         ctx.close()
+
+
+def test_full_size_c3_with_a_lone_pair_on_every_molecule():
+    """BASELINE.json C3 (111 000 particles) + one local-coordinates site per molecule (6 000 sites), size-independent properties only: every
+    site sits where its definition puts it on the positions the GPU stored, the real particles move as they do without the sites
+    (a massless site takes part in nothing: HOST:496-503, K/middle.cu:11), and the step still takes two launches."""
+    base = systems.make_config("C3")
+    spec = systems.add_virtual_sites(base, kinds=(3,), interleaved=False)
+    out = []
+    for s in (spec, base):
+        it = I.VVIntegrator(333.0, 10.0, 1.0, 40.0, 0.001)
+        it.setMaxDrudeDistance(0.02)
+        ctx = I.Context(s, it, precision="mixed", force_provider="tether")
+        try:
+            if s is spec:
+                assert ctx.info.num_virtual_sites == 6000 == len(spec.virtual_sites)
+            ctx.run_graph(64, steps_per_graph=8)
+            out.append((ctx.getPositions(), ctx.getVelm().copy(), ctx.getPosq().copy()))
+        finally:
+            ctx.close()
+    n = base.num_atoms
+    # (to rounding: the sites' lanes shift the real particles into other waves and blocks, and a block's kinetic-energy sum is formed in
+    # double before it enters the exact fixed-point accumulators -- another order of the same additions)
+    dv = np.abs(out[0][1][:n, :3] - out[1][1][:, :3]).max() / np.abs(out[1][1][:, :3]).max()
+    dx = np.abs(out[0][0][:n] - out[1][0]).max() / np.abs(out[0][0]).max()
+    assert dv < 1e-11 and dx < 1e-11, (dv, dx)
+    x = out[0][0]
+    sites = np.array([s[0] for s in spec.virtual_sites])
+    par = np.array([s[2] for s in spec.virtual_sites])
+    w = np.asarray(spec.virtual_sites[0][3], dtype=np.float32).astype(np.float64)
+    p1, p2, p3 = x[par[:, 0]], x[par[:, 1]], x[par[:, 2]]
+    o = p1 * w[0] + p2 * w[1] + p3 * w[2]
+    xd = p1 * w[3] + p2 * w[4] + p3 * w[5]
+    yd = p1 * w[6] + p2 * w[7] + p3 * w[8]
+    zd = np.cross(xd, yd)
+    xd /= np.linalg.norm(xd, axis=1)[:, None]
+    zd /= np.linalg.norm(zd, axis=1)[:, None]
+    yd = np.cross(zd, xd)
+    want = o + xd * w[9] + yd * w[10] + zd * w[11]
+    assert np.abs(x[sites] - want).max() < 1e-12 * np.abs(x).max()
