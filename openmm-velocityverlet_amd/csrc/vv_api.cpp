@@ -120,6 +120,7 @@ struct vvhip_plan {
     float4* d_slot_shake_param = nullptr;
     int2* d_slot_vsite = nullptr;
     double* d_vsite_params = nullptr;
+    int32_t* d_vsite_atom = nullptr;
     unsigned long long* d_bigacc = nullptr;
     int2* d_image_pairs = nullptr;
     void* d_fextra = nullptr;
@@ -324,6 +325,7 @@ vv::KArgs make_args(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
     a.slot_shake_param = p->d_slot_shake_param;
     a.slot_vsite = p->d_slot_vsite;
     a.vsite_params = p->d_vsite_params;
+    a.vsite_atom = p->d_vsite_atom;
     a.shake_tol = q.constraint_tolerance > 0 ? q.constraint_tolerance : 1e-5;
     a.slot_big = p->d_slot_big;
     a.bigacc = p->d_bigacc;
@@ -661,7 +663,7 @@ void vvhip_plan_destroy(vvhip_plan* p) {
     if (!p) return;
     if (p->bound) {
         (void) hipStreamSynchronize(p->stream);
-        for (void* ptr : {(void*) p->d_slots, (void*) p->d_slot_image, (void*) p->d_slot_rand, (void*) p->d_slot_shake, (void*) p->d_slot_shake_param, (void*) p->d_slot_vsite, (void*) p->d_vsite_params, (void*) p->d_slot_big, (void*) p->d_bigacc, (void*) p->d_image_pairs,
+        for (void* ptr : {(void*) p->d_slots, (void*) p->d_slot_image, (void*) p->d_slot_rand, (void*) p->d_slot_shake, (void*) p->d_slot_shake_param, (void*) p->d_slot_vsite, (void*) p->d_vsite_params, (void*) p->d_vsite_atom, (void*) p->d_slot_big, (void*) p->d_bigacc, (void*) p->d_image_pairs,
                           p->d_fextra, p->d_old_delta, p->d_pos_delta, p->d_comv, (void*) p->d_comw, (void*) p->d_seg_mass, (void*) p->d_seg_base, (void*) p->d_slot_m, (void*) p->d_slot_f, (void*) p->d_cosz, (void*) p->d_epoch, (void*) p->d_acc, (void*) p->d_nh, (void*) p->d_lane_const, (void*) p->d_dbg, (void*) p->d_dbg_span})
             if (ptr) (void) hipFree(ptr);
         drop_graphs(p);
@@ -749,6 +751,8 @@ int vvhip_bind(vvhip_plan* p, const vvhip_buffers* b) {
         HIP_TRY(p, hipMemcpy(p->d_slot_vsite, hp.slot_vsite.data(), nslots * sizeof(int2), hipMemcpyHostToDevice));
         HIP_TRY(p, hipMalloc((void**) &p->d_vsite_params, hp.vsite_params.size() * sizeof(double)));
         HIP_TRY(p, hipMemcpy(p->d_vsite_params, hp.vsite_params.data(), hp.vsite_params.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(p, hipMalloc((void**) &p->d_vsite_atom, hp.vsite_atom.size() * sizeof(int32_t)));
+        HIP_TRY(p, hipMemcpy(p->d_vsite_atom, hp.vsite_atom.data(), hp.vsite_atom.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
     if (!hp.slot_big.empty()) {
         HIP_TRY(p, hipMalloc((void**) &p->d_slot_big, nslots * sizeof(int32_t)));

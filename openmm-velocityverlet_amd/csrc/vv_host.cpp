@@ -283,13 +283,15 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
         }
     }
 
-    // ---- virtual sites (vvhip_system_desc.virtual_sites): a site gets a lane in the wave of its parents and kernel B places it there
-    // (vv_device.inc: place_virtual_site).  vs_adj = the particles a particle is tied to that way.
-    std::vector<int32_t> vs_of(n, -1);
+    // ---- virtual sites (vvhip_system_desc.virtual_sites): kernel B places a site from the lane of one of its parents -- the first parent
+    // that places no other site -- so that sites cost no lanes and the wave layout is the one the System has without them (6 000 sites on the
+    // headline box as lanes of their own: 2 100 waves instead of 1 752, past what one block per CU holds, -12 % steps/s for the layout alone).
+    // A site that has an image particle or sits in a Drude pair, or whose parents all place another site already, gets a lane of its own.
+    // vs_host[k] = the particle whose lane places site k; vs_adj = the lane-bearing particles a particle must share a wave with for that.
+    std::vector<int32_t> vs_of(n, -1), vs_host;
     std::vector<std::vector<int32_t> > vs_adj;
     bool vsites = sys.num_virtual_sites > 0 && sys.virtual_sites && sys.virtual_site_params;
     if (vsites) {
-        vs_adj.assign(n, {});
         for (int k = 0; k < sys.num_virtual_sites; k++) {
             const int32_t* rec = sys.virtual_sites + 5 * (size_t) k;
             const int site = rec[0], kind = rec[1], np = kind == VVHIP_VSITE_AVERAGE2 ? 2 : 3;
@@ -298,21 +300,40 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
             if (sys.masses[site] != 0.0) throw Error(VVHIP_ERR_INVALID, "a virtual site must have mass 0");
             if (vs_of[site] >= 0) throw Error(VVHIP_ERR_INVALID, "a particle is described as a virtual site twice");
             vs_of[site] = k;
-            for (int q = 0; q < np; q++) {
-                check_index(rec[2 + q], "virtual site parent");
-                vs_adj[site].push_back(rec[2 + q]);
-                vs_adj[rec[2 + q]].push_back(site);
-            }
+            for (int q = 0; q < np; q++) check_index(rec[2 + q], "virtual site parent");
         }
-        for (int k = 0; k < sys.num_virtual_sites && vsites; k++)       // a site that hangs on another site: left to the caller's own kernel
-            for (int q : vs_adj[sys.virtual_sites[5 * (size_t) k]])
-                if (vs_of[q] >= 0) vsites = false;
+        for (int k = 0; k < sys.num_virtual_sites && vsites; k++) {     // a site that hangs on another site: left to the caller's own kernel
+            const int32_t* rec = sys.virtual_sites + 5 * (size_t) k;
+            for (int q = 0; q < (rec[1] == VVHIP_VSITE_AVERAGE2 ? 2 : 3); q++)
+                if (vs_of[rec[2 + q]] >= 0) vsites = false;
+        }
+    }
+    if (vsites) {
+        vs_adj.assign(n, {});
+        vs_host.assign((size_t) sys.num_virtual_sites, -1);
+        std::vector<char> hosting(n, 0);
+        auto has_lane_anyway = [&](int i) { return sys.masses[i] != 0.0 || in_pair[i] || image_of[i] >= 0; };
+        for (int k = 0; k < sys.num_virtual_sites; k++) {
+            const int32_t* rec = sys.virtual_sites + 5 * (size_t) k;
+            const int site = rec[0], np = rec[1] == VVHIP_VSITE_AVERAGE2 ? 2 : 3;
+            int host = -1;
+            if (image_of[site] < 0 && !in_pair[site])
+                for (int q = 0; q < np && host < 0; q++)
+                    if (!hosting[rec[2 + q]] && has_lane_anyway(rec[2 + q])) host = rec[2 + q];
+            if (host < 0) host = site; else hosting[host] = 1;
+            vs_host[(size_t) k] = host;
+            std::vector<int32_t> bearers;
+            if (host == site) bearers.push_back(site);
+            for (int q = 0; q < np; q++) if (has_lane_anyway(rec[2 + q])) bearers.push_back(rec[2 + q]);
+            for (size_t b = 1; b < bearers.size(); b++)
+                if (bearers[b] != bearers[0]) { vs_adj[bearers[0]].push_back(bearers[b]); vs_adj[bearers[b]].push_back(bearers[0]); }
+        }
     }
 
     // ---- which particles need a lane, and which must share a wave
     auto needs_lane = [&](int i) {
         if (sys.masses[i] != 0.0) return true;      // anything massive is integrated
-        if (vsites && vs_of[i] >= 0) return true;   // a virtual site: placed by its own lane
+        if (vsites && vs_of[i] >= 0 && vs_host[(size_t) vs_of[i]] == i) return true;   // a virtual site that is placed by a lane of its own
         if (in_pair[i]) return true;                // massless Drude parent (hard-wall branch K/middle.cu:151-173)
         if (image_of[i] >= 0) return true;          // massless image parent: only the mirror copy
         return false;
@@ -767,36 +788,39 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
             }
         }
     }
-    // Virtual sites: word of the site's lane = lanes of its parents | kind, record = row of vsite_params.  A site whose parents sit in
-    // another wave (another molecule, a molecule cut into chunks) or have no lane at all: nothing is placed in-kernel, the caller keeps
-    // running its own computeVirtualSites.
+    // Virtual sites: word of the placing lane = lanes of the site's parents | kind (| hosted: the lane belongs to a parent and stores the
+    // site by its particle index, vsite_atom), record = row of vsite_params / vsite_atom.  A site whose parents sit in another wave (another
+    // molecule, a molecule cut into chunks) or have no lane at all: nothing is placed in-kernel, the caller keeps running its own
+    // computeVirtualSites.
     info.num_virtual_sites = 0;
     if (vsites) {
-        std::vector<int32_t> table((size_t) nwaves * 128, 0);
+        std::vector<int32_t> table((size_t) nwaves * 128, 0), atoms;
         std::vector<double> prm;
         bool fits = true;
         int count = 0;
         for (int k = 0; k < sys.num_virtual_sites && fits; k++) {
             const int32_t* rec = sys.virtual_sites + 5 * (size_t) k;
-            const int site = rec[0], kind = rec[1], np = kind == VVHIP_VSITE_AVERAGE2 ? 2 : 3;
+            const int site = rec[0], kind = rec[1], np = kind == VVHIP_VSITE_AVERAGE2 ? 2 : 3, host = vs_host[(size_t) k];
             bool any = in_shard(site);
             for (int q = 0; q < np; q++) any = any || in_shard(rec[2 + q]);
             if (!any) continue;
-            const int w = in_shard(site) ? wave_of[site] : -1;
-            uint32_t word = vv::VS_WORD_VALID | ((uint32_t) kind << 18);
+            const int w = in_shard(site) && in_shard(host) ? wave_of[host] : -1;
+            uint32_t word = vv::VS_WORD_VALID | ((uint32_t) kind << 18) | (host != site ? vv::VS_WORD_HOSTED : 0u);
             for (int q = 0; q < 3 && w >= 0; q++) {
                 const int par = rec[2 + (q < np ? q : 0)];
                 if (!in_shard(par) || wave_of[par] != w) { fits = false; break; }
                 word |= (uint32_t) lane_of[par] << (6 * q);
             }
             if (w < 0 || !fits) { fits = false; break; }
-            table[((size_t) w * 64 + lane_of[site]) * 2] = (int32_t) word;
-            table[((size_t) w * 64 + lane_of[site]) * 2 + 1] = count++;
+            table[((size_t) w * 64 + lane_of[host]) * 2] = (int32_t) word;
+            table[((size_t) w * 64 + lane_of[host]) * 2 + 1] = count++;
+            atoms.push_back(site - sb);
             prm.insert(prm.end(), sys.virtual_site_params + 12 * (size_t) k, sys.virtual_site_params + 12 * (size_t) k + 12);
         }
         if (fits && count > 0) {
             hp.slot_vsite.swap(table);
             hp.vsite_params.swap(prm);
+            hp.vsite_atom.swap(atoms);
             info.num_virtual_sites = count;
         }
     }

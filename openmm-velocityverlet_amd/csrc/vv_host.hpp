@@ -68,8 +68,9 @@ struct HostPlan {
     std::vector<float> slot_shake_param;
     int gc_colors = 0;                         // general constraint clusters: colours of the wave-level Gauss-Seidel sweeps (0 = none); the constraint
                                                // list of a wave then lives in slot_shake / slot_shake_param, one constraint per lane (vv_layout.h: GC_WORD_*)
-    std::vector<int32_t> slot_vsite;           // [2*64*waves] (site word, record) of the lanes that are virtual sites (vv_layout.h: VS_WORD_*); empty = none in-kernel
+    std::vector<int32_t> slot_vsite;           // [2*64*waves] (site word, record) of the lanes that place a virtual site (vv_layout.h: VS_WORD_*); empty = none in-kernel
     std::vector<double> vsite_params;          // [12*records]
+    std::vector<int32_t> vsite_atom;           // [records] shard-relative particle index of the site (where a hosting lane stores it)
     std::vector<int32_t> slot_big;     // [64*waves] index of the lane's big molecule, or -1 (empty when there is none)
     int32_t num_big = 0;               // molecules with more than 64 thermostatted particles (COM temperature group only)
     double big_scale = 1.0;            // fixed-point scale of their sum(m v) accumulators

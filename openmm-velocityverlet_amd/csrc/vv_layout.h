@@ -39,8 +39,9 @@ constexpr uint32_t META_SHAKE = 1u << 30;      // member of an in-kernel constra
 // bits 0-5 lane of particle a, 6-11 lane of particle b, 12-15 colour (constraints of one colour share no particle), bit 31 valid;
 // slot_shake_param: d^2, 0.5 / (1/m_a + 1/m_b), 1/m_a, 1/m_b
 constexpr uint32_t GC_WORD_VALID = 1u << 31;
-// virtual-site word of a lane: lanes of parents 1, 2, 3 in bits 0-5, 6-11, 12-17 | kind (VS_*, = VVHIP_VSITE_*) << 18 | bit 31 valid
+// virtual-site word of the lane that places a site: lanes of parents 1, 2, 3 in bits 0-5, 6-11, 12-17 | kind (VS_*, = VVHIP_VSITE_*) << 18 | bit 31 valid
 constexpr uint32_t VS_WORD_VALID = 1u << 31;
+constexpr uint32_t VS_WORD_HOSTED = 1u << 30;      // the lane belongs to one of the site's parents: the site itself has no lane and is stored by index
 constexpr int VS_AVERAGE2 = 0, VS_AVERAGE3 = 1, VS_OUT_OF_PLANE = 2, VS_LOCAL_COORDS = 3;
 constexpr uint32_t META_BIG_FIRST = 1u << 29;  // leader of the FIRST chunk of such a molecule (adds M*V^2 once, clears bigacc)
 

@@ -1,7 +1,8 @@
 """-m gpu: virtual sites on the fused path (integration.computeVirtualSites() follows every position update of the
 reference, CudaVVKernels.cpp:214, 374; the round-3 review lists them with the constraint topologies as work the fused step left to
-OpenMM's own launches).  A site described to the plan (vvhip_system_desc.virtual_sites) gets a lane in the wave of its parents and
-kernel B places it after the hard wall and before the image mirror (stage bit B_VSITE, vv_device.inc: place_virtual_site).
+OpenMM's own launches).  A site described to the plan (vvhip_system_desc.virtual_sites) is tied to the wave of its parents and
+kernel B places it after the hard wall and before the image mirror (stage bit B_VSITE, vv_device.inc: place_virtual_site) -- from the
+lane of one of its parents as a rule, so that sites cost no lanes; from a lane of its own where no parent is free or the site has an image.
 Checked against the oracle's statement (oracle/vv_oracle.c: vvo_compute_virtual_sites) and, independently of it, against the documented
 definitions of OpenMM's four site classes evaluated in float64 on the final parent positions.  Parity with OpenMM's own kernel is
 unpinned (its source is not under /root/reference), as for every OpenMM service on this path."""
@@ -69,6 +70,20 @@ def test_water_with_one_site_per_molecule(kind, middle, prec):
         assert list(ctx.info.dof)[0] == list(osys.t["dof"])[0] == 3 * 180 - 3          # a massless site adds no degree of freedom (HOST:496-503)
         _check(spec, osys, ctx, prec, f"water/kind {kind}/{prec}/middle={middle}")
         assert tuple(ctx.generic_launches()[0]) == (0, 0)                # the stage set with B_VSITE is compiled at run time (csrc/vv_rtc.cpp)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("prec", O.PRECISIONS)
+@pytest.mark.parametrize("middle", [True, False])
+def test_more_sites_than_parents(middle, prec):
+    """Four sites on a three-site molecule: three are placed from their parents' lanes (a site costs no lane as a rule), the fourth has no
+    parent left that places nothing yet and gets a lane of its own -- both ways of placing in one wave."""
+    spec = systems.add_virtual_sites(systems.spce_water(60, seed=5), kinds=(1, 3, 0, 2))
+    osys, ctx = _run(spec, prec, middle, 10)
+    try:
+        assert ctx.info.num_virtual_sites == 240 and ctx.info.num_slots_used == 180 + 60
+        _check(spec, osys, ctx, prec, f"crowded/{prec}/middle={middle}")
     finally:
         ctx.close()
 

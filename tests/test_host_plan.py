@@ -332,20 +332,24 @@ def test_virtual_sites_share_a_wave_with_their_parents():
             wave_of = np.full(spec.num_atoms, -1)
             live = slots[:, 0] >= 0
             wave_of[slots[live, 0]] = np.nonzero(live)[0] // 64
-            for site, kind, parents, prm in spec.virtual_sites:
-                assert wave_of[site] >= 0 and all(wave_of[q] == wave_of[site] for q in parents)
+            for site, kind, parents, prm in spec.virtual_sites:           # placed from a parent's lane: the site itself has none
+                assert wave_of[site] == -1 and wave_of[parents[0]] >= 0 and all(wave_of[q] == wave_of[parents[0]] for q in parents)
             info0, _ = I.plan_layout(base, it)
-            assert list(info.dof) == list(info0.dof) and info.num_slots_used == info0.num_slots_used + 80
+            assert list(info.dof) == list(info0.dof) and info.num_slots_used == info0.num_slots_used and info.num_waves == info0.num_waves
+    # more sites than parents on a molecule: the ones no parent is free for get lanes of their own
+    crowded = systems.add_virtual_sites(systems.spce_water(8), kinds=(1, 1, 0, 2))
+    info, slots = I.plan_layout(crowded, I.VVIntegrator(300.0, 10, 1.0, 40, 0.001))
+    assert info.num_virtual_sites == 32 and info.num_slots_used == 24 + 8
     spec = systems.add_virtual_sites(systems.spce_water(8), kinds=(1,))
     it = I.VVIntegrator(300.0, 10, 1.0, 40, 0.001)
     # a site hanging on another site: left to the caller
     s2 = systems.add_virtual_sites(systems.spce_water(8), kinds=(1,))
     s2.virtual_sites[1] = (s2.virtual_sites[1][0], 0, (s2.virtual_sites[0][0], 4), (0.5, 0.5))
     assert I.plan_layout(s2, it)[0].num_virtual_sites == 0
-    # parents in another molecule while molecules are kept together for the molecular temperature group: not in one wave, left to the caller
+    # parents in two molecules far apart while molecules are kept together for the molecular temperature group: not in one wave, left to the caller
     s3 = systems.add_virtual_sites(systems.drude_il(cells=(1, 1, 1), pairs_per_cell=40, seed=2), kinds=(0,), interleaved=False)
-    far = s3.virtual_sites[-1]
-    s3.virtual_sites[0] = (s3.virtual_sites[0][0], 0, far[2], far[3])
+    near, far = s3.virtual_sites[0], s3.virtual_sites[-1]
+    s3.virtual_sites[0] = (near[0], 0, (near[2][0], far[2][1]), far[3])
     itc = I.VVIntegrator(333.0, 10, 1.0, 40, 0.001)
     itc.setUseCOMTempGroup(True)
     assert I.plan_layout(s3, itc)[0].num_virtual_sites == 0

@@ -22,3 +22,6 @@ for hang in (False, True):
     t0 = time.time(); spec = S.constrain_all_bonds(S.make_config("C3"), hangles=hang); tb = time.time() - t0
     r = rate(spec)
     print("C3 %s (%6d constraints, general solver; fused %d; built in %.0f s): %8.0f steps/s, worst constraint %.1e, generic launches %s" % ("HAngles " if hang else "AllBonds", r[2], r[3], tb, r[0], r[4], tuple(r[5])))
+spec = S.add_virtual_sites(S.make_config("C3"), kinds=(3,), interleaved=False)
+r = rate(spec)
+print("C3 + a lone pair per molecule (%d virtual sites placed by kernel B): %8.0f steps/s, generic launches %s" % (len(spec.virtual_sites), r[0], tuple(r[5])))
