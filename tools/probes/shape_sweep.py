@@ -1,0 +1,25 @@
+"""Launch shapes (k blocks per CU x t tile waves per block) just above the size that one block per CU holds (1 792 tile waves): steps/s of the
+graph-replayed step for every shape pick_launch_shape considers, next to its own choice.  C3 tiled further along z."""
+import importlib, os, sys, time
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+pkg = importlib.import_module("openmm-velocityverlet_amd")
+I, S = pkg.integrator, pkg.systems
+os.environ["VVHIP_PERIODIC"] = "0"          # the best-fit layout at every size: the shape is the only variable
+def rate(spec, tune, n=3000):
+    it = I.VVIntegrator(333.0, 10, 1.0, 40, 0.001); it.setMaxDrudeDistance(0.02)
+    ctx = I.Context(spec, it, precision="mixed", force_provider="tether", tune=tune)
+    ctx.run_graph(300, 100); ctx.synchronize()
+    t0 = time.perf_counter(); ctx.run_graph(n, 100); ctx.synchronize(); t = time.perf_counter() - t0
+    w = ctx.info.num_waves; ctx.close()
+    return n / t, w
+for cells in ((2, 2, 4), (2, 2, 5), (2, 3, 3), (2, 3, 4)):
+    spec = S.bulk_Im21(cells=cells)
+    r0, w = rate(spec, {})
+    out = []
+    for k in (1, 2, 3, 4):
+        for t in (2, 3, 4, 5, 6, 7):
+            if k * (t + 1) > 12: continue
+            r, _ = rate(spec, {"block_threads": 64 * t, "grid_cap_a": 256 * k, "grid_cap_b": 256 * k})
+            out.append((r, k, t))
+    out.sort(reverse=True)
+    print("%d particles, %d waves: own choice %.0f steps/s; best shapes: %s" % (spec.num_atoms, w, r0, ", ".join("k=%d t=%d %.0f" % (k, t, r) for r, k, t in out[:5])))
