@@ -82,7 +82,8 @@ typedef struct {
     /* Optional.  System::getVirtualSite for every massless site (OpenMM's TwoParticleAverageSite, ThreeParticleAverageSite,
      * OutOfPlaneSite, LocalCoordinatesSite with three parents -- what examples/ommhelper/oplspsffile.py:982-991 creates for lone pairs).
      * Kernel B then places the sites right after its position update, where the reference calls integration.computeVirtualSites()
-     * (HOST:214, 374), and vvhip_plan_info.num_virtual_sites says so; the caller need not launch OpenMM's kernel.
+     * (HOST:214, 374), and vvhip_plan_info.num_virtual_sites says so; the caller need not launch OpenMM's kernel.  A site is placed from
+     * the lane of one of its parents and stored by index (x, y, z; the charge in posq.w stays), so sites cost no work items.
      *   virtual_sites       [5*n]  site particle, kind (VVHIP_VSITE_*), parents 1, 2, 3 (parent 3 = -1 for a two-particle average)
      *   virtual_site_params [12*n] AVERAGE2: w1 w2; AVERAGE3: w1 w2 w3; OUT_OF_PLANE: w12 w13 wCross;
      *                              LOCAL_COORDS: origin weights[3], x weights[3], y weights[3], local position[3] */
