@@ -426,6 +426,48 @@ def add_virtual_sites(spec: SystemSpec, kinds=(1,), interleaved: bool = True) ->
     return out
 
 
+def add_random_virtual_sites(spec: SystemSpec, rng) -> SystemSpec:
+    """Random virtual sites behind the last particle (tools/probes/fuzz_sites.py, tests/test_gpu_virtual_sites.py): on ~70 % of the molecules one to
+    four sites of random kind and weights, hanging on any massive particles of the molecule (Drude particles included), several per parent."""
+    n = spec.num_atoms
+    mol = np.asarray(spec.mol_id)
+    masses = np.asarray(spec.masses, float)
+    extra = []
+    for m in np.unique(mol):
+        if rng.random() < 0.3:
+            continue
+        members = np.nonzero((mol == m) & (masses != 0))[0]
+        for _ in range(int(rng.integers(1, 5))):
+            kind = int(rng.integers(0, 4))
+            npar = 2 if kind == 0 else 3
+            if len(members) < npar:
+                continue
+            par = [int(i) for i in rng.choice(members, npar, replace=False)]
+            if kind == 0:
+                w = rng.uniform(-0.5, 1.5); prm = (w, 1 - w)
+            elif kind == 1:
+                a, b = rng.uniform(-0.3, 0.9, 2); prm = (a, b, 1 - a - b)
+            elif kind == 2:
+                prm = tuple(rng.uniform(-0.5, 0.5, 2)) + (float(rng.uniform(-3, 3)),)
+            else:
+                ow = rng.uniform(-0.2, 0.8, 2); xw = rng.uniform(-1, 1, 2); yw = rng.uniform(-1, 1, 2)
+                prm = (ow[0], ow[1], 1 - ow.sum(), xw[0], xw[1], -xw.sum(), yw[0], yw[1], -yw.sum()) + tuple(rng.uniform(-0.05, 0.05, 3))
+            extra.append((int(m), kind, par, tuple(float(x) for x in prm)))
+    k = len(extra)
+    pos = np.concatenate([spec.positions, np.zeros((k, 3))])
+    vs = []
+    for j, (m, kind, par, prm) in enumerate(extra):
+        pos[n + j] = virtual_site_position(kind, prm, *[np.asarray(spec.positions[i], float) for i in par])
+        vs.append((n + j, kind, tuple(par), prm))
+    out = SystemSpec(name=spec.name + "+random sites", masses=np.concatenate([masses, np.zeros(k)]), charges=np.concatenate([spec.charges, np.full(k, -0.2)]),
+                       positions=pos, velocities=np.concatenate([spec.velocities, np.zeros((k, 3))]), box=spec.box,
+                       mol_id=np.concatenate([mol, np.array([e[0] for e in extra], dtype=mol.dtype)]).astype(np.int32), drude_pairs=spec.drude_pairs,
+                       constraints=spec.constraints, constraint_distances=spec.constraint_distances, has_cm_motion_remover=spec.has_cm_motion_remover,
+                       particles_ld=list(spec.particles_ld), image_pairs=list(spec.image_pairs), particles_electrolyte=list(spec.particles_electrolyte),
+                       virtual_sites=vs)
+    return out
+
+
 def have_reference_topologies() -> bool:
     return all(os.path.exists(os.path.join(_TOPO_DIR, f)) for f in ("topo_bulk_Im21.npz", "topo_edl_Im21.npz"))
 

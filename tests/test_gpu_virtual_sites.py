@@ -209,3 +209,43 @@ def test_full_size_c3_with_a_lone_pair_on_every_molecule():
     yd = np.cross(zd, xd)
     want = o + xd * w[9] + yd * w[10] + zd * w[11]
     assert np.abs(x[sites] - want).max() < 1e-12 * np.abs(x).max()
+
+
+@pytest.mark.parametrize("seed", range(3000, 3024))
+def test_random_sites_on_random_small_systems(seed):
+    """tools/probes/fuzz_sites.py in small: any massive particles of a molecule as parents, several sites per molecule and per parent (placed
+    from a parent's lane or from a lane of their own), random kinds and weights, both schemes, with / without the molecular temperature
+    group, on plain, hydrogen-constrained, rigid and all-bonds-constrained molecules and on the electrode slab."""
+    rng = np.random.default_rng(seed)
+    flavour, mirror = seed % 6, 0.0
+    if flavour == 0: base = systems.spce_water(int(rng.integers(5, 60)), seed=seed)
+    elif flavour == 1: base = systems.rigid_water(systems.spce_water(int(rng.integers(5, 60)), seed=seed))
+    elif flavour == 2: base = systems.drude_il(cells=(1, 1, 1), pairs_per_cell=int(rng.integers(3, 30)), seed=seed)
+    elif flavour == 3: base = systems.constrain_hydrogens(systems.drude_il(cells=(1, 1, 1), pairs_per_cell=int(rng.integers(3, 30)), seed=seed))
+    elif flavour == 4: base = systems.constrain_all_bonds(systems.bulk_Im21(cells=(1, 1, 1), pairs_per_cell=int(rng.integers(3, 16))))
+    else:
+        base = systems.edl_slab(num_ion_pairs=int(rng.integers(3, 14)), num_electrode=int(rng.integers(4, 30)), seed=seed)
+        mirror = float(base.box[2]) / 2
+    spec = systems.add_random_virtual_sites(base, rng)
+    middle = bool(rng.integers(0, 2))
+    com = [None, True, False][int(rng.integers(0, 3))]
+    maxd = 0.02 if len(spec.drude_pairs) else 0.0
+    p = O.Params(temperature=300.0, drude_temperature=1.0, max_drude_distance=maxd, use_middle_scheme=middle, mirror_location=mirror)
+    if com is not None:
+        p.use_com_temp_group, p.auto_set_com_temp_group = com, False
+    rnd = np.random.default_rng(seed + 1).standard_normal((4096, 4)).astype(np.float32)
+    osys = O.OracleSystem(spec, p, "mixed", random=rnd, force_mode=1)
+    it = I.VVIntegrator(300.0, 10.0, 1.0, 40.0, 0.001)
+    it.setMaxDrudeDistance(maxd)
+    it.setUseMiddleScheme(middle)
+    it.setMirrorLocation(mirror)
+    if com is not None:
+        it.setUseCOMTempGroup(com)
+    ctx = I.Context(spec, it, precision="mixed", force_provider="tether", random=rnd)
+    try:
+        assert ctx.info.num_virtual_sites == len(spec.virtual_sites) > 0
+        osys.step(6)
+        it.step(6)
+        _check(spec, osys, ctx, "mixed", f"random sites seed {seed} flavour {flavour}", tol=1e-5 if flavour == 4 else 1e-10)
+    finally:
+        ctx.close()
