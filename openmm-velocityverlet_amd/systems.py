@@ -302,6 +302,62 @@ def constrain_all_bonds(spec: SystemSpec, cutoff: float = 0.165, hangles: bool =
     return spec
 
 
+def add_random_constraints(spec: SystemSpec, rng, max_degree: int = 6) -> SystemSpec:
+    """Random distance constraints inside the molecules of `spec` (tools/probes/fuzz_constraints.py, tests/test_gpu_general_constraints.py):
+    a random spanning forest over each molecule's real (massive, non-Drude) particles plus a few ring-closing edges -- chains, stars, rings,
+    triangles, at most as many constraints as particles so that none is redundant -- with the present distances as lengths (the start
+    satisfies the position constraints) and the bond-parallel relative velocities removed."""
+    is_drude = np.zeros(spec.num_atoms, dtype=bool)
+    pairs = np.asarray(spec.drude_pairs).reshape(-1, 2)
+    if len(pairs):
+        is_drude[pairs[:, 0]] = True
+    real = (~is_drude) & (spec.masses > 0)
+    cons = []
+    for m in np.unique(spec.mol_id):
+        idx = np.nonzero((spec.mol_id == m) & real)[0]
+        if idx.size < 2 or rng.random() < 0.2:
+            continue
+        deg = {int(i): 0 for i in idx}
+        perm = [int(i) for i in rng.permutation(idx)]
+        edges = set()
+        for k in range(1, len(perm)):                    # a random tree, partly cut into a forest
+            if rng.random() < 0.25:
+                continue
+            cand = [q for q in perm[:k] if deg[q] < max_degree]
+            if not cand:
+                continue
+            q = cand[int(rng.integers(0, len(cand)))]
+            edges.add((min(perm[k], q), max(perm[k], q))); deg[perm[k]] += 1; deg[q] += 1
+        for _ in range(int(rng.integers(0, 3))):         # ring closures
+            a, b = (int(i) for i in rng.choice(idx, 2, replace=False))
+            e = (min(a, b), max(a, b))
+            if e not in edges and deg[a] < max_degree and deg[b] < max_degree and len(edges) < idx.size:
+                edges.add(e); deg[a] += 1; deg[b] += 1
+        cons += sorted(edges)
+    cons = np.array(cons, dtype=np.int32).reshape(-1, 2)
+    out = SystemSpec(name=spec.name + "+random constraints", masses=spec.masses, charges=spec.charges, positions=spec.positions.copy(),
+                     velocities=spec.velocities.copy(), box=spec.box, mol_id=spec.mol_id, drude_pairs=spec.drude_pairs, constraints=cons,
+                     constraint_distances=np.linalg.norm(spec.positions[cons[:, 0]] - spec.positions[cons[:, 1]], axis=1),
+                     has_cm_motion_remover=spec.has_cm_motion_remover, particles_ld=list(spec.particles_ld), image_pairs=list(spec.image_pairs),
+                     particles_electrolyte=list(spec.particles_electrolyte), virtual_sites=list(spec.virtual_sites))
+    v, mss = out.velocities, out.masses
+    ca, cb = cons[:, 0], cons[:, 1]
+    r = out.positions[ca] - out.positions[cb]
+    rr = (r * r).sum(1)
+    ima, imb = 1.0 / mss[ca], 1.0 / mss[cb]
+    for _ in range(500):                                  # Gauss-Seidel passes, one constraint after the other (small systems only; converges for any graph)
+        worst = 0.0
+        for k in range(len(cons)):
+            a, b = ca[k], cb[k]
+            rv = float(((v[a] - v[b]) * r[k]).sum() / rr[k])
+            v[a] -= r[k] * (rv * ima[k] / (ima[k] + imb[k]))
+            v[b] += r[k] * (rv * imb[k] / (ima[k] + imb[k]))
+            worst = max(worst, abs(rv))
+        if worst < 1e-12:
+            break
+    return out
+
+
 def rigid_water(spec: SystemSpec, d_oh: float = 0.1, d_hh: float = 0.1633) -> SystemSpec:
     """Rigid three-site water as OpenMM's rigidWater=True asks for it: O-H, O-H and H-H constrained in every (O, H, H) molecule
     of `spec`; the hydrogens are put on the rigid geometry and the molecule's velocity is made rigid-body compatible (the

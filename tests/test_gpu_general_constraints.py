@@ -128,3 +128,51 @@ def test_general_constraints_with_the_cos_perturbation_and_without_com_group():
         _check(spec, osys, ctx, "mixed", True, "allbonds, no COM group")
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("seed", range(4000, 4024))
+def test_random_constraint_graphs(seed):
+    """Random forests and rings of constraints inside the molecules (systems.add_random_constraints: chains, stars up to degree 6, rings,
+    triangles, lengths of every size the molecule offers), on water, on the polarisable liquid and on the electrode slab, both schemes, with
+    and without the molecular temperature group: the in-wave sweeps against the oracle's, and the constraints themselves."""
+    rng = np.random.default_rng(seed)
+    flavour, mirror = seed % 3, 0.0
+    if flavour == 0: base = systems.spce_water(int(rng.integers(5, 60)), seed=seed)
+    elif flavour == 1: base = systems.drude_il(cells=(1, 1, 1), pairs_per_cell=int(rng.integers(3, 24)), seed=seed)
+    else:
+        base = systems.edl_slab(num_ion_pairs=int(rng.integers(3, 14)), num_electrode=int(rng.integers(4, 30)), seed=seed)
+        mirror = float(base.box[2]) / 2
+    spec = systems.add_random_constraints(base, rng)
+    middle = bool(rng.integers(0, 2))
+    com = [None, True, False][int(rng.integers(0, 3))]
+    maxd = 0.02 if len(spec.drude_pairs) else 0.0
+    p = O.Params(temperature=300.0, drude_temperature=1.0, max_drude_distance=maxd, use_middle_scheme=middle, mirror_location=mirror)
+    if com is not None:
+        p.use_com_temp_group, p.auto_set_com_temp_group = com, False
+    rnd = np.random.default_rng(seed + 1).standard_normal((4096, 4)).astype(np.float32)
+    osys = O.OracleSystem(spec, p, "mixed", random=rnd, force_mode=1)
+    it = I.VVIntegrator(300.0, 10.0, 1.0, 40.0, 0.001)
+    it.setMaxDrudeDistance(maxd)
+    it.setUseMiddleScheme(middle)
+    it.setMirrorLocation(mirror)
+    if com is not None:
+        it.setUseCOMTempGroup(com)
+    ctx = I.Context(spec, it, precision="mixed", force_provider="tether", random=rnd)
+    try:
+        info = ctx.info
+        assert info.constraints_fused == 1
+        if osys.general is not None:
+            assert info.num_general_constraints == len(spec.constraints) > 0
+        osys.step(8)
+        it.step(8)
+        x_o, x_g = osys.positions(), ctx.getPositions()
+        v_o, v_g = osys.velm[:, :3].astype(np.float64), ctx.getVelocities()
+        massive = np.asarray(spec.masses) != 0
+        ex = np.abs(x_g - x_o).max() / np.abs(x_o).max()
+        ev = np.abs(v_g[massive] - v_o[massive]).max() / np.abs(v_o[massive]).max()
+        assert ex < 1e-5 and ev < 1e-4, (seed, ex, ev)
+        c, d = np.asarray(spec.constraints), np.asarray(spec.constraint_distances)
+        r = x_g[c[:, 0]] - x_g[c[:, 1]]
+        assert np.abs((r * r).sum(1) - d * d).max() < 2.5e-5 * (d * d).max(), seed
+    finally:
+        ctx.close()
