@@ -1,7 +1,7 @@
 """Random virtual sites on random small systems, GPU against the oracle and against the sites' definitions: any massive particles of a molecule as
 parents (Drude particles included), several sites per molecule and per parent (so that some are placed from a parent's lane and some from a lane of
 their own), all four kinds with random weights, both schemes, with and without the molecular temperature group, on plain / hydrogen-constrained /
-rigid / all-bonds-constrained molecules and on the electrode slab (Langevin wall, images)."""
+rigid / all-bonds-constrained / randomly constrained molecules and on the electrode slab (Langevin wall, images)."""
 import importlib, os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np
@@ -18,13 +18,14 @@ worst = 0.0
 hosted = own = 0
 for seed in range(3000, 3000 + int(sys.argv[1]) if len(sys.argv) > 1 else 3060):
     rng = np.random.default_rng(seed)
-    flavour = seed % 6
+    flavour = seed % 7
     mirror = 0.0
     if flavour == 0: base = S.spce_water(int(rng.integers(5, 60)), seed=seed)
     elif flavour == 1: base = S.rigid_water(S.spce_water(int(rng.integers(5, 60)), seed=seed))
     elif flavour == 2: base = S.drude_il(cells=(1, 1, 1), pairs_per_cell=int(rng.integers(3, 30)), seed=seed)
     elif flavour == 3: base = S.constrain_hydrogens(S.drude_il(cells=(1, 1, 1), pairs_per_cell=int(rng.integers(3, 30)), seed=seed))
     elif flavour == 4: base = S.constrain_all_bonds(S.bulk_Im21(cells=(1, 1, 1), pairs_per_cell=int(rng.integers(3, 16))))
+    elif flavour == 6: base = S.add_random_constraints(S.drude_il(cells=(1, 1, 1), pairs_per_cell=int(rng.integers(3, 20)), seed=seed), rng)
     else:
         base = S.edl_slab(num_ion_pairs=int(rng.integers(3, 14)), num_electrode=int(rng.integers(4, 30)), seed=seed); mirror = float(base.box[2]) / 2
     spec = with_random_sites(base, rng)
@@ -49,7 +50,7 @@ for seed in range(3000, 3000 + int(sys.argv[1]) if len(sys.argv) > 1 else 3060):
     ctx.close()
     if nsites != len(spec.virtual_sites):
         print("NOT PLACED IN-KERNEL", seed, flavour, nsites, len(spec.virtual_sites)); bad += 1; continue
-    tol = 1e-5 if flavour == 4 else 1e-10
+    tol = 1e-5 if flavour in (4, 6) else 1e-10
     ex = np.abs(x_g - x_o).max() / np.abs(x_o).max()
     dev = 0.0
     for site, kind, par, prm in spec.virtual_sites:
