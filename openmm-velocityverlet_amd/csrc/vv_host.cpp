@@ -801,10 +801,12 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
         for (int k = 0; k < sys.num_virtual_sites && fits; k++) {
             const int32_t* rec = sys.virtual_sites + 5 * (size_t) k;
             const int site = rec[0], kind = rec[1], np = kind == VVHIP_VSITE_AVERAGE2 ? 2 : 3, host = vs_host[(size_t) k];
-            bool any = in_shard(site);
-            for (int q = 0; q < np; q++) any = any || in_shard(rec[2 + q]);
+            bool any = in_shard(site), all = in_shard(site);
+            for (int q = 0; q < np; q++) { any = any || in_shard(rec[2 + q]); all = all && in_shard(rec[2 + q]); }
             if (!any) continue;
-            const int w = in_shard(site) && in_shard(host) ? wave_of[host] : -1;
+            // (a shard that holds a site but not its parents, or the reverse, could place it nowhere and no other rank would: refuse it)
+            if (!all) throw Error(VVHIP_ERR_INVALID, "particle shard cuts a virtual site from its parents");
+            const int w = wave_of[host];
             uint32_t word = vv::VS_WORD_VALID | ((uint32_t) kind << 18) | (host != site ? vv::VS_WORD_HOSTED : 0u);
             for (int q = 0; q < 3 && w >= 0; q++) {
                 const int par = rec[2 + (q < np ? q : 0)];

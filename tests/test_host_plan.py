@@ -359,3 +359,13 @@ def test_virtual_sites_share_a_wave_with_their_parents():
         s4.virtual_sites.append(bad)
         with pytest.raises(H.VVHipError, match=text):
             I.plan_layout(s4, it)
+
+
+def test_a_shard_must_not_cut_a_virtual_site_from_its_parents():
+    spec = systems.add_virtual_sites(systems.spce_water(8), kinds=(1,), interleaved=False)      # sites behind the last molecule
+    it = I.VVIntegrator(300.0, 10, 1.0, 40, 0.001)
+    with pytest.raises(H.VVHipError, match="virtual site"):
+        I.plan_layout(spec, it, shard=(0, 12))              # molecules 0..3 without their sites (which sit at 24..27)
+    inter = systems.add_virtual_sites(systems.spce_water(8), kinds=(1,))                         # O H H M: sites travel with their molecule
+    info, _ = I.plan_layout(inter, it, shard=(0, 16))
+    assert info.num_virtual_sites == 4
