@@ -239,6 +239,13 @@ class Context:
         self.plan, self.info, self._keep = create_plan(system, integrator, precision, self.shard, self._particles_ld,
                                                        self._image_pairs, self._electrolyte)
         plan = self.plan
+        if getattr(system, "virtual_sites", None) and self.info.num_virtual_sites == 0:
+            # (in the OpenMM plugin the adapters then keep calling OpenMM's computeVirtualSites; this stand-alone host has no such kernel)
+            H.lib.vvhip_plan_destroy(plan)
+            self.plan = None
+            raise H.VVHipError(H.ERR_UNSUPPORTED,
+                               "the System's virtual sites cannot be placed by kernel B (a site on a site, or parents outside the site's wave) "
+                               "and this host has no computeVirtualSites of its own")
         for key, value in {**DEFAULT_TUNE, **(tune or {})}.items():
             H.check(H.lib.vvhip_debug_tune(plan, key.encode(), int(value)), plan)
 

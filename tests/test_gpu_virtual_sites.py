@@ -249,3 +249,13 @@ def test_random_sites_on_random_small_systems(seed):
         _check(spec, osys, ctx, "mixed", f"random sites seed {seed} flavour {flavour}", tol=1e-5 if flavour == 4 else 1e-10)
     finally:
         ctx.close()
+
+
+def test_sites_that_cannot_be_placed_are_refused_by_this_host():
+    """A site hanging on another site is left to the caller's own kernel (vvhip_plan_info.num_virtual_sites == 0); the OpenMM adapters
+    then keep calling computeVirtualSites, the stand-alone Python host has nothing of the kind and says so instead of leaving sites stale."""
+    spec = systems.add_virtual_sites(systems.spce_water(8), kinds=(1,))
+    spec.virtual_sites[1] = (spec.virtual_sites[1][0], 0, (spec.virtual_sites[0][0], 4), (0.5, 0.5))
+    it = I.VVIntegrator(300.0, 10.0, 1.0, 40.0, 0.001)
+    with pytest.raises(H.VVHipError, match="virtual sites cannot be placed"):
+        I.Context(spec, it, precision="mixed", force_provider="tether")
