@@ -146,6 +146,7 @@ typedef struct {
                                                     System has none, or if a component of the constraint graph does not fit one wave */
     int32_t num_virtual_sites;                   /* virtual sites placed by kernel B itself (0: none given, or one of them cannot share a wave with
                                                     its parents -- then the caller runs its own computeVirtualSites after every step, as before) */
+    double general_relaxation;                   /* relaxation factor of the general clusters' sweeps (1.2; 1.4 when constraints close triangles); 0 if none */
 } vvhip_plan_info;
 
 /* Nose-Hoover chain state + last reduction results (HOST: CudaVVKernels.h:206-215).  The reference
@@ -391,7 +392,8 @@ int vvhip_debug_launch(vvhip_plan* plan, int kernel, uint32_t flags, uint32_t ra
 /* One of the plan's tuning choices by name (call between vvhip_plan_create and vvhip_bind; later calls drop the captured graphs):
  * "grid_cap_a" / "grid_cap_b" (most blocks per launch), "block_threads", "split_chain_waves" (the chain becomes its own launch from n waves
  * on), "periodic_kernels" / "periodic_a" (0: load slot words although the layout is arithmetic), "rekick", "no_moments", "mass_tab_a" /
- * "mass_tab_b", "acc_store".  Tests use it to run large-system code paths at small sizes. */
+ * "periodic_b", "mass_tab_b", "acc_store", "gc_omega_permille" (relaxation factor of the general clusters' sweeps x 1000, for rate scans).  Tests
+ * use it to run large-system code paths at small sizes. */
 int vvhip_debug_tune(vvhip_plan* plan, const char* key, int value);
 int vvhip_debug_read_accumulators(vvhip_plan* plan, double out[4], int zero_after);  /* blocks */
 int vvhip_debug_set_scales(vvhip_plan* plan, const double scales[4]);                /* vscale[3], bias V; blocks */

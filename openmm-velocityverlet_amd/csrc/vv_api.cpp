@@ -350,6 +350,7 @@ vv::KArgs make_args(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
     a.dbg_parity = p->dbg_seq >= 0 ? p->dbg_seq++ % 6 : p->dbg_parity;
     a.padded = p->hp.padded_num_atoms;
     a.gc_colors = p->hp.gc_colors;
+    a.gc_omega = p->hp.gc_omega;
     {   // posq / posqCorrection as a buffer resource (kernel A's member-only position fetch): 32-bit sizes and offsets
         const unsigned long long bytes = (unsigned long long) (p->hp.shard_end - p->hp.shard_begin) * (p->hp.precision == VVHIP_DOUBLE ? 32ull : 16ull);
         a.pos_bytes = bytes < 0xFFFFFFE0ull ? (uint32_t) bytes : 0u;
@@ -641,6 +642,7 @@ int vvhip_debug_tune(vvhip_plan* p, const char* key, int value) {
     if (k == "periodic_kernels") p->periodic_kernels = value != 0;          // 0: keep the arithmetic layout's slot order but load the slot words
     else if (k == "periodic_a") p->periodic_a = value != 0;                 // kernel A alone
     else if (k == "periodic_b") p->periodic_b = value != 0;                 // kernel B alone
+    else if (k == "gc_omega_permille") p->hp.gc_omega = value / 1000.0;     // relaxation factor of the general clusters' sweeps (rate scans)
     else if (k == "rekick") p->rekick = value != 0;                         // 0: kernel A stores the kicked velocities, kernel B does not repeat the kick
     else if (k == "no_moments") p->no_moments = value != 0;                 // 1: cos perturbation as three launches (bias, sums, scale)
     else if (k == "mass_tab_a") p->mass_tab_a = value != 0;

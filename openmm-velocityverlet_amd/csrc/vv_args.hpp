@@ -206,6 +206,7 @@ struct KArgs {
     uint32_t pos_bytes;             // size of the posq (= posqCorrection) array in bytes if below 4 GB, else 0: kernel A fetches the positions of
     int32_t gc_colors;              // constraint-cluster members through a buffer resource (load_wanted), other lanes fetch nothing; gc_colors:
                                     // colours of the general clusters' sweeps (A_GCONS / B_GCONS)
+    double gc_omega;                // A_GCONS / B_GCONS: relaxation factor of the sweeps (vv_layout.h: GC_OMEGA_*)
     const int2* slot_vsite;         // B_VSITE: [64*waves] (site word, vv_layout.h: VS_WORD_*; record number) of the site the lane places
     const double* vsite_params;     // B_VSITE: [12*records] weights / local position of each site (vvhip_system_desc.virtual_site_params)
     const int32_t* vsite_atom;      // B_VSITE: [records] particle index of the site: a lane that places a site for its parent stores it there

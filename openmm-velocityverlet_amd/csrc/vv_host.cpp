@@ -827,8 +827,17 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
         }
     }
     info.num_general_constraints = 0;
+    info.general_relaxation = 0.0;
     hp.gc_colors = 0;
     if (general) {
+        // relaxation factor of the sweeps (vv_layout.h: GC_OMEGA_*): by whether any three constraints close a triangle
+        bool triangles = false;
+        for (int k = 0; k < sys.num_constraints && !triangles; k++) {
+            const int a = sys.constraints[2 * k], b = sys.constraints[2 * k + 1];
+            for (int q : gc_adj[a])
+                if (q != b && std::find(gc_adj[b].begin(), gc_adj[b].end(), q) != gc_adj[b].end()) { triangles = true; break; }
+        }
+        hp.gc_omega = triangles ? vv::GC_OMEGA_TRIANGLES : vv::GC_OMEGA_PLAIN;
         // Per wave: its constraints, coloured greedily in System order (two constraints that share a particle get different colours: a
         // colour's constraints are relaxed side by side, one per lane), sorted by colour and handed to lanes 0, 1, ... of the wave.
         // Word: bit 31 valid | colour << 12 | lane of b << 6 | lane of a; parameters: d^2, 0.5 / (1/m_a + 1/m_b), 1/m_a, 1/m_b (float, as
@@ -862,6 +871,7 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
             info.constraints_fused = 0;
             hp.gc_colors = 0;
         } else {
+            info.general_relaxation = hp.gc_omega;
             hp.slot_shake.assign((size_t) nwaves * 64, 0);
             hp.slot_shake_param.assign((size_t) nwaves * 64 * 4, 0.0f);
             for (int w = 0; w < nwaves; w++) {

@@ -66,6 +66,7 @@ struct HostPlan {
     //   y = partner-partner distance (masses are taken from velm.w)
     std::vector<int32_t> slot_shake;
     std::vector<float> slot_shake_param;
+    double gc_omega = 1.0;                     // ... and their relaxation factor (vv_layout.h: GC_OMEGA_*)
     int gc_colors = 0;                         // general constraint clusters: colours of the wave-level Gauss-Seidel sweeps (0 = none); the constraint
                                                // list of a wave then lives in slot_shake / slot_shake_param, one constraint per lane (vv_layout.h: GC_WORD_*)
     std::vector<int32_t> slot_vsite;           // [2*64*waves] (site word, record) of the lanes that place a virtual site (vv_layout.h: VS_WORD_*); empty = none in-kernel

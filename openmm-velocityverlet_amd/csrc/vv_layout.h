@@ -39,6 +39,12 @@ constexpr uint32_t META_SHAKE = 1u << 30;      // member of an in-kernel constra
 // bits 0-5 lane of particle a, 6-11 lane of particle b, 12-15 colour (constraints of one colour share no particle), bit 31 valid;
 // slot_shake_param: d^2, 0.5 / (1/m_a + 1/m_b), 1/m_a, 1/m_b
 constexpr uint32_t GC_WORD_VALID = 1u << 31;
+// Relaxation factor of the general clusters' sweeps (successive over-relaxation of the Gauss-Seidel SHAKE update): every update is taken
+// GC_OMEGA times.  Chains and rings converge fastest slightly above 1; clusters that contain TRIANGLES of constraints (HAngles: H-X-H as an
+// H-H distance) are stiff and want more.  Full C3 box, steps/s against the factor (tools/probes/gc_omega_scan.py, round 4, every run
+// ends with all constraints within tolerance): AllBonds 25.0 / 29.2 / 32.9 / 32.0 / 30.2 k at 1.0 / 1.1 / 1.2 / 1.25 / 1.3;
+// HAngles 8.9 / 14.5 / 17.3 / 17.7 / 16.4 / 13.4 k at 1.0 / 1.3 / 1.4 / 1.45 / 1.5 / 1.6.
+constexpr double GC_OMEGA_PLAIN = 1.2, GC_OMEGA_TRIANGLES = 1.4;
 // virtual-site word of the lane that places a site: lanes of parents 1, 2, 3 in bits 0-5, 6-11, 12-17 | kind (VS_*, = VVHIP_VSITE_*) << 18 | bit 31 valid
 constexpr uint32_t VS_WORD_VALID = 1u << 31;
 constexpr uint32_t VS_WORD_HOSTED = 1u << 30;      // the lane belongs to one of the site's parents: the site itself has no lane and is stored by index

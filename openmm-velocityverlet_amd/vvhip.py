@@ -78,7 +78,7 @@ class PlanInfo(C.Structure):
                 ("inv_mass_total", C.c_double), ("num_waves", C.c_int32), ("num_slots_used", C.c_int32),
                 ("max_cluster", C.c_int32), ("num_shake_clusters", C.c_int32), ("constraints_fused", C.c_int32),
                 ("num_settle_clusters", C.c_int32), ("periodic_layout", C.c_int32), ("num_general_constraints", C.c_int32),
-                ("num_virtual_sites", C.c_int32)]
+                ("num_virtual_sites", C.c_int32), ("general_relaxation", C.c_double)]
 
 
 class NHState(C.Structure):

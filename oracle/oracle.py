@@ -278,6 +278,23 @@ def build_general_constraints(spec):
     return atoms, params, (int(colours.max()) + 1 if rows else 0), colours
 
 
+GC_OMEGA_PLAIN, GC_OMEGA_TRIANGLES = 1.2, 1.4       # csrc/vv_layout.h: GC_OMEGA_*
+
+
+def general_relaxation(spec) -> float:
+    """Relaxation factor of the general clusters' sweeps, by the product's rule (csrc/vv_host.cpp): 1.4 when three constraints close a
+    triangle anywhere in the System (HAngles), else 1.2."""
+    adj = {}
+    cons = [(int(a), int(b)) for a, b in np.asarray(spec.constraints).reshape(-1, 2)]
+    for a, b in cons:
+        adj.setdefault(a, set()).add(b)
+        adj.setdefault(b, set()).add(a)
+    for a, b in cons:
+        if (adj[a] & adj[b]) - {a, b}:
+            return GC_OMEGA_TRIANGLES
+    return GC_OMEGA_PLAIN
+
+
 def build_shake(spec):
     """(atoms, params) of the SHAKE clusters only; None without constraint distances."""
     c = build_constraint_clusters(spec)
@@ -348,7 +365,7 @@ class _System(C.Structure):
         ("num_shake", C.c_int), ("shake_atoms", C.c_void_p), ("shake_params", C.c_void_p), ("constraint_tolerance", C.c_double),
         ("num_settle", C.c_int), ("settle_atoms", C.c_void_p), ("settle_params", C.c_void_p),
         ("shake_mode", C.c_int),
-        ("num_general", C.c_int), ("general_atoms", C.c_void_p), ("general_params", C.c_void_p),
+        ("num_general", C.c_int), ("general_atoms", C.c_void_p), ("general_params", C.c_void_p), ("general_omega", C.c_double),
         ("num_vsites", C.c_int), ("vsite_atoms", C.c_void_p), ("vsite_params", C.c_void_p),
     ]
 
@@ -465,6 +482,7 @@ class OracleSystem:
             self.clusters = None
             self.general = build_general_constraints(spec)
             s.num_general, s.general_atoms, s.general_params = len(self.general[0]), _p(self.general[0]), _p(self.general[1])
+            s.general_omega = self.general_omega = general_relaxation(spec)
         vsites = list(getattr(spec, "virtual_sites", None) or [])
         if vsites:                               # (site, kind, parents, parameters) as SystemSpec.virtual_sites
             self.vsite_atoms = np.full((len(vsites), 5), -1, dtype=np.int32)

@@ -704,7 +704,7 @@ void vvo_shake_velocities(int nclusters, const int* atoms, const float* params, 
  * OpenMM's SHAKE update (as vvo_shake_positions / vvo_shake_velocities), a constraint inside its tolerance is left alone, and sweeps
  * repeat until nothing moved (<= 150).  The product sweeps wave by wave until THAT wave's constraints rest: the same values, because a
  * resting constraint is not touched by further sweeps. */
-void vvo_general_positions(int n, const int* atoms, const float* params, mixed tol, const real4* posq, const real4* posq_corr, mixed4* pos_delta) {
+void vvo_general_positions(int n, const int* atoms, const float* params, mixed tol, mixed omega, const real4* posq, const real4* posq_corr, mixed4* pos_delta) {
     for (int iteration = 0; iteration < 150; iteration++) {
         int moved = 0;
         for (int k = 0; k < n; k++) {
@@ -720,7 +720,7 @@ void vvo_general_positions(int n, const int* atoms, const float* params, mixed t
             const mixed rrpr = r0 * rp0 + r1 * rp1 + r2 * rp2;
             const mixed num = ld - 2.0f * rrpr - rpsq;
             if (fabs(num) >= d2tol) {
-                const mixed acor = num * avgMass / (rrpr + rsq);
+                const mixed acor = omega * (num * avgMass / (rrpr + rsq));      /* omega: successive over-relaxation of the sweep, see vvo_system */
                 const mixed e0 = r0 * acor, e1 = r1 * acor, e2 = r2 * acor;
                 pos_delta[a].x = pos_delta[a].x + e0 * ima; pos_delta[a].y = pos_delta[a].y + e1 * ima; pos_delta[a].z = pos_delta[a].z + e2 * ima;
                 pos_delta[b].x = pos_delta[b].x - e0 * imb; pos_delta[b].y = pos_delta[b].y - e1 * imb; pos_delta[b].z = pos_delta[b].z - e2 * imb;
@@ -730,7 +730,7 @@ void vvo_general_positions(int n, const int* atoms, const float* params, mixed t
         if (!moved) break;
     }
 }
-void vvo_general_velocities(int n, const int* atoms, const float* params, mixed tol, const real4* posq, const real4* posq_corr, mixed4* velm) {
+void vvo_general_velocities(int n, const int* atoms, const float* params, mixed tol, mixed omega, const real4* posq, const real4* posq_corr, mixed4* velm) {
     for (int iteration = 0; iteration < 150; iteration++) {
         int moved = 0;
         for (int k = 0; k < n; k++) {
@@ -744,7 +744,8 @@ void vvo_general_velocities(int n, const int* atoms, const float* params, mixed 
             const mixed rrpr = (velm[a].x - velm[b].x) * r0 + (velm[a].y - velm[b].y) * r1 + (velm[a].z - velm[b].z) * r2;
             const mixed delta = -2.0f * avgMass * rrpr * rinv;
             if (fabs(delta) > tol) {
-                const mixed e0 = r0 * delta, e1 = r1 * delta, e2 = r2 * delta;
+                const mixed od = omega * delta;
+                const mixed e0 = r0 * od, e1 = r1 * od, e2 = r2 * od;
                 velm[a].x = velm[a].x + e0 * ima; velm[a].y = velm[a].y + e1 * ima; velm[a].z = velm[a].z + e2 * ima;
                 velm[b].x = velm[b].x - e0 * imb; velm[b].y = velm[b].y - e1 * imb; velm[b].z = velm[b].z - e2 * imb;
                 moved = 1;
@@ -1200,14 +1201,14 @@ static void step_middle(vvo_system* s) {           /* API:232-270; constraints/v
     vvo_integrate_middle_vel(n, s->padded_num_atoms, s->velm, s->force, s->force_extra, (mixed) s->dt);  /* HOST:144-148 */
     if (s->num_shake > 0)   /* integration.applyVelocityConstraints, HOST:151 */
         shake_v(s);
-    if (s->num_general > 0) vvo_general_velocities(s->num_general, s->general_atoms, s->general_params, (mixed) s->constraint_tolerance, s->posq, s->posq_corr, s->velm);
+    if (s->num_general > 0) vvo_general_velocities(s->num_general, s->general_atoms, s->general_params, (mixed) s->constraint_tolerance, (mixed) s->general_omega, s->posq, s->posq_corr, s->velm);
     if (s->num_settle > 0) vvo_settle_velocities(s->num_settle, s->settle_atoms, s->posq, s->posq_corr, s->velm);
     vvo_integrate_middle_pos1(n, s->velm, s->pos_delta, s->old_delta, (mixed) s->dt);                     /* HOST:154-158 */
     nh_half(s);
     vvo_integrate_middle_pos2(n, s->velm, s->pos_delta, s->old_delta, (mixed) s->dt);                     /* HOST:169-173 */
     if (s->num_shake > 0)   /* integration.applyConstraints, HOST:176 */
         shake_x(s);
-    if (s->num_general > 0) vvo_general_positions(s->num_general, s->general_atoms, s->general_params, (mixed) s->constraint_tolerance, s->posq, s->posq_corr, s->pos_delta);
+    if (s->num_general > 0) vvo_general_positions(s->num_general, s->general_atoms, s->general_params, (mixed) s->constraint_tolerance, (mixed) s->general_omega, s->posq, s->posq_corr, s->pos_delta);
     if (s->num_settle > 0) vvo_settle_positions(s->num_settle, s->settle_atoms, s->settle_params, s->posq, s->posq_corr, s->velm, s->pos_delta);
     vvo_integrate_middle_pos3(n, s->posq, s->posq_corr, s->pos_delta, s->old_delta, s->velm, (mixed) s->dt); /* HOST:179-185 */
     hard_wall(s);
@@ -1227,7 +1228,7 @@ static void step_vv(vvo_system* s) {               /* API:272-338 */
                                 (mixed) s->dt, (mixed) fscale, 1);                                        /* HOST:341-348 */
     if (s->num_shake > 0)   /* HOST:351 */
         shake_x(s);
-    if (s->num_general > 0) vvo_general_positions(s->num_general, s->general_atoms, s->general_params, (mixed) s->constraint_tolerance, s->posq, s->posq_corr, s->pos_delta);
+    if (s->num_general > 0) vvo_general_positions(s->num_general, s->general_atoms, s->general_params, (mixed) s->constraint_tolerance, (mixed) s->general_omega, s->posq, s->posq_corr, s->pos_delta);
     if (s->num_settle > 0) vvo_settle_positions(s->num_settle, s->settle_atoms, s->settle_params, s->posq, s->posq_corr, s->velm, s->pos_delta);
     vvo_vv_integrate_positions(n, s->posq, s->posq_corr, s->pos_delta, s->velm, (mixed) s->dt);           /* HOST:355-360 */
     hard_wall(s);
@@ -1241,7 +1242,7 @@ static void step_vv(vvo_system* s) {               /* API:272-338 */
                                 (mixed) s->dt, (mixed) fscale, 0);                                        /* HOST:417-424 */
     if (s->num_shake > 0)   /* HOST:427 */
         shake_v(s);
-    if (s->num_general > 0) vvo_general_velocities(s->num_general, s->general_atoms, s->general_params, (mixed) s->constraint_tolerance, s->posq, s->posq_corr, s->velm);
+    if (s->num_general > 0) vvo_general_velocities(s->num_general, s->general_atoms, s->general_params, (mixed) s->constraint_tolerance, (mixed) s->general_omega, s->posq, s->posq_corr, s->velm);
     if (s->num_settle > 0) vvo_settle_velocities(s->num_settle, s->settle_atoms, s->posq, s->posq_corr, s->velm);
     nh_half(s);
 }

@@ -124,6 +124,8 @@ typedef struct {
      * constraints of one colour never share a particle */
     int num_general; const int* general_atoms;     /* [2*n]: a, b */
     const float* general_params;                   /* [4*n]: d^2, 0.5/(1/m_a + 1/m_b), 1/m_a, 1/m_b */
+    double general_omega;                          /* relaxation factor of those sweeps: every update is taken omega times (1.2; 1.4 when the
+                                                      constraints close triangles: csrc/vv_layout.h GC_OMEGA_*, the product's rule) */
     /* virtual sites, see vvo_compute_virtual_sites */
     int num_vsites; const int* vsite_atoms;        /* [5*n]: site, kind (0 average of two, 1 average of three, 2 out of plane, 3 local
                                                       coordinates), parents 1, 2, 3 */
