@@ -273,6 +273,11 @@ void fill_scales(vvhip_plan* p) {
 // kernel ends with its slowest CU.  C3, 1 752 tiles: 876 blocks of 2 tiles (3.4 per CU) 69.4 k steps/s; 251 blocks of 7 tiles (one
 // per CU) 74.3 k.  So: k blocks per CU, T tile waves per block (+1 thermostat wave in kernel B, whose 140 VGPRs allow 12 waves
 // per CU), chosen to maximise the fill of the last pass; fewer blocks per CU and larger blocks win ties.
+// Waves per CU a shape may ask for: kernel B's stage sets without the cos perturbation and without hydrogen-type / general constraint
+// clusters are built with 128 VGPRs (four waves per SIMD, 16 per CU), the others with 144-162 (three per SIMD, 12 per CU); kernel A fits
+// either.  Round 4 (tools/probes/shape_sweep.py, profiles/r04v_shape_sweep.txt): with 12 everywhere, 2 628 / 2 920 / 3 504 tile waves
+// (166-222 k particles) ran in two passes, 66.8 / 65.7 / 64.0 k steps/s; two blocks of 6-7 tile waves per CU hold them in one, 73.3 / 70.9 /
+// 67.0 k.
 void pick_launch_shape(vvhip_plan* p) {
     // cus = what the bound device reports (256 on an MI355X in SPX mode; 32 per XCD partition in CPX mode); before vvhip_bind the
     // plan assumes a whole MI355X.
@@ -280,11 +285,13 @@ void pick_launch_shape(vvhip_plan* p) {
     if (nw <= cus) { p->block_threads = 64; p->grid_cap_a = p->grid_cap_b = cus; return; }
     // bandwidth-bound regime (the chain runs as its own launch there, kernel B fits 6 waves per SIMD): tuned at 0.9 M / 8.9 M particles
     if (nw >= p->split_chain_waves) { p->block_threads = 256; p->grid_cap_a = 8 * cus; p->grid_cap_b = 4 * cus; return; }
+    const int max_waves = (p->hp.params.cos_acceleration != 0 || p->hp.info.num_shake_clusters > 0 || p->hp.info.num_general_constraints > 0 ||
+                           p->hp.info.num_virtual_sites > 0) ? 12 : 16;
     double best = -1;
     int bk = 1, bt = 1;
     for (int k = 1; k <= 4; k++)
         for (int t = 1; t <= 7; t++) {
-            if (k * (t + 1) > 12) continue;
+            if (k * (t + 1) > max_waves) continue;
             const long cap = (long) cus * k * t;
             const long passes = (nw + cap - 1) / cap;
             // fill of the last pass; once several passes are needed, shapes with fewer than 8 tile waves per CU in flight are
@@ -292,6 +299,10 @@ void pick_launch_shape(vvhip_plan* p) {
             const double fill = (double) nw / (double) (cap * passes) * (passes > 1 ? std::min(1.0, k * t / 8.0) : 1.0);
             if (fill > best + 1e-9 || (fill > best - 1e-9 && (k < bk || (k == bk && t > bt)))) { best = fill; bk = k; bt = t; }
         }
+    // Past what two blocks of seven tile waves per CU hold in one pass (16-wave stage sets): that very shape, strided.  The fill rule above
+    // prefers shapes whose last pass is fuller, and measured they lose: 5 256 / 7 008 / 10 512 tile waves 51.0 / 39.0 / 27.0 k steps/s against
+    // 46.8 / 36.5-37.6 / 26.2-26.6 k for the runners-up (profiles/r04v_shape_sweep.txt).
+    if (max_waves == 16 && nw > (long) cus * 14) { bk = 2; bt = 7; }
     p->block_threads = 64 * bt;
     p->grid_cap_a = p->grid_cap_b = cus * bk;
 }
@@ -833,6 +844,7 @@ int vvhip_set_params(vvhip_plan* p, const vvhip_params* q) {
     }
     if (cos_switch) p->fextra_virtual = false;
     p->hp.params = n;
+    if (cos_switch && !p->launch_shape_forced) pick_launch_shape(p);      // (the cos stage sets of kernel B need more registers: another limit)
     drop_graphs(p);
     if (cos_switch && p->bound) {        // the accumulator copies are laid out by the rows in use: start the new layout from zeros
         HIP_TRY(p, hipStreamSynchronize(p->stream));

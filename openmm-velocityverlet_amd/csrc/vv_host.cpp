@@ -457,13 +457,16 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
     int per_R = 0, per_clusters_per_cell = 0;
     std::vector<int> reg_cluster_start;                              // first cluster (cell-local) of region r
     auto try_periodic = [&]() -> bool {
-        // Measured on MI355X (same box, alternating runs): with 8.9 M particles kernel B 305 -> 277 us; whole steps per second with 222 k / 333 k /
-        // 555 k particles +3 / +5 / +7 %; with 111 k particles the block's copy of the pattern rows and its barrier cost more than the slot
-        // load did (kernel B 6.0 -> 6.4 us) and best-fit packing needs 13 % fewer waves.  So: from 0.2 M lanes, unless VVHIP_PERIODIC=1 / 0
-        // says always / never.
+        // Measured on MI355X (same box, alternating runs): with 8.9 M particles kernel B 305 -> 277 us.  At 111 k particles the block's copy of
+        // the pattern rows and its barrier cost more than the slot load did (kernel B 6.0 -> 6.4 us) and best-fit packing needs 13 % fewer
+        // waves.  In between (round 4, tools/probes/layout_crossover.py, each layout with its own best launch shape, steps/s best-fit |
+        // arithmetic): 222 k particles 66.0 | 57.7 k, 444 k 38.5 | 35.5 k, 666 k 26.8 | 25.0 k, 888 k 18.75 | 18.91 k, 1.33 M 13.6 | 14.1 k,
+        // 2.7 M 7.1 | 7.5 k, 4.4 M 4.12 | 4.63 k: the layouts cross where the chain becomes its own launch.  (Round 2 had put the switch at
+        // 0.2 M lanes, +3 .. +7 % then: two blocks of 6-7 tile waves per CU, vv_api.cpp: pick_launch_shape, took the best-fit layout past it.)
+        // So: from 0.85 M lanes, unless VVHIP_PERIODIC=1 / 0 says always / never.
         size_t lanes = 0;
         for (const Cluster& c : clusters) lanes += c.members.size();
-        bool want = lanes >= 200000;
+        bool want = lanes >= 850000;
         if (const char* e = std::getenv("VVHIP_PERIODIC")) want = std::atoi(e) != 0;
         if (!want) return false;
         if (hp.has_ld || hp.has_images || hp.num_big > 0 || clusters.empty() || general || vsites) return false;

@@ -167,7 +167,7 @@ constexpr uint32_t SF_B_VV1_EDL_SHAKE = SF_B_VV1_EDL | B_SHAKE;
 constexpr uint32_t SF_B_COS_SCALE_MOM = B_CHAIN | B_SCALE | B_UNBIAS | B_CZ_LOAD | B_KE_MOM;   // cos perturbation: second half's scaling
 constexpr uint32_t SF_B_COS_VV1_HW_MOM = SF_B_COS_SCALE_MOM | B_VV_KICK | B_HARDWALL;          // ... first half
 constexpr uint32_t SF_B_COS_VV1_HW_MOM_SHAKE = SF_B_COS_VV1_HW_MOM | B_SHAKE;
-constexpr uint32_t SF_B_MIDDLE_SETTLE_P = SF_B_MIDDLE_SETTLE | B_PERIODIC;                      // rigid water between 0.2 M and 0.8 M particles
+constexpr uint32_t SF_B_MIDDLE_SETTLE_P = SF_B_MIDDLE_SETTLE | B_PERIODIC;                      // rigid water with the arithmetic layout and the chain in the kernel (forced layouts: automatic ones start where the chain is its own launch)
 
 // Which specialised kernels are compiled with the static mass tables; a launch whose flags disagree with the build falls through to
 // the generic kernel.  Measured on MI355X (gpurun_out/r02c-e): kernel B gains at every size (two IEEE fp64 divisions per pair lane

@@ -171,6 +171,7 @@ def mailbox_periodic(rank, world):
     layout: two processes whose device-filling grids of polling thermostat waves cannot be resident together starve each other, with
     loaded slot words just the same.  vvhip_mailbox_connect now notices ranks that share its device and gives each its share of the CUs."""
     I = pkg.integrator
+    os.environ["VVHIP_PERIODIC"] = "1"          # (a shard of 222 000 particles: the arithmetic layout is automatic only from 0.85 M lanes)
     spec = S.make_config("C3", 4.0)
     bounds = D.shard_bounds(spec, world)
 
