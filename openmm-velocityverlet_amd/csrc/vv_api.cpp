@@ -299,10 +299,11 @@ void pick_launch_shape(vvhip_plan* p) {
             const double fill = (double) nw / (double) (cap * passes) * (passes > 1 ? std::min(1.0, k * t / 8.0) : 1.0);
             if (fill > best + 1e-9 || (fill > best - 1e-9 && (k < bk || (k == bk && t > bt)))) { best = fill; bk = k; bt = t; }
         }
-    // Past what two blocks of seven tile waves per CU hold in one pass (16-wave stage sets): that very shape, strided.  The fill rule above
-    // prefers shapes whose last pass is fuller, and measured they lose: 5 256 / 7 008 / 10 512 tile waves 51.0 / 39.0 / 27.0 k steps/s against
-    // 46.8 / 36.5-37.6 / 26.2-26.6 k for the runners-up (profiles/r04v_shape_sweep.txt).
-    if (max_waves == 16 && nw > (long) cus * 14) { bk = 2; bt = 7; }
+    // Past what two blocks of seven tile waves per CU hold in one pass: that very shape, strided.  The fill rule above prefers shapes whose
+    // last pass is fuller, and measured they lose: 5 256 / 7 008 / 10 512 tile waves 51.0 / 39.0 / 27.0 k steps/s against 46.8 / 36.5-37.6 /
+    // 26.2-26.6 k for the runners-up; with the 12-wave stage sets as well (7 008 tile waves with HBonds 28.3 k against the rule's 24.7 k, with
+    // the cos perturbation 31.6 against 29.3 k; 5 256: 36.7 / 35.8 k and 41.0 / 40.4 k) (profiles/r04zd_mid_sizes.txt).
+    if (nw > (long) cus * 14) { bk = 2; bt = 7; }
     p->block_threads = 64 * bt;
     p->grid_cap_a = p->grid_cap_b = cus * bk;
 }

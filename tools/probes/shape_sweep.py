@@ -8,13 +8,14 @@ if os.environ.get("SWEEP_LAYOUT", "bestfit") == "bestfit":
     os.environ["VVHIP_PERIODIC"] = "0"      # the best-fit layout at every size: the shape is the only variable (SWEEP_LAYOUT=auto: the plan's own choice)
 def rate(spec, tune, n=3000):
     it = I.VVIntegrator(333.0, 10, 1.0, 40, 0.001); it.setMaxDrudeDistance(0.02)
+    if os.environ.get("SWEEP_COS", "0") == "1": it.setCosAcceleration(0.02)
     ctx = I.Context(spec, it, precision="mixed", force_provider="tether", tune=tune)
     ctx.run_graph(300, 100); ctx.synchronize()
     t0 = time.perf_counter(); ctx.run_graph(n, 100); ctx.synchronize(); t = time.perf_counter() - t0
     w = ctx.info.num_waves; ctx.close()
     return n / t, w
 for cells in [tuple(int(x) for x in c.split("x")) for c in os.environ.get("SWEEP_CELLS", "2x2x4,2x2x5,2x3x3,2x3x4").split(",")]:
-    spec = S.bulk_Im21(cells=cells)
+    spec = S.bulk_Im21(cells=cells, hbonds=os.environ.get("SWEEP_HBONDS", "0") == "1")
     r0, w = rate(spec, {})
     out = []
     for k in (1, 2, 3, 4):
