@@ -201,7 +201,7 @@ int vvhip_set_nh_state(vvhip_plan* plan, const vvhip_nh_state* in);
  *           moments of the still biased velocities, so that no launch is needed between bias and 2KE
  *   pass B: NH chain (device) + velocity scaling + bias remove/restore + both half drifts (+ position
  *           constraints) + hard wall + image mirror
- * Only molecules larger than one 64-lane wave, chains longer than 4 and systems beyond ~0.8 M particles take more
+ * Only molecules larger than one 64-lane wave, chains longer than 4 and systems beyond ~2.6 M particles take more
  * launches (per-molecule COM accumulation, stand-alone chain kernel, the three-launch cos sequence).
  * Classic scheme: vvhip_step_vv_first() = API:295-310, vvhip_step_vv_second() = API:316-336.
  * `random_index` = integration.prepareRandomNumbers(...) for this step (HOST:863), ignored unless
@@ -369,7 +369,7 @@ int vvhip_timing_read(vvhip_plan* plan, double* ms_pass_a, double* ms_pass_b, do
 /* ---------------------------------------------------------------- environment (read once, at vvhip_plan_create)
  * Behaviour switches, all optional.  (The tuning switches of rounds 1-3 -- launch shape, mass tables, velocity round trip, cos moments --
  * are closed experiments, TUNING_LOG.md; what tests still need of them is the per-plan hook vvhip_debug_tune below.)
- *   VVHIP_PERIODIC=1|0        arithmetic work-item layout (vv_host.hpp: PeriodicLayout) always / never; default: from 0.85 M lanes, when the
+ *   VVHIP_PERIODIC=1|0        arithmetic work-item layout (vv_host.hpp: PeriodicLayout) always / never; default: from 1.1 M lanes, when the
  *                             system is runs of identical molecules (vvhip_plan_info.periodic_layout tells)
  *   VVHIP_PERIODIC_DEBUG=1    the decomposition into regions and why the layout was (not) enabled, on stderr
  *   VVHIP_SHAKE_MODE=0        hydrogen-type constraint clusters by Gauss-Seidel sweeps of the central lane (OpenMM's iteration; generic

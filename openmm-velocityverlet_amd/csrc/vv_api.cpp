@@ -84,7 +84,9 @@ struct vvhip_plan {
     double acc_scale[vv::NUM_ACC], acc_inv_scale[vv::NUM_ACC];
     int block_threads = 256;       // 64 x tile waves per block, the same for the force provider, kernel A and kernel B
     int grid_cap_a = 2048, grid_cap_b = 1024;   // most blocks per launch (multiples of the CU count): see pick_launch_shape
-    int split_chain_waves = 12288;   // systems with at least this many waves (~0.8 M particles; measured +3 % at 0.9 M, +5 % at 8.9 M) run the chain as its own launch (VVHIP_SPLIT_CHAIN_WAVES)
+    int split_chain_waves = 44000;   // systems with at least this many waves (~2.6 M particles) run the chain as its own launch.  Round 4, with two blocks of seven tile
+                                     // waves per CU below it (profiles/r04zd_mid_sizes.txt; chain in kernel B | own launch, steps/s): 888 k particles 20.8 | 18.9 k,
+                                     // 1.33 M 14.5 | 14.0 k, 1.78 M 11.4 | 11.1 k, 2.66 M 7.38 | 7.37 k, 4.4 M 4.14 | 4.20 k, 8.9 M 2.16 | 2.21 k (round 2 had it at 12 288)
     bool trace = false;            // roctx range + one stderr line per launch group (the reference's setDebugEnabled, VVIntegrator.h:417-419)
     bool fextra_dirty = false;     // forceExtra holds something since the last reset (split entry points)
     // The reference's kick kernels add forceExtra ALWAYS (K/middle.cu:11-21, K/velocityVerlet.cu:20-22) and the array is only reset in
@@ -283,7 +285,7 @@ void pick_launch_shape(vvhip_plan* p) {
     // plan assumes a whole MI355X.
     const int nw = p->hp.info.num_waves, cus = p->num_cus;
     if (nw <= cus) { p->block_threads = 64; p->grid_cap_a = p->grid_cap_b = cus; return; }
-    // bandwidth-bound regime (the chain runs as its own launch there, kernel B fits 6 waves per SIMD): tuned at 0.9 M / 8.9 M particles
+    // bandwidth-bound regime (the chain runs as its own launch there, kernel B fits 6 waves per SIMD): tuned at 8.9 M particles
     if (nw >= p->split_chain_waves) { p->block_threads = 256; p->grid_cap_a = 8 * cus; p->grid_cap_b = 4 * cus; return; }
     const int max_waves = (p->hp.params.cos_acceleration != 0 || p->hp.info.num_shake_clusters > 0 || p->hp.info.num_general_constraints > 0 ||
                            p->hp.info.num_virtual_sites > 0) ? 12 : 16;

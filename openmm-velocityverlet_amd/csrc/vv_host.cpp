@@ -461,12 +461,13 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
         // the pattern rows and its barrier cost more than the slot load did (kernel B 6.0 -> 6.4 us) and best-fit packing needs 13 % fewer
         // waves.  In between (round 4, tools/probes/layout_crossover.py, each layout with its own best launch shape, steps/s best-fit |
         // arithmetic): 222 k particles 66.0 | 57.7 k, 444 k 38.5 | 35.5 k, 666 k 26.8 | 25.0 k, 888 k 18.75 | 18.91 k, 1.33 M 13.6 | 14.1 k,
-        // 2.7 M 7.1 | 7.5 k, 4.4 M 4.12 | 4.63 k: the layouts cross where the chain becomes its own launch.  (Round 2 had put the switch at
-        // 0.2 M lanes, +3 .. +7 % then: two blocks of 6-7 tile waves per CU, vv_api.cpp: pick_launch_shape, took the best-fit layout past it.)
-        // So: from 0.85 M lanes, unless VVHIP_PERIODIC=1 / 0 says always / never.
+        // 2.7 M 7.1 | 7.5 k, 4.4 M 4.12 | 4.63 k.  (Round 2 had put the switch at 0.2 M lanes, +3 .. +7 % then: two blocks of 6-7 tile waves
+        // per CU, vv_api.cpp: pick_launch_shape, took the best-fit layout past it.)  With the chain kept inside kernel B up to 2.6 M particles
+        // (vv_api.cpp: split_chain_waves) the two meet a little higher: 888 k particles 20.8 | 20.6 k, 1.33 M 14.3 | 14.5 k, 1.78 M 11.2 | 11.4 k.
+        // So: from 1.1 M lanes, unless VVHIP_PERIODIC=1 / 0 says always / never.
         size_t lanes = 0;
         for (const Cluster& c : clusters) lanes += c.members.size();
-        bool want = lanes >= 850000;
+        bool want = lanes >= 1100000;
         if (const char* e = std::getenv("VVHIP_PERIODIC")) want = std::atoi(e) != 0;
         if (!want) return false;
         if (hp.has_ld || hp.has_images || hp.num_big > 0 || clusters.empty() || general || vsites) return false;

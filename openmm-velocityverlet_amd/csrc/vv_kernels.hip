@@ -146,6 +146,8 @@ constexpr uint32_t SF_B_COS_HW_NC_P = SF_B_COS_HW_NC | B_PERIODIC;
 // the classic scheme's two thermostat applications in large boxes: scale + half kick + positions (+ hard wall), and scale alone
 constexpr uint32_t SF_B_VV1_HW_NC = B_SCALE | B_VV_KICK | B_HARDWALL;
 constexpr uint32_t SF_B_VV1_HW_NC_P = SF_B_VV1_HW_NC | B_PERIODIC;
+constexpr uint32_t SF_B_VV1_HW_P = SF_B_VV1_HW | B_PERIODIC;                   // classic scheme, arithmetic layout, chain in the kernel (1.1 - 2.6 M particles)
+constexpr uint32_t SF_B_SCALE_P = SF_B_SCALE | B_PERIODIC;
 constexpr uint32_t SF_B_SCALE_NC = B_SCALE;
 constexpr uint32_t SF_B_SCALE_NC_P = SF_B_SCALE_NC | B_PERIODIC;
 
@@ -296,6 +298,8 @@ hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_c
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_HW_MB_K_P)
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_MB_K_P)
     VV_TRY_SF(vv_kernel_b, SF_B_COS_HW_MOM_MB_K_P)
+    VV_TRY_SF(vv_kernel_b, SF_B_VV1_HW_P)
+    VV_TRY_SF(vv_kernel_b, SF_B_SCALE_P)
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_HW_K)
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_K)
     VV_TRY_SF(vv_kernel_b, SF_B_MIDDLE_HW_NC_K)

@@ -1,5 +1,5 @@
 """-m gpu: the arithmetic ("periodic") work-item layout -- particle indices computed from the wave index, role words from the pattern wave
-(vv_host.hpp: PeriodicLayout) -- forced on small systems (it is automatic from ~0.85 M particles) and compared with the oracle like
+(vv_host.hpp: PeriodicLayout) -- forced on small systems (it is automatic from ~1.1 M particles) and compared with the oracle like
 every other path, in kernel B alone (the default where the layout is on) and in both kernels; plus bit-equality of the trajectory with
 the explicit-slot kernels on the same layout, which is what the change must preserve."""
 import importlib
@@ -119,13 +119,13 @@ def test_periodic_kernels_in_the_large_system_launch_shape(cos, monkeypatch):
 
 
 def test_periodic_layout_switches_itself_on_and_matches_the_oracle_at_that_size(monkeypatch):
-    """C3 tiled eight times (888 000 particles): the first tiling at which the arithmetic layout is chosen without being asked for (from 0.85 M lanes;
+    """C3 tiled ten times (1 110 000 particles): the first tiling at which the arithmetic layout is chosen without being asked for (from 1.1 M lanes;
     C3 tiled twice, 222 000 particles, must not get it)."""
     monkeypatch.delenv("VVHIP_PERIODIC", raising=False)
     it2 = I.VVIntegrator(333.0, 10.0, 1.0, 40.0, 0.001)
     it2.setMaxDrudeDistance(0.02)
     assert I.plan_layout(systems.make_config("C3", scale=2), it2)[0].periodic_layout == 0
-    spec = systems.make_config("C3", scale=8)
+    spec = systems.make_config("C3", scale=10)
     flag, v, x, c, ke = _run(spec, "mixed", 6, {}, monkeypatch, maxd=0.02)
     assert flag == 1
     osys = O.OracleSystem(spec, O.Params(temperature=333.0, drude_temperature=1.0, max_drude_distance=0.02), "mixed", force_mode=1, num_threads=8)

@@ -77,11 +77,11 @@ def test_run_time_kernel_equals_compiled_kernel(cfg, hbonds, middle, prec):
 
 @pytest.mark.parametrize("what", ["large", "sharded", "large rigid water"])
 def test_run_time_kernel_equals_compiled_kernel_large_and_sharded(what):
-    """The arithmetic work-item layout with the stand-alone chain launch (C3x8, 0.9 M particles) and the mailbox stage sets of a sharded plan
+    """The arithmetic work-item layout with the stand-alone chain launch (C3x30, 3.3 M particles) and the mailbox stage sets of a sharded plan
     (one rank of two, its own handle as the only peer): run-time kernels against the compiled ones, bit for bit."""
     D = pkg.distributed
     cfg = "C2" if "water" in what else "C3"
-    spec = S.make_config("C2", 30.0, hbonds=True) if cfg == "C2" else S.make_config("C3", 8.0 if what == "large" else 0.08)
+    spec = S.make_config("C2", 120.0, hbonds=True) if cfg == "C2" else S.make_config("C3", 30.0 if what == "large" else 0.08)
     res = []
     for mode in (0, 2):
         I.Context.rtc_mode(mode)

@@ -82,13 +82,17 @@ def test_sharded_plans_run_compiled_stage_sets(cfg, hbonds, no_run_time_kernels)
         ctx.close()
 
 
-@pytest.mark.parametrize("cfg,scale,hbonds,middle", [("C3", 8.0, False, True), ("C3", 8.0, True, True), ("C3", 8.0, False, False), ("C2", 30.0, False, True), ("C2", 30.0, True, True)])
+@pytest.mark.parametrize("cfg,scale,hbonds,middle", [("C3", 8.0, False, True), ("C3", 10.0, False, True), ("C3", 10.0, True, True), ("C3", 10.0, False, False),
+                                                     ("C3", 30.0, False, True), ("C3", 30.0, True, True), ("C3", 30.0, False, False),
+                                                     ("C2", 120.0, False, True), ("C2", 120.0, True, True)])
 def test_large_boxes_run_compiled_stage_sets(cfg, scale, hbonds, middle, no_run_time_kernels):
-    """0.9 M particles (C3x8) / 0.3 M (water x30): arithmetic layout, capped grids; C3x8 also the stand-alone chain launch."""
+    """0.9 M particles (C3x8): best-fit layout, strided grid; 1.1 M (C3x10) / 1.2 M (water x120): arithmetic layout, chain in kernel B;
+    3.3 M (C3x30): arithmetic layout, capped grids, the stand-alone chain launch."""
     spec = S.make_config(cfg, scale, hbonds=hbonds)
     it = _integrator(cfg, middle)
     ctx = I.Context(spec, it, precision="mixed", force_provider="tether")
     try:
+        assert ctx.info.periodic_layout == (0 if scale < 10 else 1)
         it.step(2)
         ctx.synchronize()
         counts, sets = ctx.generic_launches()

@@ -198,7 +198,7 @@ def test_rigid_water_is_recognised_as_settle_clusters():
 @pytest.mark.parametrize("cfg,expect", [("C1", 1), ("C2", 1), ("C3", 1), ("C4", 1), ("C5", 0)])
 def test_periodic_layout_is_found_for_runs_of_identical_molecules(cfg, expect, monkeypatch):
     """vv_host.hpp PeriodicLayout: the BASELINE bulk boxes are runs of identical molecules (C3: 12 cells of 250 cations + 250 anions), the
-    electrode slab with its image particles is not.  Forced on here (auto only from ~0.85 M particles); analyze() itself verifies, lane
+    electrode slab with its image particles is not.  Forced on here (auto only from ~1.1 M particles); analyze() itself verifies, lane
     for lane, that the arithmetic layout reproduces the explicit slot table before enabling it -- these are the invariants seen from outside."""
     monkeypatch.setenv("VVHIP_PERIODIC", "1")
     spec = systems.make_config(cfg)
@@ -221,10 +221,10 @@ def test_periodic_layout_is_found_for_runs_of_identical_molecules(cfg, expect, m
 
 
 def test_periodic_layout_auto_threshold():
-    spec = systems.make_config("C3", scale=8)
+    spec = systems.make_config("C3", scale=10)
     info, _ = I.plan_layout(spec, _integrator(O.Params(temperature=333.0, max_drude_distance=0.02)))
-    assert info.periodic_layout == 1 and info.num_waves == 8 * 2004
-    for scale in (1, 4):                      # 111 000 and 444 000 particles: best-fit packing
+    assert info.periodic_layout == 1 and info.num_waves == 10 * 2004
+    for scale in (1, 4, 8):                   # 111 000, 444 000 and 888 000 particles: best-fit packing
         info, _ = I.plan_layout(systems.make_config("C3", scale=scale), _integrator(O.Params(temperature=333.0, max_drude_distance=0.02)))
         assert info.periodic_layout == 0
 
