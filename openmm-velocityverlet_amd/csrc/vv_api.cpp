@@ -286,7 +286,9 @@ void pick_launch_shape(vvhip_plan* p) {
     const int nw = p->hp.info.num_waves, cus = p->num_cus;
     if (nw <= cus) { p->block_threads = 64; p->grid_cap_a = p->grid_cap_b = cus; return; }
     // bandwidth-bound regime (the chain runs as its own launch there, kernel B fits 6 waves per SIMD): tuned at 8.9 M particles
-    if (nw >= p->split_chain_waves) { p->block_threads = 256; p->grid_cap_a = 8 * cus; p->grid_cap_b = 4 * cus; return; }
+    // (kernel B: two blocks per CU, not four -- round 4, three alternating runs: 2.66 M particles 7 330 -> 7 540 steps/s, 4.4 M 4 226 -> 4 326,
+    // 8.9 M 1 970 -> 2 042; kernel A's eight blocks per CU against four: 7 540 / 7 547, 4 326 / 4 272, 2 042 / 2 074)
+    if (nw >= p->split_chain_waves) { p->block_threads = 256; p->grid_cap_a = 8 * cus; p->grid_cap_b = 2 * cus; return; }
     const int max_waves = (p->hp.params.cos_acceleration != 0 || p->hp.info.num_shake_clusters > 0 || p->hp.info.num_general_constraints > 0 ||
                            p->hp.info.num_virtual_sites > 0) ? 12 : 16;
     double best = -1;
