@@ -308,6 +308,9 @@ void pick_launch_shape(vvhip_plan* p) {
     // 26.2-26.6 k for the runners-up; with the 12-wave stage sets as well (7 008 tile waves with HBonds 28.3 k against the rule's 24.7 k, with
     // the cos perturbation 31.6 against 29.3 k; 5 256: 36.7 / 35.8 k and 41.0 / 40.4 k) (profiles/r04zd_mid_sizes.txt).
     if (nw > (long) cus * 14) { bk = 2; bt = 7; }
+    // The 12-wave stage sets between 2 048 and 3 072 tile waves: the fill rule ties one block of seven with two of four and takes the former;
+    // measured the latter wins (HBonds 2 628 / 2 920 tile waves 54.9 / 53.8 k against 51.3 / 50.4 k steps/s, cos 60.2 / 58.6 against 59.3 / 58.2 k)
+    else if (max_waves == 12 && nw > (long) cus * 8 && nw <= (long) cus * 12) { bk = 2; bt = 4; }
     p->block_threads = 64 * bt;
     p->grid_cap_a = p->grid_cap_b = cus * bk;
 }
