@@ -41,7 +41,9 @@ enum {
     VVHIP_ERR_HIP = -4,           /* a HIP runtime call failed */
     VVHIP_ERR_NO_DEVICE = -5,     /* no usable GPU: the product has no CPU path */
     VVHIP_ERR_EXCHANGE = -6,      /* multi-GPU: a mailbox wait on the peers timed out; the ranks have diverged, the run is void (sticky) */
-    VVHIP_ERR_OVERFLOW = -7       /* a fixed-point accumulator left its range (2KE > 1024 x the thermostat target); sticky */
+    VVHIP_ERR_OVERFLOW = -7,      /* a fixed-point accumulator left its range (2KE > 1024 x the thermostat target); sticky */
+    VVHIP_ERR_RENDEZVOUS = -8,    /* one-launch step: the blocks did not meet in the in-kernel rendezvous (not resident together); run void; sticky */
+    VVHIP_ERR_CONSTRAINT = -9     /* in-kernel constraints: a cluster hit its iteration cap without converging; sticky */
 };
 
 /* OpenMM's CudaPrecision / HipPrecision property (examples/run-bulk.py:78) */
@@ -309,7 +311,17 @@ int vvhip_synchronize(vvhip_plan* plan);         /* hipStreamSynchronize + the s
  * to start and vvhip_synchronize returns the error once a flag is up; vvhip_status_clear resets them (after the host has
  * restored a valid state). */
 int vvhip_status(vvhip_plan* plan, int32_t* mailbox_timed_out, int32_t* accumulator_overflow);
+/* All four words: [0] mailbox wait ran out, [1] accumulator overflow, [2] the one-launch step's in-kernel rendezvous ran out
+ * (VVHIP_ERR_RENDEZVOUS), [3] an in-kernel constraint cluster reached its iteration cap unconverged (VVHIP_ERR_CONSTRAINT). */
+int vvhip_status_words(vvhip_plan* plan, int32_t words[4]);
 int vvhip_status_clear(vvhip_plan* plan);
+/* The middle scheme's step as ONE launch (kernels A and B around an in-kernel rendezvous of co-resident blocks): *active = 1 if
+ * vvhip_step_middle takes it for this plan as it stands (a thermostat with <= 4 links, every tile a wave of its own on <= 256
+ * co-resident blocks, no RCCL exchange between the halves, a kernel for the plan's pair of stage sets), *launches = fused launches
+ * so far (captured ones count once), *wait_units = where the self-tuning wait between a block's publish and its first poll round
+ * stands (units of 256 shader clocks; reading it synchronises).  vvhip_debug_tune(plan, "fused", 0) forces the two-launch step
+ * (bit-identical results); "fused_poll_delay" >= 0 pins the wait.  Any of the three pointers may be NULL. */
+int vvhip_fused_status(vvhip_plan* plan, int32_t* active, int64_t* launches, int32_t* wait_units);
 int vvhip_stream_create(void** stream);          /* hipStreamCreateWithFlags(non-blocking) */
 int vvhip_stream_destroy(void* stream);
 int vvhip_synth_tether_force(vvhip_plan* plan, const void* site /* real4[n] */, double k_tether, double k_drude);
@@ -392,12 +404,13 @@ int vvhip_debug_launch(vvhip_plan* plan, int kernel, uint32_t flags, uint32_t ra
 /* One of the plan's tuning choices by name (call between vvhip_plan_create and vvhip_bind; later calls drop the captured graphs):
  * "grid_cap_a" / "grid_cap_b" (most blocks per launch), "block_threads", "split_chain_waves" (the chain becomes its own launch from n waves
  * on), "periodic_kernels" / "periodic_a" (0: load slot words although the layout is arithmetic), "rekick", "no_moments", "mass_tab_a" /
- * "periodic_b", "mass_tab_b", "acc_store", "gc_omega_permille" (relaxation factor of the general clusters' sweeps x 1000, for rate scans).  Tests
+ * "periodic_b", "mass_tab_b", "acc_store", "fused" (0: the middle scheme's step as two launches also where one would do), "gc_omega_permille" (relaxation factor of the general clusters' sweeps x 1000, for rate scans).  Tests
  * use it to run large-system code paths at small sizes. */
 int vvhip_debug_tune(vvhip_plan* plan, const char* key, int value);
 int vvhip_debug_read_accumulators(vvhip_plan* plan, double out[4], int zero_after);  /* blocks */
 int vvhip_debug_set_scales(vvhip_plan* plan, const double scales[4]);                /* vscale[3], bias V; blocks */
 int vvhip_debug_timestamps(vvhip_plan* plan, uint32_t flags, int block, long long out[128]);  /* instrumented builds only (tools/probes) */
+int vvhip_debug_timestamps_fused(vvhip_plan* plan, int block, long long out[128]);            /* ... one real one-launch step, stamped */
 int vvhip_debug_span(vvhip_plan* plan, int kernel, uint32_t flags, int reps, double out[8]);   /* instrumented builds only */
 int vvhip_debug_fused_flags(vvhip_plan* plan, int kernel, uint32_t* flags);          /* stage bits of the fused middle step's kernel A (0) / B (1) */
 int vvhip_debug_step_spans(vvhip_plan* plan, int nsteps, const void* site, double k_tether, double k_drude, double out[36]);   /* instrumented builds only */

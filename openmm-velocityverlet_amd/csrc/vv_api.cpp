@@ -113,6 +113,18 @@ struct vvhip_plan {
     long long generic_launches[2] = {0, 0};   // kernel A / B launches of this plan (captured ones count once) that ran the generic kernel
     uint32_t generic_flags[2] = {0, 0};       // ... and the last stage set that did (vvhip_generic_launches)
     bool rekick = true;            // fused middle step: kick repeated in kernel B instead of a velm store in kernel A (use_rekick)
+    // One launch per step (vv_device.inc: "fused step"): kernels A and B of the middle scheme as one launch of co-resident blocks around an
+    // in-kernel rendezvous.  `fused` = allowed (vvhip_debug_tune "fused": A/B comparisons and the bit-for-bit tests switch it off);
+    // d_rv = the rendezvous words, [2 thermostat parities][NUM_ACC][ACC_SLOTS], uncached; fused_checked_* = the last pair of stage sets /
+    // launch shape whose kernel and occupancy were looked up, fused_ok = what came of it.
+    bool fused = true;
+    int fused_late_shift = 4;      // the wait grows when more than blocks / 2^shift blocks needed a second round (test hook "fused_late_shift")
+    int fused_poll_delay = -1;     // >= 0: pins the wait between a block's publish and its first poll round, units of 256 clocks (test hook "fused_poll_delay"); -1: self-tuning
+    unsigned long long* d_rv = nullptr;
+    uint32_t fused_checked_a = 0, fused_checked_b = 0;
+    int fused_checked_threads = 0, fused_checked_waves = 0;
+    bool fused_ok = false;
+    long long fused_launches = 0;
     // plan-owned device state
     int2* d_slots = nullptr;
     int32_t* d_slot_image = nullptr;
@@ -213,8 +225,11 @@ int fail(vvhip_plan* p, int code, const std::string& msg) {
 int check_exchange_health(vvhip_plan* p) {
     if (!p->h_status) return VVHIP_OK;
     const unsigned int mb = __atomic_load_n(&p->h_status[0], __ATOMIC_RELAXED), ov = __atomic_load_n(&p->h_status[1], __ATOMIC_RELAXED);
+    const unsigned int rv = __atomic_load_n(&p->h_status[2], __ATOMIC_RELAXED), cs = __atomic_load_n(&p->h_status[3], __ATOMIC_RELAXED);
     if (mb) return fail(p, VVHIP_ERR_EXCHANGE, "multi-GPU mailbox: a wait on the peers' thermostat totals timed out; this rank went on with incomplete sums, the run is void");
     if (ov) return fail(p, VVHIP_ERR_OVERFLOW, "a fixed-point accumulator overflowed (kinetic energy beyond 1024 x the thermostat target): the thermostat input is invalid");
+    if (rv) return fail(p, VVHIP_ERR_RENDEZVOUS, "fused step: the blocks of the one-launch step did not meet within 0.2 s (not resident together: another process on the device?); the thermostat went on with incomplete sums, the run is void -- vvhip_debug_tune(plan, \"fused\", 0) selects the two-launch step");
+    if (cs) return fail(p, VVHIP_ERR_CONSTRAINT, "in-kernel constraints: a cluster reached the iteration cap without converging (a degenerate geometry, or a step that is too large); positions / velocities of that cluster are not within tolerance");
     return VVHIP_OK;
 }
 int hip_fail(vvhip_plan* p, hipError_t e, const char* what) {
@@ -590,6 +605,61 @@ int run_chain_and_b(vvhip_plan* p, uint32_t bflags, bool with_bias) {
     return rc != VVHIP_OK ? rc : run_b(p, bflags);
 }
 
+// ---- the one-launch step (vv_device.inc: "fused step")
+// Shape: the plan's own (pick_launch_shape) when it gives every tile a wave of its own on at most ACC_SLOTS blocks, one block per CU.
+bool fused_shape_ok(const vvhip_plan* p) {
+    const int tiles = p->block_threads / 64, nw = p->hp.info.num_waves;
+    if (tiles < 1 || tiles > 7) return false;
+    const int blocks = (nw + tiles - 1) / tiles;
+    return blocks >= 1 && blocks <= vv::ACC_SLOTS && blocks <= std::min(p->grid_cap_b, p->grid_cap_a) && blocks <= p->num_cus;
+}
+// What the plan's state allows, before any kernel is looked up.  The two halves must not need anything between them: no RCCL exchange
+// (sharded runs with a communicator), no stand-alone chain launch (long chains, very large systems), no partial sums of molecules larger
+// than a wave, no three-launch cos sequence; ranks that share this device (test set-ups) keep the two-launch step, whose kernels need
+// not be resident together.
+bool fused_state_ok(const vvhip_plan* p) {
+    const vv::HostPlan& hp = p->hp;
+    if (!p->fused || !hp.params.use_middle_scheme || !hp.has_nh || hp.params.num_nh_chains > 4 || hp.num_big != 0) return false;
+    if (hp.info.num_waves >= p->split_chain_waves || p->comm || p->mb_on) return false;
+    if (hp.params.cos_acceleration != 0 && (p->no_moments || hp.params.num_nh_chains > 4)) return false;
+    if (p->mass_tab_a || !p->mass_tab_b || p->shake_mode == 0) return false;      // (comparison builds of the two-launch kernels)
+    if (hp.per.enabled && p->periodic_kernels) return false;                      // the arithmetic layout belongs to the many-pass regime
+    return fused_shape_ok(p);
+}
+int run_fused(vvhip_plan* p, uint32_t aflags, uint32_t bflags, uint32_t random_index, bool* taken) {
+    *taken = false;
+    if (!fused_state_ok(p)) return VVHIP_OK;
+    bflags |= vv::B_CHAIN | vv::B_MTAB;
+    // kernel and occupancy of this pair of stage sets on this launch shape: looked up once
+    if (p->fused_checked_a != aflags || p->fused_checked_b != bflags || p->fused_checked_threads != p->block_threads || p->fused_checked_waves != p->hp.info.num_waves) {
+        p->fused_checked_a = aflags; p->fused_checked_b = bflags; p->fused_checked_threads = p->block_threads; p->fused_checked_waves = p->hp.info.num_waves;
+        vv::KArgs q = make_args(p, bflags, random_index);
+        q.flags_a = aflags;
+        int per_cu = 0;
+        const hipError_t e = vv::launch_fused(p->hp.precision, q, p->block_threads, p->d_rv, p->stream, nullptr, nullptr, nullptr, &per_cu);
+        const int tiles = p->block_threads / 64, blocks = (p->hp.info.num_waves + tiles - 1) / tiles;
+        p->fused_ok = e == hipSuccess && per_cu >= 1 && (long) per_cu * p->num_cus >= blocks;
+        if (e != hipSuccess) (void) hipGetLastError();
+    }
+    if (!p->fused_ok) return VVHIP_OK;
+    TRY(ensure_mass_table(p));
+    debug_stall(p);
+    ScopedTimer t(p, T_B, true);
+    int route = vv::ROUTE_COMPILED;
+    vv::KArgs q = make_args(p, bflags, random_index);
+    q.flags_a = aflags;
+    q.fused_poll_delay = p->fused_poll_delay;
+    // the "a block polled twice" words of this step and of the one before (by thermostat parity), behind the two copies of the rendezvous words
+    q.rv_late_cur = (unsigned int*) (p->d_rv + 2 * kAccN) + vv::ACC_SLOTS * p->parity;
+    q.rv_late_prev = (const unsigned int*) (p->d_rv + 2 * kAccN) + vv::ACC_SLOTS * (p->parity ^ 1);
+    q.fused_late_shift = p->fused_late_shift;
+    HIP_TRY(p, vv::launch_fused(p->hp.precision, q, p->block_threads, p->d_rv + p->parity * kAccN, p->stream, t.e0, t.e1, &route, nullptr));
+    p->parity ^= 1;            // the advanced thermostat state now lives in the other copy
+    p->fused_launches++;
+    *taken = true;
+    return VVHIP_OK;
+}
+
 uint32_t extra_flags(const vvhip_plan* p) {
     uint32_t f = 0;
     if (p->hp.has_ld) f |= vv::A_LD;
@@ -664,6 +734,9 @@ int vvhip_debug_tune(vvhip_plan* p, const char* key, int value) {
     else if (k == "gc_omega_permille") p->hp.gc_omega = value / 1000.0;     // relaxation factor of the general clusters' sweeps (rate scans)
     else if (k == "rekick") p->rekick = value != 0;                         // 0: kernel A stores the kicked velocities, kernel B does not repeat the kick
     else if (k == "no_moments") p->no_moments = value != 0;                 // 1: cos perturbation as three launches (bias, sums, scale)
+    else if (k == "fused") { p->fused = value != 0; p->fused_checked_b = 0; }
+    else if (k == "fused_late_shift") p->fused_late_shift = std::max(0, std::min(value, 16));
+    else if (k == "fused_poll_delay") p->fused_poll_delay = std::max(-1, std::min(value, 64));   // 0: the middle scheme's step as two launches (A, B) also where one would do
     else if (k == "mass_tab_a") p->mass_tab_a = value != 0;
     else if (k == "mass_tab_b") p->mass_tab_b = value != 0;
     else if (k == "acc_store") p->acc_store = value != 0;                   // 0: atomics also where a block owns its accumulator slot
@@ -685,7 +758,7 @@ void vvhip_plan_destroy(vvhip_plan* p) {
     if (p->bound) {
         (void) hipStreamSynchronize(p->stream);
         for (void* ptr : {(void*) p->d_slots, (void*) p->d_slot_image, (void*) p->d_slot_rand, (void*) p->d_slot_shake, (void*) p->d_slot_shake_param, (void*) p->d_slot_vsite, (void*) p->d_vsite_params, (void*) p->d_vsite_atom, (void*) p->d_slot_big, (void*) p->d_bigacc, (void*) p->d_image_pairs,
-                          p->d_fextra, p->d_old_delta, p->d_pos_delta, p->d_comv, (void*) p->d_comw, (void*) p->d_seg_mass, (void*) p->d_seg_base, (void*) p->d_slot_m, (void*) p->d_slot_f, (void*) p->d_cosz, (void*) p->d_epoch, (void*) p->d_acc, (void*) p->d_nh, (void*) p->d_lane_const, (void*) p->d_dbg, (void*) p->d_dbg_span})
+                          p->d_fextra, p->d_old_delta, p->d_pos_delta, p->d_comv, (void*) p->d_comw, (void*) p->d_seg_mass, (void*) p->d_seg_base, (void*) p->d_slot_m, (void*) p->d_slot_f, (void*) p->d_cosz, (void*) p->d_epoch, (void*) p->d_acc, (void*) p->d_rv, (void*) p->d_nh, (void*) p->d_lane_const, (void*) p->d_dbg, (void*) p->d_dbg_span})
             if (ptr) (void) hipFree(ptr);
         drop_graphs(p);
         if (p->comm) (void) rccl_api().commDestroy(p->comm);
@@ -807,10 +880,15 @@ int vvhip_bind(vvhip_plan* p, const vvhip_buffers* b) {
     HIP_TRY(p, hipMemsetAsync(p->d_epoch, 0, sizeof(unsigned long long), p->stream));
     HIP_TRY(p, hipMalloc((void**) &p->d_acc, 2 * kAccN * sizeof(unsigned long long)));
     HIP_TRY(p, hipMemsetAsync(p->d_acc, 0, 2 * kAccN * sizeof(unsigned long long), p->stream));
+    // rendezvous words of the fused step: uncached (every block's thermostat wave polls what the other blocks -- on other XCDs, behind other
+    // L2s -- have just stored); zero = "no step's word" (tags run from 1)
+    HIP_TRY(p, hipExtMallocWithFlags((void**) &p->d_rv, (size_t) (2 * kAccN + vv::ACC_SLOTS) * sizeof(unsigned long long), hipDeviceMallocUncached));
+    HIP_TRY(p, hipMemsetAsync(p->d_rv, 0, (size_t) (2 * kAccN + vv::ACC_SLOTS) * sizeof(unsigned long long), p->stream));
     HIP_TRY(p, hipMalloc((void**) &p->d_nh, 2 * sizeof(vv::NHDevState)));
     vv::NHDevState init[2] = {};
     for (int c = 0; c < 2; c++)
         for (int g = 0; g < 3; g++) { init[c].s.vscale[g] = 1.0; init[c].scales[g] = 1.0; }
+    for (int c = 0; c < 2; c++) init[c].rv_delay = 6;      // where the wait of the fused step's rendezvous starts (it tunes itself from there)
     HIP_TRY(p, hipMemcpy(p->d_nh, init, sizeof(init), hipMemcpyHostToDevice));
     HIP_TRY(p, hipMalloc((void**) &p->d_lane_const, VVHIP_NUM_TG * sizeof(vv::ChainLaneBlock)));
     HIP_TRY(p, hipHostMalloc((void**) &p->h_status, 4 * sizeof(unsigned int), hipHostMallocMapped));
@@ -942,6 +1020,24 @@ int vvhip_algorithmic_bytes(const vvhip_plan* p, int32_t* bytes_a, int32_t* byte
     return VVHIP_OK;
 }
 
+// The stage sets of the one-launch step: phase 0's kick + sums and phase 1's scaling + drift of vvhip_step_middle_phase, without the
+// hand-over bits between them (A_NOSTORE / B_KICK, the cos(kz) cache load).
+static int step_middle_fused(vvhip_plan* p, uint32_t random_index, bool* taken) {
+    *taken = false;
+    if (!p->hp.info.constraints_fused || !fused_state_ok(p)) return VVHIP_OK;
+    const uint32_t stale = (extra_flags(p) == 0 && (p->fextra_dirty || p->fextra_external)) ? vv::A_FE_LOAD : 0u;
+    uint32_t fa = vv::A_KICK_FULL | extra_flags(p) | stale | cons_a(p) | vv::A_KE;
+    uint32_t fb = vv::B_SCALE | vv::B_DRIFT_MIDDLE | tail_flags(p) | cons_b(p);
+    if (cos_on(p)) {
+        if (!use_moments(p)) return VVHIP_OK;
+        fa |= vv::A_BIAS | vv::A_CZ_STORE | vv::A_KE_MOM;
+        fb |= vv::B_UNBIAS | vv::B_KE_MOM;
+    }
+    TRY(run_fused(p, fa, fb, random_index, taken));
+    if (*taken && cos_on(p) && !p->hp.has_ld && !p->hp.has_ef) p->fextra_virtual = true;      // as phase 0 of the two-launch step
+    return VVHIP_OK;
+}
+
 int vvhip_step_middle_phase(vvhip_plan* p, int phase, uint32_t random_index) {
     NEED_BOUND(p);
     NEED_FUSABLE(p);
@@ -1002,6 +1098,11 @@ static int exchange_accumulators(vvhip_plan* p, int phase) {
 int vvhip_step_middle(vvhip_plan* p, uint32_t random_index) {
     NEED_BOUND(p);
     if (!p->hp.params.use_middle_scheme) return fail(p, VVHIP_ERR_INVALID, "plan was created for the classic scheme");
+    {   // one launch where the plan allows it (bit for bit the two launches below)
+        bool taken = false;
+        TRY(step_middle_fused(p, random_index, &taken));
+        if (taken) return VVHIP_OK;
+    }
     const int n = vvhip_step_middle_phases(p);
     for (int ph = 0; ph < n; ph++) {
         TRY(vvhip_step_middle_phase(p, ph, random_index));
@@ -1173,6 +1274,33 @@ int vvhip_status(vvhip_plan* p, int32_t* mailbox_timed_out, int32_t* accumulator
     NEED_BOUND(p);
     if (mailbox_timed_out) *mailbox_timed_out = (int32_t) __atomic_load_n(&p->h_status[0], __ATOMIC_RELAXED);
     if (accumulator_overflow) *accumulator_overflow = (int32_t) __atomic_load_n(&p->h_status[1], __ATOMIC_RELAXED);
+    return VVHIP_OK;
+}
+int vvhip_status_words(vvhip_plan* p, int32_t words[4]) {
+    NEED_BOUND(p);
+    if (!words) return VVHIP_ERR_INVALID;
+    for (int i = 0; i < 4; i++) words[i] = (int32_t) __atomic_load_n(&p->h_status[i], __ATOMIC_RELAXED);
+    return VVHIP_OK;
+}
+int vvhip_fused_status(vvhip_plan* p, int32_t* active, int64_t* launches, int32_t* wait_units) {
+    NEED_BOUND(p);
+    if (launches) *launches = p->fused_launches;
+    if (wait_units) {                  // where the self-tuning wait of the rendezvous stands (blocks: it lives in the device-resident state)
+        *wait_units = p->fused_poll_delay;
+        if (p->fused_poll_delay < 0) {
+            HIP_TRY(p, hipStreamSynchronize(p->stream));
+            unsigned int d = 0;
+            HIP_TRY(p, hipMemcpy(&d, &p->d_nh[p->parity].rv_delay, sizeof(d), hipMemcpyDeviceToHost));
+            *wait_units = (int32_t) d;
+        }
+    }
+    if (active) {
+        *active = 0;
+        if (p->hp.info.constraints_fused && fused_state_ok(p) && (!cos_on(p) || use_moments(p))) {
+            // (the kernel itself is looked up at the first step; a pair of stage sets already found wanting says so here)
+            *active = (p->fused_checked_b != 0 && !p->fused_ok) ? 0 : 1;
+        }
+    }
     return VVHIP_OK;
 }
 int vvhip_status_clear(vvhip_plan* p) {
@@ -1377,6 +1505,28 @@ int vvhip_debug_timestamps(vvhip_plan* p, uint32_t flags, int block, long long o
 #endif
 }
 
+// Instrumented build: ONE real step of the one-launch path (it advances the state), shader-clock stamps of block `block`: tile waves
+// w = 0..6: 0 entry, 6 loads arrived + extra forces, 7 kick + sums done, 8 partials in LDS, 9 behind barrier 1, 1 / 2 preparation, 3 scales
+// received, 4 compute done, 5 stores drained; thermostat wave (w = 7): 0 entry, 6 at barrier 1, 7 behind it, 8 published, 9 all blocks' words
+// held, 10 = poll rounds (a count, not a time), 1 folded, 4 ke2, 5 released, 2 chain done, 3 state stored.
+int vvhip_debug_timestamps_fused(vvhip_plan* p, int block, long long out[128]) {
+    NEED_BOUND(p);
+#ifndef VV_KERNEL_TIMESTAMPS
+    (void) block; (void) out;
+    return fail(p, VVHIP_ERR_UNSUPPORTED, "not an instrumented build");
+#else
+    if (!p->d_dbg) HIP_TRY(p, hipMalloc((void**) &p->d_dbg, 128 * sizeof(long long)));
+    HIP_TRY(p, hipMemsetAsync(p->d_dbg, 0, 128 * sizeof(long long), p->stream));
+    p->dbg_block = block;
+    bool taken = false;
+    TRY(step_middle_fused(p, 0, &taken));
+    if (!taken) return fail(p, VVHIP_ERR_UNSUPPORTED, "the plan does not take the one-launch step");
+    HIP_TRY(p, hipStreamSynchronize(p->stream));
+    HIP_TRY(p, hipMemcpy(out, p->d_dbg, 128 * sizeof(long long), hipMemcpyDeviceToHost));
+    return VVHIP_OK;
+#endif
+}
+
 // Instrumented build: `reps` back-to-back launches of kernel A (kernel = 0) or B (1) with `flags`; every wave stamps the 100 MHz
 // wall clock at entry and (after draining its memory operations) at exit.  out[0] = first entry -> last exit of the last launch,
 // out[1] = last exit of the launch before -> first entry of the last launch, out[2] = median wave entry - first entry,
@@ -1449,6 +1599,7 @@ int vvhip_debug_step_spans(vvhip_plan* p, int nsteps, const void* site, double k
     long long* keep = p->d_dbg_span;
     p->dbg_seq = 0;
     int rc = VVHIP_OK;
+    const long long fused_before = p->fused_launches;
     for (int i = 0; i < 2 && rc == VVHIP_OK; i++) rc = plan_step(p, site, k_tether, k_drude, false);
     p->dbg_seq = -1;
     p->d_dbg_span = nullptr;
@@ -1458,7 +1609,10 @@ int vvhip_debug_step_spans(vvhip_plan* p, int nsteps, const void* site, double k
     HIP_TRY(p, hipMemcpy(h.data(), keep, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
     p->d_dbg_span = keep;
     long long t0 = 0;
-    for (int l = 0; l < 6; l++) {
+    // (the one-launch step: provider + one kernel per step, four launches; rows 4 and 5 stay zero)
+    const int nlaunch = p->fused_launches > fused_before ? 4 : 6;
+    for (int l = 0; l < 36; l++) out[l] = 0;
+    for (int l = 0; l < nlaunch; l++) {
         std::vector<long long> in, ex;
         for (size_t r = 0; r < (size_t) 4096 * 8; r++) {
             const long long a0 = h[((size_t) l * 4096 * 8 + r) * 2], a1 = h[((size_t) l * 4096 * 8 + r) * 2 + 1];

@@ -107,7 +107,9 @@ struct NHDevState {
     vvhip_nh_state s;
     double scales[4];        // what kernel B consumes: vscale[3] and the periodic bias V
     unsigned int mb_seq;     // mailbox exchanges done so far (advanced with the state by a B_MAILBOX launch)
-    unsigned int pad_;
+    unsigned int rv_seq;     // fused steps done so far: the tag of the rendezvous words (advanced with the state by a fused launch)
+    unsigned int rv_delay;   // fused step: units of 256 clocks a block waits between its publish and its first poll round (self-tuning, vv_device.inc)
+    unsigned int rv_calm;    // ... and fused steps since a block last needed a second round
 };
 
 // Constants of the chain (HOST:577-594 fixed at init; temperatures read live as API:728 does)
@@ -210,6 +212,11 @@ struct KArgs {
     const int2* slot_vsite;         // B_VSITE: [64*waves] (site word, vv_layout.h: VS_WORD_*; record number) of the site the lane places
     const double* vsite_params;     // B_VSITE: [12*records] weights / local position of each site (vvhip_system_desc.virtual_site_params)
     const int32_t* vsite_atom;      // B_VSITE: [records] particle index of the site: a lane that places a site for its parent stores it there
+    uint32_t flags_a;               // fused step (vv_kernel_b<.., SFA>): kernel A's stage set executed by the same launch, 0 otherwise (launch_b dispatches on it)
+    int32_t fused_poll_delay;       // fused step: >= 0 pins the wait between a block's publish and its first poll round (units of 256 clocks); -1: NHDevState::rv_delay
+    unsigned int* rv_late_cur;      // fused step: [ACC_SLOTS] uncached words, block b's = 1 if it needed a second poll round in THIS step ...
+    const unsigned int* rv_late_prev;   // ... and the previous fused step's
+    int32_t fused_late_shift, fused_pad_;   // the wait grows when more than blocks >> shift blocks were late
 };
 
 struct TetherArgs {

@@ -357,6 +357,55 @@ hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_c
     return hipGetLastError();
 #undef VV_PRE_ARGS
 }
+// ---- fused step: kernel A's stage set `a.flags_a` and kernel B's `a.flags` in ONE launch (vv_device.inc: "fused step").  Every tile needs a
+// wave of its own (it stays in registers across the rendezvous) and the blocks must be resident together: the caller (vv_api.cpp:
+// use_fused) has checked the launch shape; `blocks_per_cu` != nullptr only ASKS how many blocks of this kernel a CU holds and launches
+// nothing.  hipErrorNotSupported: no kernel for this pair of stage sets (the caller then takes the two-launch path).
+constexpr uint32_t SF_B_COS_HW_MOM_F = B_CHAIN | B_SCALE | B_UNBIAS | B_DRIFT_MIDDLE | B_HARDWALL | B_KE_MOM;      // (no cos(kz) cache between the halves)
+hipError_t launch_fused(int precision, const KArgs& a, int block_threads, const unsigned long long* rendezvous, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int* route, int* blocks_per_cu) {
+    if (route) *route = ROUTE_COMPILED;
+    const dim3 g = grid_for(a.nwaves, block_threads);
+    const dim3 b(block_threads + 64);                      // the tile waves + the block's thermostat wave
+    if (!(a.flags & B_CHAIN) || a.flags_a == 0 || (int) g.x > ACC_SLOTS || b.x > 512) return hipErrorNotSupported;
+    const unsigned lds = (a.flags & (B_CONS | B_VSITE)) ? (unsigned) (block_threads / 64) * 64u * 7u * (precision == VVHIP_SINGLE ? 4u : 8u) : 0u;      // one page per tile wave
+    vv_last_grid_value = g.x;
+    constexpr uint32_t XM = SF_BM;
+#define VV_PRE_ARGS a.slots, a.nwaves, (int) (b.x >> 6), rendezvous, a.nh, a.lane_const, a.seg_base
+#define VV_FUSED_ONE(REAL, MIXED, SFB, SFA) { \
+        if (blocks_per_cu) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, vv_kernel_b<REAL, MIXED, (SFB) | XM, SFA>, (int) b.x, lds); \
+        vv_launch((vv_kernel_b<REAL, MIXED, (SFB) | XM, SFA>), g, b, lds, s, ev0, ev1, VV_PRE_ARGS, a); return hipGetLastError(); }
+#define VV_TRY_FUSED(SFB, SFA) if (a.flags == ((SFB) | XM) && a.flags_a == (SFA) && a.chain.num_chains == 3) { \
+        switch (precision) { case VVHIP_SINGLE: VV_FUSED_ONE(float, float, SFB, SFA) case VVHIP_MIXED: VV_FUSED_ONE(float, double, SFB, SFA) default: VV_FUSED_ONE(double, double, SFB, SFA) } }
+    if (rtc_mode() < 2) {
+        VV_TRY_FUSED(SF_B_MIDDLE_HW, SF_A_MIDDLE)                    // BASELINE C3
+        VV_TRY_FUSED(SF_B_MIDDLE, SF_A_MIDDLE)                       // C1, C2
+        VV_TRY_FUSED(SF_B_EDL, SF_A_EDL)                             // C5
+        VV_TRY_FUSED(SF_B_COS_HW_MOM_F, SF_A_COS_MOM)                // C4
+        VV_TRY_FUSED(SF_B_MIDDLE_HW_SHAKE, SF_A_MIDDLE_SHAKE)        // ... with their HBonds / rigid water
+        VV_TRY_FUSED(SF_B_MIDDLE_SETTLE, SF_A_MIDDLE_SETTLE)
+        VV_TRY_FUSED(SF_B_EDL_SHAKE, SF_A_EDL_SHAKE)
+        VV_TRY_FUSED(SF_B_COS_HW_MOM_F | B_SHAKE, SF_A_COS_MOM_SHAKE)
+    }
+#undef VV_TRY_FUSED
+#undef VV_FUSED_ONE
+    // any other pair of stage sets (and every pair with VVHIP_RTC=2): compiled at run time from the library's own source
+    if (rtc_mode() >= 1) {
+        hipFunction_t f = rtc_kernel('B', precision, a.flags, a.chain.num_chains, a.flags_a);
+        if (f) {
+            if (blocks_per_cu) return hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, f, (int) b.x, lds);
+            const int2* p_slots = a.slots; int p_nwaves = a.nwaves, p_wpb = (int) (b.x >> 6);
+            const unsigned long long* p_acc = rendezvous; const NHDevState* p_nh = a.nh; const ChainLaneBlock* p_lc = a.lane_const; const int* p_sb = a.seg_base;
+            KArgs copy = a;
+            void* params[] = {&p_slots, &p_nwaves, &p_wpb, &p_acc, &p_nh, &p_lc, &p_sb, &copy};
+            const hipError_t e = vv_launch_module(f, g, b, lds, s, ev0, ev1, params);
+            vv_rtc_launches[1]++;
+            if (route) *route = ROUTE_RUNTIME;
+            return e;
+        }
+    }
+    return hipErrorNotSupported;
+#undef VV_PRE_ARGS
+}
 hipError_t launch_chain(const NHConst& c, NHDevState* st, unsigned long long* acc, hipStream_t s) {
     hipLaunchKernelGGL(vv_kernel_chain, dim3(1), dim3(64), 0, s, c, st, acc);
     return hipGetLastError();

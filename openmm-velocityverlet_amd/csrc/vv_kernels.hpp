@@ -28,6 +28,11 @@ inline PeriodicArgs periodic_args(const PeriodicLayout& q) {
 enum LaunchRoute { ROUTE_COMPILED = 0, ROUTE_RUNTIME = 1, ROUTE_GENERIC = 2 };
 hipError_t launch_a(int precision, const KArgs& a, int block_threads, int grid_cap, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, int* route = nullptr);
 hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_cap, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, int* route = nullptr);
+// The fused step: kernel A's stage set a.flags_a and kernel B's a.flags in one launch of vv_kernel_b<.., SFA> over `rendezvous` (an uncached
+// [NUM_ACC][ACC_SLOTS] array of 8-byte words); block_threads = 64 x tile waves per block, one pass.  blocks_per_cu != nullptr: only report the
+// kernel's occupancy (blocks of this shape per CU).  hipErrorNotSupported: no kernel for the pair, or a shape the rendezvous cannot take.
+hipError_t launch_fused(int precision, const KArgs& a, int block_threads, const unsigned long long* rendezvous, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
+                        int* route = nullptr, int* blocks_per_cu = nullptr);
 // launches of kernel A / B (index 0 / 1) that ran the generic kernel, process-wide (statistics only)
 extern std::atomic<unsigned long long> vv_generic_count[2];
 hipError_t launch_chain(const NHConst& c, NHDevState* st, unsigned long long* acc, hipStream_t s);

@@ -73,14 +73,16 @@ std::string replaced(std::string s, const std::string& from, const std::string& 
 }  // namespace
 
 bool rtc_compile(char kind, int precision, uint32_t flags, int num_chains, const std::string& arch, std::vector<char>& code, std::string& lowered_name,
-                 std::string& log) {
+                 std::string& log, uint32_t flags_a) {
     Rtc& r = rtc();
     if (!r.ok) { log = "libhiprtc.so could not be opened"; return false; }
     if (flags == 0 || (kind != 'A' && kind != 'B')) { log = "no stage bits"; return false; }
     const char* real = precision == VVHIP_DOUBLE ? "double" : "float";
     const char* mixed = precision == VVHIP_SINGLE ? "float" : "double";
     char expr[160];
-    std::snprintf(expr, sizeof expr, "vv::vv_kernel_%c<%s, %s, %uu>", kind == 'A' ? 'a' : 'b', real, mixed, flags);
+    if (flags_a != 0 && kind != 'B') { log = "the fused step is an instance of kernel B"; return false; }
+    if (flags_a != 0) std::snprintf(expr, sizeof expr, "vv::vv_kernel_b<%s, %s, %uu, %uu>", real, mixed, flags, flags_a);
+    else std::snprintf(expr, sizeof expr, "vv::vv_kernel_%c<%s, %s, %uu>", kind == 'A' ? 'a' : 'b', real, mixed, flags);
     // the translation unit: the library's own headers and device code, then the one instantiation asked for
     // (hipRTC keeps its fixed-width integer types in a namespace of its own)
     const std::string unit = std::string("using __hip_internal::int32_t; using __hip_internal::uint32_t; using __hip_internal::int64_t; using __hip_internal::uint64_t;\n"
@@ -115,14 +117,14 @@ bool rtc_compile(char kind, int precision, uint32_t flags, int num_chains, const
     return ok;
 }
 
-hipFunction_t rtc_kernel(char kind, int precision, uint32_t flags, int num_chains) {
+hipFunction_t rtc_kernel(char kind, int precision, uint32_t flags, int num_chains, uint32_t flags_a) {
     static std::mutex mutex;
-    static std::map<std::tuple<int, char, int, uint32_t, int>, hipFunction_t> cache;      // (device, kernel, precision, stage bits, chain length)
+    static std::map<std::tuple<int, char, int, uint32_t, int, uint32_t>, hipFunction_t> cache;      // (device, kernel, precision, stage bits, chain length, fused: A's stage bits)
     std::lock_guard<std::mutex> lock(mutex);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     if (kind == 'A' || !(flags & B_CHAIN)) num_chains = 3;          // only kernel B's thermostat wave (B_CHAIN) depends on it
-    const auto key = std::make_tuple(dev, kind, precision, flags, num_chains);
+    const auto key = std::make_tuple(dev, kind, precision, flags, num_chains, flags_a);
     const auto it = cache.find(key);
     if (it != cache.end()) return it->second;
     hipFunction_t fn = nullptr;
@@ -146,7 +148,7 @@ hipFunction_t rtc_kernel(char kind, int precision, uint32_t flags, int num_chain
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
         std::vector<char> code;
         std::string name, log;
-        if (rtc_compile(kind, precision, flags, num_chains, prop.gcnArchName, code, name, log)) {
+        if (rtc_compile(kind, precision, flags, num_chains, prop.gcnArchName, code, name, log, flags_a)) {
             // a plan may meet its stage set for the first time while its step is being captured into a graph: loading a code object is
             // not a stream operation, but it allocates, which a thread-local capture forbids -- relax the mode around the load
             hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;

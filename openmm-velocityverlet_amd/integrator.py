@@ -410,6 +410,26 @@ class Context:
     def status_clear(self):
         H.check(H.lib.vvhip_status_clear(self.plan), self.plan)
 
+    def status_words(self):
+        """[mailbox wait ran out, accumulator overflow, one-launch rendezvous ran out, constraint cluster hit its iteration cap]: all four
+        sticky health words (vvhip_status_words)."""
+        w = (C.c_int32 * 4)()
+        H.check(H.lib.vvhip_status_words(self.plan, C.byref(w)), self.plan)
+        return [int(x) for x in w]
+
+    def fused_status(self):
+        """(active, launches): whether vvhip_step_middle runs this plan's step as ONE launch (kernels A and B around an in-kernel
+        rendezvous), and how many such launches it has enqueued (vvhip_fused_status)."""
+        a, n = C.c_int32(0), C.c_int64(0)
+        H.check(H.lib.vvhip_fused_status(self.plan, C.byref(a), C.byref(n), None), self.plan)
+        return bool(a.value), int(n.value)
+
+    def fused_wait_units(self) -> int:
+        """Where the self-tuning wait of the one-launch step's rendezvous stands (units of 256 shader clocks; synchronises)."""
+        w = C.c_int32(0)
+        H.check(H.lib.vvhip_fused_status(self.plan, None, None, C.byref(w)), self.plan)
+        return int(w.value)
+
     def fill_random(self, seed=None):
         """Refill the Langevin random buffer with the device generator (Philox4x32-10 + Box-Muller)."""
         if seed is not None:

@@ -20,7 +20,7 @@ SINGLE, MIXED, DOUBLE = 0, 1, 2
 PRECISION = {"single": SINGLE, "mixed": MIXED, "double": DOUBLE}
 REAL = {"single": np.float32, "mixed": np.float32, "double": np.float64}
 MIXED_T = {"single": np.float32, "mixed": np.float64, "double": np.float64}
-OK, ERR_INVALID, ERR_TOPOLOGY, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE, ERR_EXCHANGE, ERR_OVERFLOW = 0, -1, -2, -3, -4, -5, -6, -7
+OK, ERR_INVALID, ERR_TOPOLOGY, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE, ERR_EXCHANGE, ERR_OVERFLOW, ERR_RENDEZVOUS, ERR_CONSTRAINT = 0, -1, -2, -3, -4, -5, -6, -7, -8, -9
 
 # stage bits of csrc/vv_args.hpp (only the test hooks need them)
 A_FE_LOAD, A_FE_STORE, A_LD, A_EF, A_COS, A_KICK_FULL, A_KICK_HALF, A_POSDELTA_VV, A_POS1, A_BIAS, A_KE, A_UNBIAS_ACC, A_COMPART, A_CZ_STORE, A_CZ_LOAD = \
@@ -126,6 +126,7 @@ def _load():
         "vvhip_run_graph": [vp, C.c_int, C.c_int, vp, dbl, dbl],
         "vvhip_graph_prepare": [vp, C.c_int, vp, dbl, dbl],
         "vvhip_status": [vp, P(i32), P(i32)], "vvhip_status_clear": [vp], "vvhip_masses_changed": [vp],
+        "vvhip_status_words": [vp, P(i32 * 4)], "vvhip_fused_status": [vp, P(i32), P(C.c_int64), P(i32)],
         "vvhip_run_eager": [vp, C.c_int, vp, dbl, dbl],
         "vvhip_run_eager_unfused": [vp, C.c_int, vp, dbl, dbl],
         "vvhip_set_random_seed": [vp, C.c_uint64], "vvhip_fill_random": [vp],
@@ -147,6 +148,7 @@ def _load():
         "vvhip_set_trace": [vp, C.c_int],
         "vvhip_debug_span": [vp, C.c_int, C.c_uint32, C.c_int, P(C.c_double * 8)],
         "vvhip_debug_timestamps": [vp, C.c_uint32, C.c_int, P(C.c_longlong * 128)],
+        "vvhip_debug_timestamps_fused": [vp, C.c_int, P(C.c_longlong * 128)],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)

@@ -1,0 +1,151 @@
+"""-m gpu: the middle scheme's step as ONE launch (vv_kernel_b<.., SFA>: kernel A's stages, an in-kernel rendezvous of the co-resident
+blocks, kernel B's stages) against the two-launch step it replaces (/root/reference/platforms/cuda/src/CudaVVKernels.cpp:129-231,
+670-754 are >= 10 launches + a blocking download / upload).  The bar is BIT FOR BIT: the tile waves evaluate kernel A's expressions on
+the same operands, the block's partial sums go through kernel A's tail, the fixed-point words are folded as integers, the chain is the
+same code -- so positions, velocities, corrections and the thermostat state must be identical, eager and replayed from a graph, in all
+three precision modes and for every stage set with a compiled fused kernel (plus one compiled at run time).  The oracle comparison of
+the fused path itself is tests/test_gpu_steps.py (fused is the default wherever the plan allows it)."""
+import importlib
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pkg = importlib.import_module("openmm-velocityverlet_amd")
+H, I, systems = pkg.vvhip, pkg.integrator, pkg.systems
+pytestmark = pytest.mark.gpu
+
+
+def _run(spec, prec, fused, steps, mode="eager", cos=0.0, maxd=0.02, T=333.0, dt=0.001, efield=0.0, mirror=0.0, tune=None, chains=3, shard=None):
+    it = I.VVIntegrator(T, 10.0, 1.0, 40.0, dt, numNHChains=chains)
+    it.setMaxDrudeDistance(maxd)
+    it.setCosAcceleration(cos)
+    it.setElectricField(efield)
+    it.setMirrorLocation(mirror)
+    rnd = np.random.default_rng(1).standard_normal((4096, 4)).astype(np.float32)
+    ctx = I.Context(spec, it, precision=prec, force_provider="tether", random=rnd, tune={"fused": int(fused), **(tune or {})}, shard=shard)
+    try:
+        if mode == "eager":
+            it.step(steps)
+        elif mode == "c-loop":
+            ctx.run_eager(steps)
+        else:
+            ctx.run_graph(steps, steps_per_graph=4)
+        active, launches = ctx.fused_status()
+        out = dict(posq=ctx.getPosq(), velm=ctx.getVelm(), corr=ctx.getPosqCorrection() if prec == "mixed" else None, nh=bytes(ctx.getNHState()),
+                   active=active, launches=launches, words=ctx.status_words())
+    finally:
+        ctx.close()
+    return out
+
+
+def _same(a, b, label):
+    for k in ("posq", "velm", "corr"):
+        if a[k] is None:
+            continue
+        assert np.array_equal(a[k].view(np.uint8), b[k].view(np.uint8)), f"{label}: {k} differs between the one-launch and the two-launch step"
+    assert a["nh"] == b["nh"], f"{label}: thermostat state differs"
+
+
+CASES = {
+    # name: (system factory, keyword arguments of _run)
+    "drude_il": (lambda: systems.drude_il(cells=(1, 1, 1), pairs_per_cell=40, seed=7), {}),
+    "drude_il_cos": (lambda: systems.drude_il(cells=(1, 1, 1), pairs_per_cell=40, seed=7), dict(cos=0.02)),
+    "drude_il_hbonds": (lambda: systems.constrain_hydrogens(systems.drude_il(cells=(1, 1, 1), pairs_per_cell=40, seed=7)), {}),
+    "drude_il_hbonds_cos": (lambda: systems.constrain_hydrogens(systems.drude_il(cells=(1, 1, 1), pairs_per_cell=40, seed=7)), dict(cos=0.02)),
+    "water": (lambda: systems.spce_water(300, seed=5), dict(maxd=0.0, T=300.0, dt=0.002)),
+    "rigid_water": (lambda: systems.rigid_water(systems.spce_water(300, seed=5)), dict(maxd=0.0, T=300.0, dt=0.002)),
+    "nondrude": (lambda: systems.nondrude_il(60, seed=3), dict(maxd=0.0)),
+}
+
+
+def _edl_kw(spec):
+    lz = float(spec.box[2])
+    return dict(mirror=lz / 2, efield=2.0 / lz * 2 * 1.602176634e-22)
+
+
+@pytest.mark.parametrize("prec", O.PRECISIONS)
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_one_launch_step_equals_two_launch_step(case, prec):
+    make, kw = CASES[case]
+    spec = make()
+    one = _run(spec, prec, True, 12, **kw)
+    two = _run(spec, prec, False, 12, **kw)
+    assert one["active"] and one["launches"] == 12, (one["active"], one["launches"])
+    assert not two["active"] and two["launches"] == 0
+    assert one["words"] == [0, 0, 0, 0] and two["words"] == [0, 0, 0, 0]
+    _same(one, two, f"{case}/{prec}")
+
+
+@pytest.mark.parametrize("prec", O.PRECISIONS)
+@pytest.mark.parametrize("hbonds", [False, True])
+def test_one_launch_step_electrode_slab(prec, hbonds):
+    """Langevin subset + field + image mirror in the one-launch step (BASELINE C5's stage sets, +- HBonds)."""
+    spec = systems.edl_slab(num_ion_pairs=20, num_electrode=60, seed=9)
+    if hbonds:
+        spec = systems.constrain_hydrogens(spec)
+    kw = _edl_kw(spec)
+    one = _run(spec, prec, True, 10, **kw)
+    two = _run(spec, prec, False, 10, **kw)
+    assert one["active"] and one["launches"] == 10
+    _same(one, two, f"edl/{prec}/hbonds={hbonds}")
+
+
+@pytest.mark.parametrize("mode", ["c-loop", "graph"])
+@pytest.mark.parametrize("case", ["drude_il", "drude_il_cos", "rigid_water"])
+def test_one_launch_step_replayed(case, mode):
+    """Enqueued from C and replayed from a hipGraph (the rendezvous number travels in the device-resident thermostat state, so a replay
+    needs nothing from the host): the same bits as the two-launch step and as the step-by-step host loop."""
+    make, kw = CASES[case]
+    spec = make()
+    ref = _run(spec, "mixed", False, 16, **kw)
+    one = _run(spec, "mixed", True, 16, mode=mode, **kw)
+    assert one["active"] and one["launches"] > 0
+    _same(one, ref, f"{case}/{mode}")
+
+
+def test_one_launch_step_compiled_at_run_time():
+    """A pair of stage sets outside the compiled list (a two-link chain) gets its fused kernel from hipRTC, bit-identical again."""
+    spec = systems.drude_il(cells=(1, 1, 1), pairs_per_cell=30, seed=11)
+    before = I.Context.rtc_stats()[0]
+    one = _run(spec, "mixed", True, 8, chains=2)
+    two = _run(spec, "mixed", False, 8, chains=2)
+    assert one["active"] and one["launches"] == 8
+    assert I.Context.rtc_stats()[0] > before
+    _same(one, two, "two-link chain")
+
+
+def test_the_plan_falls_back_where_one_launch_cannot_hold_the_step():
+    """More tiles than one pass of co-resident blocks holds, or a launch shape with several blocks per CU: two launches, same results as ever."""
+    spec = systems.drude_il(cells=(1, 1, 1), pairs_per_cell=40, seed=7)
+    out = _run(spec, "mixed", True, 4, tune={"block_threads": 64, "grid_cap_b": 4})
+    assert not out["active"] and out["launches"] == 0
+
+
+@pytest.mark.parametrize("cfg,cos,hbonds", [("C5", 0.0, False), ("C2", 0.0, False), ("C2", 0.0, True), ("C1", 0.0, False), ("C3", 0.0, False), ("C3", 0.02, False), ("C3", 0.0, True)])
+def test_one_launch_step_at_full_size(cfg, cos, hbonds):
+    """BASELINE's configurations at full size: one launch against two, bit for bit, from a graph."""
+    spec = systems.make_config(cfg, hbonds=hbonds)
+    kw = {}
+    if cfg in ("C1", "C2"):
+        kw = dict(maxd=0.0, T=300.0 if cfg == "C2" else 333.0, dt=0.002 if cfg == "C2" else 0.001)
+    if cfg == "C5":
+        kw = _edl_kw(spec)
+    one = _run(spec, "mixed", True, 8, mode="graph", cos=cos, **kw)
+    two = _run(spec, "mixed", False, 8, mode="graph", cos=cos, **kw)
+    assert one["active"] and one["launches"] > 0, f"{cfg}: the one-launch step was not taken"
+    assert one["words"] == [0, 0, 0, 0]
+    _same(one, two, f"full {cfg} cos={cos} hbonds={hbonds}")
+
+
+def test_one_eighth_shard_of_c4():
+    """The per-rank shape of BASELINE's 8-GPU series (C4 / 8 = 13 875 particles, 219 tile waves): rank 0's shard of the full box, stepped on
+    its own (no exchange: the sums are the shard's -- this tests the launch shape, not the physics), one launch = two."""
+    D = importlib.import_module("openmm-velocityverlet_amd").distributed
+    spec = systems.make_config("C3")
+    shard = D.shard_bounds(spec, 8)[0]
+    one = _run(spec, "mixed", True, 8, mode="graph", cos=0.02, shard=shard)
+    two = _run(spec, "mixed", False, 8, mode="graph", cos=0.02, shard=shard)
+    assert one["active"] and one["launches"] > 0
+    _same(one, two, "C4 / 8")
