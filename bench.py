@@ -20,9 +20,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # Algorithmic bytes per particle per launch come from the plan (vvhip_algorithmic_bytes; SURVEY.md §8d's accounting).  Mixed precision:
-# 94 (A) + 134 (B) = 228 B/atom/step where kernel A writes the kicked velocities back; 62 + 158 = 220 where it keeps them in registers
-# and kernel B repeats the kick from velm + force (the headline path: no extra forces, no in-kernel constraints).
+# 94 (A) + 134 (B) = 228 B/atom/step is SURVEY's two-pass floor (kernel A writes the kicked velocities back); 62 + 158 = 220 where A
+# keeps them in registers and kernel B repeats the kick from velm + force (the two-launch step of rounds 2-4); 158 for the ONE-launch
+# step of round 5 (vv_kernel_b<.., SFA>: velm, force and position read once, velm and position written once, 6 bytes of index).
 HBM_PEAK_GBS = 8000.0      # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured float4 copy)
+SURVEY_TWO_PASS_FLOOR = {"single": 132, "mixed": 228, "double": 228}      # SURVEY.md §8d (bytes / particle / step; the same for every round)
 
 
 def kernel_times(ctx, reps, batches):
@@ -35,6 +37,28 @@ def kernel_times(ctx, reps, batches):
       back to back  two HIP events around `reps` launches of the same kernel, median of `batches`: kinder to a kernel than its place
                     in the step (it finds its own output in the cache), reported beside the other for comparison only."""
     import statistics
+    import numpy as np
+    if ctx.fused_status()[0]:
+        # The one-launch step: ONE integrator kernel per step (an instance of vv_kernel_b that also runs kernel A's stages).  Its clock here is a
+        # graph replay of the integrator ALONE (forces resident and zeroed: thermostatted free flight, no provider kernel in the loop): one kernel
+        # per step back to back, so 1 / rate is the kernel from its predecessor's end to its own end -- what rocprofv3 reports for a kernel in a
+        # serialised replay.  Per-launch start / stop events are NOT used for this kernel: launches that carry them start their blocks so unevenly
+        # that the in-kernel rendezvous measures the events (11.3 us against 7.5 us in rocprofv3's trace of the replayed step, C3; the self-tuning
+        # wait climbs from 6 to its cap meanwhile: tools/probes/fused_eager_clock.py).
+        prov = ctx.force_provider
+        ctx.synchronize()
+        ctx.force.upload(np.zeros(3 * ctx.padded, dtype=np.int64))
+        ctx.force_provider = "static"
+        n = max(200, 20 * reps)
+        ctx.run_graph(200, 100); ctx.synchronize()
+        ts = []
+        for _ in range(max(3, batches)):
+            t0 = time.perf_counter(); ctx.run_graph(n, 100); ctx.synchronize(); ts.append((time.perf_counter() - t0) / n)
+        ctx.force_provider = prov
+        return {"A": None, "B": 1e3 * statistics.median(ts), "A_back_to_back": None, "B_back_to_back": None, "one_launch": True,
+                "how": "one-launch step: 1 / (steps per second) of a graph replay of the integrator alone (%d steps, median of %d; forces resident, no provider "
+                       "kernel) = the kernel from its predecessor's end to its own end; launches with start / stop events disturb its in-kernel rendezvous "
+                       "and are not used" % (n, max(3, batches))}
     ctx.run_eager(8)
     ctx.timing(4 * reps + 16)
     ctx.run_eager(reps)
@@ -44,7 +68,7 @@ def kernel_times(ctx, reps, batches):
     seq_b = r["ms_b"] / max(r["launches"][1], 1)
     bb_a = statistics.median(ctx.time_kernel(0, reps) for _ in range(batches))
     bb_b = statistics.median(ctx.time_kernel(1, reps) for _ in range(batches))
-    return {"A": seq_a, "B": seq_b, "A_back_to_back": bb_a, "B_back_to_back": bb_b,
+    return {"A": seq_a, "B": seq_b, "A_back_to_back": bb_a, "B_back_to_back": bb_b, "one_launch": False,
             "how": "in sequence: dispatch timestamps (hipExtLaunchKernel start/stop events) of every launch of %d eager steps; "
                    "back to back: two HIP events around %d launches of the same kernel, median of %d" % (reps, reps, batches)}
 
@@ -210,7 +234,7 @@ def rocprof_reference(key, algo, n_local):
     out = {"file": st.get("file"), "round": st.get("round"), "commit": st.get("commit"), "avg_launch_us": {}, "frac": {}}
     for k in "AB":
         cand = {n: v for n, v in st["kernels"].items() if n.startswith(f"vv_kernel_{k.lower()}<")}
-        if not cand:
+        if not cand or not algo.get(k):
             continue
         name = max(cand, key=lambda n: cand[n]["calls"])
         us = cand[name]["avg_ns"] * 1e-3
@@ -220,36 +244,46 @@ def rocprof_reference(key, algo, n_local):
 
 
 def roofline_block(ctx, n_local, times, rec=None, src=None, note=None, ref_key=None, live=None):
-    """roofline objects of kernel A, kernel B and the dominant one for context `ctx`.  Clock of `achieved` / `frac`: the rocprofv3 child
-    run of this very workload when there is one (`live` = its kernel_stats; the average duration of the most-launched variant of each
-    kernel, i.e. the kernel in its place in the replayed step), else the dispatch-timestamp clock of kernel_times.  All clocks are printed."""
+    """roofline objects of the integrator kernel(s) of context `ctx` -- kernel A and kernel B of the two-launch step, or the ONE kernel of
+    the one-launch step -- and the dominant one.  Clock of `achieved` / `frac`: the rocprofv3 child run of this very workload when there
+    is one (`live` = its kernel_stats; the average duration of the most-launched variant of each kernel, i.e. the kernel in its place in
+    the replayed step), else the dispatch-timestamp clock of kernel_times.  All clocks are printed."""
     algo = dict(zip("AB", ctx.algorithmic_bytes()))
+    kernels = [k for k in "AB" if algo[k] > 0 and times.get(k) is not None]
     prof_ms = {}
     if isinstance(live, dict):
-        for k in "AB":
+        for k in kernels:
             cand = {n: v for n, v in live.items() if n.startswith(f"vv_kernel_{k.lower()}<")}
             if cand:
                 prof_ms[k] = cand[max(cand, key=lambda n: cand[n]["calls"])]["avg_ns"] * 1e-6
-    clock = prof_ms if len(prof_ms) == 2 else times
+    from_profiler = len(prof_ms) == len(kernels)
+    clock = prof_ms if from_profiler else times
+    us = lambda v: None if v is None else round(v * 1e3, 3)
     per = {}
-    for k in "AB":
+    for k in kernels:
         by = algo[k] * n_local
         ach = by / (clock[k] * 1e-3) / 1e9
         per[k] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                   "traffic": rec.get(f"hbm_bytes_per_launch_{k}") if rec else None, "algorithmic_bytes_per_launch": by,
-                  "avg_launch_us": round(clock[k] * 1e3, 3), "avg_launch_us_dispatch_timestamps": round(times[k] * 1e3, 3),
-                  "avg_launch_us_back_to_back": round(times[k + "_back_to_back"] * 1e3, 3)}
-    dom = "B" if clock["B"] >= clock["A"] else "A"
+                  "avg_launch_us": us(clock[k]), "avg_launch_us_dispatch_timestamps": us(times[k]),
+                  "avg_launch_us_back_to_back": us(times.get(k + "_back_to_back"))}
+    dom = max(kernels, key=lambda k: clock[k])
+    one = bool(times.get("one_launch"))
     out = dict(per[dom])
-    out.update({"kernel": f"vv_kernel_{dom.lower()}", "traffic_source": src, "algorithmic_bytes_per_particle": algo,
-                "avg_launch_us": {"A": per["A"]["avg_launch_us"], "B": per["B"]["avg_launch_us"]},
-                "avg_launch_us_dispatch_timestamps": {"A": per["A"]["avg_launch_us_dispatch_timestamps"], "B": per["B"]["avg_launch_us_dispatch_timestamps"]},
-                "avg_launch_us_back_to_back": {"A": per["A"]["avg_launch_us_back_to_back"], "B": per["B"]["avg_launch_us_back_to_back"]},
+    name = {k: f"vv_kernel_{k.lower()}" for k in kernels}
+    if one:
+        name["B"] = "vv_kernel_b<.., SFA> (the one-launch step: kernel A's stages, in-kernel rendezvous, kernel B's stages)"
+    out.update({"kernel": name[dom], "traffic_source": src, "algorithmic_bytes_per_particle": algo,
+                "survey_two_pass_floor_bytes_per_particle": SURVEY_TWO_PASS_FLOOR.get(ctx.precision),
+                "launches_per_step": 1 if one else 2,
+                "avg_launch_us": {k: per[k]["avg_launch_us"] for k in kernels},
+                "avg_launch_us_dispatch_timestamps": {k: per[k]["avg_launch_us_dispatch_timestamps"] for k in kernels},
+                "avg_launch_us_back_to_back": {k: per[k]["avg_launch_us_back_to_back"] for k in kernels},
                 "launch_timing": ("avg_launch_us / achieved / frac: rocprofv3 --kernel-trace --stats of a child run of this workload (graph replay), started by "
-                                  "this bench run before it touched the GPU -- the kernel from its predecessor's end to its own end; " if len(prof_ms) == 2 else
+                                  "this bench run before it touched the GPU -- the kernel from its predecessor's end to its own end; " if from_profiler else
                                   "avg_launch_us / achieved / frac: dispatch timestamps (no rocprofv3 child run: %s); " % (live if isinstance(live, str) else "not requested"))
                                  + times["how"],
-                "per_kernel": {"vv_kernel_a": per["A"], "vv_kernel_b": per["B"]}})
+                "per_kernel": {f"vv_kernel_{k.lower()}": per[k] for k in kernels}})
     if ref_key:
         out["rocprofv3_cross_check"] = rocprof_reference(ref_key, algo, n_local)
     if note:
@@ -281,6 +315,7 @@ def main():
     ap.add_argument("--child", action="store_true", help="(internal) the run rocprofv3 wraps: headline measurement only, no secondary blocks")
     ap.add_argument("--headline-only", action="store_true", help="headline measurement only, no secondary blocks (what the counter passes of tools/profile_round.sh wrap: one variant of each kernel per run)")
     ap.add_argument("--no-rocprof", action="store_true", help="do not spawn the rocprofv3 child runs; roofline.frac then comes from the dispatch-timestamp clock")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip config.other_configs (C4, C5, C2, C1 under the driver's flags)")
     ap.add_argument("--hbonds", action="store_true", help="constraints solved in-kernel: HBonds (SHAKE) for the ionic liquids, rigid water (SETTLE) for C2; not the headline workload")
     args = ap.parse_args()
 
@@ -735,7 +770,64 @@ def main():
             ab = sum(ctx.algorithmic_bytes()) * n_local
             # the whole step (force provider + A + B) against the same roofline: algorithmic bytes of the integrator path / step time
             out["step"] = {"algorithmic_bytes_per_step": ab, "achieved": round(ab * steps_per_s / 1e9, 1), "unit": "GB/s",
-                           "frac": round(ab * steps_per_s / 1e9 / HBM_PEAK_GBS, 4), "ms_per_step": round(1e3 * elapsed / args.steps, 6)}
+                           "frac": round(ab * steps_per_s / 1e9 / HBM_PEAK_GBS, 4), "ms_per_step": round(1e3 * elapsed / args.steps, 6),
+                           # (the step's own algorithmic bytes fell from 220 to 158 per particle when the two launches became one: the
+                           # same step time against SURVEY's constant two-pass floor, for comparison across rounds)
+                           "frac_on_survey_two_pass_floor": round(SURVEY_TWO_PASS_FLOOR[args.precision] * n_local * steps_per_s / 1e9 / HBM_PEAK_GBS, 4)}
+
+    # ---- what the launches of this run were: the one-launch step or two launches, the self-tuned rendezvous wait, and whether any launch fell
+    # off the compiled / run-time compiled kernels onto the generic one (15-20 % slower) or any run-time compilation failed
+    if rank == 0:
+        H = pkg.vvhip
+        failed, stats = H.C.c_int64(0), (H.C.c_int64 * 3)()
+        secs = H.C.c_double(0)
+        H.lib.vvhip_rtc_failures(H.C.byref(failed)); H.lib.vvhip_rtc_stats(H.C.byref(stats), H.C.byref(secs))
+        one, nfused = ctx.fused_status()
+        out["config"]["step_launches"] = {
+            "integrator_launches_per_step": 1 if one else 2,
+            "what": ("one launch: kernel A's stages, an in-kernel rendezvous of the co-resident blocks, kernel B's stages (vv_kernel_b<.., SFA>)" if one else
+                     "two launches: kernel A (kick + sums), kernel B (thermostat + drift)") + "; + the synthetic force provider's launch",
+            "one_launch_step_launches": nfused, "rendezvous_wait_units_of_256_clocks": ctx.fused_wait_units() if one else None,
+            "generic_kernel_launches": {"A": ctx.generic_launches()[0][0], "B": ctx.generic_launches()[0][1]},
+            "rtc": {"kernels_compiled_at_run_time": int(stats[0]), "failed": int(failed.value), "compile_seconds": round(secs.value, 2)}}
+
+    # ---- every BASELINE configuration under the driver's flags (config.other_configs): one replay of a 20-step graph per timed region,
+    # median of 25 regions -- the protocol of the headline when K = 20 -- plus the long-run figure and the integrator kernel's duration
+    # (dispatch timestamps) against the roofline.  Secondary figures; the headline stays the configuration the metric is quoted on.
+    if world == 1 and rank == 0 and not use_dist and cfg == "C3" and args.forces == "tether" and not args.eager and not args.hbonds and not args.no_other_configs:
+        others = {}
+        for oc in ("C4", "C5", "C2", "C1"):
+            try:
+                spec_o = S.make_config("C3" if oc == "C4" else oc, synthetic=args.synthetic)
+                dt_o = 0.002 if oc == "C2" else 0.001
+                it_o = I.VVIntegrator(300.0 if oc == "C2" else 333.0, 10.0, 1.0, 40.0, dt_o)
+                if oc not in ("C1", "C2"):
+                    it_o.setMaxDrudeDistance(0.02)
+                if oc == "C4":
+                    it_o.setCosAcceleration(0.02)
+                if oc == "C5":
+                    lz_o = float(spec_o.box[2])
+                    it_o.setMirrorLocation(lz_o / 2)
+                    it_o.setElectricField(2.0 / lz_o * 2 * 1.602176634e-22)
+                ctx_o = I.Context(spec_o, it_o, precision=args.precision, force_provider="tether", device=local_rank)
+                ctx_o.run_graph(600, 100); ctx_o.synchronize()
+                sps_drv = driver_protocol(ctx_o)
+                sps_long = secondary(ctx_o, 4000)
+                t_o = kernel_times(ctx_o, 100, 3)
+                rb_o = roofline_block(ctx_o, spec_o.num_atoms, t_o)
+                ab_o = sum(ctx_o.algorithmic_bytes()) * spec_o.num_atoms
+                others[oc] = {"particles": int(spec_o.num_atoms), "steps_per_s_driver_flags": round(sps_drv, 1), "steps_per_s": round(sps_long, 1),
+                              "ns_per_day_driver_flags": round(sps_drv * dt_o * 1e3 * 0.0864, 1),
+                              "integrator_launches_per_step": rb_o["launches_per_step"], "kernel": rb_o["kernel"],
+                              "roofline": {"bound": "hbm", "frac": rb_o["frac"], "achieved": rb_o["achieved"], "unit": "GB/s", "avg_launch_us": rb_o["avg_launch_us"],
+                                           "algorithmic_bytes_per_particle": rb_o["algorithmic_bytes_per_particle"], "clock": t_o["how"]},
+                              "step": {"algorithmic_bytes_per_step": ab_o, "frac": round(ab_o * sps_long / 1e9 / HBM_PEAK_GBS, 4)},
+                              "generic_kernel_launches": sum(ctx_o.generic_launches()[0])}
+                ctx_o.close()
+            except Exception as e:                                   # noqa: BLE001 -- a secondary block must never break the bench line
+                others[oc] = f"skipped: {type(e).__name__}: {e}"
+        out["config"]["other_configs"] = {"protocol": "steps_per_s_driver_flags: one replay of a 20-step hipGraph per timed region, median of 25 regions (the headline's protocol "
+                                                      "under --steps 20 --warmup 5); steps_per_s: median of 3 regions of 4000 steps (100-step graphs)", **others}
 
     # ---- the bandwidth-bound regime of the same kernels: the C3 cell tiled 80x along z (8.88 M particles, ~2 GB working set), where
     # the HBM roofline is the real bound.  Secondary block (config.large_n); the headline stays the workload BASELINE.json names.

@@ -227,9 +227,10 @@ int check_exchange_health(vvhip_plan* p) {
     const unsigned int mb = __atomic_load_n(&p->h_status[0], __ATOMIC_RELAXED), ov = __atomic_load_n(&p->h_status[1], __ATOMIC_RELAXED);
     const unsigned int rv = __atomic_load_n(&p->h_status[2], __ATOMIC_RELAXED), cs = __atomic_load_n(&p->h_status[3], __ATOMIC_RELAXED);
     if (mb) return fail(p, VVHIP_ERR_EXCHANGE, "multi-GPU mailbox: a wait on the peers' thermostat totals timed out; this rank went on with incomplete sums, the run is void");
+    // (an unconverged constraint cluster is reported before the overflow it usually causes a step or two later)
+    if (cs) return fail(p, VVHIP_ERR_CONSTRAINT, "in-kernel constraints: a cluster reached the iteration cap without converging (a degenerate geometry, or a step that is too large); positions / velocities of that cluster are not within tolerance");
     if (ov) return fail(p, VVHIP_ERR_OVERFLOW, "a fixed-point accumulator overflowed (kinetic energy beyond 1024 x the thermostat target): the thermostat input is invalid");
     if (rv) return fail(p, VVHIP_ERR_RENDEZVOUS, "fused step: the blocks of the one-launch step did not meet within 0.2 s (not resident together: another process on the device?); the thermostat went on with incomplete sums, the run is void -- vvhip_debug_tune(plan, \"fused\", 0) selects the two-launch step");
-    if (cs) return fail(p, VVHIP_ERR_CONSTRAINT, "in-kernel constraints: a cluster reached the iteration cap without converging (a degenerate geometry, or a step that is too large); positions / velocities of that cluster are not within tolerance");
     return VVHIP_OK;
 }
 int hip_fail(vvhip_plan* p, hipError_t e, const char* what) {
@@ -620,7 +621,10 @@ bool fused_shape_ok(const vvhip_plan* p) {
 bool fused_state_ok(const vvhip_plan* p) {
     const vv::HostPlan& hp = p->hp;
     if (!p->fused || !hp.params.use_middle_scheme || !hp.has_nh || hp.params.num_nh_chains > 4 || hp.num_big != 0) return false;
-    if (hp.info.num_waves >= p->split_chain_waves || p->comm || p->mb_on) return false;
+    if (hp.info.num_waves >= p->split_chain_waves) return false;
+    // sharded runs: the xGMI mailbox exchanges the ranks' totals inside the thermostat wave, right behind the local rendezvous (one wait after
+    // the other, no launch in between); an RCCL all-reduce needs the kernel boundary, and ranks that share this device cannot all be resident
+    if ((p->comm && !use_mailbox(p)) || (p->mb_on && (!use_mailbox(p) || p->mb_shared_device))) return false;
     if (hp.params.cos_acceleration != 0 && (p->no_moments || hp.params.num_nh_chains > 4)) return false;
     if (p->mass_tab_a || !p->mass_tab_b || p->shake_mode == 0) return false;      // (comparison builds of the two-launch kernels)
     if (hp.per.enabled && p->periodic_kernels) return false;                      // the arithmetic layout belongs to the many-pass regime
@@ -629,7 +633,7 @@ bool fused_state_ok(const vvhip_plan* p) {
 int run_fused(vvhip_plan* p, uint32_t aflags, uint32_t bflags, uint32_t random_index, bool* taken) {
     *taken = false;
     if (!fused_state_ok(p)) return VVHIP_OK;
-    bflags |= vv::B_CHAIN | vv::B_MTAB;
+    bflags |= vv::B_CHAIN | vv::B_MTAB | (use_mailbox(p) ? vv::B_MAILBOX : 0u);
     // kernel and occupancy of this pair of stage sets on this launch shape: looked up once
     if (p->fused_checked_a != aflags || p->fused_checked_b != bflags || p->fused_checked_threads != p->block_threads || p->fused_checked_waves != p->hp.info.num_waves) {
         p->fused_checked_a = aflags; p->fused_checked_b = bflags; p->fused_checked_threads = p->block_threads; p->fused_checked_waves = p->hp.info.num_waves;
@@ -996,11 +1000,29 @@ static bool use_rekick(const vvhip_plan* p) {
 // in-kernel constraints kernel A reads the positions of the cluster MEMBERS (their share of the particles, rounded to whole bytes) and
 // both kernels read the cluster word and parameters (4 + 16 bytes per lane) wherever those come from memory, i.e. not in the
 // arithmetic layout, where they are pattern rows in LDS.
+// Does vvhip_step_middle take the one-launch step for this plan as it stands?  (The kernel itself is looked up at the first step; a pair
+// of stage sets already found wanting says so here.)
+static bool fused_active(const vvhip_plan* p) {
+    if (!p->bound || !p->hp.info.constraints_fused || !fused_state_ok(p) || (cos_on(p) && !use_moments(p))) return false;
+    return !(p->fused_checked_b != 0 && !p->fused_ok);
+}
+
 int vvhip_algorithmic_bytes(const vvhip_plan* p, int32_t* bytes_a, int32_t* bytes_b) {
     if (!p || !bytes_a || !bytes_b) return VVHIP_ERR_INVALID;
     const int v = p->hp.precision == VVHIP_SINGLE ? 16 : 32;                       // velm: mixed4
     const int x = p->hp.precision == VVHIP_SINGLE ? 16 : 32;                       // posq (+ posqCorrection in mixed mode; double4 in double mode)
     const int xr = p->hp.precision == VVHIP_DOUBLE ? 32 : 16;                      // posq alone
+    if (fused_active(p)) {
+        // the one-launch step: everything is read once and written once -- R velm, R force, R position, W velm, W position + 6 bytes of
+        // index; the cos perturbation and the constrained positions read nothing more (the positions are there), constraint clusters
+        // their word and parameters, a virtual site its word.  (The cos(kz) the kernel keeps for vvhip_set_params is a hand-off of this
+        // implementation, not counted: the figure stays a lower bound of what the step must move.)
+        *bytes_a = 0;
+        *bytes_b = v + 24 + x + v + x + 6;
+        if (shake_on(p)) *bytes_b += 20;
+        if (!p->hp.slot_vsite.empty()) *bytes_b += 8;
+        return VVHIP_OK;
+    }
     const bool per = p->hp.per.enabled && p->periodic_kernels;
     const bool per_a = per && (p->periodic_a || shake_on(p)), per_b = periodic_b(p);      // as run_a / run_b decide
     const int ia = per_a ? 0 : 6, ib = per_b ? 0 : 6;
@@ -1283,6 +1305,7 @@ int vvhip_status_words(vvhip_plan* p, int32_t words[4]) {
     return VVHIP_OK;
 }
 int vvhip_fused_status(vvhip_plan* p, int32_t* active, int64_t* launches, int32_t* wait_units) {
+    // (see fused_active)
     NEED_BOUND(p);
     if (launches) *launches = p->fused_launches;
     if (wait_units) {                  // where the self-tuning wait of the rendezvous stands (blocks: it lives in the device-resident state)
@@ -1294,13 +1317,7 @@ int vvhip_fused_status(vvhip_plan* p, int32_t* active, int64_t* launches, int32_
             *wait_units = (int32_t) d;
         }
     }
-    if (active) {
-        *active = 0;
-        if (p->hp.info.constraints_fused && fused_state_ok(p) && (!cos_on(p) || use_moments(p))) {
-            // (the kernel itself is looked up at the first step; a pair of stage sets already found wanting says so here)
-            *active = (p->fused_checked_b != 0 && !p->fused_ok) ? 0 : 1;
-        }
-    }
+    if (active) *active = fused_active(p) ? 1 : 0;
     return VVHIP_OK;
 }
 int vvhip_status_clear(vvhip_plan* p) {

@@ -385,6 +385,9 @@ hipError_t launch_fused(int precision, const KArgs& a, int block_threads, const 
         VV_TRY_FUSED(SF_B_MIDDLE_SETTLE, SF_A_MIDDLE_SETTLE)
         VV_TRY_FUSED(SF_B_EDL_SHAKE, SF_A_EDL_SHAKE)
         VV_TRY_FUSED(SF_B_COS_HW_MOM_F | B_SHAKE, SF_A_COS_MOM_SHAKE)
+        VV_TRY_FUSED(SF_B_MIDDLE_HW_MB, SF_A_MIDDLE)                 // sharded runs (xGMI mailbox behind the local rendezvous): C3, C4, water
+        VV_TRY_FUSED(SF_B_COS_HW_MOM_F | B_MAILBOX, SF_A_COS_MOM)
+        VV_TRY_FUSED(SF_B_MIDDLE_MB, SF_A_MIDDLE)
     }
 #undef VV_TRY_FUSED
 #undef VV_FUSED_ONE

@@ -36,17 +36,28 @@ def test_driver_flags_give_the_long_run_figure():
         assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "avg_launch_us", "avg_launch_us_dispatch_timestamps",
                 "avg_launch_us_back_to_back", "launch_timing"} <= set(r)
         # frac = algorithmic bytes of the dominant kernel / its launch duration / peak, by the clock launch_timing names
-        k = "B" if r["kernel"].endswith("_b") else "A"
+        k = "A" if r["kernel"] == "vv_kernel_a" else "B"      # (the one-launch step is an instance of kernel B)
         assert abs(r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"][k] * 1e-6) / 1e9 / r["peak"] - r["frac"]) < 2e-3
         assert r["traffic"] is None or (r["traffic_source"] and r["traffic_source"]["file"].startswith("profiles/"))
         assert 0 < line["step"]["frac"] < r["frac"] < 1
         wc = line["config"]["with_constraints"]
-        assert wc["roofline"]["kernel"] in ("vv_kernel_a", "vv_kernel_b") and 0 < wc["step"]["frac"] < 1
+        assert wc["roofline"]["kernel"].startswith("vv_kernel_") and 0 < wc["step"]["frac"] < 1
+        # round 5: what the step's launches were, and every other BASELINE configuration under the driver's flags
+        sl = line["config"]["step_launches"]
+        assert sl["integrator_launches_per_step"] == r["launches_per_step"] and sl["integrator_launches_per_step"] in (1, 2)
+        assert sl["rtc"]["failed"] == 0 and sl["generic_kernel_launches"] == {"A": 0, "B": 0}
+        oc = line["config"]["other_configs"]
+        for name in ("C4", "C5", "C2", "C1"):
+            assert isinstance(oc[name], dict), oc[name]
+            assert oc[name]["steps_per_s_driver_flags"] > 1000 and oc[name]["steps_per_s"] > 1000 and 0 < oc[name]["roofline"]["frac"] < 1
+            assert oc[name]["generic_kernel_launches"] == 0
     import shutil
     if shutil.which("rocprofv3"):          # the live rocprofv3 child run is the clock of frac, and agrees with the dispatch timestamps of kernel B
         r = short["roofline"]
         assert r["launch_timing"].startswith("avg_launch_us / achieved / frac: rocprofv3"), r["launch_timing"]
-        assert abs(r["avg_launch_us"]["B"] / r["avg_launch_us_dispatch_timestamps"]["B"] - 1) < 0.15
+        # (two-launch step: dispatch timestamps of eager steps; one-launch step: the integrator-alone replay, whose kernel follows 7 MB of its own
+        # dirty lines instead of the provider's 2.7 MB -- ~1 us more boundary)
+        assert abs(r["avg_launch_us"]["B"] / r["avg_launch_us_dispatch_timestamps"]["B"] - 1) < (0.25 if r["launches_per_step"] == 1 else 0.15)
 
 
 @pytest.mark.gpu

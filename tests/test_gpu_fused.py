@@ -149,3 +149,29 @@ def test_one_eighth_shard_of_c4():
     two = _run(spec, "mixed", False, 8, mode="graph", cos=0.02, shard=shard)
     assert one["active"] and one["launches"] > 0
     _same(one, two, "C4 / 8")
+
+
+@pytest.mark.parametrize("cos", [0.0, 0.02])
+def test_one_launch_step_next_to_the_mailbox(cos):
+    """A sharded plan whose exchange is the xGMI mailbox (one rank of one here: its own box is the only peer) keeps the one-launch step -- the
+    thermostat wave exchanges the ranks' totals right behind the local rendezvous -- and lands on the two-launch step's bits."""
+    D = importlib.import_module("openmm-velocityverlet_amd").distributed
+    spec = systems.make_config("C3", 0.08)
+    outs = []
+    for fused in (True, False):
+        it = I.VVIntegrator(333.0, 10.0, 1.0, 40.0, 0.001)
+        it.setMaxDrudeDistance(0.02)
+        it.setCosAcceleration(cos)
+        ctx = I.Context(spec, it, precision="mixed", force_provider="tether", shard=D.shard_bounds(spec, 2)[0], tune={"fused": int(fused)})
+        try:
+            ctx.mailbox_connect(ctx.mailbox_create(1, 0))
+            it.step(6)
+            ctx.run_graph(8, 4)
+            ctx.synchronize()
+            assert ctx.mailbox_status() == (True, False)
+            assert ctx.fused_status()[0] == fused and (ctx.fused_status()[1] > 0) == fused
+            outs.append((ctx.getPosq(), ctx.getVelm(), bytes(ctx.getNHState())))
+        finally:
+            ctx.close()
+    assert np.array_equal(outs[0][0].view(np.uint8), outs[1][0].view(np.uint8)) and np.array_equal(outs[0][1].view(np.uint8), outs[1][1].view(np.uint8))
+    assert outs[0][2] == outs[1][2]

@@ -127,3 +127,44 @@ def test_mass_tables_follow_velm():
         assert not np.array_equal(a.getVelocities(), b.getVelocities())
     finally:
         a.close(); b.close()
+
+
+def test_a_solver_that_hits_its_iteration_cap_says_so():
+    """A rigid triangle with an angle of ~1.2 degrees between two of its bonds: the coloured Gauss-Seidel sweeps of the general clusters
+    (vv_device.inc: general_positions / general_velocities) do not converge it in their 150 rounds -- found by the random-topology fuzz of
+    round 4, where GPU and oracle stopped at the cap alike and nobody was told.  Now the kernels raise sticky word [3] and the host gets
+    VVHIP_ERR_CONSTRAINT from the next synchronisation; a well-conditioned copy of the same system leaves the word alone."""
+    def build(angle_deg):
+        spec = S.spce_water(12, seed=21)
+        x = spec.positions
+        u = np.array([1.0, 0.0, 0.0])
+        th = np.deg2rad(angle_deg)
+        x[1] = x[0] + 0.10 * u
+        x[2] = x[0] + 0.13 * np.array([np.cos(th), np.sin(th), 0.0])          # scalene: not a SETTLE molecule, a general cluster of three constraints
+        cons = np.array([[0, 1], [0, 2], [1, 2]], dtype=np.int32)
+        spec.constraints = cons
+        spec.constraint_distances = np.linalg.norm(x[cons[:, 0]] - x[cons[:, 1]], axis=1)
+        return spec
+
+    for angle, expect in ((60.0, 0), (1.2, 1)):
+        spec = build(angle)
+        it = I.VVIntegrator(300.0, 10.0, 1.0, 40.0, 0.002)
+        ctx = I.Context(spec, it, precision="mixed", force_provider="tether")
+        try:
+            assert ctx.info.constraints_fused and ctx.info.num_general_constraints == 3
+            raised = None
+            try:
+                it.step(2)
+                ctx.synchronize()
+            except H.VVHipError as e:
+                raised = e
+            words = ctx.status_words()
+            assert words[3] == expect, (angle, words)
+            if expect:
+                assert raised is not None and raised.code == H.ERR_CONSTRAINT and "iteration cap" in raised.message
+                ctx.status_clear()
+                assert ctx.status_words() == [0, 0, 0, 0]
+            else:
+                assert raised is None
+        finally:
+            ctx.close()
