@@ -388,6 +388,7 @@ hipError_t launch_fused(int precision, const KArgs& a, int block_threads, const 
         VV_TRY_FUSED(SF_B_MIDDLE_HW_MB, SF_A_MIDDLE)                 // sharded runs (xGMI mailbox behind the local rendezvous): C3, C4, water
         VV_TRY_FUSED(SF_B_COS_HW_MOM_F | B_MAILBOX, SF_A_COS_MOM)
         VV_TRY_FUSED(SF_B_MIDDLE_MB, SF_A_MIDDLE)
+        VV_TRY_FUSED(SF_B_MIDDLE_HW_SHAKE_MB, SF_A_MIDDLE_SHAKE)
     }
 #undef VV_TRY_FUSED
 #undef VV_FUSED_ONE

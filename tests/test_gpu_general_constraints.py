@@ -164,7 +164,15 @@ def test_random_constraint_graphs(seed):
         if osys.general is not None:
             assert info.num_general_constraints == len(spec.constraints) > 0
         osys.step(8)
-        it.step(8)
+        # (a random topology now and then holds a cluster that the sweeps leave at their cap of 150 rounds -- on the GPU and in the oracle alike,
+        # seed 4007 of this range -- still inside the tolerance asserted below: since round 5 the kernels SAY so, tests/test_gpu_status.py)
+        try:
+            it.step(8)
+            ctx.synchronize()
+        except H.VVHipError as e:
+            assert e.code == H.ERR_CONSTRAINT, e
+            assert ctx.status_words()[3] == 1
+            ctx.status_clear()
         x_o, x_g = osys.positions(), ctx.getPositions()
         v_o, v_g = osys.velm[:, :3].astype(np.float64), ctx.getVelocities()
         massive = np.asarray(spec.masses) != 0
