@@ -97,11 +97,11 @@ struct vvhip_plan {
     // without sources loads the array whenever it is dirty -- the reference's behaviour to the bit, quirk included.
     bool fextra_virtual = false;
     bool fextra_external = false;  // the host asked for the pointer (vvhip_force_extra) and may write to it: never assume zeros
-    bool no_moments = false;       // VVHIP_NO_MOMENTS=1: keep the three-launch cos sequence (comparison runs)
-    // with an arithmetic work-item layout (HostPlan::per) the kernels compute particle indices instead of loading slot words (VVHIP_PERIODIC_K=0:
+    bool no_moments = false;       // test hook "no_moments": keep the three-launch cos sequence (comparison runs)
+    // with an arithmetic work-item layout (HostPlan::per) the kernels compute particle indices instead of loading slot words (test hook "periodic_kernels" = 0:
     // comparison runs).  Kernel A: no slot traffic (1.13 -> 1.0 x the algorithmic bytes) and the next tile's loads in flight during this tile's
     // arithmetic: 133 vs 138 us in sequence at 8.9 M particles (round 2 without the second tile in flight: 113.6 vs 115.7 back to back);
-    // VVHIP_PERIODIC_A=0 switches it off
+    // test hook "periodic_a" = 0 switches it off
     bool periodic_kernels = true, periodic_a = true, periodic_b = true;
     int shake_mode = 1;            // hydrogen-type constraint clusters: 1 = all constraints of a cluster at once (direct velocity solve, coupled Newton
                                    // for positions), 0 = Gauss-Seidel sweeps by the central lane (OpenMM's iteration; generic kernels) -- VVHIP_SHAKE_MODE
@@ -109,9 +109,10 @@ struct vvhip_plan {
     // the GPU drains, anything that was only ordered by the depth of the queue (a fill or copy on another stream, a host read without a
     // synchronisation) lands differently, and the trajectory changes.  tests/test_gpu_stalls.py compares stalled and unstalled runs bit for bit.
     long stall_us = 0, stall_period = 1, stall_count = 0;
-    bool acc_store = true;         // kernel A launches of <= 256 blocks store old + new into their accumulator slots instead of atomics (VVHIP_ACC_STORE=0: atomics)
+    bool acc_store = true;         // kernel A launches of <= 256 blocks store old + new into their accumulator slots instead of atomics (test hook "acc_store" = 0: atomics)
     long long generic_launches[2] = {0, 0};   // kernel A / B launches of this plan (captured ones count once) that ran the generic kernel
     uint32_t generic_flags[2] = {0, 0};       // ... and the last stage set that did (vvhip_generic_launches)
+    std::vector<uint32_t> generic_seen[2];    // every stage set that did (VVHIP_WARN_GENERIC prints each once)
     bool rekick = true;            // fused middle step: kick repeated in kernel B instead of a velm store in kernel A (use_rekick)
     // One launch per step (vv_device.inc: "fused step"): kernels A and B of the middle scheme as one launch of co-resident blocks around an
     // in-kernel rendezvous.  `fused` = allowed (vvhip_debug_tune "fused": A/B comparisons and the bit-for-bit tests switch it off);
@@ -143,7 +144,7 @@ struct vvhip_plan {
     void* d_comv = nullptr;        // per-segment COM velocities handed from kernel A to kernel B
     double* d_slot_m = nullptr;    // static per-lane RECIP(velm.w) (vv_args.hpp: A_MTAB), filled on the device from velm.w
     double* d_slot_f = nullptr;    // static per-lane Drude-pair mass fraction (A_MTAB / B_MTAB)
-    bool mass_tab_a = false, mass_tab_b = true;   // kernel A / B launches read the tables (defaults follow the build; VVHIP_MTAB_A / VVHIP_MTAB_B override: comparison runs)
+    bool mass_tab_a = false, mass_tab_b = true;   // kernel A / B launches read the tables (defaults follow the build; test hooks "mass_tab_a" / "mass_tab_b" override: comparison runs)
     bool mass_tab_valid = false;   // tables match the bound velm.w (vvhip_bind / vvhip_masses_changed reset it)
     double* d_seg_mass = nullptr;  // static (mass, 1/mass) per COM segment
     int* d_seg_base = nullptr;     // per wave: COM segments in the waves before it
@@ -195,7 +196,7 @@ struct vvhip_plan {
     // and in vvhip_synchronize / vvhip_status.
     unsigned int* h_status = nullptr;
     unsigned int* d_status = nullptr;             // the same words as the device sees them
-    bool launch_shape_forced = false;             // VVHIP_BLOCK given: keep it at bind
+    bool launch_shape_forced = false;             // a test hook fixed the launch shape ("block_threads", "grid_cap_a / b"): keep it at bind
     int num_cus = 256;                            // hipDeviceProp_t::multiProcessorCount of the bound device
     vv::ChainLaneBlock* d_lane_const = nullptr;   // [3] chain constants per temperature group (kernel B's thermostat wave)
     vv::ChainLaneBlock lane_const_host[VVHIP_NUM_TG] = {};
@@ -516,7 +517,10 @@ static inline void debug_stall(vvhip_plan* p) {
 // plan (vvhip_generic_launches); VVHIP_WARN_GENERIC=1 also prints one line per plan, kernel and stage set.
 void note_generic_launch(vvhip_plan* p, int kernel, uint32_t flags) {
     p->generic_launches[kernel]++;
-    const bool seen = p->generic_flags[kernel] == flags;
+    // (two stage sets that alternate -- a classic step's halves -- would print on every launch if only the last one were remembered)
+    bool seen = false;
+    for (uint32_t f : p->generic_seen[kernel]) seen = seen || f == flags;
+    if (!seen && p->generic_seen[kernel].size() < 64) p->generic_seen[kernel].push_back(flags);
     p->generic_flags[kernel] = flags;
     static const bool warn = std::getenv("VVHIP_WARN_GENERIC") != nullptr;
     if (warn && !seen) std::fprintf(stderr, "vvhip: kernel %c runs stage set 0x%x on the generic kernel (no compiled specialisation)\n", kernel == 0 ? 'A' : 'B', flags);
@@ -985,7 +989,7 @@ int vvhip_step_middle_phases(const vvhip_plan* p) {
 // repeats the kick from velm + force (vv_args.hpp: A_NOSTORE / B_KICK).  Needs what A adds to the velocities beyond the plain
 // kick to be absent or cheap to repeat: no Langevin subset and no field (kernel B repeats the cos force from the cached cos(kz), in
 // the two-launch moment form only), no in-kernel velocity constraints; and a thermostat, i.e. the A -> B pair of one step
-// (VVHIP_REKICK=0 switches it off: comparison runs).
+// (test hook "rekick" = 0 switches it off: comparison runs).
 static bool use_rekick(const vvhip_plan* p) {
     const uint32_t ex = extra_flags(p);
     const bool extra_ok = ex == 0 || (ex == vv::A_COS && use_moments(p));
@@ -1189,6 +1193,7 @@ int vvhip_middle_finish(vvhip_plan* p) {
     NEED_BOUND(p);
     uint32_t f = vv::B_POS3;
     if (p->hp.params.max_drude_distance > 0 && p->hp.has_pairs) f |= vv::B_HARDWALL;
+    if (!p->hp.slot_vsite.empty()) f |= vv::B_VSITE;      // sites described to the plan follow EVERY position update (HOST:203-214): also on the split path
     return run_b(p, f);
 }
 int vvhip_vv_half_kick(vvhip_plan* p, int update_pos_delta) {
@@ -1199,6 +1204,7 @@ int vvhip_vv_positions(vvhip_plan* p) {
     NEED_BOUND(p);
     uint32_t f = vv::B_VV_POS;
     if (p->hp.params.max_drude_distance > 0 && p->hp.has_pairs) f |= vv::B_HARDWALL;
+    if (!p->hp.slot_vsite.empty()) f |= vv::B_VSITE;      // (as vvhip_middle_finish)
     return run_b(p, f);
 }
 int vvhip_scale_velocity(vvhip_plan* p) {                  // HOST:670-754 without the download/upload
@@ -1341,8 +1347,10 @@ int vvhip_synth_tether_force(vvhip_plan* p, const void* site, double k_tether, d
     NEED_BOUND(p);
     if (!site) return VVHIP_ERR_INVALID;
     ScopedTimer t(p, T_OTHER, true);
+    // (instrumented build: the provider stamps its waves only while vvhip_debug_step_spans numbers the launches -- its grid is not capped like the
+    // kernels', and rows beyond the span buffer's 4096 per launch would be written past its end)
     vv::TetherArgs ta{p->buf.posq, site, p->buf.velm, (long long*) p->buf.force, p->d_slots,
-                      p->hp.padded_num_atoms, p->hp.info.num_waves, k_tether, k_drude, p->d_dbg_span, p->dbg_parity, 0};
+                      p->hp.padded_num_atoms, p->hp.info.num_waves, k_tether, k_drude, p->dbg_seq >= 0 ? p->d_dbg_span : nullptr, p->dbg_parity, 0};
     if (p->dbg_seq >= 0) ta.dbg_parity = p->dbg_seq++ % 6;       // vvhip_debug_step_spans: every launch of the sequence stamps rows of its own
     HIP_TRY(p, vv::launch_tether(p->hp.precision, ta, p->block_threads, p->stream, t.e0, t.e1));
     return VVHIP_OK;
@@ -1724,6 +1732,11 @@ int vvhip_mailbox_connect(vvhip_plan* p, const void* handles) {
     NEED_BOUND(p);
     if (!p->mb_local || !handles) return fail(p, VVHIP_ERR_INVALID, "vvhip_mailbox_create has not been called");
     std::vector<unsigned long long*> peers((size_t) p->mb_ranks, nullptr);
+    p->mb_shared_device = false;       // (a second connect must not count the first one's ranks again)
+    p->mb_device_ranks = 1;
+    for (void* m : p->mb_opened) (void) hipIpcCloseMemHandle(m);
+    p->mb_opened.clear();
+    if (p->d_mb_peers) { (void) hipFree(p->d_mb_peers); p->d_mb_peers = nullptr; }
     for (int r = 0; r < p->mb_ranks; r++) {
         if (r == p->mb_rank) { peers[r] = p->mb_local; continue; }
         hipIpcMemHandle_t h;

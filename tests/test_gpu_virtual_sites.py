@@ -259,3 +259,26 @@ def test_sites_that_cannot_be_placed_are_refused_by_this_host():
     it = I.VVIntegrator(300.0, 10.0, 1.0, 40.0, 0.001)
     with pytest.raises(H.VVHipError, match="virtual sites cannot be placed"):
         I.Context(spec, it, precision="mixed", force_provider="tether")
+
+
+def test_sites_follow_the_position_update_of_the_split_entry_points_too():
+    """The per-KernelImpl entry points (vvhip_middle_finish behind OpenMM's constraint solver; run_eager_unfused drives them in the reference's
+    order) place the plan's sites with the same stage as the fused step (round-4 advisor: they used to leave the sites where they were)."""
+    spec = systems.add_virtual_sites(systems.spce_water(40, seed=3), kinds=(1,))
+    outs = []
+    for split in (False, True):
+        it = I.VVIntegrator(300.0, 10.0, 1.0, 40.0, 0.001)
+        ctx = I.Context(spec, it, precision="mixed", force_provider="tether")
+        try:
+            assert ctx.info.num_virtual_sites == len(spec.virtual_sites) > 0
+            (ctx.run_eager_unfused if split else ctx.run_eager)(5)
+            ctx.synchronize()
+            outs.append(ctx.getPositions())
+        finally:
+            ctx.close()
+    sites = [s[0] for s in spec.virtual_sites]
+    assert np.abs(outs[0] - outs[1]).max() < 1e-12                      # the two paths agree (sums in another order: rounding level)
+    x = outs[1]
+    for site, kind, parents, prm in spec.virtual_sites[:8]:            # ... and the sites sit where their definition puts them
+        want = systems.virtual_site_position(kind, prm, *[x[q] for q in parents])
+        assert np.abs(x[site] - want).max() < 1e-6
