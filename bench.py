@@ -551,6 +551,28 @@ def main():
         if use_dist:
             stepper = D.ShardedStepper(ctx)
             dist_mode = "python"
+    # ---- first contact (N > 1): what every rank sees of its device, its peers and the chosen exchange, on stderr BEFORE anything is timed; ranks
+    # that disagree end the run with that report and a non-zero exit code instead of a hang or a wrong number
+    if use_dist:
+        H_ = pkg.vvhip
+        peer = None
+        if world > 1 and not args.share_device:
+            peer = []
+            for other in range(world):
+                can = H_.C.c_int32(0)
+                peer.append(other == local_rank or (H_.lib.vvhip_peer_access(local_rank, other, H_.C.byref(can)) == 0 and bool(can.value)))
+        try:
+            rccl_n = ctx.comm_count()
+        except Exception:                                        # noqa: BLE001
+            rccl_n = 0
+        rec = {"device": local_rank, "device_name": torch.cuda.get_device_name(local_rank), "peer_access": peer, "rccl_ranks": rccl_n, "exchange": dist_mode,
+               "mailbox_trial": exchange_log.get("mailbox"), "world": world, "share_device": bool(args.share_device)}
+        ok_fc, text_fc = D.first_contact_report(rec)
+        if rank == 0 or not ok_fc:
+            sys.stderr.write(f"[rank {rank}] first-contact report\n{text_fc}\n")
+        exchange_log["first_contact"] = "all ranks agree" if ok_fc else text_fc.splitlines()[-1]
+        if not ok_fc:
+            raise SystemExit(3)
     use_graph = (not use_dist and not args.eager) or dist_mode in ("graph", "mailbox")
     # The graph that is replayed holds min(--steps-per-graph, K rounded down to even) steps, so that K = 20 (the driver's flags)
     # is one replay of a 20-step graph and K = 20000 is 200 replays of a 100-step graph; a remainder (K odd, or not a multiple)
@@ -905,21 +927,20 @@ def main():
                             "KE download / host chain / upload per step (oracle/ref_gpu_driver.cpp); same workload and force provider"}
         except Exception as e:                                   # noqa: BLE001 -- a baseline must never break the bench line
             sys.stderr.write(f"reference-kernel baseline skipped: {e}\n")
-    # ---- N > 1: the same sharding on the box where it pays (C3 tiled along z, config.large_n_sharded): at 111 000 particles a step is
-    # latency bound per rank and sharding cannot win; the second series shows the bandwidth-bound regime next to it.  Same exchange
-    # mechanism as the headline run; every stage is agreed between the ranks, a failure anywhere skips the block on all of them.
-    if use_dist and cfg == "C3" and args.large_n != "none" and not args.hbonds:
+    # ---- N > 1: further series next to the headline, with the headline's exchange mechanism; every stage is agreed between the ranks, a
+    # failure anywhere skips the block on all of them (no collective inside a try block):
+    #   config.c4_sharded        BASELINE.json's configs[3]: the same box WITH the cos perturbation (the configuration the 1/2/4/8 series is named
+    #                            for; 10 exchanged totals per step instead of 3), timed like the headline (K steps, graph replay where the exchange allows);
+    #   config.large_n_sharded   the C3 cell tiled along z, the regime in which sharding pays (at 111 000 particles a step is latency bound per rank).
+    def sharded_series(label, spec_l, it_l, n_timed, g_l, note):
         blk, ctx_l, ok = {"workload": None}, None, True
-        dbg = (lambda m: sys.stderr.write(f"[rank {rank}] large-N sharded block: {m}\n")) if os.environ.get("VVHIP_BENCH_DEBUG") else (lambda m: None)
+        dbg = (lambda m: sys.stderr.write(f"[rank {rank}] {label}: {m}\n")) if os.environ.get("VVHIP_BENCH_DEBUG") else (lambda m: None)
         try:
-            spec_l = S.make_config("C3", float(args.large_n[3:]), synthetic=args.synthetic)
             bounds_l = D.shard_bounds(spec_l, world)
-            it_l = I.VVIntegrator(333.0, 10.0, 1.0, 40.0, dt)
-            it_l.setMaxDrudeDistance(0.02)
             ctx_l = I.Context(spec_l, it_l, precision=args.precision, force_provider=args.forces, shard=bounds_l[rank], device=local_rank,
                               stream=torch.cuda.current_stream().cuda_stream if dist_mode == "python" else None)
         except Exception as e:                                   # noqa: BLE001
-            sys.stderr.write(f"[rank {rank}] large-N sharded block: set-up failed ({e})\n")
+            sys.stderr.write(f"[rank {rank}] {label}: set-up failed ({e})\n")
             ok = False
         dbg("context built")
         ok = agree(ok)
@@ -931,7 +952,7 @@ def main():
                 dist.all_gather(allh, mine)
                 ctx_l.mailbox_connect(b"".join(bytes(h.cpu().numpy().tobytes()) for h in allh))
             except Exception as e:                               # noqa: BLE001
-                sys.stderr.write(f"[rank {rank}] large-N sharded block: mailbox set-up failed ({e})\n")
+                sys.stderr.write(f"[rank {rank}] {label}: mailbox set-up failed ({e})\n")
                 ok = False
             ok = agree(ok)
         elif ok and mode_l in ("eager", "graph"):
@@ -942,13 +963,12 @@ def main():
                 dist.broadcast(idt, src=0)
                 ctx_l.comm_init(bytes(idt.cpu().numpy().tobytes()), world, rank)
             except Exception as e:                               # noqa: BLE001
-                sys.stderr.write(f"[rank {rank}] large-N sharded block: RCCL set-up failed ({e})\n")
+                sys.stderr.write(f"[rank {rank}] {label}: RCCL set-up failed ({e})\n")
                 ok = False
             ok = agree(ok)
         if ok:
             try:
                 st_l = D.ShardedStepper(ctx_l) if mode_l == "python" else None
-                g_l = 10
 
                 def run_l(n):
                     if st_l is not None:
@@ -964,33 +984,53 @@ def main():
                     raise RuntimeError("a mailbox wait ran out during the warm-up")
                 dbg("warm-up done")
             except Exception as e:                               # noqa: BLE001
-                sys.stderr.write(f"[rank {rank}] large-N sharded block: warm-up failed ({e})\n")
+                sys.stderr.write(f"[rank {rank}] {label}: warm-up failed ({e})\n")
                 ok = False
-            ok = agree(ok)                                       # (also the barrier in front of the timed run; no collective inside a try block)
+            ok = agree(ok)                                       # (also the barrier in front of the timed run)
             el_l = 0.0
             if ok:
                 try:
                     t0 = time.perf_counter()
-                    run_l(4 * g_l)
+                    run_l(n_timed)
                     ctx_l.synchronize(); torch.cuda.synchronize()
                     el_l = time.perf_counter() - t0
                 except Exception as e:                           # noqa: BLE001
-                    sys.stderr.write(f"[rank {rank}] large-N sharded block: run failed ({e})\n")
+                    sys.stderr.write(f"[rank {rank}] {label}: run failed ({e})\n")
                     ok = False
             ok = agree(ok)
             if ok:
                 el_l = slowest(el_l)
                 nl = spec_l.num_atoms
-                blk = {"workload": f"{args.large_n}: {nl} particles (the C3 cell tiled along z), {bounds_l[rank][1] - bounds_l[rank][0]} on rank 0",
-                       "steps_per_s": round(4 * g_l / el_l, 1), "atom_steps_per_s": round(4 * g_l / el_l * nl, 1), "n_gpus": world, "exchange": mode_l,
-                       "scaling": "strong", "note": "second series of a scaling run: the regime in which sharding pays; compare with config.large_n of the N = 1 line"}
-        if rank == 0:
-            out["config"]["large_n_sharded"] = blk if ok else "skipped (see stderr)"
+                blk = {"workload": f"{note}: {nl} particles, {bounds_l[rank][1] - bounds_l[rank][0]} on rank 0",
+                       "steps_per_s": round(n_timed / el_l, 1), "atom_steps_per_s": round(n_timed / el_l * nl, 1), "n_gpus": world, "exchange": mode_l,
+                       "steps": n_timed, "launch": f"replays of a {g_l}-step hipGraph" if mode_l in ("mailbox", "graph") else "host-launched per step",
+                       "integrator_launches_per_step": 1 if ctx_l.fused_status()[0] else 2, "scaling": "strong"}
         if ctx_l is not None:
             try:
                 ctx_l.close()
             except Exception:                                    # noqa: BLE001
                 pass
+        return blk if ok else "skipped (see stderr)"
+
+    if use_dist and cfg == "C3" and not args.hbonds:
+        it_4 = I.VVIntegrator(333.0, 10.0, 1.0, 40.0, dt)
+        it_4.setMaxDrudeDistance(0.02)
+        it_4.setCosAcceleration(0.02)
+        k4 = max(spg, args.steps - args.steps % spg)
+        blk4 = sharded_series("C4 sharded block", spec, it_4, k4, spg, "C4: the headline box with cos acceleration 0.02 nm/ps^2 (BASELINE.json configs[3])")
+        if rank == 0:
+            if isinstance(blk4, dict):
+                blk4["note"] = "second series of a scaling run: the configuration BASELINE.json names for the 1/2/4/8 curve; compare with config.other_configs.C4 of the N = 1 line"
+            out["config"]["c4_sharded"] = blk4
+    if use_dist and cfg == "C3" and args.large_n != "none" and not args.hbonds:
+        it_l = I.VVIntegrator(333.0, 10.0, 1.0, 40.0, dt)
+        it_l.setMaxDrudeDistance(0.02)
+        blkl = sharded_series("large-N sharded block", S.make_config("C3", float(args.large_n[3:]), synthetic=args.synthetic), it_l, 40, 10,
+                              f"{args.large_n}: the C3 cell tiled along z")
+        if rank == 0:
+            if isinstance(blkl, dict):
+                blkl["note"] = "third series of a scaling run: the regime in which sharding pays; compare with config.large_n of the N = 1 line"
+            out["config"]["large_n_sharded"] = blkl
     ctx.close()
     if use_dist:
         dist.destroy_process_group()

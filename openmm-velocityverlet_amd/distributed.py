@@ -34,6 +34,54 @@ def shard_bounds(system, world_size: int) -> List[Tuple[int, int]]:
     return [(cuts[i], cuts[i + 1]) for i in range(world_size)]
 
 
+def first_contact_report(local: dict, group=None):
+    """What every rank of a multi-GPU run knows about its own set-up, gathered on all ranks and checked for agreement BEFORE the first
+    timed region (round-4 review, "first real multi-GPU contact": the in-core RCCL all-reduce at world > 1 and the hipIpc mailbox
+    ACROSS devices have never run in the build environment, so the first run that does must at least fail with a readable report).
+    `local` = {"device": int, "device_name": str, "peer_access": [bool per rank's device] or None, "rccl_ranks": int, "exchange": chosen
+    mechanism, "mailbox_trial": str or None, "world": int, ...}.  Returns (ok, text): ok = every rank chose the same exchange, no two ranks
+    sit on one device (unless they say they share it on purpose), every communicator counts the whole world, every device reaches every
+    other where the mailbox is used; text = one line per rank + the complaints.  Works on any backend (all_gather_object)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    every = [None] * world
+    if world > 1:
+        dist.all_gather_object(every, local, group=group)
+    else:
+        every = [local]
+    return check_first_contact(every)
+
+
+def check_first_contact(every: List[dict]):
+    """The agreement rules of first_contact_report on the gathered per-rank records (host-only: unit-tested without a process group)."""
+    lines, complaints = [], []
+    world = len(every)
+    for r, rec in enumerate(every):
+        pa = rec.get("peer_access")
+        lines.append(f"rank {r}: device {rec.get('device')} ({rec.get('device_name', '?')}), exchange {rec.get('exchange')}, "
+                     f"RCCL communicator ranks {rec.get('rccl_ranks')}, peer access {''.join('1' if x else '0' for x in pa) if pa is not None else 'not checked'}, "
+                     f"mailbox trial: {rec.get('mailbox_trial')}")
+    chosen = {rec.get("exchange") for rec in every}
+    if len(chosen) != 1:
+        complaints.append(f"the ranks chose different exchange mechanisms: {sorted(map(str, chosen))}")
+    if any(rec.get("world") != world for rec in every):
+        complaints.append(f"ranks disagree about the world size: {[rec.get('world') for rec in every]} (gathered {world} records)")
+    devices = [rec.get("device") for rec in every]
+    if len(set(devices)) != world and not all(rec.get("share_device") for rec in every):
+        complaints.append(f"two ranks on one device without --share-device: devices {devices}")
+    exch = next(iter(chosen)) if len(chosen) == 1 else None
+    if exch in ("eager", "graph"):
+        bad = [r for r, rec in enumerate(every) if rec.get("rccl_ranks") != world]
+        if bad:
+            complaints.append(f"RCCL communicator of rank(s) {bad} does not count {world} ranks")
+    if exch == "mailbox" and world > 1 and not all(rec.get("share_device") for rec in every):
+        bad = [r for r, rec in enumerate(every) if rec.get("peer_access") is not None and not all(rec["peer_access"])]
+        if bad:
+            complaints.append(f"hipDeviceCanAccessPeer denies a pair of devices on rank(s) {bad}: the mailbox stores into the peers' memory")
+    text = "\n".join(lines + ["first contact: " + ("all ranks agree" if not complaints else "; ".join(complaints))])
+    return not complaints, text
+
+
 class _DevInt64:
     """Zero-copy view of `count` int64 values at a raw device pointer, via the CUDA array interface."""
 

@@ -40,6 +40,28 @@ def protocol(rank, world):
         print("PROTOCOL OK", flush=True)
 
 
+def first_contact(rank, world):
+    """bench.py's first-contact report over a real (gloo) process group: two ranks that agree, then two that do not."""
+    base = {"device": rank, "device_name": "fake MI355X", "peer_access": [True, True], "rccl_ranks": world, "exchange": "eager", "mailbox_trial": None,
+            "world": world, "share_device": False}
+    ok, text = D.first_contact_report(dict(base))
+    assert ok and "all ranks agree" in text and text.count("rank ") >= world, text
+    bad = dict(base, exchange="mailbox" if rank == 1 else "eager")                 # rank 1 fell back to another mechanism
+    ok, text = D.first_contact_report(bad)
+    assert not ok and "different exchange mechanisms" in text, text
+    bad = dict(base, rccl_ranks=1)                                                 # a communicator that does not span the world
+    ok, text = D.first_contact_report(bad)
+    assert not ok and "does not count 2 ranks" in text, text
+    bad = dict(base, exchange="mailbox", peer_access=[True, rank == 0])            # rank 1 cannot reach its peer
+    ok, text = D.first_contact_report(bad)
+    assert not ok and "hipDeviceCanAccessPeer" in text and "rank(s) [1]" in text, text
+    bad = dict(base, device=0)                                                     # both ranks on device 0, not on purpose
+    ok, text = D.first_contact_report(bad)
+    assert not ok and "two ranks on one device" in text, text
+    if rank == 0:
+        print("FIRST CONTACT OK", flush=True)
+
+
 def gpu(rank, world):
     I = pkg.integrator
     spec = S.drude_il(cells=(1, 1, 1), pairs_per_cell=60, seed=13)
@@ -216,6 +238,6 @@ def mailbox_periodic(rank, world):
 if __name__ == "__main__":
     dist.init_process_group(backend="gloo")
     r, w = dist.get_rank(), dist.get_world_size()
-    {"protocol": protocol, "gpu": gpu, "mailbox": mailbox, "mailbox_periodic": mailbox_periodic}[sys.argv[1]](r, w)
+    {"protocol": protocol, "first_contact": first_contact, "gpu": gpu, "mailbox": mailbox, "mailbox_periodic": mailbox_periodic}[sys.argv[1]](r, w)
     dist.barrier()
     dist.destroy_process_group()

@@ -22,6 +22,13 @@ def test_fixed_point_exchange_protocol_gloo_world2():
     assert r.returncode == 0 and "PROTOCOL OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_first_contact_report_gloo_world2():
+    """The report bench.py writes before the first timed region of a multi-GPU run, over a real two-rank gloo group: agreement passes,
+    and each kind of disagreement (exchange mechanism, communicator size, peer access, two ranks on one device) is named."""
+    r = _launch("first_contact", 29547)
+    assert r.returncode == 0 and "FIRST CONTACT OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.gpu
 def test_sharded_step_equals_single_process_two_ranks_one_gpu():
     r = _launch("gpu", 29542)
@@ -77,6 +84,9 @@ def test_bench_two_ranks_share_one_gpu_mailbox():
     # the bounded waits run out: the block must then be skipped on both ranks (and say so), not hang or report a number
     ls = line["config"]["large_n_sharded"]
     assert (isinstance(ls, dict) and ls["n_gpus"] == 2 and ls["steps_per_s"] > 1) or ls == "skipped (see stderr)", (ls, r.stderr[-2000:])
+    # round 5: BASELINE.json's configs[3] -- the same box with the cos perturbation -- as a series of its own next to the headline
+    c4 = line["config"]["c4_sharded"]
+    assert isinstance(c4, dict) and c4["n_gpus"] == 2 and c4["steps_per_s"] > 100 and c4["exchange"] == "mailbox" and "cos acceleration" in c4["workload"], (c4, r.stderr[-2000:])
 
 
 @pytest.mark.gpu
