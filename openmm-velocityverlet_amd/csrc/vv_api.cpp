@@ -334,6 +334,7 @@ void pick_launch_shape(vvhip_plan* p) {
 
 vv::NHConst make_chain(vvhip_plan* p, uint32_t flags);
 constexpr int kAccN = vv::NUM_ACC * vv::ACC_SLOTS;
+constexpr int kRvCopy = 6 * kAccN;      // rendezvous words of one thermostat parity: up to 6 replicas (vv_device.inc: RV_REPLICAS) of [NUM_ACC][ACC_SLOTS]
 // distance between the two parity copies: only the rows in use (4 without the cos moments)
 int acc_stride(const vvhip_plan* p) { return (p->hp.params.cos_acceleration != 0 ? vv::NUM_ACC : 4) * vv::ACC_SLOTS; }
 
@@ -644,7 +645,7 @@ int run_fused(vvhip_plan* p, uint32_t aflags, uint32_t bflags, uint32_t random_i
         vv::KArgs q = make_args(p, bflags, random_index);
         q.flags_a = aflags;
         int per_cu = 0;
-        const hipError_t e = vv::launch_fused(p->hp.precision, q, p->block_threads, p->d_rv, p->stream, nullptr, nullptr, nullptr, &per_cu);
+        const hipError_t e = vv::launch_fused(p->hp.precision, q, p->block_threads, p->d_rv, p->stream, nullptr, nullptr, nullptr, &per_cu);      // (asks only; launches nothing)
         const int tiles = p->block_threads / 64, blocks = (p->hp.info.num_waves + tiles - 1) / tiles;
         p->fused_ok = e == hipSuccess && per_cu >= 1 && (long) per_cu * p->num_cus >= blocks;
         if (e != hipSuccess) (void) hipGetLastError();
@@ -658,10 +659,10 @@ int run_fused(vvhip_plan* p, uint32_t aflags, uint32_t bflags, uint32_t random_i
     q.flags_a = aflags;
     q.fused_poll_delay = p->fused_poll_delay;
     // the "a block polled twice" words of this step and of the one before (by thermostat parity), behind the two copies of the rendezvous words
-    q.rv_late_cur = (unsigned int*) (p->d_rv + 2 * kAccN) + vv::ACC_SLOTS * p->parity;
-    q.rv_late_prev = (const unsigned int*) (p->d_rv + 2 * kAccN) + vv::ACC_SLOTS * (p->parity ^ 1);
+    q.rv_late_cur = (unsigned int*) (p->d_rv + 2 * kRvCopy) + vv::ACC_SLOTS * p->parity;
+    q.rv_late_prev = (const unsigned int*) (p->d_rv + 2 * kRvCopy) + vv::ACC_SLOTS * (p->parity ^ 1);
     q.fused_late_shift = p->fused_late_shift;
-    HIP_TRY(p, vv::launch_fused(p->hp.precision, q, p->block_threads, p->d_rv + p->parity * kAccN, p->stream, t.e0, t.e1, &route, nullptr));
+    HIP_TRY(p, vv::launch_fused(p->hp.precision, q, p->block_threads, p->d_rv + p->parity * kRvCopy, p->stream, t.e0, t.e1, &route, nullptr));
     p->parity ^= 1;            // the advanced thermostat state now lives in the other copy
     p->fused_launches++;
     *taken = true;
@@ -890,8 +891,8 @@ int vvhip_bind(vvhip_plan* p, const vvhip_buffers* b) {
     HIP_TRY(p, hipMemsetAsync(p->d_acc, 0, 2 * kAccN * sizeof(unsigned long long), p->stream));
     // rendezvous words of the fused step: uncached (every block's thermostat wave polls what the other blocks -- on other XCDs, behind other
     // L2s -- have just stored); zero = "no step's word" (tags run from 1)
-    HIP_TRY(p, hipExtMallocWithFlags((void**) &p->d_rv, (size_t) (2 * kAccN + vv::ACC_SLOTS) * sizeof(unsigned long long), hipDeviceMallocUncached));
-    HIP_TRY(p, hipMemsetAsync(p->d_rv, 0, (size_t) (2 * kAccN + vv::ACC_SLOTS) * sizeof(unsigned long long), p->stream));
+    HIP_TRY(p, hipExtMallocWithFlags((void**) &p->d_rv, (size_t) (2 * kRvCopy + vv::ACC_SLOTS) * sizeof(unsigned long long), hipDeviceMallocUncached));
+    HIP_TRY(p, hipMemsetAsync(p->d_rv, 0, (size_t) (2 * kRvCopy + vv::ACC_SLOTS) * sizeof(unsigned long long), p->stream));
     HIP_TRY(p, hipMalloc((void**) &p->d_nh, 2 * sizeof(vv::NHDevState)));
     vv::NHDevState init[2] = {};
     for (int c = 0; c < 2; c++)
