@@ -384,6 +384,10 @@ int vvhip_timing_read(vvhip_plan* plan, double* ms_pass_a, double* ms_pass_b, do
  *   VVHIP_PERIODIC=1|0        arithmetic work-item layout (vv_host.hpp: PeriodicLayout) always / never; default: from 1.1 M lanes, when the
  *                             system is runs of identical molecules (vvhip_plan_info.periodic_layout tells)
  *   VVHIP_PERIODIC_DEBUG=1    the decomposition into regions and why the layout was (not) enabled, on stderr
+ *   VVHIP_FUSED=0             the middle scheme's step as TWO launches also where the one-launch step (kernels A and B around an in-kernel
+ *                             rendezvous of co-resident blocks; vvhip_fused_status) would be taken -- for a GPU that other processes compute
+ *                             on at the same time: blocks that are not resident together meet the rendezvous' 0.2 s bound
+ *                             (VVHIP_ERR_RENDEZVOUS).  Same results bit for bit
  *   VVHIP_SHAKE_MODE=0        hydrogen-type constraint clusters by Gauss-Seidel sweeps of the central lane (OpenMM's iteration; generic
  *                             kernels) instead of the direct velocity solve / coupled Newton iteration of all lanes of a cluster
  *   VVHIP_ROCTX=1             roctx ranges (see vvhip_set_trace)
@@ -404,7 +408,7 @@ int vvhip_debug_launch(vvhip_plan* plan, int kernel, uint32_t flags, uint32_t ra
 /* One of the plan's tuning choices by name (call between vvhip_plan_create and vvhip_bind; later calls drop the captured graphs):
  * "grid_cap_a" / "grid_cap_b" (most blocks per launch), "block_threads", "split_chain_waves" (the chain becomes its own launch from n waves
  * on), "periodic_kernels" / "periodic_a" (0: load slot words although the layout is arithmetic), "rekick", "no_moments", "mass_tab_a" /
- * "periodic_b", "mass_tab_b", "acc_store", "fused" (0: the middle scheme's step as two launches also where one would do), "gc_omega_permille" (relaxation factor of the general clusters' sweeps x 1000, for rate scans).  Tests
+ * "periodic_b", "mass_tab_b", "acc_store", "fused" (0: the middle scheme's step as two launches also where one would do), "fused_poll_delay" (>= 0 pins the wait in front of the rendezvous' first poll round, units of 256 clocks; -1: self-tuning), "fused_late_shift", "gc_omega_permille" (relaxation factor of the general clusters' sweeps x 1000, for rate scans).  Tests
  * use it to run large-system code paths at small sizes. */
 int vvhip_debug_tune(vvhip_plan* plan, const char* key, int value);
 int vvhip_debug_read_accumulators(vvhip_plan* plan, double out[4], int zero_after);  /* blocks */

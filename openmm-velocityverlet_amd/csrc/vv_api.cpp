@@ -717,6 +717,7 @@ int vvhip_plan_create(const vvhip_system_desc* system, const vvhip_params* param
             if (const char* c = std::strchr(e, ':')) p->stall_period = std::max(1L, std::atol(c + 1));
         }
         if (const char* e = std::getenv("VVHIP_SHAKE_MODE")) p->shake_mode = std::atoi(e) != 0 ? 1 : 0;
+        if (const char* e = std::getenv("VVHIP_FUSED")) p->fused = std::atoi(e) != 0;
         p->mass_tab_a = vv::sf_kernels_use_mass_table(0);
         p->mass_tab_b = vv::sf_kernels_use_mass_table(1);
         if (const char* e = std::getenv("VVHIP_ROCTX")) p->trace = std::atoi(e) != 0;

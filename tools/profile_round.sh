@@ -29,7 +29,7 @@ else
     python3 "$ROOT/bench.py" --config "$CFG" $EXTRA --large-n none --steps 200 --warmup 40 --no-cpu-baseline 2>"$OUT/bench_$CFG.stderr" | tail -1 > "$OUT/bench_${CFG}${SUF}_mixed.json"
     STEPS="--steps 100 --warmup 20"; PSTEPS="--steps 40 --warmup 10"
 fi
-[ -z "${ONLY_PMC:-}" ] && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$CFG" -o run -- python3 "$ROOT/bench.py" --config "$CFG" $EXTRA --large-n none $STEPS --no-cpu-baseline --no-rocprof > "$OUT/stats_$CFG.log" 2>&1
+[ -z "${ONLY_PMC:-}" ] && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$CFG" -o run -- python3 "$ROOT/bench.py" --config "$CFG" $EXTRA --large-n none $STEPS --no-cpu-baseline --no-rocprof --no-other-configs > "$OUT/stats_$CFG.log" 2>&1
 [ -z "${ONLY_PMC:-}" ] && cp "$OUT/stats_$CFG"/run_kernel_stats.csv "$OUT/kernel_stats_$CFG$SUF.csv" 2>/dev/null || find "$OUT/stats_$CFG" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_$CFG$SUF.csv" \;
 for C in FETCH_SIZE WRITE_SIZE; do
     # (--headline-only: the secondary blocks launch OTHER variants of the kernels -- the constrained box's -- more often than the headline's)
