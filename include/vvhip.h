@@ -175,6 +175,11 @@ const char* vvhip_last_error(const vvhip_plan* plan);
 int vvhip_plan_get_info(const vvhip_plan* plan, vvhip_plan_info* info);
 /* Copies the wave layout: slots[2*i] = particle index (shard-relative, -1 = idle lane),
  * slots[2*i+1] = packed role word.  `capacity` in slots; returns the number of slots or <0. */
+/* Why vvhip_plan_info.constraints_fused is 0 for this plan ("" when it is 1 or the System has no constraints): what of the constraint topology
+ * did not fit the in-kernel solvers -- a component with more than the 64 constraints of a wave's list, a particle in more constraints than the 16
+ * colours of the sweeps, a constraint across two waves.  The fused steps then refuse (VVHIP_ERR_UNSUPPORTED, with this text) and the split
+ * entry points leave the gaps for the host's own solver. */
+const char* vvhip_plan_unfused_reason(const vvhip_plan* plan);
 int vvhip_plan_get_slots(const vvhip_plan* plan, int32_t* slots, int32_t capacity);
 
 /* Binds device arrays and allocates the plan's own device state (forceExtra, oldDelta, accumulators,

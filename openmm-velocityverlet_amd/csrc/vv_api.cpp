@@ -691,7 +691,8 @@ uint32_t cons_b(const vvhip_plan* p) { return (p->hp.info.num_shake_clusters > 0
 #define NEED_FUSABLE(p)                                                                                                   \
     do {                                                                                                                \
         if (!(p)->hp.info.constraints_fused)                                                                            \
-            return fail(p, VVHIP_ERR_UNSUPPORTED, "the System has constraints this backend cannot solve in-kernel: use the split entry points around the host's constraint solver"); \
+            return fail(p, VVHIP_ERR_UNSUPPORTED, std::string("the System has constraints this backend cannot solve in-kernel") + ((p)->hp.unfused_reason.empty() ? "" : " (" + (p)->hp.unfused_reason + ")") + \
+                                                  ": use the split entry points around the host's constraint solver"); \
     } while (0)
 
 }  // namespace
@@ -788,6 +789,8 @@ int vvhip_plan_get_info(const vvhip_plan* p, vvhip_plan_info* info) {
     *info = p->hp.info;
     return VVHIP_OK;
 }
+
+const char* vvhip_plan_unfused_reason(const vvhip_plan* p) { return p ? p->hp.unfused_reason.c_str() : "null plan"; }
 
 int vvhip_plan_get_slots(const vvhip_plan* p, int32_t* slots, int32_t capacity) {
     if (!p) return VVHIP_ERR_INVALID;

@@ -608,20 +608,35 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
     const bool best_fit = total_lanes < ((size_t) 1 << 20);
     int last_wave = -1;
     size_t cluster_index = 0;
+    // General constraint clusters: a wave's constraint list lives one constraint per LANE, so a wave holds 64 of them whatever its lanes
+    // hold -- the packer counts them too (round-4 advisor: HAngles on hydrocarbon-rich molecules, ~1.5 constraints per particle, filled the
+    // lanes of a wave with molecules whose constraints did not fit its list, and the whole System lost the fused path).
+    std::vector<int32_t> cons_fill;                     // general constraints per wave
+    auto cons_of = [&](const Cluster& c) {
+        if (!general) return 0;
+        size_t deg = 0;
+        for (int i : c.members) deg += gc_adj[i].size();
+        return (int) (deg / 2);
+    };
     for (const Cluster& c : clusters) {
-        const int sz = (int) c.members.size();
+        const int sz = (int) c.members.size(), nc = cons_of(c);
         wave = -1;
         if (periodic) {
             periodic_place(cluster_index, wave, lane);
             fill[wave] = lane;
         } else if (best_fit) {
-            for (int f = sz; f <= 63 && wave < 0; f++)
-                if (!open_by_free[f].empty()) { wave = open_by_free[f].back(); open_by_free[f].pop_back(); }
-        } else if (last_wave >= 0 && fill[last_wave] + sz <= 64) {
+            for (int f = sz; f <= 63 && wave < 0; f++) {
+                auto& bucket = open_by_free[f];
+                for (size_t t = bucket.size(); t-- > 0 && wave < 0;)
+                    if (cons_fill[bucket[t]] + nc <= 64) { wave = bucket[t]; bucket.erase(bucket.begin() + (long) t); }
+            }
+        } else if (last_wave >= 0 && fill[last_wave] + sz <= 64 && cons_fill[last_wave] + nc <= 64) {
             wave = last_wave;
         }
         cluster_index++;
         if (wave < 0) wave = new_wave();
+        if ((size_t) wave >= cons_fill.size()) cons_fill.resize((size_t) wave + 1, 0);
+        cons_fill[wave] += nc;
         last_wave = wave;
         lane = fill[wave];
         fill[wave] += sz;
@@ -856,18 +871,18 @@ HostPlan analyze(const vvhip_system_desc& sys, const vvhip_params& params_in, in
             if (!in_shard(a) && !in_shard(b)) continue;
             if (!in_shard(a) || !in_shard(b)) throw Error(VVHIP_ERR_INVALID, "particle shard cuts a Drude pair or a constraint cluster");
             const int w = wave_of[a];
-            if (w < 0 || wave_of[b] != w) { fits = false; break; }
+            if (w < 0 || wave_of[b] != w) { fits = false; hp.unfused_reason = "a constraint connects particles of two waves (a molecule larger than a wave, cut into chunks)"; break; }
             const int la = lane_of[a], lb = lane_of[b];
             const uint32_t taken = used_colours[(size_t) w * 64 + la] | used_colours[(size_t) w * 64 + lb];
             int colour = 0;
             while (colour < 16 && ((taken >> colour) & 1u)) colour++;
-            if (colour >= 16) { fits = false; break; }
+            if (colour >= 16) { fits = false; hp.unfused_reason = "a particle takes part in more constraints than the 16 colours of a wave's sweeps can separate"; break; }
             used_colours[(size_t) w * 64 + la] |= 1u << colour;
             used_colours[(size_t) w * 64 + lb] |= 1u << colour;
             const double ima = 1.0 / sys.masses[a], imb = 1.0 / sys.masses[b], d = sys.constraint_distances[k];
             GC g{la, lb, colour, {(float) (d * d), (float) (0.5 / (ima + imb)), (float) ima, (float) imb}};
             per_wave[(size_t) w].push_back(g);
-            if (per_wave[(size_t) w].size() > 64) fits = false;
+            if (per_wave[(size_t) w].size() > 64) { fits = false; hp.unfused_reason = "a connected component of the constraint graph holds more than the 64 constraints of a wave's list"; }
             hp.gc_colors = std::max(hp.gc_colors, colour + 1);
         }
         if (!fits) {

@@ -73,6 +73,7 @@ struct HostPlan {
     std::vector<double> vsite_params;          // [12*records]
     std::vector<int32_t> vsite_atom;           // [records] shard-relative particle index of the site (where a hosting lane stores it)
     std::vector<int32_t> slot_big;     // [64*waves] index of the lane's big molecule, or -1 (empty when there is none)
+    std::string unfused_reason;        // why info.constraints_fused is 0 (general clusters: what did not fit a wave); empty otherwise
     int32_t num_big = 0;               // molecules with more than 64 thermostatted particles (COM temperature group only)
     double big_scale = 1.0;            // fixed-point scale of their sum(m v) accumulators
     std::vector<int32_t> image_pairs;  // (image, parent) shard-relative, for the stand-alone image kernel

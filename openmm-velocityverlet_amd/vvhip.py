@@ -158,6 +158,8 @@ def _load():
     lib.vvhip_plan_destroy.restype = None
     lib.vvhip_last_error.argtypes = [vp]
     lib.vvhip_last_error.restype = C.c_char_p
+    lib.vvhip_plan_unfused_reason.argtypes = [vp]
+    lib.vvhip_plan_unfused_reason.restype = C.c_char_p
     return lib
 
 

@@ -369,3 +369,26 @@ def test_a_shard_must_not_cut_a_virtual_site_from_its_parents():
     inter = systems.add_virtual_sites(systems.spce_water(8), kinds=(1,))                         # O H H M: sites travel with their molecule
     info, _ = I.plan_layout(inter, it, shard=(0, 16))
     assert info.num_virtual_sites == 4
+
+
+def test_a_plan_that_cannot_fuse_its_constraints_says_why():
+    """Round-4 advisor: a bare constraints_fused = 0 told a host nothing.  The procedural look-alike box with `constrain_all_bonds` (random
+    geometry: every pair within the cut-off becomes a "bond", one component holds far more than the 64 constraints of a wave's list) names its
+    reason; the reference's own model with HAngles fuses and has none.  The wave packer counts constraints as well as lanes since round 5."""
+    import ctypes as C
+    for spec, fused in ((systems.constrain_all_bonds(systems.drude_il(cells=(1, 1, 1), pairs_per_cell=30, seed=1)), 0),
+                        (systems.constrain_all_bonds(systems.bulk_Im21(cells=(1, 1, 1), pairs_per_cell=20), hangles=True), 1)):
+        it = I.VVIntegrator(333.0, 10, 1.0, 40, 0.001)
+        it.setMaxDrudeDistance(0.02)
+        plan, info, _keep = I.create_plan(spec, it)
+        try:
+            reason = H.lib.vvhip_plan_unfused_reason(plan).decode()
+            assert info.constraints_fused == fused
+            if fused:
+                assert reason == "" and info.num_general_constraints == len(spec.constraints)
+                nslots = H.lib.vvhip_plan_get_slots(plan, None, 0)
+                assert nslots == info.num_waves * 64
+            else:
+                assert "64 constraints of a wave's list" in reason or "16 colours" in reason or "two waves" in reason, reason
+        finally:
+            H.lib.vvhip_plan_destroy(plan)
