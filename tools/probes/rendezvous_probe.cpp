@@ -16,7 +16,7 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { std::printf("%s -> %s\n", #x, hipGetErrorString(e)); std::exit(3); } } while (0)
 typedef unsigned long long u64;
 
-enum { V_A2A = 0, V_HOP2 = 1, V_CNT = 2 };
+enum { V_A2A = 0, V_HOP2 = 1, V_CNT = 2, V_SPLIT = 3 };      // V_SPLIT: all-to-all, the block's waves poll one row (or two) each
 
 template <bool SYS>
 __device__ __forceinline__ void st(u64* p, u64 v) {
@@ -40,6 +40,46 @@ __global__ void __launch_bounds__(512) rendezvous(u64* box, u64* bcast, u64* cou
     double4 v = data[(size_t) (blockIdx.x * (blockDim.x >> 6) + wib) * 64 + lane];
     for (int i = 0; i < work; i++) { v.x = v.x * 1.0000001 + v.y; v.y = v.y * 0.9999999 + v.z; v.z = v.z * 1.0000001 + v.x; }
     __syncthreads();
+    if (VARIANT == V_SPLIT) {
+        // wave 0 publishes (as in the other variants), then wave w polls rows w, w + nwaves, ...: 4 loads per row per lane, a sum per row, LDS
+        __shared__ long long sh_row[16];
+        __shared__ long long sh_t[2];
+        const int nwv = blockDim.x >> 6;
+        const u64 tag = (u64) (seq & 3u) << 62;
+        const long long mine = (long long) (blockIdx.x + 1) * 1000 + (long long) (v.x != 12345.0);
+        if (wib == 0) {
+            if (lane == 0) sh_t[0] = wall_clock64();
+            if (lane < W * R) st<SYS>(&box[(lane / W) * (16 * 256) + (lane % W) * 256 + blockIdx.x], tag | ((u64) (mine + lane % W) & 0x3FFFFFFFFFFFFFFFull));
+        }
+        const u64* mybox = box + (blockIdx.x % R) * (16 * 256);
+        const long long t0 = wall_clock64();
+        bool timeout = false;
+        for (int k = wib; k < W; k += nwv) {
+            u64 x[4];
+            for (;;) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) x[j] = ld<SYS>(&mybox[k * 256 + lane + 64 * j]);
+                bool all = true;
+#pragma unroll
+                for (int j = 0; j < 4; j++) if (lane + 64 * j < G && (x[j] >> 62) != (u64) (seq & 3u)) all = false;
+                if (!__any(!all)) break;
+                if (wall_clock64() - t0 > 20000000LL) { timeout = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            long long part = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) if (lane + 64 * j < G) part += (long long) (x[j] << 2) >> 2;
+            part = wave_sum_ll(part);
+            if (lane == 0) sh_row[k] = part;
+        }
+        __syncthreads();
+        if (wib == 0 && lane == 0) {
+            const long long t_got = wall_clock64();
+            sh_tot[0] = sh_row[0];
+            stamps[blockIdx.x * 4 + 0] = t_in; stamps[blockIdx.x * 4 + 1] = sh_t[0]; stamps[blockIdx.x * 4 + 2] = t_got; stamps[blockIdx.x * 4 + 3] = sh_row[0];
+            if (timeout) status[0] = 1;
+        }
+    } else
     if (wib == 0) {
         const u64 tag = (u64) (seq & 3u) << 62;
         const long long mine = (long long) (blockIdx.x + 1) * 1000 + (long long) (v.x != 12345.0);      // payload: depends on the work
@@ -109,6 +149,7 @@ __global__ void __launch_bounds__(512) rendezvous(u64* box, u64* bcast, u64* cou
 
 template <int VARIANT, bool SYS, int W, int R>
 static void run1(const char* name, int G, int threads, int work, u64* box, u64* bcast, u64* counter, u64* plain, long long* stamps, double4* a, double4* b, unsigned* status, hipStream_t s) {
+    if (W * R > 64) return;      // (the replicas are written by one store instruction)
     const int reps = 40;
     std::vector<long long> h((size_t) G * 4);
     std::vector<double> lat_last, lat_first, pub_spread, kernel_us;
@@ -164,8 +205,10 @@ int main(int argc, char** argv) {
     run1<V_A2A, true, WW, 8>("a2a-uc-r8", G, threads, work, box_uc, bcast_uc, cnt_uc, plain_uc, stamps, a, b, status, s); \
     run1<V_A2A, false, WW, 1>("a2a-ag-r1", G, threads, work, box, bcast, cnt, plain, stamps, a, b, status, s); \
     run1<V_A2A, false, WW, 8>("a2a-ag-r8", G, threads, work, box, bcast, cnt, plain, stamps, a, b, status, s); \
+    run1<V_SPLIT, true, WW, 1>("split-uc-r1", G, threads, work, box_uc, bcast_uc, cnt_uc, plain_uc, stamps, a, b, status, s); \
+    run1<V_SPLIT, true, WW, 4>("split-uc-r4", G, threads, work, box_uc, bcast_uc, cnt_uc, plain_uc, stamps, a, b, status, s); \
     run1<V_HOP2, true, WW, 1>("hop2-uc", G, threads, work, box_uc, bcast_uc, cnt_uc, plain_uc, stamps, a, b, status, s); } while (0)
     if (G > 256) return 2;
-    if (W == 3) RUNALL(3); else if (W == 7) RUNALL(7); else return 2;
+    if (W == 3) RUNALL(3); else if (W == 7) RUNALL(7); else if (W == 10) RUNALL(10); else return 2;
     return 0;
 }
