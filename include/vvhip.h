@@ -325,7 +325,10 @@ int vvhip_status_clear(vvhip_plan* plan);
  * co-resident blocks, no RCCL exchange between the halves, a kernel for the plan's pair of stage sets), *launches = fused launches
  * so far (captured ones count once), *wait_units = where the self-tuning wait between a block's publish and its first poll round
  * stands (units of 256 shader clocks; reading it synchronises).  vvhip_debug_tune(plan, "fused", 0) forces the two-launch step
- * (bit-identical results); "fused_poll_delay" >= 0 pins the wait.  Any of the three pointers may be NULL. */
+ * (bit-identical results); "fused_poll_delay" >= 0 pins the wait.  Any of the three pointers may be NULL.
+ * The classic scheme's two thermostat applications per step (vvhip_step_vv_first / _second) and vvhip_scale_velocity take the same kernel
+ * under the same conditions -- sums, rendezvous, chain, scaling (+ half kick and drift / half kick in front) in one launch each, two per
+ * classic step instead of four; they count in *launches, *active speaks of the middle scheme only. */
 int vvhip_fused_status(vvhip_plan* plan, int32_t* active, int64_t* launches, int32_t* wait_units);
 int vvhip_stream_create(void** stream);          /* hipStreamCreateWithFlags(non-blocking) */
 int vvhip_stream_destroy(void* stream);
@@ -389,7 +392,7 @@ int vvhip_timing_read(vvhip_plan* plan, double* ms_pass_a, double* ms_pass_b, do
  *   VVHIP_PERIODIC=1|0        arithmetic work-item layout (vv_host.hpp: PeriodicLayout) always / never; default: from 1.1 M lanes, when the
  *                             system is runs of identical molecules (vvhip_plan_info.periodic_layout tells)
  *   VVHIP_PERIODIC_DEBUG=1    the decomposition into regions and why the layout was (not) enabled, on stderr
- *   VVHIP_FUSED=0             the middle scheme's step as TWO launches also where the one-launch step (kernels A and B around an in-kernel
+ *   VVHIP_FUSED=0             the middle scheme's step (and each thermostat application of the classic scheme) as TWO launches also where the one-launch step (kernels A and B around an in-kernel
  *                             rendezvous of co-resident blocks; vvhip_fused_status) would be taken -- for a GPU that other processes compute
  *                             on at the same time: blocks that are not resident together meet the rendezvous' 0.2 s bound
  *                             (VVHIP_ERR_RENDEZVOUS).  Same results bit for bit

@@ -125,6 +125,9 @@ struct vvhip_plan {
     uint32_t fused_checked_a = 0, fused_checked_b = 0;
     int fused_checked_threads = 0, fused_checked_waves = 0;
     bool fused_ok = false;
+    struct FusedCheck { uint32_t a = 0, b = 0; int threads = 0, waves = 0; bool ok = false; };
+    FusedCheck fused_checks[4];    // (the classic scheme alternates between the pairs of its two halves)
+    int fused_check_next = 0;
     long long fused_launches = 0;
     // plan-owned device state
     int2* d_slots = nullptr;
@@ -625,7 +628,7 @@ bool fused_shape_ok(const vvhip_plan* p) {
 // not be resident together.
 bool fused_state_ok(const vvhip_plan* p) {
     const vv::HostPlan& hp = p->hp;
-    if (!p->fused || !hp.params.use_middle_scheme || !hp.has_nh || hp.params.num_nh_chains > 4 || hp.num_big != 0) return false;
+    if (!p->fused || !hp.has_nh || hp.params.num_nh_chains > 4 || hp.num_big != 0) return false;
     if (hp.info.num_waves >= p->split_chain_waves) return false;
     // sharded runs: the xGMI mailbox exchanges the ranks' totals inside the thermostat wave, right behind the local rendezvous (one wait after
     // the other, no launch in between); an RCCL all-reduce needs the kernel boundary, and ranks that share this device cannot all be resident
@@ -641,6 +644,12 @@ int run_fused(vvhip_plan* p, uint32_t aflags, uint32_t bflags, uint32_t random_i
     bflags |= vv::B_CHAIN | vv::B_MTAB | (use_mailbox(p) ? vv::B_MAILBOX : 0u);
     // kernel and occupancy of this pair of stage sets on this launch shape: looked up once
     if (p->fused_checked_a != aflags || p->fused_checked_b != bflags || p->fused_checked_threads != p->block_threads || p->fused_checked_waves != p->hp.info.num_waves) {
+        for (const vvhip_plan::FusedCheck& c : p->fused_checks)
+            if (c.b != 0 && c.a == aflags && c.b == bflags && c.threads == p->block_threads && c.waves == p->hp.info.num_waves) {
+                p->fused_checked_a = aflags; p->fused_checked_b = bflags; p->fused_checked_threads = c.threads; p->fused_checked_waves = c.waves; p->fused_ok = c.ok;
+            }
+    }
+    if (p->fused_checked_a != aflags || p->fused_checked_b != bflags || p->fused_checked_threads != p->block_threads || p->fused_checked_waves != p->hp.info.num_waves) {
         p->fused_checked_a = aflags; p->fused_checked_b = bflags; p->fused_checked_threads = p->block_threads; p->fused_checked_waves = p->hp.info.num_waves;
         vv::KArgs q = make_args(p, bflags, random_index);
         q.flags_a = aflags;
@@ -649,6 +658,8 @@ int run_fused(vvhip_plan* p, uint32_t aflags, uint32_t bflags, uint32_t random_i
         const int tiles = p->block_threads / 64, blocks = (p->hp.info.num_waves + tiles - 1) / tiles;
         p->fused_ok = e == hipSuccess && per_cu >= 1 && (long) per_cu * p->num_cus >= blocks;
         if (e != hipSuccess) (void) hipGetLastError();
+        vvhip_plan::FusedCheck& c = p->fused_checks[p->fused_check_next++ & 3];
+        c.a = aflags; c.b = bflags; c.threads = p->block_threads; c.waves = p->hp.info.num_waves; c.ok = p->fused_ok;
     }
     if (!p->fused_ok) return VVHIP_OK;
     TRY(ensure_mass_table(p));
@@ -745,7 +756,7 @@ int vvhip_debug_tune(vvhip_plan* p, const char* key, int value) {
     else if (k == "gc_omega_permille") p->hp.gc_omega = value / 1000.0;     // relaxation factor of the general clusters' sweeps (rate scans)
     else if (k == "rekick") p->rekick = value != 0;                         // 0: kernel A stores the kicked velocities, kernel B does not repeat the kick
     else if (k == "no_moments") p->no_moments = value != 0;                 // 1: cos perturbation as three launches (bias, sums, scale)
-    else if (k == "fused") { p->fused = value != 0; p->fused_checked_b = 0; }
+    else if (k == "fused") { p->fused = value != 0; p->fused_checked_b = 0; for (vvhip_plan::FusedCheck& c : p->fused_checks) c.b = 0; }
     else if (k == "fused_late_shift") p->fused_late_shift = std::max(0, std::min(value, 16));
     else if (k == "fused_poll_delay") p->fused_poll_delay = std::max(-1, std::min(value, 64));   // 0: the middle scheme's step as two launches (A, B) also where one would do
     else if (k == "mass_tab_a") p->mass_tab_a = value != 0;
@@ -1012,7 +1023,7 @@ static bool use_rekick(const vvhip_plan* p) {
 // Does vvhip_step_middle take the one-launch step for this plan as it stands?  (The kernel itself is looked up at the first step; a pair
 // of stage sets already found wanting says so here.)
 static bool fused_active(const vvhip_plan* p) {
-    if (!p->bound || !p->hp.info.constraints_fused || !fused_state_ok(p) || (cos_on(p) && !use_moments(p))) return false;
+    if (!p->bound || !p->hp.params.use_middle_scheme || !p->hp.info.constraints_fused || !fused_state_ok(p) || (cos_on(p) && !use_moments(p))) return false;
     return !(p->fused_checked_b != 0 && !p->fused_ok);
 }
 
@@ -1055,7 +1066,7 @@ int vvhip_algorithmic_bytes(const vvhip_plan* p, int32_t* bytes_a, int32_t* byte
 // hand-over bits between them (A_NOSTORE / B_KICK, the cos(kz) cache load).
 static int step_middle_fused(vvhip_plan* p, uint32_t random_index, bool* taken) {
     *taken = false;
-    if (!p->hp.info.constraints_fused || !fused_state_ok(p)) return VVHIP_OK;
+    if (!p->hp.params.use_middle_scheme || !p->hp.info.constraints_fused || !fused_state_ok(p)) return VVHIP_OK;
     const uint32_t stale = (extra_flags(p) == 0 && (p->fextra_dirty || p->fextra_external)) ? vv::A_FE_LOAD : 0u;
     uint32_t fa = vv::A_KICK_FULL | extra_flags(p) | stale | cons_a(p) | vv::A_KE;
     uint32_t fb = vv::B_SCALE | vv::B_DRIFT_MIDDLE | tail_flags(p) | cons_b(p);
@@ -1149,6 +1160,13 @@ static int nh_half(vvhip_plan* p, uint32_t a_first, uint32_t random_index, uint3
         if (b_extra) TRY(run_b(p, b_extra));
         return VVHIP_OK;
     }
+    // one launch per thermostat application where the plan allows it (as the middle scheme's step: sums, rendezvous, chain, scaling)
+    if (!cos_on(p) || use_moments(p)) {
+        bool taken = false;
+        if (!cos_on(p)) TRY(run_fused(p, a_first | vv::A_KE, vv::B_SCALE | b_extra, random_index, &taken));
+        else TRY(run_fused(p, a_first | vv::A_BIAS | vv::A_CZ_STORE | vv::A_KE | vv::A_KE_MOM, vv::B_SCALE | vv::B_UNBIAS | vv::B_KE_MOM | b_extra, random_index, &taken));
+        if (taken) return VVHIP_OK;
+    }
     if (!cos_on(p)) {
         TRY(run_ke(p, a_first, random_index, false));
         TRY(exchange_accumulators(p, 0));
@@ -1215,6 +1233,11 @@ int vvhip_vv_positions(vvhip_plan* p) {
 int vvhip_scale_velocity(vvhip_plan* p) {                  // HOST:670-754 without the download/upload
     NEED_BOUND(p);
     if (!p->hp.has_nh) return VVHIP_OK;
+    {
+        bool taken = false;
+        TRY(run_fused(p, vv::A_KE, vv::B_SCALE, 0, &taken));
+        if (taken) return VVHIP_OK;
+    }
     TRY(run_ke(p, 0, 0, false));
     return run_chain_and_b(p, vv::B_SCALE, false);
 }

@@ -367,7 +367,7 @@ hipError_t launch_fused(int precision, const KArgs& a, int block_threads, const 
     const dim3 g = grid_for(a.nwaves, block_threads);
     const dim3 b(block_threads + 64);                      // the tile waves + the block's thermostat wave
     if (!(a.flags & B_CHAIN) || a.flags_a == 0 || (int) g.x > ACC_SLOTS || b.x > 512) return hipErrorNotSupported;
-    const unsigned lds = (a.flags & (B_CONS | B_VSITE)) ? (unsigned) (block_threads / 64) * 64u * 7u * (precision == VVHIP_SINGLE ? 4u : 8u) : 0u;      // one page per tile wave
+    const unsigned lds = ((a.flags & (B_CONS | B_VSITE)) || (a.flags_a & A_CONS)) ? (unsigned) (block_threads / 64) * 64u * 7u * (precision == VVHIP_SINGLE ? 4u : 8u) : 0u;      // one page per tile wave
     vv_last_grid_value = g.x;
     constexpr uint32_t XM = SF_BM;
 #define VV_PRE_ARGS a.slots, a.nwaves, (int) (b.x >> 6), rendezvous, a.nh, a.lane_const, a.seg_base
@@ -389,6 +389,10 @@ hipError_t launch_fused(int precision, const KArgs& a, int block_threads, const 
         VV_TRY_FUSED(SF_B_COS_HW_MOM_F | B_MAILBOX, SF_A_COS_MOM)
         VV_TRY_FUSED(SF_B_MIDDLE_MB, SF_A_MIDDLE)
         VV_TRY_FUSED(SF_B_MIDDLE_HW_SHAKE_MB, SF_A_MIDDLE_SHAKE)
+        VV_TRY_FUSED(SF_B_VV1_HW, SF_A_KE)                           // classic scheme, first half: sums + scaling + half kick + drift (C3)
+        VV_TRY_FUSED(SF_B_VV1, SF_A_KE)                              // ... C1, C2
+        VV_TRY_FUSED(SF_B_SCALE, SF_A_VV2)                           // classic scheme, second half: half kick + sums + scaling
+        VV_TRY_FUSED(SF_B_SCALE, SF_A_KE)                            // a thermostat application on its own (vvhip_scale_velocity)
     }
 #undef VV_TRY_FUSED
 #undef VV_FUSED_ONE

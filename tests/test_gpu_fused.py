@@ -17,8 +17,9 @@ H, I, systems = pkg.vvhip, pkg.integrator, pkg.systems
 pytestmark = pytest.mark.gpu
 
 
-def _run(spec, prec, fused, steps, mode="eager", cos=0.0, maxd=0.02, T=333.0, dt=0.001, efield=0.0, mirror=0.0, tune=None, chains=3, shard=None):
+def _run(spec, prec, fused, steps, mode="eager", cos=0.0, maxd=0.02, T=333.0, dt=0.001, efield=0.0, mirror=0.0, tune=None, chains=3, shard=None, middle=True):
     it = I.VVIntegrator(T, 10.0, 1.0, 40.0, dt, numNHChains=chains)
+    it.setUseMiddleScheme(middle)
     it.setMaxDrudeDistance(maxd)
     it.setCosAcceleration(cos)
     it.setElectricField(efield)
@@ -76,6 +77,43 @@ def test_one_launch_step_equals_two_launch_step(case, prec):
     assert not two["active"] and two["launches"] == 0
     assert one["words"] == [0, 0, 0, 0] and two["words"] == [0, 0, 0, 0]
     _same(one, two, f"{case}/{prec}")
+
+
+@pytest.mark.parametrize("case,prec", [(c, "mixed") for c in sorted(CASES)] + [("drude_il", "single"), ("drude_il", "double"), ("rigid_water", "single"), ("drude_il_hbonds_cos", "double")])
+def test_classic_scheme_one_launch_per_thermostat_application(case, prec):
+    """The classic scheme (stepVV, /root/reference/openmmapi/src/VVIntegrator.cpp:295-336) applies the thermostat twice per step: sums ->
+    chain -> scaling (+ half kick + drift in the first half; half kick + sums in front in the second).  Each application is one launch of
+    the same kernel around the same rendezvous, bit for bit the two launches it replaces."""
+    make, kw = CASES[case]
+    spec = make()
+    one = _run(spec, prec, True, 10, middle=False, **kw)
+    two = _run(spec, prec, False, 10, middle=False, **kw)
+    assert one["launches"] == 20 and two["launches"] == 0, (one["launches"], two["launches"])
+    assert one["words"] == [0, 0, 0, 0] and two["words"] == [0, 0, 0, 0]
+    _same(one, two, f"classic {case}/{prec}")
+
+
+def test_classic_scheme_one_launch_electrode_slab_and_graph():
+    spec = systems.edl_slab(num_ion_pairs=20, num_electrode=60, seed=9)
+    kw = _edl_kw(spec)
+    one = _run(spec, "mixed", True, 10, middle=False, **kw)
+    two = _run(spec, "mixed", False, 10, middle=False, **kw)
+    assert one["launches"] == 20
+    _same(one, two, "classic edl")
+    spec = systems.drude_il(cells=(1, 1, 1), pairs_per_cell=40, seed=7)
+    ref = _run(spec, "mixed", False, 16, middle=False)
+    for mode in ("c-loop", "graph"):
+        one = _run(spec, "mixed", True, 16, mode=mode, middle=False)
+        assert one["launches"] > 0
+        _same(one, ref, f"classic {mode}")
+
+
+def test_classic_scheme_one_launch_at_full_size():
+    spec = systems.make_config("C3")
+    one = _run(spec, "mixed", True, 8, mode="graph", middle=False)
+    two = _run(spec, "mixed", False, 8, mode="graph", middle=False)
+    assert one["launches"] > 0 and one["words"] == [0, 0, 0, 0]
+    _same(one, two, "classic full C3")
 
 
 @pytest.mark.parametrize("prec", O.PRECISIONS)

@@ -1,6 +1,7 @@
 """One-launch step against the two-launch step on ONE box, in rotation (round 5, TUNING_LOG section 13): steps/s of 20 000-step graph
 runs with the force provider, and without it (integrator alone), per BASELINE configuration.
-usage: python tools/probes/fused_ab.py [configs, e.g. C3,C4,C5,C2,C1,C3hb] [rotations] [steps]"""
+usage: python tools/probes/fused_ab.py [configs, e.g. C3,C4,C5,C2,C1,C3hb] [rotations] [steps]      (CLASSIC=1: the classic scheme, two thermostat
+applications per step: two launches against four)"""
 import importlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
@@ -10,6 +11,7 @@ EXTRA = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("FUSED_TU
 configs = (sys.argv[1] if len(sys.argv) > 1 else "C3,C4,C5,C2,C1").split(",")
 rot = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20000
+CLASSIC = os.environ.get("CLASSIC", "0") == "1"
 
 
 def make(cfg, fused, provider=True):
@@ -21,6 +23,7 @@ def make(cfg, fused, provider=True):
     it = I.VVIntegrator(T, 10, 1.0, 40, dt)
     it.setMaxDrudeDistance(maxd)
     it.setCosAcceleration(cos)
+    it.setUseMiddleScheme(not CLASSIC)
     if base == "C5":
         lz = float(spec.box[2])
         it.setMirrorLocation(lz / 2)
@@ -38,7 +41,7 @@ def rate(ctx, n):
 for cfg in (configs if __name__ == "__main__" else []):
     ctxs = {f: make(cfg, f) for f in (True, False)}
     alone = {f: make(cfg, f, provider=False) for f in (True, False)}      # zero forces throughout: the integrator's launches alone
-    print(f"{cfg}: {ctxs[True][0].system.num_atoms} particles, {ctxs[True][0].info.num_waves} waves; one launch active: {ctxs[True][0].fused_status()[0]}", flush=True)
+    print(f"{cfg}: {ctxs[True][0].system.num_atoms} particles, {ctxs[True][0].info.num_waves} waves; one launch active: {ctxs[True][0].fused_status()[0]}{' (classic scheme)' if CLASSIC else ''}", flush=True)
     for r in range(rot):
         row = []
         for f in (True, False):
