@@ -362,6 +362,8 @@ hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_c
 // use_fused) has checked the launch shape; `blocks_per_cu` != nullptr only ASKS how many blocks of this kernel a CU holds and launches
 // nothing.  hipErrorNotSupported: no kernel for this pair of stage sets (the caller then takes the two-launch path).
 constexpr uint32_t SF_B_COS_HW_MOM_F = B_CHAIN | B_SCALE | B_UNBIAS | B_DRIFT_MIDDLE | B_HARDWALL | B_KE_MOM;      // (no cos(kz) cache between the halves)
+constexpr uint32_t SF_B_COS_SCALE_MOM_F = B_CHAIN | B_SCALE | B_UNBIAS | B_KE_MOM;                                  // classic scheme: second half / first half
+constexpr uint32_t SF_B_COS_VV1_HW_MOM_F = SF_B_COS_SCALE_MOM_F | B_VV_KICK | B_HARDWALL;
 hipError_t launch_fused(int precision, const KArgs& a, int block_threads, const unsigned long long* rendezvous, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int* route, int* blocks_per_cu) {
     if (route) *route = ROUTE_COMPILED;
     const dim3 g = grid_for(a.nwaves, block_threads);
@@ -393,6 +395,18 @@ hipError_t launch_fused(int precision, const KArgs& a, int block_threads, const 
         VV_TRY_FUSED(SF_B_VV1, SF_A_KE)                              // ... C1, C2
         VV_TRY_FUSED(SF_B_SCALE, SF_A_VV2)                           // classic scheme, second half: half kick + sums + scaling
         VV_TRY_FUSED(SF_B_SCALE, SF_A_KE)                            // a thermostat application on its own (vvhip_scale_velocity)
+        VV_TRY_FUSED(SF_B_VV1_HW_SHAKE, SF_A_KE)                     // ... the classic scheme of the other BASELINE configurations and their constraints
+        VV_TRY_FUSED(SF_B_SCALE, SF_A_VV2_SHAKE)
+        VV_TRY_FUSED(SF_B_VV1_SETTLE, SF_A_KE)
+        VV_TRY_FUSED(SF_B_SCALE, SF_A_VV2_SETTLE)
+        VV_TRY_FUSED(SF_B_VV1_EDL, SF_A_KE)
+        VV_TRY_FUSED(SF_B_SCALE, SF_A_VV2_EDL)
+        VV_TRY_FUSED(SF_B_VV1_EDL_SHAKE, SF_A_KE)
+        VV_TRY_FUSED(SF_B_SCALE, SF_A_VV2_EDL_SHAKE)
+        VV_TRY_FUSED(SF_B_COS_VV1_HW_MOM_F, SF_A_COS_MOM_VV1)
+        VV_TRY_FUSED(SF_B_COS_SCALE_MOM_F, SF_A_COS_MOM_VV2)
+        VV_TRY_FUSED(SF_B_COS_VV1_HW_MOM_F | B_SHAKE, SF_A_COS_MOM_VV1)
+        VV_TRY_FUSED(SF_B_COS_SCALE_MOM_F, SF_A_COS_MOM_VV2_SHAKE)
     }
 #undef VV_TRY_FUSED
 #undef VV_FUSED_ONE
