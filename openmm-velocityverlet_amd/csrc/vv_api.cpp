@@ -308,7 +308,10 @@ void pick_launch_shape(vvhip_plan* p) {
     // bandwidth-bound regime (the chain runs as its own launch there, kernel B fits 6 waves per SIMD): tuned at 8.9 M particles
     // (kernel B: two blocks per CU, not four -- round 4, three alternating runs: 2.66 M particles 7 330 -> 7 540 steps/s, 4.4 M 4 226 -> 4 326,
     // 8.9 M 1 970 -> 2 042; kernel A's eight blocks per CU against four: 7 540 / 7 547, 4 326 / 4 272, 2 042 / 2 074)
-    if (nw >= p->split_chain_waves) { p->block_threads = 256; p->grid_cap_a = 8 * cus; p->grid_cap_b = 2 * cus; return; }
+    // Round 5 (tools/probes/large_n_shape.py, profiles/r05j_large_n_shape.txt, three rotations each on two boxes): kernel A holds 74 VGPRs = six
+    // waves per SIMD, so eight blocks of four waves per CU run as one round and a third; four per CU from 5 M particles: 5.5 M 3 350 -> 3 456
+    // steps/s, 8.9 M 2 116 -> 2 248 (the other box 2 032 -> 2 060), 3.3 M 6 273 -> 6 253 (eight stay there); three or two per CU lose again.
+    if (nw >= p->split_chain_waves) { p->block_threads = 256; p->grid_cap_a = (nw >= 80000 ? 4 : 8) * cus; p->grid_cap_b = 2 * cus; return; }
     const int max_waves = (p->hp.params.cos_acceleration != 0 || p->hp.info.num_shake_clusters > 0 || p->hp.info.num_general_constraints > 0 ||
                            p->hp.info.num_virtual_sites > 0) ? 12 : 16;
     double best = -1;

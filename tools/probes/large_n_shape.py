@@ -8,10 +8,11 @@ I, S = pkg.integrator, pkg.systems
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 80.0
 spec = S.make_config("C3", scale=scale)
 nsteps = int(120000 / scale)
-shapes = [(256, 2048, 512), (256, 1536, 512), (256, 1280, 512), (256, 1024, 512), (256, 768, 512), (512, 768, 512), (512, 512, 512), (384, 1024, 512),
-          (256, 1536, 768), (256, 1536, 1024), (256, 1536, 256)]
+shapes = [(256, 2048, 512), (256, 1024, 512), (256, 768, 512), (256, 512, 512)]
+if os.environ.get("SHAPES"):
+    shapes = [tuple(int(x) for x in t.split("x")) for t in os.environ["SHAPES"].split(",")]
 res = {s: [] for s in shapes}
-for rep in range(2):
+for rep in range(int(os.environ.get('ROT', '2'))):
     for s in shapes:
         it = I.VVIntegrator(333.0, 10, 1.0, 40, 0.001); it.setMaxDrudeDistance(0.02)
         ctx = I.Context(spec, it, precision="mixed", force_provider="tether", tune={"block_threads": s[0], "grid_cap_a": s[1], "grid_cap_b": s[2]})
