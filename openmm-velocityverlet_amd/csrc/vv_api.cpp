@@ -304,6 +304,10 @@ void pick_launch_shape(vvhip_plan* p) {
     // cus = what the bound device reports (256 on an MI355X in SPX mode; 32 per XCD partition in CPX mode); before vvhip_bind the
     // plan assumes a whole MI355X.
     const int nw = p->hp.info.num_waves, cus = p->num_cus;
+    // The cos perturbation's one-launch step collects ten rows in its rendezvous, shared by the waves of a block: three tile waves per block
+    // (a third of the words to poll, four waves to share the rows) beat one or two up to 3 x CUs tile waves -- one rank's eighth / quarter of C4
+    // 89.1 -> 92.8 k / 89.5 -> 91.1 k steps/s; with three rows the plan's choice below stays the best (profiles/r05j_small_shape.txt)
+    if (p->hp.params.cos_acceleration != 0 && p->hp.has_nh && nw > 3 && nw <= 3L * cus) { p->block_threads = 192; p->grid_cap_a = p->grid_cap_b = cus; return; }
     if (nw <= cus) { p->block_threads = 64; p->grid_cap_a = p->grid_cap_b = cus; return; }
     // bandwidth-bound regime (the chain runs as its own launch there, kernel B fits 6 waves per SIMD): tuned at 8.9 M particles
     // (kernel B: two blocks per CU, not four -- round 4, three alternating runs: 2.66 M particles 7 330 -> 7 540 steps/s, 4.4 M 4 226 -> 4 326,
