@@ -16,6 +16,15 @@
 // -ffp-contract=off, so element-wise results equal the CPU oracle bit for bit; only the reductions
 // differ (their order, and the reciprocals that feed nothing but sums: Prec::RECIP_SUM).  No MFMA:
 // there is no contraction on this path (HBM / latency / fp64-issue bound).
+// Build: the Makefile compiles this file twice, in parallel -- VV_KERNELS_PART=1: launch_a / launch_b and the small launchers, =2: launch_fused
+// (the one-launch step's instances of vv_kernel_b are half of the device code) -- and links both objects; without the macro one translation
+// unit holds everything (make asm, instrumented probe builds).
+#ifndef VV_KERNELS_PART
+#define VV_KERNELS_PART 0
+#endif
+#if VV_KERNELS_PART == 2
+#define VV_DEVICE_NO_PLAIN_KERNELS      // (vv_kernel_chain / vv_kernel_bump_epoch are not templates: one definition, in part 1)
+#endif
 #include "vv_kernels.hpp"
 
 #include <hip/hip_ext.h>
@@ -183,9 +192,12 @@ constexpr uint32_t SF_B_MIDDLE_SETTLE_P = SF_B_MIDDLE_SETTLE | B_PERIODIC;      
 #define VV_SF_MTAB_B 1
 #endif
 constexpr uint32_t SF_AM = VV_SF_MTAB_A ? A_MTAB : 0u, SF_BM = VV_SF_MTAB_B ? B_MTAB : 0u;
+#if VV_KERNELS_PART != 2
 bool sf_kernels_use_mass_table(int kernel) { return kernel == 0 ? VV_SF_MTAB_A != 0 : VV_SF_MTAB_B != 0; }
+#endif
 #define VV_TRY_SF(KERNEL, SFV) if (a.flags == ((SFV) | XM)) { VV_DISPATCH_SF(KERNEL, ((SFV) | XM), g, b, lds, s, ev0, ev1, VV_PRE_ARGS, a); return hipGetLastError(); }
 
+#if VV_KERNELS_PART != 2
 // Launches that found no compiled specialisation of their stage set and ran the generic kernel with run-time stage bits (15-20 % slower):
 // counted per kernel with the last such stage set (vvhip_generic_launches reads them); VVHIP_WARN_GENERIC=1 also prints one line on
 // stderr per stage set.
@@ -357,6 +369,8 @@ hipError_t launch_b(int precision, const KArgs& a, int block_threads, int grid_c
     return hipGetLastError();
 #undef VV_PRE_ARGS
 }
+#endif      // VV_KERNELS_PART != 2
+#if VV_KERNELS_PART != 1
 // ---- fused step: kernel A's stage set `a.flags_a` and kernel B's `a.flags` in ONE launch (vv_device.inc: "fused step").  Every tile needs a
 // wave of its own (it stays in registers across the rendezvous) and the blocks must be resident together: the caller (vv_api.cpp:
 // use_fused) has checked the launch shape; `blocks_per_cu` != nullptr only ASKS how many blocks of this kernel a CU holds and launches
@@ -428,6 +442,8 @@ hipError_t launch_fused(int precision, const KArgs& a, int block_threads, const 
     return hipErrorNotSupported;
 #undef VV_PRE_ARGS
 }
+#endif      // VV_KERNELS_PART != 1
+#if VV_KERNELS_PART != 2
 hipError_t launch_chain(const NHConst& c, NHDevState* st, unsigned long long* acc, hipStream_t s) {
     hipLaunchKernelGGL(vv_kernel_chain, dim3(1), dim3(64), 0, s, c, st, acc);
     return hipGetLastError();
@@ -458,5 +474,6 @@ hipError_t launch_image_pairs(int precision, void* posq, void* corr, const int2*
     VV_DISPATCH(vv_kernel_images, dim3(blocks), dim3(256), 0, s, posq, corr, pairs, npairs, mirror);
     return hipGetLastError();
 }
+#endif      // VV_KERNELS_PART != 2
 
 }  // namespace vv
