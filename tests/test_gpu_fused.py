@@ -189,8 +189,8 @@ def test_one_eighth_shard_of_c4():
     _same(one, two, "C4 / 8")
 
 
-@pytest.mark.parametrize("cos", [0.0, 0.02])
-def test_one_launch_step_next_to_the_mailbox(cos):
+@pytest.mark.parametrize("cos,middle", [(0.0, True), (0.02, True), (0.0, False)])
+def test_one_launch_step_next_to_the_mailbox(cos, middle):
     """A sharded plan whose exchange is the xGMI mailbox (one rank of one here: its own box is the only peer) keeps the one-launch step -- the
     thermostat wave exchanges the ranks' totals right behind the local rendezvous -- and lands on the two-launch step's bits."""
     D = importlib.import_module("openmm-velocityverlet_amd").distributed
@@ -200,6 +200,7 @@ def test_one_launch_step_next_to_the_mailbox(cos):
         it = I.VVIntegrator(333.0, 10.0, 1.0, 40.0, 0.001)
         it.setMaxDrudeDistance(0.02)
         it.setCosAcceleration(cos)
+        it.setUseMiddleScheme(middle)      # (the classic scheme: two exchanges per step, each inside its half's one launch)
         ctx = I.Context(spec, it, precision="mixed", force_provider="tether", shard=D.shard_bounds(spec, 2)[0], tune={"fused": int(fused)})
         try:
             ctx.mailbox_connect(ctx.mailbox_create(1, 0))
@@ -207,7 +208,7 @@ def test_one_launch_step_next_to_the_mailbox(cos):
             ctx.run_graph(8, 4)
             ctx.synchronize()
             assert ctx.mailbox_status() == (True, False)
-            assert ctx.fused_status()[0] == fused and (ctx.fused_status()[1] > 0) == fused
+            assert ctx.fused_status()[0] == (fused and middle) and (ctx.fused_status()[1] > 0) == fused
             outs.append((ctx.getPosq(), ctx.getVelm(), bytes(ctx.getNHState())))
         finally:
             ctx.close()

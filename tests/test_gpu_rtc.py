@@ -247,3 +247,31 @@ def test_random_stage_sets_specialised_kernel_equals_generic_kernel():
             assert np.array_equal(np.ascontiguousarray(x).view(np.uint8), np.ascontiguousarray(y).view(np.uint8)), \
                 f"launch {i}: kernel {'AB'[kernel]} stage set 0x{flags:x}: {what} differs between the generic and the specialised kernel"
 
+
+
+@pytest.mark.parametrize("middle", [True, False])
+def test_first_launch_inside_a_graph_capture(middle):
+    """A plan whose very first step is enqueued by vvhip_run_graph meets its uncompiled stage set (a two-link chain) INSIDE the stream capture:
+    the kernel is compiled and loaded there, the captured graph replays it, and the trajectory is the one of step-by-step launches."""
+    I.Context.rtc_mode(1)
+    spec = S.drude_il(cells=(1, 1, 1), pairs_per_cell=24, seed=77)
+    out = []
+    before = I.Context.rtc_stats()[0]
+    for graph_first in (True, False):
+        it = I.VVIntegrator(333.0, 10.0, 1.0, 40.0, 0.001, 2, 1)
+        it.setMaxDrudeDistance(0.02)
+        it.setUseMiddleScheme(middle)
+        ctx = I.Context(spec, it, precision="single", force_provider="tether")      # (two links in single precision: no other test has compiled these)
+        try:
+            if graph_first:
+                ctx.run_graph(8, 4)
+                assert I.Context.rtc_stats()[0] > before, "nothing was compiled inside the capture"
+            else:
+                it.step(8)
+            ctx.synchronize()
+            assert ctx.generic_launches()[0] == (0, 0)
+            out.append((ctx.getPosq().copy(), ctx.getVelm().copy(), bytes(ctx.getNHState())))
+        finally:
+            ctx.close()
+    assert np.array_equal(out[0][0].view(np.uint8), out[1][0].view(np.uint8)) and np.array_equal(out[0][1].view(np.uint8), out[1][1].view(np.uint8))
+    assert out[0][2] == out[1][2]
