@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np
 pkg = importlib.import_module("openmm-velocityverlet_amd")
 I, S = pkg.integrator, pkg.systems
-EXTRA = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("FUSED_TUNE", "").split(",") if kv)}      # e.g. FUSED_TUNE=fused_warm=0 (one-launch contexts only)
+EXTRA = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("FUSED_TUNE", "").split(",") if kv)}      # e.g. FUSED_TUNE=fused_poll_delay=6 (one-launch contexts only)
 configs = (sys.argv[1] if len(sys.argv) > 1 else "C3,C4,C5,C2,C1").split(",")
 rot = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20000
