@@ -848,6 +848,22 @@ def main():
                 ctx_o.close()
             except Exception as e:                                   # noqa: BLE001 -- a secondary block must never break the bench line
                 others[oc] = f"skipped: {type(e).__name__}: {e}"
+        try:      # the classic scheme (stepVV, VVIntegrator.cpp:295-336) of the headline box: two thermostat applications per step, one launch each
+            it_c = I.VVIntegrator(333.0, 10.0, 1.0, 40.0, 0.001)
+            it_c.setMaxDrudeDistance(0.02)
+            it_c.setUseMiddleScheme(False)
+            ctx_c = I.Context(spec, it_c, precision=args.precision, force_provider="tether", device=local_rank)
+            ctx_c.run_graph(600, 100); ctx_c.synchronize()
+            n0 = ctx_c.fused_status()[1]
+            sps_drv = driver_protocol(ctx_c)
+            sps_long = secondary(ctx_c, 4000)
+            ctx_c.run_eager(10); ctx_c.synchronize()
+            others["C3_classic_scheme"] = {"particles": int(spec.num_atoms), "steps_per_s_driver_flags": round(sps_drv, 1), "steps_per_s": round(sps_long, 1),
+                                           "integrator_launches_per_step": 2 if ctx_c.fused_status()[1] > n0 else 4,
+                                           "generic_kernel_launches": sum(ctx_c.generic_launches()[0])}
+            ctx_c.close()
+        except Exception as e:                                       # noqa: BLE001
+            others["C3_classic_scheme"] = f"skipped: {type(e).__name__}: {e}"
         out["config"]["other_configs"] = {"protocol": "steps_per_s_driver_flags: one replay of a 20-step hipGraph per timed region, median of 25 regions (the headline's protocol "
                                                       "under --steps 20 --warmup 5); steps_per_s: median of 3 regions of 4000 steps (100-step graphs)", **others}
 

@@ -51,6 +51,8 @@ def test_driver_flags_give_the_long_run_figure():
             assert isinstance(oc[name], dict), oc[name]
             assert oc[name]["steps_per_s_driver_flags"] > 1000 and oc[name]["steps_per_s"] > 1000 and 0 < oc[name]["roofline"]["frac"] < 1
             assert oc[name]["generic_kernel_launches"] == 0
+        cl = oc["C3_classic_scheme"]          # the classic scheme of the headline box: one launch per thermostat application
+        assert isinstance(cl, dict) and cl["steps_per_s_driver_flags"] > 1000 and cl["integrator_launches_per_step"] == 2 and cl["generic_kernel_launches"] == 0
     import shutil
     if shutil.which("rocprofv3"):          # the live rocprofv3 child run is the clock of frac, and agrees with the dispatch timestamps of kernel B
         r = short["roofline"]
