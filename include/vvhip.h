@@ -425,6 +425,10 @@ int vvhip_debug_timestamps(vvhip_plan* plan, uint32_t flags, int block, long lon
 int vvhip_debug_timestamps_fused(vvhip_plan* plan, int block, long long out[128]);            /* ... one real one-launch step, stamped */
 int vvhip_debug_span(vvhip_plan* plan, int kernel, uint32_t flags, int reps, double out[8]);   /* instrumented builds only */
 int vvhip_debug_fused_flags(vvhip_plan* plan, int kernel, uint32_t* flags);          /* stage bits of the fused middle step's kernel A (0) / B (1) */
+/* The launch shape the plan chose (host-only: before vvhip_bind a whole MI355X of 256 CUs is assumed): shape[0] = threads of the tile waves of a
+ * block (the one-launch step and kernel B add the block's thermostat wave), shape[1] / shape[2] = most blocks per launch of kernel A / kernel B,
+ * shape[3] = tile waves per block of the one-launch step, 0 where the launch shape rules it out (its other conditions: vvhip_fused_status). */
+int vvhip_debug_launch_shape(const vvhip_plan* plan, int32_t shape[4]);
 int vvhip_debug_step_spans(vvhip_plan* plan, int nsteps, const void* site, double k_tether, double k_drude, double out[36]);   /* instrumented builds only */
 int vvhip_debug_old_delta(vvhip_plan* plan, void** device_ptr);                       /* plan-owned oldDelta (mixed4[n]) */
 

@@ -1505,6 +1505,12 @@ int vvhip_run_graph(vvhip_plan* p, int nsteps, int steps_per_graph, const void* 
 }
 
 // The stage bits vvhip_step_middle launches kernel A (kernel = 0) / kernel B with for this plan (timing and probe entry points)
+int vvhip_debug_launch_shape(const vvhip_plan* p, int32_t shape[4]) {
+    if (!p || !shape) return VVHIP_ERR_INVALID;
+    shape[0] = p->block_threads; shape[1] = p->grid_cap_a; shape[2] = p->grid_cap_b;
+    shape[3] = fused_shape_ok(p) ? p->block_threads / 64 : 0;
+    return VVHIP_OK;
+}
 int vvhip_debug_fused_flags(vvhip_plan* p, int kernel, uint32_t* flags) {
     NEED_BOUND(p);
     if (!flags) return VVHIP_ERR_INVALID;

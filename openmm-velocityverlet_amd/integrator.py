@@ -205,6 +205,18 @@ def plan_layout(system: SystemSpec, integrator: "VVIntegrator", precision: str =
     return info, slots
 
 
+def plan_launch_shape(system: SystemSpec, integrator: "VVIntegrator", precision: str = "mixed", shard=None):
+    """Host-only: (threads of a block's tile waves, most blocks of kernel A, of kernel B, tile waves per block of the one-launch step or 0) as the
+    plan chooses them for a whole MI355X (vvhip_debug_launch_shape)."""
+    plan, _, _ = create_plan(system, integrator, precision, shard)
+    try:
+        shape = (C.c_int32 * 4)()
+        H.check(H.lib.vvhip_debug_launch_shape(plan, C.byref(shape)), plan)
+    finally:
+        H.lib.vvhip_plan_destroy(plan)
+    return tuple(shape)
+
+
 DEFAULT_TUNE: dict = {}      # see Context(tune=...)
 
 

@@ -140,7 +140,7 @@ def _load():
         "vvhip_rtc_stats": [P(C.c_int64 * 3), P(C.c_double)], "vvhip_rtc_failures": [P(C.c_int64)],
         "vvhip_rtc_mode": [C.c_int],
         "vvhip_timing_enable": [vp, C.c_int], "vvhip_timing_read": [vp, P(dbl), P(dbl), P(dbl), P(i32 * 3)],
-        "vvhip_debug_step_spans": [vp, C.c_int, vp, dbl, dbl, P(dbl * 36)], "vvhip_debug_fused_flags": [vp, C.c_int, P(u32)],
+        "vvhip_debug_step_spans": [vp, C.c_int, vp, dbl, dbl, P(dbl * 36)], "vvhip_debug_fused_flags": [vp, C.c_int, P(u32)], "vvhip_debug_launch_shape": [vp, P(C.c_int32 * 4)],
         "vvhip_debug_launch": [vp, C.c_int, u32, u32], "vvhip_debug_tune": [vp, C.c_char_p, C.c_int],
         "vvhip_debug_read_accumulators": [vp, P(dbl * 4), C.c_int],
         "vvhip_debug_set_scales": [vp, P(dbl * 4)],

@@ -392,3 +392,37 @@ def test_a_plan_that_cannot_fuse_its_constraints_says_why():
                 assert "64 constraints of a wave's list" in reason or "16 colours" in reason or "two waves" in reason, reason
         finally:
             H.lib.vvhip_plan_destroy(plan)
+
+
+def test_launch_shapes_of_the_measured_regimes():
+    """The launch shapes the measurements of TUNING_LOG sections 12-13 settled on, as the plan chooses them for a whole MI355X (256 CUs) before any
+    device is bound: one block of seven tile waves per CU at the headline size (one launch per step), three tile waves per block for a rank's
+    share of the cos-perturbed box (ten rendezvous rows, shared by the block's waves), two blocks per CU past one pass, whole rounds of
+    four-wave blocks in the bandwidth-bound regime."""
+    def shape(cfg, scale=1.0, cos=0.0, shard=None, hbonds=False):
+        spec = systems.make_config(cfg, scale, hbonds=hbonds)
+        it = I.VVIntegrator(333.0, 10, 1.0, 40, 0.001)
+        it.setMaxDrudeDistance(0.02 if cfg in ("C3", "C5") else 0.0)
+        it.setCosAcceleration(cos)
+        sh = None if shard is None else pkg.distributed.shard_bounds(spec, shard)[0]
+        info, _ = I.plan_layout(spec, it, shard=sh)
+        return info.num_waves, I.plan_launch_shape(spec, it, shard=sh)
+
+    nw, s = shape("C3")
+    assert nw == 1752 and s == (448, 256, 256, 7)                  # 251 blocks of 7 tile waves + the thermostat wave: the one-launch step
+    nw, s = shape("C3", cos=0.02)
+    assert s == (448, 256, 256, 7)                                 # C4: same shape, the ten rows collected by all eight waves
+    nw, s = shape("C3", cos=0.02, shard=8)
+    assert nw <= 256 and s == (192, 256, 256, 3)                   # one rank's eighth of C4: three tile waves per block
+    nw, s = shape("C3", shard=8)
+    assert s == (64, 256, 256, 1)                                  # ... of C3 (three rows): one tile wave per block stays the best
+    nw, s = shape("C2")
+    assert nw == 157 and s == (64, 256, 256, 1)
+    nw, s = shape("C5")
+    assert nw == 338 and s[0] == 128 and s[3] == 2                 # 169 blocks of two tile waves
+    nw, s = shape("C3", 1.5)
+    assert nw > 1792 and s[1] == 512 and s[3] == 0                 # past one pass: two blocks per CU, two launches
+    nw, s = shape("C3", 30.0)
+    assert s == (256, 2048, 512, 0)                                # 3.3 M particles: stand-alone chain, kernel A eight blocks per CU
+    nw, s = shape("C3", 80.0)
+    assert s == (256, 1024, 512, 0)                                # 8.9 M particles: kernel A in whole rounds (four per CU)
