@@ -32,7 +32,7 @@ for arg in sys.argv[1:] or ["C3"]:
         ws = [w for w in range(7) if t[w, 0] > 0]
         t0 = min([t[w, 0] for w in ws] + ([t[7, 0]] if t[7, 0] > 0 else []))
         f = lambda w, k: f"{(t[w, k] - t0) / GHZ:5.0f}" if t[w, k] > 0 else "    -"
-        line = f"  block {block:4d}: " + " | ".join(f"t{w} " + " ".join(f(w, k) for k in (0, 6, 7, 8, 9, 2, 3, 4, 5)) for w in ws[:2])
+        line = f"  block {block:4d}: " + " | ".join(f"t{w} " + " ".join(f(w, k) for k in (0, 6, 7, 8, 9, 2, 3, 4, 5)) for w in (ws if os.environ.get("ALL_WAVES") else ws[:2]))
         line += " | thermo " + " ".join(f(7, k) for k in (0, 6, 7, 8, 9)) + f" ({t[7, 10] if 0 <= t[7, 10] < 100 else 'shared'} rounds) " + " ".join(f(7, k) for k in (1, 4, 5, 2, 3))
         print(line, flush=True)
     ctx.close()
