@@ -21,7 +21,8 @@ def make(cfg, fused, provider=True):
     spec = S.make_config("C3" if base == "C4" else base, hbonds=hb)
     T, dt, maxd = (300.0, 0.002, 0.0) if base == "C2" else ((333.0, 0.001, 0.0) if base == "C1" else (333.0, 0.001, 0.02))
     it = I.VVIntegrator(T, 10, 1.0, 40, dt)
-    it.setMaxDrudeDistance(maxd)
+    # (integrator alone = free flight: the hard wall is checked as ever but moved out of reach, or its rare hit path runs for most pairs after ~150 steps)
+    it.setMaxDrudeDistance(maxd if provider or maxd == 0 else 1.0e3)
     it.setCosAcceleration(cos)
     it.setUseMiddleScheme(not CLASSIC)
     if base == "C5":
