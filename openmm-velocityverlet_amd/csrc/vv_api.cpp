@@ -119,7 +119,11 @@ struct vvhip_plan {
     // d_rv = the rendezvous words, [2 thermostat parities][NUM_ACC][ACC_SLOTS], uncached; fused_checked_* = the last pair of stage sets /
     // launch shape whose kernel and occupancy were looked up, fused_ok = what came of it.
     bool fused = true;
-    int fused_late_shift = 4;      // the wait grows when more than blocks / 2^shift blocks needed a second round (test hook "fused_late_shift")
+    // the wait grows when more than blocks / 2^shift blocks needed a second round (test hook "fused_late_shift").  1/16 of the blocks (shift 4,
+    // the first choice) let the wait climb where the blocks finish their front unevenly (constraint clusters: 11 units against the best pinned 7);
+    // half of them: C3 + HBonds 80.2 -> 81.9 k steps/s, C4 83.1 -> 84.2 k, C5 + HBonds 96.0 -> 97.4 k, C2 150.4 -> 152.4 k, C3 / C5 + 0.4 %
+    // (profiles/r05s_late_shift_scan.txt)
+    int fused_late_shift = 1;
     int fused_poll_delay = -1;     // >= 0: pins the wait between a block's publish and its first poll round, units of 256 clocks (test hook "fused_poll_delay"); -1: self-tuning
     unsigned long long* d_rv = nullptr;
     uint32_t fused_checked_a = 0, fused_checked_b = 0;
