@@ -183,10 +183,10 @@ def test_distributed_code_path_costs_nothing_at_one_rank():
             assert ex["chosen"] in ("mailbox", "eager", "graph", "python") and ex["process_group_ranks"] == 1
             assert ex["rccl_ranks"] in (0, 1) and isinstance(ex["log"], dict)
     plain, distv = max(vals["plain"], vals["plain2"]), max(vals["dist"], vals["dist2"])
-    assert distv > 0.95 * plain, vals
+    assert distv > 0.93 * plain, vals
     # the 4000-step form: 0.95-0.96 over a dozen boxes (kernel for kernel the two runs take the same time in rocprofv3's trace: B with the
-    # exchange 5.63 us, without 5.64 us)
-    assert vals["dist_long"] > 0.92 * vals["plain_long"], vals
+    # exchange 5.63 us, without 5.64 us; round 5, one launch per step: the mailbox words are one more wait of ~0.2 us in a 10 us step)
+    assert vals["dist_long"] > 0.90 * vals["plain_long"], vals
 
 
 @pytest.mark.gpu
