@@ -265,24 +265,32 @@ def rocprof_reference(key, algo, n_local):
 
 def roofline_block(ctx, n_local, times, rec=None, src=None, note=None, ref_key=None, live=None):
     """roofline objects of the integrator kernel(s) of context `ctx` -- kernel A and kernel B of the two-launch step, or the ONE kernel of
-    the one-launch step -- and the dominant one.  Clock of `achieved` / `frac`: the rocprofv3 child run of this very workload when there
-    is one (`live` = its kernel_stats; the average duration of the most-launched variant of each kernel, i.e. the kernel in its place in
-    the replayed step), else the dispatch-timestamp clock of kernel_times.  All clocks are printed."""
+    the one-launch step -- and the dominant one.  Clock of `achieved` / `frac` / `avg_launch_us`, the first that exists (`clock` says which):
+      rocprofv3_child          rocprofv3 --kernel-trace --stats of a child run of this very workload, started by this bench run before it touched
+                               the GPU (`live` = its kernel_stats; average duration of the most-launched variant of each kernel: the kernel in its
+                               place in the replayed step, from its predecessor's end to its own end);
+      rocprofv3_committed_csv  the committed summary of the same command (profiles/kernel_stats_latest.json <- profiles/r*_rocprofv3_kernel_stats_*.csv);
+      self_clocked             no profiler figure for this workload: dispatch timestamps (two launches) / the integrator-alone replay (one launch).
+    The self-clocked figures are always printed beside it (`avg_launch_us_dispatch_timestamps`; for the one-launch step
+    `frac_integrator_alone_replay` -- a MODIFIED workload: forces resident and zero, no provider kernel, hard wall out of reach -- round 5
+    reported that one as `frac`; the review asked for the figure profiles/ reproduces)."""
     algo = dict(zip("AB", ctx.algorithmic_bytes()))
     kernels = [k for k in "AB" if algo[k] > 0 and times.get(k) is not None]
+    one = bool(times.get("one_launch"))
     prof_ms = {}
     if isinstance(live, dict):
         for k in kernels:
             cand = {n: v for n, v in live.items() if n.startswith(f"vv_kernel_{k.lower()}<")}
             if cand:
                 prof_ms[k] = cand[max(cand, key=lambda n: cand[n]["calls"])]["avg_ns"] * 1e-6
-    one = bool(times.get("one_launch"))
-    # The one-launch step: its clock is the graph replay of the integrator alone (kernel_times) also where a rocprofv3 child run exists.  The
-    # profiler's per-dispatch handling starts the blocks of a launch unevenly, which this kernel's in-kernel rendezvous turns into time (child
-    # runs of one code on one box: 7.0 ... 8.8 us, the replay 7.18 ... 7.21 us, the stand-alone rocprofv3 profile 7.5 us); the child's figure is
-    # printed beside it (`avg_launch_us_rocprofv3_child`), the committed profile is the cross-check.
-    from_profiler = len(prof_ms) == len(kernels) and not one
-    clock = prof_ms if from_profiler else times
+    ref = rocprof_reference(ref_key, algo, n_local) if ref_key else None
+    csv_ms = {k: ref["avg_launch_us"][k] * 1e-3 for k in kernels if ref and k in ref.get("avg_launch_us", {})}
+    if len(prof_ms) == len(kernels):
+        clock, source = prof_ms, "rocprofv3_child"
+    elif len(csv_ms) == len(kernels):
+        clock, source = csv_ms, "rocprofv3_committed_csv"
+    else:
+        clock, source = times, "self_clocked"
     us = lambda v: None if v is None else round(v * 1e3, 3)
     per = {}
     for k in kernels:
@@ -294,27 +302,34 @@ def roofline_block(ctx, n_local, times, rec=None, src=None, note=None, ref_key=N
                   "avg_launch_us_back_to_back": us(times.get(k + "_back_to_back"))}
     dom = max(kernels, key=lambda k: clock[k])
     out = dict(per[dom])
-    if one and "B" in prof_ms:
-        out["avg_launch_us_rocprofv3_child"] = {"B": us(prof_ms["B"])}
-        out["frac_rocprofv3_child"] = round(algo["B"] * n_local / (prof_ms["B"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    out["clock"] = source
+    if "B" in prof_ms:
+        out["avg_launch_us_rocprofv3_child"] = {k: us(prof_ms[k]) for k in prof_ms}
+        out["frac_rocprofv3_child"] = round(algo[dom] * n_local / (prof_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dom in prof_ms else None
+    if one:
+        out["avg_launch_us_integrator_alone_replay"] = us(times["B"])
+        out["frac_integrator_alone_replay"] = round(algo["B"] * n_local / (times["B"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        out["integrator_alone_replay_caveat"] = ("a MODIFIED workload, comparison only: graph replay of the integrator alone -- forces resident and zero, no provider kernel in "
+                                                 "the loop, hard wall checked but moved out of reach of the free flight; 1 / rate = the kernel from its predecessor's end to its own end")
     name = {k: f"vv_kernel_{k.lower()}" for k in kernels}
     if one:
         name["B"] = "vv_kernel_b<.., SFA> (the one-launch step: kernel A's stages, in-kernel rendezvous, kernel B's stages)"
+    how = {"rocprofv3_child": "avg_launch_us / achieved / frac: rocprofv3 --kernel-trace --stats of a child run of this workload (graph replay), started by this bench "
+                              "run before it touched the GPU -- the kernel from its predecessor's end to its own end; ",
+           "rocprofv3_committed_csv": "avg_launch_us / achieved / frac: the committed rocprofv3 --kernel-trace --stats summary of this workload (%s; no live child run: %s); "
+                                      % ((ref or {}).get("file"), live if isinstance(live, str) else "not requested"),
+           "self_clocked": "avg_launch_us / achieved / frac: self-clocked (no rocprofv3 figure for this workload: %s) -- %s; "
+                           % (live if isinstance(live, str) else "no child run, no committed summary", "the integrator-alone replay" if one else "dispatch timestamps")}[source]
     out.update({"kernel": name[dom], "traffic_source": src, "algorithmic_bytes_per_particle": algo,
                 "survey_two_pass_floor_bytes_per_particle": SURVEY_TWO_PASS_FLOOR.get(ctx.precision),
                 "launches_per_step": 1 if one else 2,
                 "avg_launch_us": {k: per[k]["avg_launch_us"] for k in kernels},
                 "avg_launch_us_dispatch_timestamps": {k: per[k]["avg_launch_us_dispatch_timestamps"] for k in kernels},
                 "avg_launch_us_back_to_back": {k: per[k]["avg_launch_us_back_to_back"] for k in kernels},
-                "launch_timing": ("avg_launch_us / achieved / frac: rocprofv3 --kernel-trace --stats of a child run of this workload (graph replay), started by "
-                                  "this bench run before it touched the GPU -- the kernel from its predecessor's end to its own end; " if from_profiler else
-                                  ("avg_launch_us / achieved / frac: the one-launch kernel's own clock (below); avg_launch_us_rocprofv3_child / frac_rocprofv3_child: rocprofv3 "
-                                   "--kernel-trace --stats of a child run of this workload, whose per-dispatch handling disturbs the kernel's in-kernel rendezvous; " if one and prof_ms else
-                                   "avg_launch_us / achieved / frac: dispatch timestamps (no rocprofv3 child run: %s); " % (live if isinstance(live, str) else "not requested")))
-                                 + times["how"],
+                "launch_timing": how + times["how"],
                 "per_kernel": {f"vv_kernel_{k.lower()}": per[k] for k in kernels}})
     if ref_key:
-        out["rocprofv3_cross_check"] = rocprof_reference(ref_key, algo, n_local)
+        out["rocprofv3_cross_check"] = ref
     if note:
         out["note"] = note
     return out
