@@ -45,7 +45,7 @@ def restore_hard_wall(ctx, old):
         ctx.integrator.setMaxDrudeDistance(old)
 
 
-def kernel_times(ctx, reps, batches):
+def kernel_times(ctx, reps, batches, one_launch=None):
     """Average launch duration [ms] of kernel A and kernel B with the fused step's stage bits, two clocks:
       in sequence   every launch of `reps` eager steps (force provider -> A -> B, enqueued from C) timed by the dispatch's own begin /
                     end timestamps (hipExtLaunchKernel start / stop events: nothing is added to the stream; the timestamps rocprofv3's
@@ -56,7 +56,9 @@ def kernel_times(ctx, reps, batches):
                     in the step (it finds its own output in the cache), reported beside the other for comparison only."""
     import statistics
     import numpy as np
-    if ctx.fused_status()[0]:
+    # (`one_launch`: what ALL ranks of a sharded run agreed on -- the two branches launch different numbers of steps, and ranks that disagree
+    # would leave the mailbox's sequence numbers out of step)
+    if ctx.fused_status()[0] if one_launch is None else one_launch:
         # The one-launch step: ONE integrator kernel per step (an instance of vv_kernel_b that also runs kernel A's stages).  Its clock here is a
         # graph replay of the integrator ALONE (forces resident and zeroed: thermostatted free flight, no provider kernel in the loop): one kernel
         # per step back to back, so 1 / rate is the kernel from its predecessor's end to its own end -- what rocprofv3 reports for a kernel in a
@@ -65,16 +67,24 @@ def kernel_times(ctx, reps, batches):
         # wait climbs from 6 to its cap meanwhile: tools/probes/fused_eager_clock.py).
         prov = ctx.force_provider
         ctx.synchronize()
-        ctx.force.upload(np.zeros(3 * ctx.padded, dtype=np.int64))
-        ctx.force_provider = "static"
-        wall = widen_hard_wall(ctx)
+        # (the physical state is saved and put back, whatever happens in between: the free flight scrambles it, and later blocks reuse the context)
+        snap = (ctx.getPosq(), ctx.getPosqCorrection(), ctx.getVelm(), ctx.getNHState(), ctx.getForce())
+        wall = None
         n = max(200, 20 * reps)
-        ctx.run_graph(200, 100); ctx.synchronize()
         ts = []
-        for _ in range(max(3, batches)):
-            t0 = time.perf_counter(); ctx.run_graph(n, 100); ctx.synchronize(); ts.append((time.perf_counter() - t0) / n)
-        ctx.force_provider = prov
-        restore_hard_wall(ctx, wall)
+        try:
+            ctx.force.upload(np.zeros(3 * ctx.padded, dtype=np.int64))
+            ctx.force_provider = "static"
+            wall = widen_hard_wall(ctx)
+            ctx.run_graph(200, 100); ctx.synchronize()
+            for _ in range(max(3, batches)):
+                t0 = time.perf_counter(); ctx.run_graph(n, 100); ctx.synchronize(); ts.append((time.perf_counter() - t0) / n)
+        finally:
+            ctx.force_provider = prov
+            if wall is not None:
+                restore_hard_wall(ctx, wall)
+            ctx.synchronize()
+            ctx.posq.upload(snap[0]); ctx.posq_corr.upload(snap[1]); ctx.velm.upload(snap[2]); ctx.setNHState(snap[3]); ctx.force.upload(snap[4])
         return {"A": None, "B": 1e3 * statistics.median(ts), "A_back_to_back": None, "B_back_to_back": None, "one_launch": True,
                 "how": "one-launch step: 1 / (steps per second) of a graph replay of the integrator alone (%d steps, median of %d; forces resident and zero, no provider "
                        "kernel, hard wall checked but out of reach of the free flight) = the kernel from its predecessor's end to its own end; launches with start / stop events disturb its in-kernel rendezvous "
@@ -826,10 +836,19 @@ def main():
     # is a N = 1 figure taken from the committed summary (traffic_source says which).  Runs after the headline measurement: the
     # back-to-back batches scramble the physical state.
     if (world == 1 and rank == 0 and not use_dist) or (use_dist and stepper is None):
-        times = kernel_times(ctx, 100, 5)
+        one_all = bool(ctx.fused_status()[0])
+        mixed = False
+        if use_dist:          # the two clocks of kernel_times launch different numbers of steps: all ranks take the same one, or none is taken
+            all_one, none_one = agree(one_all), agree(not one_all)
+            mixed = not (all_one or none_one)
+            one_all = all_one
+        times = kernel_times(ctx, 100, 5, one_launch=one_all) if not mixed else None
         n_local = bounds[rank][1] - bounds[rank][0]
         rec, src = traffic_record(os.path.join(ROOT, "profiles", "pmc_latest_hbonds.json" if args.hbonds else "pmc_latest.json"), cfg, args.precision) if world == 1 else (None, None)
-        if rank == 0:
+        if rank == 0 and times is None:
+            out["roofline"] = None
+            out["config"]["roofline_skipped"] = "some ranks run the one-launch step and some two launches (different shard shapes): the kernels are not clocked"
+        if rank == 0 and times is not None:
             out["roofline"] = roofline_block(ctx, n_local, times, rec, src, ref_key=(cfg + ("_hbonds" if args.hbonds else "")) if world == 1 else None, live=prof.get("main"),
                                              note=(("working set (%.0f MB) is L2 / Infinity-Cache resident at this size: the launch is latency and VALU-issue bound "
                                                     "(two waves per SIMD), see config.large_n for the bandwidth-bound regime" % (228e-6 * n_local)) if n_local < 2_000_000 else
@@ -882,13 +901,17 @@ def main():
                 sps_drv = driver_protocol(ctx_o)
                 sps_long = secondary(ctx_o, 4000)
                 t_o = kernel_times(ctx_o, 100, 3)
-                rb_o = roofline_block(ctx_o, spec_o.num_atoms, t_o)
+                rb_o = roofline_block(ctx_o, spec_o.num_atoms, t_o, ref_key=oc)
                 ab_o = sum(ctx_o.algorithmic_bytes()) * spec_o.num_atoms
                 others[oc] = {"particles": int(spec_o.num_atoms), "steps_per_s_driver_flags": round(sps_drv, 1), "steps_per_s": round(sps_long, 1),
                               "ns_per_day_driver_flags": round(sps_drv * dt_o * 1e3 * 0.0864, 1),
                               "integrator_launches_per_step": rb_o["launches_per_step"], "kernel": rb_o["kernel"],
                               "roofline": {"bound": "hbm", "frac": rb_o["frac"], "achieved": rb_o["achieved"], "unit": "GB/s", "avg_launch_us": rb_o["avg_launch_us"],
-                                           "algorithmic_bytes_per_particle": rb_o["algorithmic_bytes_per_particle"], "clock": t_o["how"]},
+                                           "clock": rb_o["clock"], "launch_timing": rb_o["launch_timing"],
+                                           "frac_integrator_alone_replay": rb_o.get("frac_integrator_alone_replay"),
+                                           "avg_launch_us_integrator_alone_replay": rb_o.get("avg_launch_us_integrator_alone_replay"),
+                                           "rocprofv3_cross_check": rb_o.get("rocprofv3_cross_check"),
+                                           "algorithmic_bytes_per_particle": rb_o["algorithmic_bytes_per_particle"]},
                               "step": {"algorithmic_bytes_per_step": ab_o, "frac": round(ab_o * sps_long / 1e9 / HBM_PEAK_GBS, 4)},
                               "generic_kernel_launches": sum(ctx_o.generic_launches()[0])}
                 ctx_o.close()

@@ -320,6 +320,18 @@ int vvhip_status(vvhip_plan* plan, int32_t* mailbox_timed_out, int32_t* accumula
  * (VVHIP_ERR_RENDEZVOUS), [3] an in-kernel constraint cluster reached its iteration cap unconverged (VVHIP_ERR_CONSTRAINT). */
 int vvhip_status_words(vvhip_plan* plan, int32_t words[4]);
 int vvhip_status_clear(vvhip_plan* plan);
+/* A missed rendezvous of the one-launch step ([2]: its blocks were not resident together within 0.2 s -- another process's kernels on the
+ * device) is the one failure the plan-driven loops repair themselves.  vvhip_run_graph / vvhip_run_eager calls of >= 64 steps (test hook
+ * "recover_min_steps") start from a device-side snapshot of the physical state (positions, correction, velocities, forces, extra forces,
+ * both thermostat copies, the random generator's state), kept with the list of run calls since until a vvhip_synchronize has seen them end
+ * well; the vvhip_synchronize that finds [2] raised instead puts the snapshot back, pins the plan to two launches per step (bit for bit
+ * the same step; vvhip_fused_status: active = 0), repeats the calls, prints one line on stderr and returns VVHIP_OK -- the trajectory is
+ * the one an undisturbed run gives.  Anything else that touches the plan in between (a split entry point, vvhip_set_params, ...) settles
+ * the pending calls first.  Not in multi-GPU runs (every rank would have to repeat).  Without a snapshot (short calls, vvhip_step_* driven
+ * by the host, "recover" = 0 / VVHIP_RECOVER=0) the failure is VVHIP_ERR_RENDEZVOUS as before, and the plan is pinned to two launches
+ * all the same.  *recoveries: how often it has happened to this plan.  Reference contract: one context per device,
+ * platforms/cuda/src/CudaVVKernelFactory.cpp:68. */
+int vvhip_recovery_count(vvhip_plan* plan, int64_t* recoveries);
 /* The middle scheme's step as ONE launch (kernels A and B around an in-kernel rendezvous of co-resident blocks): *active = 1 if
  * vvhip_step_middle takes it for this plan as it stands (a thermostat with <= 4 links, every tile a wave of its own on <= 256
  * co-resident blocks, no RCCL exchange between the halves, a kernel for the plan's pair of stage sets), *launches = fused launches

@@ -133,6 +133,27 @@ struct vvhip_plan {
     FusedCheck fused_checks[4];    // (the classic scheme alternates between the pairs of its two halves)
     int fused_check_next = 0;
     long long fused_launches = 0;
+    // Recovery from a missed rendezvous (round 6).  The one-launch step needs its blocks resident together; another process's kernel on the
+    // device can break that, the blocks' bounded wait then runs out (sticky word [2]) and the step -- and every step enqueued behind it -- has
+    // worked on incomplete sums.  The plan-driven loops (vvhip_run_graph / vvhip_run_eager) therefore keep a device-side copy of the physical
+    // state from the entry of the first run call that is not yet known to have ended well (positions, correction, velocities, forces, extra
+    // forces, both thermostat copies, the random generator's epoch: 116 B per particle in mixed precision, taken only for calls of at least
+    // `min_steps` steps) together with the run calls since; the next vvhip_synchronize that finds word [2] raised puts the copy back, pins
+    // the plan to two launches per step (bit for bit the same step), repeats the calls and says so once on stderr.  No multi-GPU exchange in
+    // between (the other ranks would have to repeat theirs).  `vvhip_debug_tune(plan, "recover", 0)` / VVHIP_RECOVER=0 switch it off.
+    struct Recovery {
+        bool enabled = true, valid = false, replaying = false, in_loop = false;
+        int min_steps = 64;
+        void *posq = nullptr, *corr = nullptr, *velm = nullptr, *force = nullptr, *fextra = nullptr, *random = nullptr;
+        vv::NHDevState* nh = nullptr;
+        unsigned long long* epoch = nullptr;
+        int parity = 0;
+        uint32_t random_pos = 0;
+        bool fextra_dirty = false, fextra_virtual = false;
+        struct Run { int kind, nsteps, spg; const void* site; double kt, kd; };
+        std::vector<Run> runs;
+        long long recoveries = 0;
+    } rec;
     // plan-owned device state
     int2* d_slots = nullptr;
     int32_t* d_slot_image = nullptr;
@@ -229,16 +250,29 @@ int fail(vvhip_plan* p, int code, const std::string& msg) {
     if (p) p->err = msg;
     return code;
 }
+int recover_rendezvous(vvhip_plan* p);
+// Work on the plan from OUTSIDE the plan-driven loops while their snapshot is still unverified (a split entry point, a parameter change, a
+// fill): the calls since the snapshot are settled first -- synchronised and, if their rendezvous failed, repeated -- because what comes
+// now is not in the list a recovery would repeat.
+int settle_recovery(vvhip_plan* p) {
+    if (!p->rec.valid || p->rec.in_loop || p->rec.replaying || p->capturing) return VVHIP_OK;
+    return vvhip_synchronize(p);
+}
 // Sticky failures the kernels reported through the pinned status word (no synchronisation: the word lives in host memory).
 int check_exchange_health(vvhip_plan* p) {
     if (!p->h_status) return VVHIP_OK;
     const unsigned int mb = __atomic_load_n(&p->h_status[0], __ATOMIC_RELAXED), ov = __atomic_load_n(&p->h_status[1], __ATOMIC_RELAXED);
     const unsigned int rv = __atomic_load_n(&p->h_status[2], __ATOMIC_RELAXED), cs = __atomic_load_n(&p->h_status[3], __ATOMIC_RELAXED);
     if (mb) return fail(p, VVHIP_ERR_EXCHANGE, "multi-GPU mailbox: a wait on the peers' thermostat totals timed out; this rank went on with incomplete sums, the run is void");
+    // (a missed rendezvous first: an overflowed accumulator or an unconverged cluster next to it is what steps on incomplete sums produce)
+    if (rv) {
+        // (the plan is pinned to two launches per step from here on whatever else happens: the next run does not meet the same fate)
+        if (p->fused) { p->fused = false; drop_graphs(p); }
+        return fail(p, VVHIP_ERR_RENDEZVOUS, "fused step: the blocks of the one-launch step did not meet within 0.2 s (not resident together: another process's kernels on the device?); the thermostat went on with incomplete sums and the state since the last good synchronisation is void.  The plan now takes two launches per step (vvhip_fused_status: active = 0); vvhip_status_clear + restoring the state continues the run.  Runs of >= 64 steps through vvhip_run_graph / vvhip_run_eager recover by themselves (vvhip_debug_tune \"recover\")");
+    }
     // (an unconverged constraint cluster is reported before the overflow it usually causes a step or two later)
     if (cs) return fail(p, VVHIP_ERR_CONSTRAINT, "in-kernel constraints: a cluster reached the iteration cap without converging (a degenerate geometry, or a step that is too large); positions / velocities of that cluster are not within tolerance");
     if (ov) return fail(p, VVHIP_ERR_OVERFLOW, "a fixed-point accumulator overflowed (kinetic energy beyond 1024 x the thermostat target): the thermostat input is invalid");
-    if (rv) return fail(p, VVHIP_ERR_RENDEZVOUS, "fused step: the blocks of the one-launch step did not meet within 0.2 s (not resident together: another process on the device?); the thermostat went on with incomplete sums, the run is void -- vvhip_debug_tune(plan, \"fused\", 0) selects the two-launch step");
     return VVHIP_OK;
 }
 int hip_fail(vvhip_plan* p, hipError_t e, const char* what) {
@@ -552,6 +586,7 @@ int ensure_mass_table(vvhip_plan* p) {
     return VVHIP_OK;
 }
 int run_a(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
+    TRY(settle_recovery(p));
     if (p->mass_tab_a) { flags |= vv::A_MTAB; TRY(ensure_mass_table(p)); }
     // (kernel A takes the arithmetic path where it also saves the 20 bytes per lane of constraint tables; else it does not gain, see periodic_a)
     if (p->hp.per.enabled && p->periodic_kernels && (p->periodic_a || (flags & vv::A_CONS))) flags |= vv::A_PERIODIC;
@@ -567,6 +602,7 @@ int run_a(vvhip_plan* p, uint32_t flags, uint32_t random_index) {
 // with two ranks on one GPU; round 4 found the cause in device-filling grids of polling waves, whatever the layout: shared_device_cap)
 bool periodic_b(const vvhip_plan* p) { return p->hp.per.enabled && p->periodic_kernels && p->periodic_b; }
 int run_b(vvhip_plan* p, uint32_t flags) {
+    TRY(settle_recovery(p));
     if (p->mass_tab_b) { flags |= vv::B_MTAB; TRY(ensure_mass_table(p)); }
     if (periodic_b(p)) flags |= vv::B_PERIODIC;
     if ((flags & vv::B_SHAKE) && p->shake_mode == 0) flags |= vv::B_SHAKE_GS;
@@ -579,6 +615,7 @@ int run_b(vvhip_plan* p, uint32_t flags) {
     return VVHIP_OK;
 }
 int run_chain(vvhip_plan* p, uint32_t flags) {
+    TRY(settle_recovery(p));
     debug_stall(p);
     ScopedTimer t(p, T_OTHER);
     HIP_TRY(p, vv::launch_chain(make_chain(p, flags), p->d_nh + p->parity, p->d_acc + p->parity * acc_stride(p), p->stream));
@@ -673,6 +710,8 @@ int run_fused(vvhip_plan* p, uint32_t aflags, uint32_t bflags, uint32_t random_i
         c.a = aflags; c.b = bflags; c.threads = p->block_threads; c.waves = p->hp.info.num_waves; c.ok = p->fused_ok;
     }
     if (!p->fused_ok) return VVHIP_OK;
+    TRY(settle_recovery(p));
+    if (!p->fused) return VVHIP_OK;      // (settling may have pinned the plan to two launches)
     TRY(ensure_mass_table(p));
     debug_stall(p);
     ScopedTimer t(p, T_B, true);
@@ -741,6 +780,7 @@ int vvhip_plan_create(const vvhip_system_desc* system, const vvhip_params* param
         }
         if (const char* e = std::getenv("VVHIP_SHAKE_MODE")) p->shake_mode = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("VVHIP_FUSED")) p->fused = std::atoi(e) != 0;
+        if (const char* e = std::getenv("VVHIP_RECOVER")) p->rec.enabled = std::atoi(e) != 0;
         p->mass_tab_a = vv::sf_kernels_use_mass_table(0);
         p->mass_tab_b = vv::sf_kernels_use_mass_table(1);
         if (const char* e = std::getenv("VVHIP_ROCTX")) p->trace = std::atoi(e) != 0;
@@ -759,6 +799,7 @@ int vvhip_plan_create(const vvhip_system_desc* system, const vvhip_params* param
 // The environment switches of rounds 1-3 (VVHIP_REKICK, VVHIP_CAP_A, ...) are gone: their experiments are closed.
 int vvhip_debug_tune(vvhip_plan* p, const char* key, int value) {
     if (!p || !key) return VVHIP_ERR_INVALID;
+    if (p->bound) TRY(settle_recovery(p));
     if (p->bound) HIP_TRY(p, hipStreamSynchronize(p->stream));
     const std::string k = key;
     if (k == "periodic_kernels") p->periodic_kernels = value != 0;          // 0: keep the arithmetic layout's slot order but load the slot words
@@ -768,6 +809,8 @@ int vvhip_debug_tune(vvhip_plan* p, const char* key, int value) {
     else if (k == "rekick") p->rekick = value != 0;                         // 0: kernel A stores the kicked velocities, kernel B does not repeat the kick
     else if (k == "no_moments") p->no_moments = value != 0;                 // 1: cos perturbation as three launches (bias, sums, scale)
     else if (k == "fused") { p->fused = value != 0; p->fused_checked_b = 0; for (vvhip_plan::FusedCheck& c : p->fused_checks) c.b = 0; }
+    else if (k == "recover") { p->rec.enabled = value != 0; p->rec.valid = false; p->rec.runs.clear(); }      // 0: a missed rendezvous stays fatal (VVHIP_ERR_RENDEZVOUS)
+    else if (k == "recover_min_steps") p->rec.min_steps = std::max(1, value);
     else if (k == "fused_late_shift") p->fused_late_shift = std::max(0, std::min(value, 16));
     else if (k == "fused_poll_delay") p->fused_poll_delay = std::max(-1, std::min(value, 64));   // 0: the middle scheme's step as two launches (A, B) also where one would do
     else if (k == "mass_tab_a") p->mass_tab_a = value != 0;
@@ -791,7 +834,8 @@ void vvhip_plan_destroy(vvhip_plan* p) {
     if (p->bound) {
         (void) hipStreamSynchronize(p->stream);
         for (void* ptr : {(void*) p->d_slots, (void*) p->d_slot_image, (void*) p->d_slot_rand, (void*) p->d_slot_shake, (void*) p->d_slot_shake_param, (void*) p->d_slot_vsite, (void*) p->d_vsite_params, (void*) p->d_vsite_atom, (void*) p->d_slot_big, (void*) p->d_bigacc, (void*) p->d_image_pairs,
-                          p->d_fextra, p->d_old_delta, p->d_pos_delta, p->d_comv, (void*) p->d_comw, (void*) p->d_seg_mass, (void*) p->d_seg_base, (void*) p->d_slot_m, (void*) p->d_slot_f, (void*) p->d_cosz, (void*) p->d_epoch, (void*) p->d_acc, (void*) p->d_rv, (void*) p->d_nh, (void*) p->d_lane_const, (void*) p->d_dbg, (void*) p->d_dbg_span})
+                          p->d_fextra, p->d_old_delta, p->d_pos_delta, p->d_comv, (void*) p->d_comw, (void*) p->d_seg_mass, (void*) p->d_seg_base, (void*) p->d_slot_m, (void*) p->d_slot_f, (void*) p->d_cosz, (void*) p->d_epoch, (void*) p->d_acc, (void*) p->d_rv, (void*) p->d_nh, (void*) p->d_lane_const, (void*) p->d_dbg, (void*) p->d_dbg_span,
+                          p->rec.posq, p->rec.corr, p->rec.velm, p->rec.force, p->rec.fextra, p->rec.random, (void*) p->rec.nh, (void*) p->rec.epoch})
             if (ptr) (void) hipFree(ptr);
         drop_graphs(p);
         if (p->comm) (void) rccl_api().commDestroy(p->comm);
@@ -835,6 +879,7 @@ int vvhip_bind(vvhip_plan* p, const vvhip_buffers* b) {
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0)
         return fail(p, VVHIP_ERR_NO_DEVICE, "no HIP device: libvvhip has no CPU path");
+    if (p->bound) TRY(settle_recovery(p));
     if (p->bound) {
         // The captured graphs bake EVERY caller-owned pointer (make_args): a re-bind that swaps any of them must drop both
         // executables, or vvhip_run_graph would replay kernels on the old arrays without a word.  The stream is not part of a
@@ -917,8 +962,9 @@ int vvhip_bind(vvhip_plan* p, const vvhip_buffers* b) {
     HIP_TRY(p, hipMemsetAsync(p->d_acc, 0, 2 * kAccN * sizeof(unsigned long long), p->stream));
     // rendezvous words of the fused step: uncached (every block's thermostat wave polls what the other blocks -- on other XCDs, behind other
     // L2s -- have just stored); zero = "no step's word" (tags run from 1)
-    HIP_TRY(p, hipExtMallocWithFlags((void**) &p->d_rv, (size_t) (2 * kRvCopy + vv::ACC_SLOTS) * sizeof(unsigned long long), hipDeviceMallocUncached));
-    HIP_TRY(p, hipMemsetAsync(p->d_rv, 0, (size_t) (2 * kRvCopy + vv::ACC_SLOTS) * sizeof(unsigned long long), p->stream));
+    // (+ ACC_SLOTS words: the two rows of "polled twice" flags; + 8: the "a rendezvous has failed" word behind them, vv_device.inc: rv_dead_word)
+    HIP_TRY(p, hipExtMallocWithFlags((void**) &p->d_rv, (size_t) (2 * kRvCopy + vv::ACC_SLOTS + 8) * sizeof(unsigned long long), hipDeviceMallocUncached));
+    HIP_TRY(p, hipMemsetAsync(p->d_rv, 0, (size_t) (2 * kRvCopy + vv::ACC_SLOTS + 8) * sizeof(unsigned long long), p->stream));
     HIP_TRY(p, hipMalloc((void**) &p->d_nh, 2 * sizeof(vv::NHDevState)));
     vv::NHDevState init[2] = {};
     for (int c = 0; c < 2; c++)
@@ -949,6 +995,7 @@ int vvhip_bind(vvhip_plan* p, const vvhip_buffers* b) {
 
 int vvhip_set_params(vvhip_plan* p, const vvhip_params* q) {
     if (!p || !q) return VVHIP_ERR_INVALID;
+    TRY(settle_recovery(p));
     // topology-affecting choices are frozen at plan creation (the reference bakes them into its tables/JIT defines)
     vvhip_params n = *q;
     n.use_com_temp_group = p->hp.params.use_com_temp_group;
@@ -991,12 +1038,14 @@ int vvhip_masses_changed(vvhip_plan* p) {
 
 int vvhip_get_nh_state(vvhip_plan* p, vvhip_nh_state* out) {
     NEED_BOUND(p);
+    TRY(settle_recovery(p));
     HIP_TRY(p, hipStreamSynchronize(p->stream));
     HIP_TRY(p, hipMemcpy(out, &p->d_nh[p->parity].s, sizeof(*out), hipMemcpyDeviceToHost));
     return VVHIP_OK;
 }
 int vvhip_set_nh_state(vvhip_plan* p, const vvhip_nh_state* in) {
     NEED_BOUND(p);
+    TRY(settle_recovery(p));
     HIP_TRY(p, hipStreamSynchronize(p->stream));
     vvhip_nh_state st = *in;
     for (int g = 0; g < VVHIP_NUM_TG; g++)            // the chain's closing element is 0 by construction (API:340-376 never writes it)
@@ -1303,6 +1352,7 @@ int vvhip_compute_kinetic_energy(vvhip_plan* p, double* kinetic_energy) {   // H
 int vvhip_update_image_positions(vvhip_plan* p) {          // HOST:904-934
     NEED_BOUND(p);
     if (!p->hp.has_images) return VVHIP_OK;
+    TRY(settle_recovery(p));
     ScopedTimer t(p, T_OTHER);
     HIP_TRY(p, vv::launch_image_pairs(p->hp.precision, p->buf.posq, p->buf.posq_correction, p->d_image_pairs,
                                       (int) p->hp.image_pairs.size() / 2, p->hp.params.mirror_location, p->stream));
@@ -1335,7 +1385,20 @@ int vvhip_memset(void* dst, int value, size_t bytes) {      // complete on retur
 int vvhip_synchronize(vvhip_plan* p) {
     NEED_BOUND(p);
     HIP_TRY(p, hipStreamSynchronize(p->stream));
+    if (p->rec.valid && !p->rec.replaying) {
+        // the run calls since the snapshot have ended: well (the snapshot is dropped), or in a missed rendezvous (they are repeated).  An overflowed
+        // accumulator or an unconverged constraint cluster next to it is what steps on incomplete sums produce; if one of them was there before, the
+        // repeat raises it again.
+        if (__atomic_load_n(&p->h_status[2], __ATOMIC_RELAXED) != 0 && !__atomic_load_n(&p->h_status[0], __ATOMIC_RELAXED)) return recover_rendezvous(p);
+        p->rec.valid = false;
+        p->rec.runs.clear();
+    }
     return check_exchange_health(p);      // a mailbox time-out / accumulator overflow of the work just finished surfaces here
+}
+int vvhip_recovery_count(vvhip_plan* p, int64_t* recoveries) {
+    if (!p || !recoveries) return VVHIP_ERR_INVALID;
+    *recoveries = p->rec.recoveries;
+    return VVHIP_OK;
 }
 int vvhip_status(vvhip_plan* p, int32_t* mailbox_timed_out, int32_t* accumulator_overflow) {
     NEED_BOUND(p);
@@ -1370,6 +1433,9 @@ int vvhip_status_clear(vvhip_plan* p) {
     HIP_TRY(p, hipStreamSynchronize(p->stream));
     std::memset(p->h_status, 0, 4 * sizeof(unsigned int));
     if (p->d_mb_ctl) HIP_TRY(p, hipMemsetAsync(p->d_mb_ctl, 0, 4 * sizeof(unsigned int), p->stream));
+    if (p->d_rv) HIP_TRY(p, hipMemsetAsync(p->d_rv + 2 * kRvCopy + vv::ACC_SLOTS, 0, 8 * sizeof(unsigned long long), p->stream));      // "a rendezvous has failed" (vv_device.inc: rv_dead_word)
+    p->rec.valid = false;          // (a snapshot from before the failure the caller has just acknowledged is nobody's to restore)
+    p->rec.runs.clear();
     return VVHIP_OK;
 }
 
@@ -1385,6 +1451,7 @@ int vvhip_stream_destroy(void* stream) { return hipStreamDestroy((hipStream_t) s
 int vvhip_synth_tether_force(vvhip_plan* p, const void* site, double k_tether, double k_drude) {
     NEED_BOUND(p);
     if (!site) return VVHIP_ERR_INVALID;
+    TRY(settle_recovery(p));
     ScopedTimer t(p, T_OTHER, true);
     // (instrumented build: the provider stamps its waves only while vvhip_debug_step_spans numbers the launches -- its grid is not capped like the
     // kernels', and rows beyond the span buffer's 4096 per launch would be written past its end)
@@ -1419,10 +1486,96 @@ int vvhip_set_random_seed(vvhip_plan* p, uint64_t seed) {
 }
 int vvhip_fill_random(vvhip_plan* p) {
     NEED_BOUND(p);
+    TRY(settle_recovery(p));
     if (!p->buf.random || !p->buf.random_size) return fail(p, VVHIP_ERR_INVALID, "no random buffer bound");
     HIP_TRY(p, vv::launch_fill_normals((float4*) p->buf.random, p->buf.random_size, p->rng_seed, p->d_epoch, p->stream));
     p->random_pos = 0;
     return VVHIP_OK;
+}
+
+// ---- recovery from a missed rendezvous (vvhip_plan::Recovery)
+static size_t rec_bytes(const vvhip_plan* p, int which) {
+    const vv::HostPlan& hp = p->hp;
+    const size_t nloc = (size_t) (hp.shard_end - hp.shard_begin), rs = sizeof_real(hp.precision), ms = sizeof_mixed(hp.precision);
+    switch (which) {
+        case 0: return nloc * 4 * rs;                                  // posq
+        case 1: return p->buf.posq_correction ? nloc * 4 * rs : 0;     // posqCorrection
+        case 2: return nloc * 4 * ms;                                  // velm
+        case 3: return (size_t) hp.padded_num_atoms * 3 * 8;           // force (planar int64)
+        case 4: return nloc * 3 * rs;                                  // forceExtra
+        default: return p->hp.has_ld ? (size_t) p->buf.random_size * sizeof(float4) : 0;      // the Langevin normals in use
+    }
+}
+static int recovery_snapshot(vvhip_plan* p) {
+    vvhip_plan::Recovery& r = p->rec;
+    void** dst[6] = {&r.posq, &r.corr, &r.velm, &r.force, &r.fextra, &r.random};
+    const void* src[6] = {p->buf.posq, p->buf.posq_correction, p->buf.velm, p->buf.force, p->d_fextra, p->buf.random};
+    for (int i = 0; i < 6; i++) {
+        const size_t n = rec_bytes(p, i);
+        if (!n) continue;
+        if (!*dst[i]) HIP_TRY(p, hipMalloc(dst[i], n));
+        HIP_TRY(p, hipMemcpyAsync(*dst[i], src[i], n, hipMemcpyDeviceToDevice, p->stream));
+    }
+    if (!r.nh) HIP_TRY(p, hipMalloc((void**) &r.nh, 2 * sizeof(vv::NHDevState)));
+    if (!r.epoch) HIP_TRY(p, hipMalloc((void**) &r.epoch, sizeof(unsigned long long)));
+    HIP_TRY(p, hipMemcpyAsync(r.nh, p->d_nh, 2 * sizeof(vv::NHDevState), hipMemcpyDeviceToDevice, p->stream));
+    HIP_TRY(p, hipMemcpyAsync(r.epoch, p->d_epoch, sizeof(unsigned long long), hipMemcpyDeviceToDevice, p->stream));
+    r.parity = p->parity; r.random_pos = p->random_pos; r.fextra_dirty = p->fextra_dirty; r.fextra_virtual = p->fextra_virtual;
+    r.runs.clear();
+    r.valid = true;
+    return VVHIP_OK;
+}
+// At the entry of a plan-driven run call: take the snapshot if there is none and the call is worth one; remember the call.
+static int recovery_note_run(vvhip_plan* p, int kind, int nsteps, int spg, const void* site, double kt, double kd) {
+    vvhip_plan::Recovery& r = p->rec;
+    if (r.replaying || p->capturing || nsteps <= 0) return VVHIP_OK;
+    if (!r.valid) {
+        if (!r.enabled || nsteps < r.min_steps || !fused_state_ok(p) || p->comm || p->mb_on) return VVHIP_OK;
+        TRY(recovery_snapshot(p));
+    }
+    r.runs.push_back({kind, nsteps, spg, site, kt, kd});
+    return VVHIP_OK;
+}
+namespace {
+int recover_rendezvous(vvhip_plan* p) {
+    vvhip_plan::Recovery& r = p->rec;
+    long long steps = 0;
+    for (const auto& run : r.runs) steps += run.nsteps;
+    std::fprintf(stderr, "libvvhip: the one-launch step's blocks did not meet within 0.2 s (another process's kernels on the device?): the last %lld step(s) "
+                         "are repeated from the plan's snapshot with two launches per step, and the plan keeps two launches from here on\n", steps);
+    void* src[6] = {r.posq, r.corr, r.velm, r.force, r.fextra, r.random};
+    void* dst[6] = {p->buf.posq, p->buf.posq_correction, p->buf.velm, p->buf.force, p->d_fextra, const_cast<void*>(p->buf.random)};
+    for (int i = 0; i < 6; i++) {
+        const size_t n = rec_bytes(p, i);
+        if (n && src[i]) HIP_TRY(p, hipMemcpyAsync(dst[i], src[i], n, hipMemcpyDeviceToDevice, p->stream));
+    }
+    HIP_TRY(p, hipMemcpyAsync(p->d_nh, r.nh, 2 * sizeof(vv::NHDevState), hipMemcpyDeviceToDevice, p->stream));
+    HIP_TRY(p, hipMemcpyAsync(p->d_epoch, r.epoch, sizeof(unsigned long long), hipMemcpyDeviceToDevice, p->stream));
+    // both accumulator copies are zero between steps; whatever the failed steps left in them goes
+    HIP_TRY(p, hipMemsetAsync(p->d_acc, 0, 2 * kAccN * sizeof(unsigned long long), p->stream));
+    if (p->d_bigacc) HIP_TRY(p, hipMemsetAsync(p->d_bigacc, 0, (size_t) p->hp.num_big * 4 * sizeof(unsigned long long), p->stream));
+    HIP_TRY(p, hipMemsetAsync(p->d_rv + 2 * kRvCopy + vv::ACC_SLOTS, 0, 8 * sizeof(unsigned long long), p->stream));
+    p->parity = r.parity; p->random_pos = r.random_pos; p->fextra_dirty = r.fextra_dirty; p->fextra_virtual = r.fextra_virtual;
+    for (int w = 1; w < 4; w++) __atomic_store_n(&p->h_status[w], 0u, __ATOMIC_RELAXED);
+    p->fused = false;
+    p->fused_checked_b = 0;
+    for (vvhip_plan::FusedCheck& c : p->fused_checks) c.b = 0;
+    drop_graphs(p);
+    r.recoveries++;
+    r.valid = false;
+    r.replaying = true;
+    int rc = VVHIP_OK;
+    const std::vector<vvhip_plan::Recovery::Run> runs = r.runs;
+    r.runs.clear();
+    for (const auto& run : runs) {
+        rc = run.kind == 0 ? vvhip_run_graph(p, run.nsteps, run.spg, run.site, run.kt, run.kd) : vvhip_run_eager(p, run.nsteps, run.site, run.kt, run.kd);
+        if (rc != VVHIP_OK) break;
+    }
+    r.replaying = false;
+    if (rc != VVHIP_OK) return rc;
+    HIP_TRY(p, hipStreamSynchronize(p->stream));
+    return check_exchange_health(p);
+}
 }
 
 // One step of the plan-driven loops (vvhip_run_graph / vvhip_run_eager): force provider + fused step, in the scheme's order.
@@ -1491,6 +1644,8 @@ int vvhip_run_graph(vvhip_plan* p, int nsteps, int steps_per_graph, const void* 
     TRY(check_exchange_health(p));
     hipStream_t s = p->stream;
     if (!s) return fail(p, VVHIP_ERR_INVALID, "graph capture needs a non-null stream in vvhip_buffers.stream");
+    TRY(recovery_note_run(p, 0, nsteps, steps_per_graph, site, k_tether, k_drude));
+    struct InLoop { vvhip_plan* p; bool was; InLoop(vvhip_plan* q) : p(q), was(q->rec.in_loop) { p->rec.in_loop = true; } ~InLoop() { p->rec.in_loop = was; } } in_loop(p);
     const bool middle = p->hp.params.use_middle_scheme;
     // classic scheme (API:272-338): every step is first half -> forces -> second half, and the first half needs the forces of the
     // current positions; they are (re)computed once per call here, outside the replayed part
@@ -1838,6 +1993,8 @@ int vvhip_run_eager(vvhip_plan* p, int nsteps, const void* site, double k_tether
     NEED_BOUND(p);
     if (nsteps < 0) return VVHIP_ERR_INVALID;
     TRY(check_exchange_health(p));
+    TRY(recovery_note_run(p, 1, nsteps, 0, site, k_tether, k_drude));
+    struct InLoop { vvhip_plan* p; bool was; InLoop(vvhip_plan* q) : p(q), was(q->rec.in_loop) { p->rec.in_loop = true; } ~InLoop() { p->rec.in_loop = was; } } in_loop(p);
     if (!p->hp.params.use_middle_scheme && site && nsteps > 0) TRY(vvhip_synth_tether_force(p, site, k_tether, k_drude));   // see vvhip_run_graph
     for (int i = 0; i < nsteps; i++) TRY(plan_step(p, site, k_tether, k_drude, false));
     return VVHIP_OK;

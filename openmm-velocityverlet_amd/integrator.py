@@ -436,6 +436,12 @@ class Context:
         H.check(H.lib.vvhip_fused_status(self.plan, C.byref(a), C.byref(n), None), self.plan)
         return bool(a.value), int(n.value)
 
+    def recovery_count(self) -> int:
+        """How often this plan has repaired a missed rendezvous of the one-launch step (include/vvhip.h: vvhip_recovery_count)."""
+        n = C.c_int64(0)
+        H.check(H.lib.vvhip_recovery_count(self.plan, C.byref(n)), self.plan)
+        return int(n.value)
+
     def fused_wait_units(self) -> int:
         """Where the self-tuning wait of the one-launch step's rendezvous stands (units of 256 shader clocks; synchronises)."""
         w = C.c_int32(0)

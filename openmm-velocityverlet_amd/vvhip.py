@@ -125,7 +125,7 @@ def _load():
         "vvhip_synth_tether_force": [vp, vp, dbl, dbl],
         "vvhip_run_graph": [vp, C.c_int, C.c_int, vp, dbl, dbl],
         "vvhip_graph_prepare": [vp, C.c_int, vp, dbl, dbl],
-        "vvhip_status": [vp, P(i32), P(i32)], "vvhip_status_clear": [vp], "vvhip_masses_changed": [vp],
+        "vvhip_status": [vp, P(i32), P(i32)], "vvhip_status_clear": [vp], "vvhip_recovery_count": [vp, P(C.c_int64)], "vvhip_masses_changed": [vp],
         "vvhip_status_words": [vp, P(i32 * 4)], "vvhip_fused_status": [vp, P(i32), P(C.c_int64), P(i32)],
         "vvhip_run_eager": [vp, C.c_int, vp, dbl, dbl],
         "vvhip_run_eager_unfused": [vp, C.c_int, vp, dbl, dbl],

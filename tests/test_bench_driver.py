@@ -55,20 +55,66 @@ def test_driver_flags_give_the_long_run_figure():
             assert oc[name]["generic_kernel_launches"] == 0
         cl = oc["C3_classic_scheme"]          # the classic scheme of the headline box: one launch per thermostat application
         assert isinstance(cl, dict) and cl["steps_per_s_driver_flags"] > 1000 and cl["integrator_launches_per_step"] == 2 and cl["generic_kernel_launches"] == 0
+    # round 6 (the review's item 1): roofline.frac is the ROCPROFV3 fraction -- the live child run's average duration of the kernel when there is
+    # one, else the committed summary's -- for the one-launch kernel too; the self-clocked replay of the integrator alone is a named side field
+    for line in (short, long_):
+        r = line["roofline"]
+        k = "A" if r["kernel"] == "vv_kernel_a" else "B"
+        assert r["clock"] in ("rocprofv3_child", "rocprofv3_committed_csv", "self_clocked"), r["clock"]
+        if r["clock"] == "rocprofv3_child":
+            child = r["avg_launch_us_rocprofv3_child"][k]
+            assert abs(r["frac"] - r["algorithmic_bytes_per_launch"] / (child * 1e-6) / 8e12) < 2e-4, (r["frac"], child)
+            assert r["frac"] == r["frac_rocprofv3_child"] and r["launch_timing"].startswith("avg_launch_us / achieved / frac: rocprofv3 --kernel-trace --stats of a child run")
+        elif r["clock"] == "rocprofv3_committed_csv":
+            csv_us = r["rocprofv3_cross_check"]["avg_launch_us"][k]
+            assert abs(r["frac"] - r["algorithmic_bytes_per_launch"] / (csv_us * 1e-6) / 8e12) < 2e-4
+            assert r["rocprofv3_cross_check"]["file"].startswith("profiles/")
+        if r["launches_per_step"] == 1:
+            # the replay is a modified workload (no provider kernel, zero forces, wall out of reach): comparison only, and says so
+            assert 0 < r["frac_integrator_alone_replay"] < 1 and "MODIFIED workload" in r["integrator_alone_replay_caveat"]
+            assert r["avg_launch_us_integrator_alone_replay"] == r["avg_launch_us_dispatch_timestamps"]["B"]
     import shutil
     if shutil.which("rocprofv3"):
         r = short["roofline"]
+        assert r["clock"] == "rocprofv3_child", (r["clock"], r["launch_timing"])
         if r["launches_per_step"] == 1:
-            # the one-launch step: the graph replay of the integrator alone is the clock of frac (the profiler's per-dispatch handling disturbs the
-            # kernel's in-kernel rendezvous: its child run is printed beside it and may only be SLOWER than the undisturbed kernel, within reason)
-            assert r["launch_timing"].startswith("avg_launch_us / achieved / frac: the one-launch kernel's own clock"), r["launch_timing"]
-            assert r["avg_launch_us"]["B"] == r["avg_launch_us_dispatch_timestamps"]["B"]
-            child = r["avg_launch_us_rocprofv3_child"]["B"]
-            assert 0.9 < child / r["avg_launch_us"]["B"] < 1.45 and 0 < r["frac_rocprofv3_child"] < 1
+            # (the profiler's per-dispatch handling disturbs the kernel's in-kernel rendezvous: the child may only be SLOWER than the replay, within reason)
+            assert 0.9 < r["avg_launch_us"]["B"] / r["avg_launch_us_integrator_alone_replay"] < 1.45
         else:
-            # two launches: the live rocprofv3 child run is the clock of frac, and agrees with the dispatch timestamps of kernel B's eager launches
-            assert r["launch_timing"].startswith("avg_launch_us / achieved / frac: rocprofv3"), r["launch_timing"]
             assert abs(r["avg_launch_us"]["B"] / r["avg_launch_us_dispatch_timestamps"]["B"] - 1) < 0.15
+
+
+class _FakeCtx:
+    precision = "mixed"
+
+    def algorithmic_bytes(self):
+        return (0, 158)
+
+
+def test_roofline_clock_is_the_profilers():
+    """No GPU needed: bench.roofline_block takes frac from the live rocprofv3 child, else from the committed csv, else (and only then) from
+    its own clock; the one-launch step's replay figure never is `frac` when a profiler figure exists."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    n = 111000
+    times = {"A": None, "B": 7.0e-3, "A_back_to_back": None, "B_back_to_back": None, "one_launch": True, "how": "replay"}
+    live = {"vv_kernel_b<float, double, 68113u, 1056u>": {"calls": 4000, "avg_ns": 8000.0}, "vv_kernel_b<float, double, 1u, 2u>": {"calls": 3, "avg_ns": 1.0},
+            "vv_kernel_tether<float, double>": {"calls": 4000, "avg_ns": 5000.0}}
+    r = bench.roofline_block(_FakeCtx(), n, times, live=live)
+    assert r["clock"] == "rocprofv3_child" and r["avg_launch_us"]["B"] == 8.0
+    assert abs(r["frac"] - 158 * n / 8.0e-6 / 8e12) < 1e-4 and r["frac"] == r["frac_rocprofv3_child"]
+    assert abs(r["frac_integrator_alone_replay"] - 158 * n / 7.0e-6 / 8e12) < 1e-4 and r["frac_integrator_alone_replay"] > r["frac"]
+    # no child: the committed summary of the same workload
+    r = bench.roofline_block(_FakeCtx(), n, times, live="rocprofv3 not on PATH", ref_key="C3")
+    ref = json.load(open(os.path.join(ROOT, "profiles", "kernel_stats_latest.json")))["C3"]
+    us = max((v for k_, v in ref["kernels"].items() if k_.startswith("vv_kernel_b<")), key=lambda v: v["calls"])["avg_ns"] * 1e-3
+    assert r["clock"] == "rocprofv3_committed_csv" and abs(r["avg_launch_us"]["B"] - us) < 1e-3
+    assert abs(r["frac"] - 158 * n / (us * 1e-6) / 8e12) < 1e-4
+    # neither: self-clocked, and the line says so
+    r = bench.roofline_block(_FakeCtx(), n, times, live="rocprofv3 not on PATH", ref_key="no such workload")
+    assert r["clock"] == "self_clocked" and r["avg_launch_us"]["B"] == 7.0 and "self-clocked" in r["launch_timing"]
 
 
 @pytest.mark.gpu
