@@ -103,6 +103,26 @@ def kernel_times(ctx, reps, batches, one_launch=None):
                    "back to back: two HIP events around %d launches of the same kernel, median of %d" % (reps, reps, batches)}
 
 
+# What a first 1 -> 8 run should show ("the curve to expect"): a rank's own share of the step measured on ONE GPU with this
+# round's kernels (profiles/r06h_shard_step.txt; large box: the size ladder) + the exchange as ASSUMED there -- 2.0 us for the xGMI mailbox's
+# one remote flight, 20 us for an RCCL all-reduce between two launches (neither measured in the build environment).  us per step.
+PREDICTED_RANK_STEP_US = {"C3": {1: 9.55, 2: 8.68, 4: 8.01, 8: 7.64}, "C4": {1: 11.31, 2: 11.06, 4: 10.62, 8: 10.33},
+                          "C3x80": {1: 455.0, 2: 217.0, 4: 111.0, 8: 59.0}}
+PREDICTED_EXCHANGE_US = {"mailbox": 2.0, "graph": 20.0, "eager": 20.0, "python": 60.0}
+
+
+def predicted_rate(series, world, exchange):
+    """steps/s the model of DESIGN.md section 6 expects for `series` on `world` GPUs with that exchange mechanism, or None outside the table."""
+    step = PREDICTED_RANK_STEP_US.get(series, {}).get(world)
+    if step is None:
+        return None
+    if world > 1:
+        if exchange != "mailbox":
+            step = PREDICTED_RANK_STEP_US[series][world] * 1.2      # (two launches per step: the one-launch step needs the mailbox)
+        step += PREDICTED_EXCHANGE_US.get(exchange, 20.0)
+    return 1e6 / step
+
+
 def kill_group(child):
     """End a child started with start_new_session=True together with everything it started, and reap it."""
     import signal
@@ -619,7 +639,8 @@ def main():
             rccl_n = ctx.comm_count()
         except Exception:                                        # noqa: BLE001
             rccl_n = 0
-        rec = {"device": local_rank, "device_name": torch.cuda.get_device_name(local_rank), "peer_access": peer, "rccl_ranks": rccl_n, "exchange": dist_mode,
+        import socket
+        rec = {"host": socket.gethostname(), "device": local_rank, "device_name": torch.cuda.get_device_name(local_rank), "peer_access": peer, "rccl_ranks": rccl_n, "exchange": dist_mode,
                "mailbox_trial": exchange_log.get("mailbox"), "world": world, "share_device": bool(args.share_device)}
         ok_fc, text_fc = D.first_contact_report(rec)
         if rank == 0 or not ok_fc:
@@ -754,6 +775,12 @@ def main():
                       "python": "torch.distributed all-reduce per step (last resort)"}.get(dist_mode, str(dist_mode))
             out["config"]["exchange"] = {"chosen": dist_mode, "what": chosen, "rccl_ranks": rccl_ranks, "process_group_ranks": world,
                                          "candidates_us_per_step": candidates, "log": exchange_log}
+            pred = predicted_rate(cfg, world, dist_mode) if not args.hbonds and not args.share_device else None
+            out["config"]["exchange"]["predicted"] = {
+                "steps_per_s": None if pred is None else round(pred, 1), "measured_over_predicted": None if pred is None else round(steps_per_s / pred, 3),
+                "model": "DESIGN.md section 6: rank 0's share of the step as measured on one GPU (profiles/r06h_shard_step.txt) + the exchange as assumed "
+                         "there (xGMI mailbox 2.0 us, RCCL all-reduce between two launches 20 us; neither ever measured in the build environment)"
+                         + ("" if pred is not None else "; no prediction for this run (ranks sharing a device, constraints, or a size outside the table)")}
 
     def secondary(c, n=None):
         """steps/s of context c from replays of a --steps-per-graph graph: graph prepared and warmed outside the timed region,
@@ -1090,6 +1117,10 @@ def main():
                        "steps_per_s": round(n_timed / el_l, 1), "atom_steps_per_s": round(n_timed / el_l * nl, 1), "n_gpus": world, "exchange": mode_l,
                        "steps": n_timed, "launch": f"replays of a {g_l}-step hipGraph" if mode_l in ("mailbox", "graph") else "host-launched per step",
                        "integrator_launches_per_step": 1 if ctx_l.fused_status()[0] else 2, "scaling": "strong"}
+                pred_l = predicted_rate(label.split()[0], world, mode_l) if not args.share_device else None
+                if pred_l is not None:
+                    blk["predicted_steps_per_s"] = round(pred_l, 1)
+                    blk["measured_over_predicted"] = round(n_timed / el_l / pred_l, 3)
         if ctx_l is not None:
             try:
                 ctx_l.close()
@@ -1110,7 +1141,7 @@ def main():
     if use_dist and cfg == "C3" and args.large_n != "none" and not args.hbonds:
         it_l = I.VVIntegrator(333.0, 10.0, 1.0, 40.0, dt)
         it_l.setMaxDrudeDistance(0.02)
-        blkl = sharded_series("large-N sharded block", S.make_config("C3", float(args.large_n[3:]), synthetic=args.synthetic), it_l, 40, 10,
+        blkl = sharded_series(f"{args.large_n} sharded block", S.make_config("C3", float(args.large_n[3:]), synthetic=args.synthetic), it_l, 40, 10,
                               f"{args.large_n}: the C3 cell tiled along z")
         if rank == 0:
             if isinstance(blkl, dict):

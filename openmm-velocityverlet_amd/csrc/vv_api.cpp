@@ -1932,6 +1932,14 @@ int vvhip_mailbox_connect(vvhip_plan* p, const void* handles) {
     NEED_BOUND(p);
     if (!p->mb_local || !handles) return fail(p, VVHIP_ERR_INVALID, "vvhip_mailbox_create has not been called");
     std::vector<unsigned long long*> peers((size_t) p->mb_ranks, nullptr);
+    // A second connect: what vvhip_mailbox_destroy does first -- captured step graphs carry the OLD peer table's address and the peers' box
+    // addresses in their kernel arguments (a replay after the free below would read unmapped memory), launches still in flight use them too,
+    // and whether the step may be one launch depends on who shares the device (re-evaluated: fused_checked_*).
+    TRY(settle_recovery(p));
+    HIP_TRY(p, hipStreamSynchronize(p->stream));
+    drop_graphs(p);
+    p->fused_checked_b = 0;
+    for (vvhip_plan::FusedCheck& c : p->fused_checks) c.b = 0;
     p->mb_shared_device = false;       // (a second connect must not count the first one's ranks again)
     p->mb_device_ranks = 1;
     for (void* m : p->mb_opened) (void) hipIpcCloseMemHandle(m);

@@ -66,7 +66,8 @@ def check_first_contact(every: List[dict]):
         complaints.append(f"the ranks chose different exchange mechanisms: {sorted(map(str, chosen))}")
     if any(rec.get("world") != world for rec in every):
         complaints.append(f"ranks disagree about the world size: {[rec.get('world') for rec in every]} (gathered {world} records)")
-    devices = [rec.get("device") for rec in every]
+    # (a device is (host, local index): on several nodes the local indices repeat)
+    devices = [(rec.get("host"), rec.get("device")) for rec in every]
     if len(set(devices)) != world and not all(rec.get("share_device") for rec in every):
         complaints.append(f"two ranks on one device without --share-device: devices {devices}")
     exch = next(iter(chosen)) if len(chosen) == 1 else None
@@ -75,6 +76,8 @@ def check_first_contact(every: List[dict]):
         if bad:
             complaints.append(f"RCCL communicator of rank(s) {bad} does not count {world} ranks")
     if exch == "mailbox" and world > 1 and not all(rec.get("share_device") for rec in every):
+        if len({rec.get("host") for rec in every}) > 1:
+            complaints.append("the mailbox maps the peers' boxes through hipIpc: ranks of ONE host only")
         bad = [r for r, rec in enumerate(every) if rec.get("peer_access") is not None and not all(rec["peer_access"])]
         if bad:
             complaints.append(f"hipDeviceCanAccessPeer denies a pair of devices on rank(s) {bad}: the mailbox stores into the peers' memory")

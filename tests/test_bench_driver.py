@@ -84,6 +84,20 @@ def test_driver_flags_give_the_long_run_figure():
             assert abs(r["avg_launch_us"]["B"] / r["avg_launch_us_dispatch_timestamps"]["B"] - 1) < 0.15
 
 
+def test_the_expected_scaling_curve_is_the_one_design_md_states():
+    """bench.py at N > 1 prints measured / predicted (config.exchange.predicted); the prediction is DESIGN.md section 6's table."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    for series, n, text in (("C3", 8, "103.7 k"), ("C3", 2, "93.6"), ("C4", 8, "81.1 k"), ("C4", 4, "79.2")):
+        assert abs(bench.predicted_rate(series, n, "mailbox") / 1e3 - float(text.split()[0])) < 0.06 and text in design
+    assert bench.predicted_rate("C3", 1, None) > bench.predicted_rate("C3", 8, "mailbox") > bench.predicted_rate("C3", 2, "mailbox")      # flat, not rising
+    assert bench.predicted_rate("C3", 8, "eager") < 40e3 and bench.predicted_rate("C3x80", 8, "mailbox") > 7 * bench.predicted_rate("C3x80", 1, None)
+    assert bench.predicted_rate("C2", 8, "mailbox") is None
+
+
 class _FakeCtx:
     precision = "mixed"
 
