@@ -1,7 +1,7 @@
 #!/bin/bash
 # A round's evidence set in one call on the GPU box:  bash tools/collect_round.sh <tag>     (then, in the build container: python tools/stamp_profiles.py <tag>)
 set -u
-R=$GRAFT_REPO_ROOT; T=${1:-r05x}; O=$R/gpurun_out/$T; mkdir -p $O
+R=$GRAFT_REPO_ROOT; T=${1:-r06x}; O=$R/gpurun_out/$T; mkdir -p $O
 cd $R
 # instrumented build (in-kernel stamps) for the timeline / anatomy probes: built here, where the sources are the ones under test
 ( cd openmm-velocityverlet_amd/csrc && mkdir -p ../../tools/probes/libs && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function -I/opt/rocm/include \
@@ -15,6 +15,8 @@ bash tools/profile_round.sh $T C3 > /dev/null 2>&1
 bash tools/profile_round.sh $T C4 > /dev/null 2>&1
 EXTRA=--hbonds SUF=_hbonds bash tools/profile_round.sh $T C3 > /dev/null 2>&1
 bash tools/profile_round.sh $T C5 > /dev/null 2>&1
+bash tools/profile_round.sh $T C2 > /dev/null 2>&1        # (C2 / C1: bench.py's config.other_configs take their rocprofv3 clock from these when no live child ran)
+bash tools/profile_round.sh $T C1 > /dev/null 2>&1
 bash tools/profile_round.sh $T C3x80 > /dev/null 2>&1
 bash tools/pmc_sq.sh $T C3 > /dev/null 2>&1
 bash tools/pmc_sq.sh $T C4 > /dev/null 2>&1
