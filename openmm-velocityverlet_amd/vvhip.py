@@ -151,7 +151,14 @@ def _load():
         "vvhip_debug_timestamps_fused": [vp, C.c_int, P(C.c_longlong * 128)],
     }
     for name, args in sig.items():
-        fn = getattr(lib, name)
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            # an OLDER build of the library named by VVHIP_LIB (A/B runs of a previous round's kernels, tools/probes/ab_lib_rates.sh) may lack the newest
+            # entry points; the product library must export every one of them (tests/test_host_plan.py checks the header's list)
+            if os.environ.get("VVHIP_LIB"):
+                continue
+            raise
         fn.argtypes = args
         fn.restype = C.c_int
     lib.vvhip_plan_destroy.argtypes = [vp]

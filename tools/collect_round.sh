@@ -8,6 +8,8 @@ cd $R
     -mllvm -amdgpu-kernarg-preload-count=16 -DVV_KERNEL_TIMESTAMPS -shared -o ../../tools/probes/libs/libvvhip_ts.so vv_host.cpp vv_api.cpp vv_rtc.cpp vv_kernels.hip -ldl > $O/ts_build.log 2>&1 ) &
 TS=$!
 timeout 900 python tools/probes/fused_ab.py C3,C4,C5,C2,C1,C3hb,C5hb,C2hb 3 > $O/fused_ab_all_configs.txt 2>&1
+# this round's kernels against the previous round's on this very box (tools/probes/build_round_lib.sh e195552 r05, in the build container)
+[ -f tools/probes/libs/libvvhip_r05.so ] && ROUNDS=3 timeout 600 bash tools/probes/ab_lib_rates.sh "C3 C4 C5 C2 C1 C3hb C5hb C2hb" tools/probes/libs/libvvhip_r05.so openmm-velocityverlet_amd/lib/libvvhip.so > $O/r05_vs_r06_ab.txt 2>&1
 CLASSIC=1 timeout 600 python tools/probes/fused_ab.py C3,C4,C5,C2 2 10000 > $O/classic_scheme_ab.txt 2>&1
 timeout 600 python tools/probes/shard_step.py C4 8,4,2 > $O/shard_step.txt 2>&1
 ( time python bench.py > $O/bench_default_timed.json 2> $O/bench_default_timed.stderr ) 2> $O/bench_default_wallclock.txt
