@@ -78,11 +78,15 @@ def test_a_second_process_on_the_gpu_costs_a_repeat_not_the_run(spec):
     finally:
         proc.stdin.close()
         proc.wait(timeout=30)
-    assert ctx.recovery_count() == 1, "the other process's kernel did not disturb the run: nothing was tested"
+    disturbed = ctx.recovery_count()
     assert ctx.status_words() == [0, 0, 0, 0]
-    assert not ctx.fused_status()[0]                   # pinned to two launches from here on
     got = _state(ctx)
-    assert _equal_bits(got, want)
+    assert _equal_bits(got, want)                      # (whether or not the intruder got in the way: the trajectory is the two-launch one)
+    if disturbed == 0:
+        ctx.close()
+        pytest.skip("the other process's kernel did not break the rendezvous on this box (the GPU time-sliced it): the repair was not exercised")
+    assert disturbed == 1
+    assert not ctx.fused_status()[0]                   # pinned to two launches from here on
     # ... and the run simply goes on
     ctx.run_graph(200, 100)
     ctx.synchronize()
@@ -107,15 +111,22 @@ def test_without_a_snapshot_the_failure_is_reported_and_the_plan_pinned(spec):
         proc.stdin.write("go\n"); proc.stdin.flush()
         ctx.run_graph(60000, 100)
         assert proc.stdout.readline().strip() == "launched"
-        with pytest.raises(H.VVHipError) as err:
+        err = None
+        try:
             ctx.synchronize()
+        except H.VVHipError as e:
+            err = e
         elapsed = time.perf_counter() - t0
         assert proc.stdout.readline().strip() == "done"
     finally:
         proc.stdin.close()
         proc.wait(timeout=30)
-    assert err.value.code == H.ERR_RENDEZVOUS
-    assert "two launches" in str(err.value)
+    if err is None:
+        assert ctx.status_words() == [0, 0, 0, 0]
+        ctx.close()
+        pytest.skip("the other process's kernel did not break the rendezvous on this box (the GPU time-sliced it): the failure path was not exercised")
+    assert err.code == H.ERR_RENDEZVOUS
+    assert "two launches" in str(err)
     assert elapsed < 5.0, f"{elapsed:.1f} s: the steps behind the failed one waited for their own time-outs"
     assert ctx.status_words()[2] == 1 and not ctx.fused_status()[0] and ctx.recovery_count() == 0      # (word [1] may be up too: sums of garbage overflow)
     ctx.status_clear()
