@@ -200,7 +200,11 @@ struct vvhip_plan {
         const void* site = nullptr;
         double kt = 0, kd = 0;
         uint32_t random_end = 0;               // prepareRandomNumbers cursor after the graph's last step
-    } graph[2];
+    };
+    // (round 6: up to four graph lengths per parity -- a host that replays a short graph in front of a long one keeps both)
+    static constexpr int kGraphWays = 4;
+    GraphSlot graph[2][kGraphWays];
+    int graph_next[2] = {0, 0};
     bool capturing = false;
     // particle sharding over GPUs: RCCL communicator for the accumulator exchange (null = single GPU)
     ncclComm_t comm = nullptr;
@@ -236,8 +240,18 @@ struct vvhip_plan {
 };
 
 static void drop_graphs(vvhip_plan* p) {
-    for (auto& g : p->graph)
-        if (g.exec) { (void) hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+    for (auto& row : p->graph)
+        for (auto& g : row)
+            if (g.exec) { (void) hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+}
+// the slot of parity q that holds (or will hold) the graph with this key
+static vvhip_plan::GraphSlot& graph_slot(vvhip_plan* p, int q, int steps, const void* site, double kt, double kd) {
+    auto& row = p->graph[q & 1];
+    for (auto& g : row)
+        if (g.exec && g.steps == steps && g.site == site && g.kt == kt && g.kd == kd) return g;
+    for (auto& g : row)
+        if (!g.exec) return g;
+    return row[p->graph_next[q & 1]++ % vvhip_plan::kGraphWays];
 }
 
 namespace vv { unsigned vv_last_grid_value = 0; }
@@ -1596,7 +1610,7 @@ static int plan_step(vvhip_plan* p, const void* site, double k_tether, double k_
 static int prepare_slot(vvhip_plan* p, int q, int steps_per_graph, const void* site, double k_tether, double k_drude) {
     hipStream_t s = p->stream;
     TRY(ensure_mass_table(p));                       // a one-off fill must not be recorded into the replayed graph
-    vvhip_plan::GraphSlot& g = p->graph[q & 1];
+    vvhip_plan::GraphSlot& g = graph_slot(p, q, steps_per_graph, site, k_tether, k_drude);
     if (g.exec && g.steps == steps_per_graph && g.site == site && g.kt == k_tether && g.kd == k_drude) return VVHIP_OK;
     if (g.exec) { (void) hipGraphExecDestroy(g.exec); g.exec = nullptr; }
     // The capture walks the host-side cursors (parity, Langevin random slice) through the graph's steps; they are put back
@@ -1653,7 +1667,7 @@ int vvhip_run_graph(vvhip_plan* p, int nsteps, int steps_per_graph, const void* 
     int done = 0;
     if (nsteps >= steps_per_graph) {
         TRY(prepare_slot(p, p->parity, steps_per_graph, site, k_tether, k_drude));     // no-op when the slot of this parity is ready
-        const vvhip_plan::GraphSlot& g = p->graph[p->parity & 1];
+        const vvhip_plan::GraphSlot& g = graph_slot(p, p->parity, steps_per_graph, site, k_tether, k_drude);
         for (; done + steps_per_graph <= nsteps; done += steps_per_graph) HIP_TRY(p, hipGraphLaunch(g.exec, s));
         p->random_pos = g.random_end;                // an even number of steps: the parity is where it was
         if (!middle && extra_flags(p)) p->fextra_dirty = true;

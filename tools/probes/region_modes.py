@@ -41,6 +41,12 @@ for k in (20, 40, 100, 2000):
         gl = min(k - lead, 100); gl -= gl % 2
         ctx.run_graph(gl, gl); ctx.synchronize()
         rows.append((f"{lead} plain steps + graphs of {gl}", lambda: (ctx.run_eager(lead), ctx.run_graph(k - lead, gl))))
+    if k >= 20:
+        for lead in (2, 4):
+            gl = k - lead
+            if gl > 100 or gl % 2: continue
+            ctx.graph_prepare(lead); ctx.graph_prepare(gl)
+            rows.append((f"graph of {lead} + graph of {gl}", (lambda lead=lead, gl=gl: (ctx.run_graph(lead, lead), ctx.run_graph(gl, gl)))))
     for name, fn in rows:
         fn(); ctx.synchronize()
         med, enq, lo = region(fn, 41 if k <= 200 else 9)
