@@ -104,9 +104,9 @@ def kernel_times(ctx, reps, batches, one_launch=None):
 
 
 # What a first 1 -> 8 run should show ("the curve to expect"): a rank's own share of the step measured on ONE GPU with this
-# round's kernels (profiles/r06h_shard_step.txt; large box: the size ladder) + the exchange as ASSUMED there -- 2.0 us for the xGMI mailbox's
+# round's kernels (profiles/r06h_shard_step.txt, C4: r06w_shard_step_C4.txt; large box: the size ladder) + the exchange as ASSUMED there -- 2.0 us for the xGMI mailbox's
 # one remote flight, 20 us for an RCCL all-reduce between two launches (neither measured in the build environment).  us per step.
-PREDICTED_RANK_STEP_US = {"C3": {1: 9.55, 2: 8.68, 4: 8.01, 8: 7.64}, "C4": {1: 11.31, 2: 11.06, 4: 10.62, 8: 10.33},
+PREDICTED_RANK_STEP_US = {"C3": {1: 9.55, 2: 8.68, 4: 8.01, 8: 7.64}, "C4": {1: 11.29, 2: 10.73, 4: 10.01, 8: 9.68},
                           "C3x80": {1: 455.0, 2: 217.0, 4: 111.0, 8: 59.0}}
 PREDICTED_EXCHANGE_US = {"mailbox": 2.0, "graph": 20.0, "eager": 20.0, "python": 60.0}
 

@@ -281,7 +281,11 @@ int check_exchange_health(vvhip_plan* p) {
     // (a missed rendezvous first: an overflowed accumulator or an unconverged cluster next to it is what steps on incomplete sums produce)
     if (rv) {
         // (the plan is pinned to two launches per step from here on whatever else happens: the next run does not meet the same fate)
-        if (p->fused) { p->fused = false; drop_graphs(p); }
+        if (p->fused) {
+            p->fused = false;
+            if (p->bound) (void) hipStreamSynchronize(p->stream);      // (the word is read without synchronising: replays of the graphs about to go may still be in flight)
+            drop_graphs(p);
+        }
         return fail(p, VVHIP_ERR_RENDEZVOUS, "fused step: the blocks of the one-launch step did not meet within 0.2 s (not resident together: another process's kernels on the device?); the thermostat went on with incomplete sums and the state since the last good synchronisation is void.  The plan now takes two launches per step (vvhip_fused_status: active = 0); vvhip_status_clear + restoring the state continues the run.  Runs of >= 64 steps through vvhip_run_graph / vvhip_run_eager recover by themselves (vvhip_debug_tune \"recover\")");
     }
     // (an unconverged constraint cluster is reported before the overflow it usually causes a step or two later)
@@ -359,7 +363,8 @@ void pick_launch_shape(vvhip_plan* p) {
     // The cos perturbation's one-launch step collects ten rows in its rendezvous, shared by the waves of a block: three tile waves per block
     // (a third of the words to poll, four waves to share the rows) beat one or two up to 3 x CUs tile waves -- one rank's eighth / quarter of C4
     // 89.1 -> 92.8 k / 89.5 -> 91.1 k steps/s; with three rows the plan's choice below stays the best (profiles/r05j_small_shape.txt)
-    if (p->hp.params.cos_acceleration != 0 && p->hp.has_nh && nw > 3 && nw <= 3L * cus) { p->block_threads = 192; p->grid_cap_a = p->grid_cap_b = cus; return; }
+    // (round 6: that rule is gone with the shared-out polling it served -- one tile wave per block again, C4 / 8 9.70 against 9.92 us per step,
+    // profiles/r06w_c4_shard_shapes.txt)
     if (nw <= cus) { p->block_threads = 64; p->grid_cap_a = p->grid_cap_b = cus; return; }
     // bandwidth-bound regime (the chain runs as its own launch there, kernel B fits 6 waves per SIMD): tuned at 8.9 M particles
     // (kernel B: two blocks per CU, not four -- round 4, three alternating runs: 2.66 M particles 7 330 -> 7 540 steps/s, 4.4 M 4 226 -> 4 326,
@@ -1612,7 +1617,7 @@ static int prepare_slot(vvhip_plan* p, int q, int steps_per_graph, const void* s
     TRY(ensure_mass_table(p));                       // a one-off fill must not be recorded into the replayed graph
     vvhip_plan::GraphSlot& g = graph_slot(p, q, steps_per_graph, site, k_tether, k_drude);
     if (g.exec && g.steps == steps_per_graph && g.site == site && g.kt == k_tether && g.kd == k_drude) return VVHIP_OK;
-    if (g.exec) { (void) hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+    if (g.exec) { (void) hipStreamSynchronize(s); (void) hipGraphExecDestroy(g.exec); g.exec = nullptr; }      // (a replay of the one that goes may still be in flight)
     // The capture walks the host-side cursors (parity, Langevin random slice) through the graph's steps; they are put back
     // afterwards, because nothing has run yet.  A replay moves them to the graph's end (vvhip_run_graph).
     const int parity0 = p->parity;

@@ -91,7 +91,7 @@ def test_the_expected_scaling_curve_is_the_one_design_md_states():
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     design = open(os.path.join(ROOT, "DESIGN.md")).read()
-    for series, n, text in (("C3", 8, "103.7 k"), ("C3", 2, "93.6"), ("C4", 8, "81.1 k"), ("C4", 4, "79.2")):
+    for series, n, text in (("C3", 8, "103.7 k"), ("C3", 2, "93.6"), ("C4", 8, "85.6 k"), ("C4", 4, "83.3")):
         assert abs(bench.predicted_rate(series, n, "mailbox") / 1e3 - float(text.split()[0])) < 0.06 and text in design
     assert bench.predicted_rate("C3", 1, None) > bench.predicted_rate("C3", 8, "mailbox") > bench.predicted_rate("C3", 2, "mailbox")      # flat, not rising
     assert bench.predicted_rate("C3", 8, "eager") < 40e3 and bench.predicted_rate("C3x80", 8, "mailbox") > 7 * bench.predicted_rate("C3x80", 1, None)

@@ -14,7 +14,7 @@ def make(n, fused):
     it = I.VVIntegrator(333.0, 10, 1.0, 40, 0.001)
     it.setMaxDrudeDistance(0.02)
     it.setCosAcceleration(0.02 if cfg == "C4" else 0.0)
-    ctx = I.Context(spec, it, precision="mixed", force_provider="tether", shard=D.shard_bounds(spec, n)[0], tune={"fused": int(fused)})
+    ctx = I.Context(spec, it, precision="mixed", force_provider="tether", shard=D.shard_bounds(spec, n)[0], tune={"fused": int(fused), **({"block_threads": int(os.environ["BLOCK_THREADS"])} if os.environ.get("BLOCK_THREADS") else {})})      # BLOCK_THREADS=64/128/192: tile waves per block
     h = ctx.mailbox_create(1, 0)
     ctx.mailbox_connect(h)
     return ctx
