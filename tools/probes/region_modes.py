@@ -13,7 +13,7 @@ spec = S.make_config("C3" if cfg == "C4" else cfg)
 it = I.VVIntegrator(300.0 if cfg == "C2" else 333.0, 10, 1.0, 40, 0.002 if cfg == "C2" else 0.001)
 if cfg not in ("C1", "C2"): it.setMaxDrudeDistance(0.02)
 if cfg == "C4": it.setCosAcceleration(0.02)
-ctx = I.Context(spec, it, precision="mixed", force_provider="tether")
+ctx = I.Context(spec, it, precision="mixed", force_provider=os.environ.get("PROVIDER", "tether"))
 ctx.run_graph(400, 100); ctx.synchronize()
 
 
