@@ -396,8 +396,8 @@ def test_a_plan_that_cannot_fuse_its_constraints_says_why():
 
 def test_launch_shapes_of_the_measured_regimes():
     """The launch shapes the measurements of TUNING_LOG sections 12-13 settled on, as the plan chooses them for a whole MI355X (256 CUs) before any
-    device is bound: one block of seven tile waves per CU at the headline size (one launch per step), three tile waves per block for a rank's
-    share of the cos-perturbed box (ten rendezvous rows, shared by the block's waves), two blocks per CU past one pass, whole rounds of
+    device is bound: one block of seven tile waves per CU at the headline size (one launch per step), one tile wave per block for a rank's
+    share of the cos-perturbed box (round 5's three-wave rule went with the shared poll in round 6), two blocks per CU past one pass, whole rounds of
     four-wave blocks in the bandwidth-bound regime."""
     def shape(cfg, scale=1.0, cos=0.0, shard=None, hbonds=False):
         spec = systems.make_config(cfg, scale, hbonds=hbonds)
@@ -411,9 +411,10 @@ def test_launch_shapes_of_the_measured_regimes():
     nw, s = shape("C3")
     assert nw == 1752 and s == (448, 256, 256, 7)                  # 251 blocks of 7 tile waves + the thermostat wave: the one-launch step
     nw, s = shape("C3", cos=0.02)
-    assert s == (448, 256, 256, 7)                                 # C4: same shape, the ten rows collected by all eight waves
+    assert s == (448, 256, 256, 7)                                 # C4: same shape (the thermostat wave polls the ten rows)
     nw, s = shape("C3", cos=0.02, shard=8)
-    assert nw <= 256 and s == (192, 256, 256, 3)                   # one rank's eighth of C4: three tile waves per block
+    assert nw <= 256 and s == (64, 256, 256, 1)                    # one rank's eighth of C4: one tile wave per block like every small system (round 6: the
+                                                                   # thermostat wave polls the ten rows alone; profiles/r06w_c4_shard_shapes.txt)
     nw, s = shape("C3", shard=8)
     assert s == (64, 256, 256, 1)                                  # ... of C3 (three rows): one tile wave per block stays the best
     nw, s = shape("C2")
