@@ -97,6 +97,32 @@ def test_rigid_water_settle(prec, middle):
         ctx.close()
 
 
+@pytest.mark.parametrize("seed", [9001, 9002, 9005, 9011, 9013, 9020])
+def test_rigid_triangles_of_other_shapes_and_masses(seed):
+    """SETTLE away from SPC/E: random apex-partner / partner-partner distances (apex angle ~20 to ~145 degrees), light or heavy apex, both schemes, three
+    step sizes -- the rigid-triangle arithmetic works from the inverse masses and from bond vectors that are not normalised (round 6), so it is held to the
+    oracle's independently written statement and to the constraints themselves over more than water's one shape (tools/probes/fuzz_settle.py: more cases)."""
+    rng = np.random.default_rng(seed)
+    spec = systems.spce_water(int(rng.integers(20, 200)), seed=seed)
+    m_apex, m_part = float(rng.uniform(1.0, 40.0)), float(rng.uniform(1.0, 40.0))
+    spec.masses = np.tile([m_apex, m_part, m_part], spec.num_atoms // 3)
+    d_ab = float(rng.uniform(0.08, 0.16))
+    d_bb = float(rng.uniform(0.35, 1.9)) * d_ab
+    spec = systems.rigid_water(spec, d_oh=d_ab, d_hh=d_bb)
+    middle = bool(rng.integers(0, 2)); prec = ["mixed", "double"][int(rng.integers(0, 2))]
+    dt = float(rng.choice([0.001, 0.002, 0.004]))
+    osys, ctx, it = _pair(spec, prec, middle, 10, maxd=0.0, T=300.0, dt=dt)
+    try:
+        assert ctx.info.constraints_fused and ctx.info.num_settle_clusters == spec.num_atoms // 3
+        _parity(osys, ctx, prec, f"triangles/{seed}/{prec}/middle={middle}/m={m_apex:.1f},{m_part:.1f}/d={d_ab:.3f},{d_bb:.3f}")
+        x = ctx.getPositions()
+        c, d = np.asarray(spec.constraints), np.asarray(spec.constraint_distances).astype(np.float32).astype(np.float64)
+        r = np.linalg.norm(x[c[:, 0]] - x[c[:, 1]], axis=1)
+        assert np.abs(r - d).max() < 1e-12, np.abs(r - d).max()
+    finally:
+        ctx.close()
+
+
 def test_rigid_water_conserves_momentum_and_holds_over_a_long_run():
     spec = systems.rigid_water(systems.spce_water(1000, seed=8))
     it = I.VVIntegrator(300.0, 10, 1.0, 40, 0.002)
