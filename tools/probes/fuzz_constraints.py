@@ -31,7 +31,13 @@ for seed in range(7000, 7000 + n):
     fused = ctx.info.constraints_fused
     if not fused:
         ctx.close(); print("not fused", seed, len(spec.constraints)); continue
-    osys.step(8); it.step(8)
+    osys.step(8)
+    try:
+        it.step(8); ctx.synchronize()
+    except pkg.vvhip.VVHipError as e:      # (since round 5 a cluster that stops at the iteration cap raises the sticky word [3]: the run is reported, not silently kept --
+        if e.code != pkg.vvhip.ERR_CONSTRAINT: raise      # here the state is compared all the same: the oracle stops at the same cap)
+        reported = globals().get("reported", 0) + 1
+        ctx.status_clear()
     x_o, x_g = osys.positions(), ctx.getPositions()
     v_o, v_g = osys.velm[:, :3].astype(np.float64), ctx.getVelocities()
     ctx.close()
@@ -47,4 +53,4 @@ for seed in range(7000, 7000 + n):
         print("unconverged at the sweep cap, GPU = oracle: seed", seed, "constraint", viol); capped += 1
     elif not (ex < 1e-5 and ev < 1e-4 and viol < 2.5e-5 and np.isfinite(x_g).all()):
         print("MISMATCH seed", seed, "flavour", flavour, prec, "middle", middle, "com", com, "pos", ex, "vel", ev, "constraint", viol); bad += 1
-print("fuzz done:", n, "systems", kinds, "; mismatches", bad, "; stopped at the sweep cap (GPU = oracle)", capped, "; worst constraint violation %.1e" % worst_c)
+print("runs that reported an unconverged cluster (VVHIP_ERR_CONSTRAINT):", globals().get("reported", 0)); print("fuzz done:", n, "systems", kinds, "; mismatches", bad, "; stopped at the sweep cap (GPU = oracle)", capped, "; worst constraint violation %.1e" % worst_c)
